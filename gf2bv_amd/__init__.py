@@ -1,0 +1,16 @@
+"""gf2bv_amd -- MI355X-native GF(2) linear-system solver behind gf2bv's API.
+
+Drop-in for the solve path of maple3142/gf2bv: ``LinearSystem`` / ``gens()`` /
+``solve_one`` / ``solve_all`` and the ``_internal`` boundary (``m4ri_solve``,
+``AffineSpace``) keep their meaning; the bit-packed matrix assembly and the elimination /
+back-substitution / kernel basis run as HIP kernels on gfx950 (gf2bv_amd/csrc).
+There is no CPU fallback: importing works anywhere, solving needs the GPU.
+"""
+from ._internal import AffineSpace, m4ri_solve, mul_bit_quad, to_bits, tuple_where, xor_tuple
+from .bitvec import BitVec
+from .linsys import DimensionTooLargeError, LinearSystem, Zeros
+
+__all__ = [
+    "AffineSpace", "BitVec", "DimensionTooLargeError", "LinearSystem", "Zeros",
+    "m4ri_solve", "mul_bit_quad", "to_bits", "tuple_where", "xor_tuple",
+]

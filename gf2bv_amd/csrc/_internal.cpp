@@ -1,0 +1,481 @@
+// _internal.cpp -- CPython extension `gf2bv_amd._internal`.
+//
+// Mirrors the native boundary of the reference (maple3142/gf2bv, gf2bv/_internal.c:767-833):
+// same callables (m4ri_solve, to_bits, xor_tuple, tuple_where, mul_bit_quad), same types
+// (AffineSpace, AffineSpaceIterator, AffineSpaceIteratorSlow), same argument meaning and
+// error behaviour -- but m4ri_solve hands the equations to libgf2bv_hip.so (HIP kernels on
+// MI355X) instead of M4RI.  No GF(2) elimination happens in this file and there is no CPU
+// fallback: without a GPU m4ri_solve raises RuntimeError.
+//
+// Host-side work kept here, as in the reference: reading CPython int digits
+// (_internal.c:5-16, 41-59 -- here a memcpy of ob_digit, the bit shuffling is the device pack
+// kernel), converting word vectors back to ints (_internal.c:32-39) and the tiny
+// origin ^ basis[i] combinations of AffineSpace.get / iteration (_internal.c:101-122, 242-273).
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/gf2bv_hip.h"
+
+#if PY_VERSION_HEX >= 0x030C0000
+#define GF2_DIGIT_COUNT(o) ((Py_ssize_t)((o)->long_value.lv_tag >> 3))
+#define GF2_DIGITS(o) ((o)->long_value.ob_digit)
+#else
+#define GF2_DIGIT_COUNT(o) (Py_SIZE(o) < 0 ? -Py_SIZE(o) : Py_SIZE(o))
+#define GF2_DIGITS(o) ((o)->ob_digit)
+#endif
+
+namespace {
+
+PyObject *words_to_pylong(const uint64_t *w, int64_t nwords)
+{
+	if (nwords <= 0) return PyLong_FromLong(0);
+	return _PyLong_FromByteArray(reinterpret_cast<const unsigned char *>(w), (size_t)nwords * 8, 1, 0);
+}
+
+// bit `i` (LSB = 0) of |v|, false beyond its digits
+inline bool long_bit(PyLongObject *v, Py_ssize_t i)
+{
+	Py_ssize_t d = i / PyLong_SHIFT;
+	if (d >= GF2_DIGIT_COUNT(v)) return false;
+	return (GF2_DIGITS(v)[d] >> (i % PyLong_SHIFT)) & 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// AffineSpace: origin + basis as 64-bit word vectors (the reference keeps two mzd_t*,
+// gf2bv/_internal.h:7-10).
+struct AffineSpaceObject {
+	PyObject_HEAD
+	int64_t dim, words;
+	uint64_t *origin;   // words
+	uint64_t *basis;    // dim x words
+};
+
+struct SpaceIterObject {
+	PyObject_HEAD
+	AffineSpaceObject *space;
+	uint64_t *cur;      // Gray: running vector; Slow: scratch
+	uint64_t idx;       // Gray index
+	uint8_t *state;     // Slow: dim+1 counter bits
+	int done;
+};
+
+PyTypeObject *AffineSpace_Type, *SpaceIterGray_Type, *SpaceIterSlow_Type;
+
+void space_dealloc(AffineSpaceObject *self)
+{
+	PyTypeObject *tp = Py_TYPE(self);
+	free(self->origin);
+	free(self->basis);
+	tp->tp_free((PyObject *)self);
+	Py_DECREF(tp);
+}
+
+PyObject *space_dimension(AffineSpaceObject *self, void *) { return PyLong_FromLongLong(self->dim); }
+PyObject *space_origin(AffineSpaceObject *self, void *) { return words_to_pylong(self->origin, self->words); }
+PyObject *space_basis(AffineSpaceObject *self, void *)
+{
+	PyObject *t = PyTuple_New(self->dim);   // a tuple, like _internal.c:218-230 (the .pyi says list)
+	if (!t) return nullptr;
+	for (int64_t i = 0; i < self->dim; i++) {
+		PyObject *v = words_to_pylong(self->basis + i * self->words, self->words);
+		if (!v) { Py_DECREF(t); return nullptr; }
+		PyTuple_SET_ITEM(t, i, v);
+	}
+	return t;
+}
+
+// AffineSpace.get(n): origin ^ XOR of basis rows at the set bits of n (binary, not Gray; only
+// the low `dimension` bits of |n| are read) -- _internal.c:242-273
+PyObject *space_get(AffineSpaceObject *self, PyObject *const *args, Py_ssize_t nargs)
+{
+	if (nargs != 1) { PyErr_SetString(PyExc_TypeError, "get requires 1 argument"); return nullptr; }
+	if (!PyLong_Check(args[0])) { PyErr_SetString(PyExc_TypeError, "Index must be an integer"); return nullptr; }
+	PyLongObject *n = (PyLongObject *)args[0];
+	int64_t sw = (self->dim + 63) / 64;
+	std::vector<uint64_t> sel((size_t)(sw ? sw : 1), 0), out((size_t)(self->words ? self->words : 1), 0);
+	for (int64_t i = 0; i < self->dim; i++)
+		if (long_bit(n, i)) sel[i >> 6] |= (uint64_t)1 << (i & 63);
+	gf2bv_space_combine(self->origin, self->basis, self->dim, self->words, sel.data(), sw, out.data());
+	return words_to_pylong(out.data(), self->words);
+}
+
+PyObject *space_iter(AffineSpaceObject *self)
+{
+	const bool gray = self->dim <= 64;       // _internal.c:185
+	PyTypeObject *tp = gray ? SpaceIterGray_Type : SpaceIterSlow_Type;
+	SpaceIterObject *it = (SpaceIterObject *)tp->tp_alloc(tp, 0);
+	if (!it) return nullptr;
+	Py_INCREF(self);
+	it->space = self;
+	it->idx = 0;
+	it->done = 0;
+	it->state = nullptr;
+	size_t nw = (size_t)(self->words ? self->words : 1);
+	it->cur = (uint64_t *)malloc(nw * sizeof(uint64_t));
+	memcpy(it->cur, self->origin, (size_t)self->words * sizeof(uint64_t));
+	if (!gray) it->state = (uint8_t *)calloc((size_t)self->dim + 1, 1);
+	return (PyObject *)it;
+}
+
+void iter_dealloc(SpaceIterObject *self)
+{
+	PyTypeObject *tp = Py_TYPE(self);
+	Py_XDECREF(self->space);
+	free(self->cur);
+	free(self->state);
+	tp->tp_free((PyObject *)self);
+	Py_DECREF(tp);
+}
+
+// Reflected Gray code walk, _internal.c:101-122: yield the running vector, then flip the basis
+// row whose index is the bit in which gray(idx) and gray(idx+1) differ.
+PyObject *iter_next_gray(SpaceIterObject *self)
+{
+	if (self->done) return nullptr;
+	AffineSpaceObject *sp = self->space;
+	PyObject *ret = words_to_pylong(self->cur, sp->words);
+	uint64_t x = self->idx ^ (self->idx >> 1);
+	self->idx++;
+	uint64_t y = self->idx ^ (self->idx >> 1);
+	int diff = __builtin_ctzll(x ^ y);
+	if (diff >= sp->dim || (sp->dim == 64 && self->idx == 0)) {
+		self->done = 1;
+		return ret;
+	}
+	const uint64_t *b = sp->basis + (int64_t)diff * sp->words;
+	for (int64_t w = 0; w < sp->words; w++) self->cur[w] ^= b[w];
+	return ret;
+}
+
+// Binary counter walk for dimension > 64, _internal.c:63-91 (basis[0] is the LSB).
+PyObject *iter_next_slow(SpaceIterObject *self)
+{
+	AffineSpaceObject *sp = self->space;
+	const int64_t n = sp->dim;
+	if (self->state[n]) return nullptr;
+	memcpy(self->cur, sp->origin, (size_t)sp->words * sizeof(uint64_t));
+	for (int64_t r = 0; r < n; r++)
+		if (self->state[r])
+			for (int64_t w = 0; w < sp->words; w++) self->cur[w] ^= sp->basis[r * sp->words + w];
+	uint8_t sentinel = 1;
+	for (int64_t r = 0; r < n; r++) {
+		self->state[r] ^= 1;
+		if (self->state[r]) { sentinel = 0; break; }
+	}
+	self->state[n] = sentinel;
+	return words_to_pylong(self->cur, sp->words);
+}
+
+PyGetSetDef space_getset[] = {
+	{"dimension", (getter)space_dimension, nullptr, "Dimension of the affine space", nullptr},
+	{"origin", (getter)space_origin, nullptr, "Origin of the affine space", nullptr},
+	{"basis", (getter)space_basis, nullptr, "Basis of the affine space", nullptr},
+	{nullptr, nullptr, nullptr, nullptr, nullptr}};
+
+PyMethodDef space_methods[] = {
+	{"get", (PyCFunction)(void (*)(void))space_get, METH_FASTCALL,
+	 "get(n)\n--\n\nGet the n-th element of the affine space, should check 0 <= n < 2**(space.dimension) first."},
+	{nullptr, nullptr, 0, nullptr}};
+
+PyType_Slot space_slots[] = {
+	{Py_tp_dealloc, (void *)space_dealloc}, {Py_tp_iter, (void *)space_iter},
+	{Py_tp_methods, (void *)space_methods}, {Py_tp_getset, (void *)space_getset}, {0, nullptr}};
+PyType_Slot gray_slots[] = {
+	{Py_tp_dealloc, (void *)iter_dealloc}, {Py_tp_iter, (void *)PyObject_SelfIter},
+	{Py_tp_iternext, (void *)iter_next_gray}, {0, nullptr}};
+PyType_Slot slow_slots[] = {
+	{Py_tp_dealloc, (void *)iter_dealloc}, {Py_tp_iter, (void *)PyObject_SelfIter},
+	{Py_tp_iternext, (void *)iter_next_slow}, {0, nullptr}};
+
+#ifndef Py_TPFLAGS_DISALLOW_INSTANTIATION
+#define Py_TPFLAGS_DISALLOW_INSTANTIATION 0
+#endif
+PyType_Spec space_spec = {"_internal.AffineSpace", sizeof(AffineSpaceObject), 0,
+                          Py_TPFLAGS_DEFAULT | Py_TPFLAGS_DISALLOW_INSTANTIATION, space_slots};
+PyType_Spec gray_spec = {"_internal.AffineSpaceIterator", sizeof(SpaceIterObject), 0,
+                         Py_TPFLAGS_DEFAULT | Py_TPFLAGS_DISALLOW_INSTANTIATION, gray_slots};
+PyType_Spec slow_spec = {"_internal.AffineSpaceIteratorSlow", sizeof(SpaceIterObject), 0,
+                         Py_TPFLAGS_DEFAULT | Py_TPFLAGS_DISALLOW_INSTANTIATION, slow_slots};
+
+// ------------------------------------------------------------------------------------------------
+// m4ri_solve(equations, cols, mode) -- gf2bv/_internal.c:359-502
+PyObject *py_m4ri_solve(PyObject *, PyObject *const *args, Py_ssize_t nargs)
+{
+	if (nargs != 3) { PyErr_SetString(PyExc_TypeError, "m4ri_solve requires 3 arguments"); return nullptr; }
+	PyObject *list = args[0];
+	if (!PyList_Check(list)) {
+		PyErr_SetString(PyExc_TypeError, "The first argument equations must be a list");
+		return nullptr;
+	}
+	Py_ssize_t cols = PyLong_AsSsize_t(args[1]);
+	if (cols <= 0) {
+		if (cols == -1 && PyErr_Occurred()) return nullptr;
+		PyErr_SetString(PyExc_ValueError, "Number of columns must be positive");
+		return nullptr;
+	}
+	long mode = PyLong_AsLong(args[2]);
+	if (mode == -1 && PyErr_Occurred()) return nullptr;
+	if (mode != GF2BV_MODE_SINGLE && mode != GF2BV_MODE_AFFINE_SPACE) {
+		PyErr_SetString(PyExc_ValueError, "Invalid mode");
+		return nullptr;
+	}
+	const Py_ssize_t rows = PyList_GET_SIZE(list);
+	if (rows < cols) {
+		PyErr_SetString(PyExc_ValueError,
+		                "Number of rows must be greater than or equal to number of columns, try pad with zeros.");
+		return nullptr;
+	}
+	// copy the digits that can hold bits 0..cols of every equation (sign ignored, higher bits ignored)
+	const Py_ssize_t need = (cols + 1 + PyLong_SHIFT - 1) / PyLong_SHIFT;
+	std::vector<int64_t> off((size_t)rows + 1, 0);
+	for (Py_ssize_t r = 0; r < rows; r++) {
+		PyObject *item = PyList_GET_ITEM(list, r);
+		if (!PyLong_Check(item)) {
+			PyErr_SetString(PyExc_TypeError, "List items must be integers");
+			return nullptr;
+		}
+		Py_ssize_t nd = GF2_DIGIT_COUNT((PyLongObject *)item);
+		off[r + 1] = off[r] + (nd < need ? nd : need);
+	}
+	std::vector<uint32_t> digits((size_t)off[rows] + 1);
+	for (Py_ssize_t r = 0; r < rows; r++) {
+		PyLongObject *v = (PyLongObject *)PyList_GET_ITEM(list, r);
+		static_assert(sizeof(digit) == sizeof(uint32_t), "30-bit digits in uint32 expected");
+		memcpy(digits.data() + off[r], GF2_DIGITS(v), (size_t)(off[r + 1] - off[r]) * sizeof(uint32_t));
+	}
+
+	gf2bv_result *res = nullptr;
+	int rc;
+	Py_BEGIN_ALLOW_THREADS          // same place the reference drops the GIL (_internal.c:429)
+	rc = gf2bv_solve_digits(digits.data(), off.data(), PyLong_SHIFT, rows, cols, (int)mode, 0, &res);
+	Py_END_ALLOW_THREADS
+	if (rc != GF2BV_OK) {
+		PyErr_Format(rc == GF2BV_ERR_ARG ? PyExc_ValueError : PyExc_RuntimeError,
+		             "gf2bv_amd: HIP solve failed (%d): %s", rc, gf2bv_last_error());
+		return nullptr;
+	}
+	if (gf2bv_result_status(res) != GF2BV_STATUS_SOLVED) {
+		gf2bv_result_free(res);
+		Py_RETURN_NONE;              // inconsistent system -> None (_internal.c:440-446)
+	}
+	const int64_t words = gf2bv_result_words(res);
+	PyObject *ret = nullptr;
+	if (mode == GF2BV_MODE_SINGLE) {
+		std::vector<uint64_t> o((size_t)(words ? words : 1));
+		gf2bv_result_origin(res, o.data());
+		ret = words_to_pylong(o.data(), words);
+	} else {
+		AffineSpaceObject *sp = (AffineSpaceObject *)AffineSpace_Type->tp_alloc(AffineSpace_Type, 0);
+		if (sp) {
+			sp->dim = gf2bv_result_dimension(res);
+			sp->words = words;
+			sp->origin = (uint64_t *)calloc((size_t)(words ? words : 1), sizeof(uint64_t));
+			sp->basis = (uint64_t *)calloc((size_t)((sp->dim * words) > 0 ? sp->dim * words : 1), sizeof(uint64_t));
+			gf2bv_result_origin(res, sp->origin);
+			gf2bv_result_basis(res, sp->basis);
+			ret = (PyObject *)sp;
+		}
+	}
+	gf2bv_result_free(res);
+	return ret;
+}
+
+// to_bits(n, a): tuple of n bools, LSB first, zero-extended (_internal.c:504-531)
+PyObject *py_to_bits(PyObject *, PyObject *const *args, Py_ssize_t nargs)
+{
+	if (nargs != 2) { PyErr_SetString(PyExc_TypeError, "to_bits requires 2 arguments"); return nullptr; }
+	Py_ssize_t n = PyLong_AsSsize_t(args[0]);
+	if (n < 0) {
+		if (n == -1 && PyErr_Occurred()) return nullptr;
+		PyErr_SetString(PyExc_ValueError, "n must be non-negative");
+		return nullptr;
+	}
+	if (!PyLong_Check(args[1])) { PyErr_SetString(PyExc_TypeError, "a must be an integer"); return nullptr; }
+	PyLongObject *a = (PyLongObject *)args[1];
+	PyObject *t = PyTuple_New(n);
+	if (!t) return nullptr;
+	for (Py_ssize_t i = 0; i < n; i++) {
+		PyObject *b = long_bit(a, i) ? Py_True : Py_False;
+		Py_INCREF(b);
+		PyTuple_SET_ITEM(t, i, b);
+	}
+	return t;
+}
+
+// xor_tuple(a, b): element-wise a[i] ^ b[i] (_internal.c:606-639)
+PyObject *py_xor_tuple(PyObject *, PyObject *const *args, Py_ssize_t nargs)
+{
+	if (nargs != 2) { PyErr_SetString(PyExc_TypeError, "xor_tuple requires 2 arguments"); return nullptr; }
+	PyObject *a = args[0], *b = args[1];
+	if (!PyTuple_Check(a) || !PyTuple_Check(b)) {
+		PyErr_SetString(PyExc_TypeError, "a and b must be tuples");
+		return nullptr;
+	}
+	const Py_ssize_t n = PyTuple_GET_SIZE(a);
+	if (n != PyTuple_GET_SIZE(b)) {
+		PyErr_SetString(PyExc_ValueError, "The length of a and b is not equal");
+		return nullptr;
+	}
+	PyObject *t = PyTuple_New(n);
+	if (!t) return nullptr;
+	for (Py_ssize_t i = 0; i < n; i++) {
+		PyObject *x = PyNumber_Xor(PyTuple_GET_ITEM(a, i), PyTuple_GET_ITEM(b, i));
+		if (!x) {
+			Py_DECREF(t);
+			PyErr_SetString(PyExc_TypeError, "Failed to compute xor, list items must be integers");
+			return nullptr;
+		}
+		PyTuple_SET_ITEM(t, i, x);
+	}
+	return t;
+}
+
+// tuple_where(cond, a, b): np.where-like; OVERWRITES cond in place and returns it; a / b may be
+// scalars (_internal.c:641-676)
+PyObject *py_tuple_where(PyObject *, PyObject *const *args, Py_ssize_t nargs)
+{
+	if (nargs != 3) { PyErr_SetString(PyExc_TypeError, "tuple_where requires 3 arguments"); return nullptr; }
+	PyObject *cond = args[0], *a = args[1], *b = args[2];
+	if (!PyTuple_Check(cond)) { PyErr_SetString(PyExc_TypeError, "cond must be a list"); return nullptr; }
+	const bool at = PyTuple_Check(a), bt = PyTuple_Check(b);
+	const Py_ssize_t n = PyTuple_GET_SIZE(cond);
+	if (at && PyTuple_GET_SIZE(a) != n) {
+		PyErr_SetString(PyExc_ValueError, "The length of a and cond is not equal");
+		return nullptr;
+	}
+	if (bt && PyTuple_GET_SIZE(b) != n) {
+		PyErr_SetString(PyExc_ValueError, "The length of b and cond is not equal");
+		return nullptr;
+	}
+	for (Py_ssize_t i = 0; i < n; i++) {
+		PyObject *c = PyTuple_GET_ITEM(cond, i);
+		int truth = PyObject_IsTrue(c);
+		if (truth < 0) return nullptr;
+		PyObject *pick = truth ? (at ? PyTuple_GET_ITEM(a, i) : a) : (bt ? PyTuple_GET_ITEM(b, i) : b);
+		Py_INCREF(pick);
+		PyTuple_SET_ITEM(cond, i, pick);
+		Py_DECREF(c);
+	}
+	Py_INCREF(cond);
+	return cond;
+}
+
+// mul_bit_quad(n, a, b, v, basis): OR basis[1+n+i(i-1)/2+j] into v for every j<i with
+// a_i b_j ^ a_j b_i = 1 (_internal.c:538-604).  Caller-side helper of QuadraticSystem.
+PyObject *py_mul_bit_quad(PyObject *, PyObject *const *args, Py_ssize_t nargs)
+{
+	if (nargs != 5) { PyErr_SetString(PyExc_TypeError, "mul_bit_quad requires 5 arguments"); return nullptr; }
+	Py_ssize_t n = PyLong_AsSsize_t(args[0]);
+	if (n <= 0) {
+		if (n == -1 && PyErr_Occurred()) return nullptr;
+		PyErr_SetString(PyExc_ValueError, "n must be positive");
+		return nullptr;
+	}
+	if (!PyLong_Check(args[1]) || !PyLong_Check(args[2]) || !PyLong_Check(args[3])) {
+		PyErr_SetString(PyExc_TypeError, "a and b and v must be integers");
+		return nullptr;
+	}
+	PyObject *basis = args[4];
+	if (!PyList_Check(basis)) { PyErr_SetString(PyExc_TypeError, "basis must be a list"); return nullptr; }
+	if (PyList_GET_SIZE(basis) != 1 + n + n * (n - 1) / 2) {
+		PyErr_SetString(PyExc_ValueError, "The length of basis is not correct");
+		return nullptr;
+	}
+	PyLongObject *a = (PyLongObject *)args[1], *b = (PyLongObject *)args[2];
+	std::vector<char> ab((size_t)n), bb((size_t)n);
+	for (Py_ssize_t i = 0; i < n; i++) { ab[i] = long_bit(a, i); bb[i] = long_bit(b, i); }
+	PyObject *v = args[3];
+	Py_INCREF(v);
+	Py_ssize_t mi = 1 + n;
+	for (Py_ssize_t i = 0; i < n; i++)
+		for (Py_ssize_t j = 0; j < i; j++, mi++)
+			if ((ab[i] & bb[j]) ^ (ab[j] & bb[i])) {
+				PyObject *nv = PyNumber_Or(v, PyList_GET_ITEM(basis, mi));
+				Py_DECREF(v);
+				if (!nv) {
+					PyErr_SetString(PyExc_TypeError, "Failed to compute or, list items must be integers");
+					return nullptr;
+				}
+				v = nv;
+			}
+	return v;
+}
+
+// Sage / libgd export (_internal.c:678-765) is outside the solve path.
+PyObject *py_sage_helper(PyObject *, PyObject *const *, Py_ssize_t)
+{
+	PyErr_SetString(PyExc_NotImplementedError,
+	                "eqs_to_sage_mat_helper (Sage/libgd export) is out of scope of gf2bv_amd");
+	return nullptr;
+}
+
+// _space_from_ints(cols, origin, basis): build an AffineSpace from host integers.  Not part of the
+// reference surface; lets the CPU test-suite exercise get()/iteration order without a GPU.
+PyObject *py_space_from_ints(PyObject *, PyObject *const *args, Py_ssize_t nargs)
+{
+	if (nargs != 3 || !PyLong_Check(args[1]) || !PyTuple_Check(args[2])) {
+		PyErr_SetString(PyExc_TypeError, "_space_from_ints(cols, origin, basis_tuple)");
+		return nullptr;
+	}
+	Py_ssize_t cols = PyLong_AsSsize_t(args[0]);
+	if (cols <= 0) { if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "cols must be positive"); return nullptr; }
+	const int64_t words = (cols + 63) / 64;
+	const int64_t dim = PyTuple_GET_SIZE(args[2]);
+	AffineSpaceObject *sp = (AffineSpaceObject *)AffineSpace_Type->tp_alloc(AffineSpace_Type, 0);
+	if (!sp) return nullptr;
+	sp->dim = dim;
+	sp->words = words;
+	sp->origin = (uint64_t *)calloc((size_t)words, sizeof(uint64_t));
+	sp->basis = (uint64_t *)calloc((size_t)((dim * words) > 0 ? dim * words : 1), sizeof(uint64_t));
+	for (int64_t k = -1; k < dim; k++) {
+		PyObject *v = k < 0 ? args[1] : PyTuple_GET_ITEM(args[2], k);
+		if (!PyLong_Check(v)) { Py_DECREF(sp); PyErr_SetString(PyExc_TypeError, "integers expected"); return nullptr; }
+		uint64_t *dst = k < 0 ? sp->origin : sp->basis + k * words;
+		for (Py_ssize_t i = 0; i < cols; i++)
+			if (long_bit((PyLongObject *)v, i)) dst[i >> 6] |= (uint64_t)1 << (i & 63);
+	}
+	return (PyObject *)sp;
+}
+
+PyObject *py_device_count(PyObject *, PyObject *) { return PyLong_FromLong(gf2bv_device_count()); }
+
+#define FAST(fn) (PyCFunction)(void (*)(void))(fn)
+PyMethodDef module_methods[] = {
+	{"m4ri_solve", FAST(py_m4ri_solve), METH_FASTCALL,
+	 "m4ri_solve(equations, cols, mode)\n--\n\nSolve the linear system on the MI355X; None when inconsistent."},
+	{"to_bits", FAST(py_to_bits), METH_FASTCALL, "to_bits(n, a)\n--\n\nLow n bits of a, LSB first."},
+	{"mul_bit_quad", FAST(py_mul_bit_quad), METH_FASTCALL, "mul_bit_quad(n, a, b, v, basis)\n--\n\n"},
+	{"xor_tuple", FAST(py_xor_tuple), METH_FASTCALL, "xor_tuple(a, b)\n--\n\nElement-wise xor."},
+	{"tuple_where", FAST(py_tuple_where), METH_FASTCALL, "tuple_where(cond, a, b)\n--\n\nIn-place select."},
+	{"eqs_to_sage_mat_helper", FAST(py_sage_helper), METH_FASTCALL, "not available in gf2bv_amd"},
+	{"_space_from_ints", FAST(py_space_from_ints), METH_FASTCALL, "test hook: AffineSpace from ints"},
+	{"device_count", py_device_count, METH_NOARGS, "number of visible HIP devices"},
+	{nullptr, nullptr, 0, nullptr}};
+
+PyModuleDef module_def = {PyModuleDef_HEAD_INIT, "_internal", "gf2bv_amd native boundary (HIP solver)", -1,
+                          module_methods, nullptr, nullptr, nullptr, nullptr};
+
+}  // namespace
+
+PyMODINIT_FUNC PyInit__internal(void)
+{
+	PyObject *m = PyModule_Create(&module_def);
+	if (!m) return nullptr;
+	AffineSpace_Type = (PyTypeObject *)PyType_FromSpec(&space_spec);
+	SpaceIterGray_Type = (PyTypeObject *)PyType_FromSpec(&gray_spec);
+	SpaceIterSlow_Type = (PyTypeObject *)PyType_FromSpec(&slow_spec);
+	if (!AffineSpace_Type || !SpaceIterGray_Type || !SpaceIterSlow_Type) { Py_DECREF(m); return nullptr; }
+	Py_INCREF(AffineSpace_Type); Py_INCREF(SpaceIterGray_Type); Py_INCREF(SpaceIterSlow_Type);
+	if (PyModule_AddObject(m, "AffineSpace", (PyObject *)AffineSpace_Type) < 0 ||
+	    PyModule_AddObject(m, "AffineSpaceIterator", (PyObject *)SpaceIterGray_Type) < 0 ||
+	    PyModule_AddObject(m, "AffineSpaceIteratorSlow", (PyObject *)SpaceIterSlow_Type) < 0) {
+		Py_DECREF(m);
+		return nullptr;
+	}
+	return m;
+}

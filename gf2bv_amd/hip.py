@@ -1,0 +1,234 @@
+"""ctypes binding of libgf2bv_hip.so (include/gf2bv_hip.h) for packed inputs.
+
+``LinearSystem`` reaches the solver through the CPython extension ``_internal``
+(list-of-int boundary, like the reference).  Synthetic / batch workloads hand over packed
+64-bit-word matrices instead -- host numpy arrays or raw device pointers (e.g.
+``torch.Tensor.data_ptr()``); that path goes through this module.  No fallback: a missing
+library or a missing GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgf2bv_hip.so")
+
+MODE_SINGLE = 0
+MODE_AFFINE_SPACE = 1
+STATUS_SOLVED = 0
+STATUS_INCONSISTENT = 1
+
+# every symbol include/gf2bv_hip.h declares (checked by tests/test_cabi.py)
+EXPORTS = [
+    "gf2bv_version", "gf2bv_device_count", "gf2bv_last_error",
+    "gf2bv_solve_digits", "gf2bv_solve_words", "gf2bv_solve_device", "gf2bv_solve_batch_device",
+    "gf2bv_result_status", "gf2bv_result_rank", "gf2bv_result_dimension", "gf2bv_result_words",
+    "gf2bv_result_origin", "gf2bv_result_basis", "gf2bv_result_pivots", "gf2bv_result_stats",
+    "gf2bv_result_free", "gf2bv_space_combine", "gf2bv_synth_device", "gf2bv_residual_device",
+    "gf2bv_device_alloc", "gf2bv_device_free", "gf2bv_device_upload", "gf2bv_device_download",
+]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [
+        ("rows", ctypes.c_int64), ("cols", ctypes.c_int64), ("stride_words", ctypes.c_int64),
+        ("rank", ctypes.c_int64), ("dimension", ctypes.c_int64),
+        ("status", ctypes.c_int32), ("n_panels", ctypes.c_int32), ("n_sweeps", ctypes.c_int32),
+        ("tables_per_sweep", ctypes.c_int32), ("table_bits", ctypes.c_int32), ("tile_words", ctypes.c_int32),
+        ("sweep_words", ctypes.c_double), ("row_xors", ctypes.c_double),
+        ("ms_pack", ctypes.c_float), ("ms_eliminate", ctypes.c_float), ("ms_sweep", ctypes.c_float),
+        ("ms_backsub", ctypes.c_float), ("ms_export", ctypes.c_float), ("ms_total", ctypes.c_float),
+    ]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
+class HipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HipError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        L = ctypes.CDLL(LIB_PATH)
+        vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
+        pp = ctypes.POINTER(ctypes.c_void_p)
+        L.gf2bv_last_error.restype = ctypes.c_char_p
+        L.gf2bv_solve_digits.argtypes = [vp, vp, i32, i64, i64, i32, i32, pp]
+        L.gf2bv_solve_words.argtypes = [vp, i64, i64, i64, i32, i32, pp]
+        L.gf2bv_solve_device.argtypes = [vp, i64, i64, i64, i32, i32, vp, i32, pp]
+        L.gf2bv_solve_batch_device.argtypes = [vp, i64, i64, i64, i64, i64, i32, i32, pp]
+        for name, res in (("gf2bv_result_status", i32), ("gf2bv_result_rank", i64),
+                          ("gf2bv_result_dimension", i64), ("gf2bv_result_words", i64)):
+            getattr(L, name).restype = res
+            getattr(L, name).argtypes = [vp]
+        for name in ("gf2bv_result_origin", "gf2bv_result_basis", "gf2bv_result_pivots"):
+            getattr(L, name).argtypes = [vp, vp]
+        L.gf2bv_result_stats.argtypes = [vp, ctypes.POINTER(Stats)]
+        L.gf2bv_result_free.argtypes = [vp]
+        L.gf2bv_result_free.restype = None
+        L.gf2bv_space_combine.argtypes = [vp, vp, i64, i64, vp, i64, vp]
+        L.gf2bv_space_combine.restype = None
+        L.gf2bv_synth_device.argtypes = [vp, i64, i64, i64, ctypes.c_uint64, i32, vp]
+        L.gf2bv_residual_device.argtypes = [vp, i64, i64, i64, vp, i32, vp, ctypes.POINTER(i64)]
+        L.gf2bv_device_alloc.argtypes = [i32, i64, pp]
+        L.gf2bv_device_free.argtypes = [i32, vp]
+        L.gf2bv_device_upload.argtypes = [i32, vp, vp, i64]
+        L.gf2bv_device_download.argtypes = [i32, vp, vp, i64]
+        _lib = L
+    return _lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        msg = lib().gf2bv_last_error().decode(errors="replace")
+        if rc == 1:
+            raise ValueError(msg)
+        raise HipError(f"gf2bv_hip error {rc}: {msg}")
+
+
+def device_count() -> int:
+    return int(lib().gf2bv_device_count())
+
+
+@dataclass
+class Solution:
+    """What one solve returns (the packed-words twin of m4ri_solve's result)."""
+    status: int
+    rank: int
+    dimension: int
+    origin: np.ndarray                         # ceil(cols/64) uint64 words, bit j = variable j
+    basis: np.ndarray                          # dimension x words (mode 1), else 0 x words
+    pivots: np.ndarray                         # column rank profile
+    stats: dict = field(default_factory=dict)
+
+    @property
+    def solved(self) -> bool:
+        return self.status == STATUS_SOLVED
+
+    def origin_int(self) -> int:
+        return int.from_bytes(self.origin.tobytes(), "little")
+
+    def basis_ints(self) -> tuple:
+        return tuple(int.from_bytes(b.tobytes(), "little") for b in self.basis)
+
+
+def _take(handle, mode: int) -> Solution:
+    L = lib()
+    try:
+        words = int(L.gf2bv_result_words(handle))
+        rank = int(L.gf2bv_result_rank(handle))
+        dim = int(L.gf2bv_result_dimension(handle))
+        status = int(L.gf2bv_result_status(handle))
+        origin = np.zeros(max(words, 1), dtype=np.uint64)
+        _check(L.gf2bv_result_origin(handle, origin.ctypes.data))
+        nb = dim if (mode == MODE_AFFINE_SPACE and status == STATUS_SOLVED) else 0
+        basis = np.zeros((nb, words), dtype=np.uint64)
+        if nb:
+            _check(L.gf2bv_result_basis(handle, basis.ctypes.data))
+        piv = np.zeros(max(rank, 1), dtype=np.int32)
+        _check(L.gf2bv_result_pivots(handle, piv.ctypes.data))
+        st = Stats()
+        _check(L.gf2bv_result_stats(handle, ctypes.byref(st)))
+        return Solution(status, rank, dim, origin[:words], basis, piv[:rank].copy(), st.as_dict())
+    finally:
+        L.gf2bv_result_free(handle)
+
+
+def solve_words(aug: np.ndarray, rows: int, cols: int, mode: int = MODE_SINGLE, device: int = 0) -> Solution:
+    """Solve a packed augmented system held in host memory (rows x stride uint64)."""
+    aug = np.ascontiguousarray(aug, dtype=np.uint64)
+    stride = aug.shape[1] if aug.ndim == 2 else (cols + 1 + 63) // 64
+    h = ctypes.c_void_p()
+    _check(lib().gf2bv_solve_words(aug.ctypes.data, rows, cols, stride, mode, device, ctypes.byref(h)))
+    return _take(h, mode)
+
+
+def solve_digits(digits: np.ndarray, offsets: np.ndarray, bits_per_digit: int, rows: int, cols: int,
+                 mode: int = MODE_SINGLE, device: int = 0) -> Solution:
+    digits = np.ascontiguousarray(digits, dtype=np.uint32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    h = ctypes.c_void_p()
+    _check(lib().gf2bv_solve_digits(digits.ctypes.data, offsets.ctypes.data, bits_per_digit, rows, cols, mode,
+                                    device, ctypes.byref(h)))
+    return _take(h, mode)
+
+
+def solve_device(d_ptr: int, rows: int, cols: int, stride: int, mode: int = MODE_SINGLE, device: int = 0,
+                 stream: int = 0, time_kernels: bool = False) -> Solution:
+    """Solve in place a matrix resident in device memory (destroys it)."""
+    h = ctypes.c_void_p()
+    _check(lib().gf2bv_solve_device(d_ptr, rows, cols, stride, mode, device, stream or None,
+                                    1 if time_kernels else 0, ctypes.byref(h)))
+    return _take(h, mode)
+
+
+def solve_batch_device(d_ptr: int, nsys: int, sys_stride: int, rows: int, cols: int, stride: int,
+                       mode: int = MODE_SINGLE, device: int = 0) -> list:
+    hs = (ctypes.c_void_p * max(nsys, 1))()
+    rc = lib().gf2bv_solve_batch_device(d_ptr, nsys, sys_stride, rows, cols, stride, mode, device, hs)
+    if rc != 0:
+        for h in hs:
+            if h:
+                lib().gf2bv_result_free(h)
+        _check(rc)
+    return [_take(ctypes.c_void_p(hs[i]), mode) for i in range(nsys)]
+
+
+def synth_device(d_ptr: int, rows: int, cols: int, stride: int, seed: int, device: int = 0, stream: int = 0):
+    _check(lib().gf2bv_synth_device(d_ptr, rows, cols, stride, seed, device, stream or None))
+
+
+def residual_device(d_ptr: int, rows: int, cols: int, stride: int, x: np.ndarray, device: int = 0,
+                    stream: int = 0) -> int:
+    x = np.ascontiguousarray(x, dtype=np.uint64)
+    bad = ctypes.c_int64(-1)
+    _check(lib().gf2bv_residual_device(d_ptr, rows, cols, stride, x.ctypes.data, device, stream or None,
+                                       ctypes.byref(bad)))
+    return int(bad.value)
+
+
+class DeviceBuffer:
+    """hipMalloc'd scratch for callers that do not bring torch (tests, plain ctypes users)."""
+
+    def __init__(self, nbytes: int, device: int = 0):
+        self.device, self.nbytes = device, nbytes
+        p = ctypes.c_void_p()
+        _check(lib().gf2bv_device_alloc(device, nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+
+    def upload(self, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        _check(lib().gf2bv_device_upload(self.device, self.ptr, arr.ctypes.data, arr.nbytes))
+
+    def download(self, dtype=np.uint64) -> np.ndarray:
+        out = np.zeros(self.nbytes // np.dtype(dtype).itemsize, dtype=dtype)
+        _check(lib().gf2bv_device_download(self.device, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().gf2bv_device_free(self.device, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def padded_stride(cols: int, multiple: int = 32) -> int:
+    """Row stride (in 64-bit words) for a device-resident system: cols+1 bits, 256-byte rows."""
+    wt = (cols + 1 + 63) // 64
+    return (wt + multiple - 1) // multiple * multiple

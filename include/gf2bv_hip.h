@@ -1,0 +1,134 @@
+/*
+ * gf2bv_hip.h -- C ABI of libgf2bv_hip.so, the MI355X (gfx950) GF(2) solver that sits where
+ * gf2bv's `_internal.c` calls M4RI.
+ *
+ * Plain C: pointers, sizes, opaque handles.  No torch / HIP types in any signature (a HIP
+ * stream or device pointer crosses as `void*`).  Reference interface each entry point
+ * replaces is cited as file:line relative to maple3142/gf2bv.
+ *
+ * Matrix layout everywhere ("augmented words"): row-major uint64, `stride` words per row,
+ * column c of A = bit (c % 64) of word (c / 64), the right-hand side b is column `cols`
+ * (so a row needs ceil((cols+1)/64) words).  This is M4RI's mzd_t bit order
+ * (_internal.c:398-426 fills it with mzd_write_bit) and int.to_bytes(...,'little').
+ *
+ * Solution vectors: ceil(cols/64) words, bit j = variable j (_internal.c:32-39).
+ *
+ * Threading: every call owns its device buffers and stream; no global mutable state except
+ * the last-error string, which is thread-local.  Matches the reference releasing the GIL
+ * around the whole factor/solve/kernel section (_internal.c:429-492).
+ */
+#ifndef GF2BV_HIP_H
+#define GF2BV_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GF2BV_OK            0
+#define GF2BV_ERR_ARG       1   /* bad argument (the binding maps these to ValueError/TypeError) */
+#define GF2BV_ERR_NODEVICE  2   /* no usable gfx950 device: the product path fails loudly, no CPU fallback */
+#define GF2BV_ERR_HIP       3   /* a HIP runtime call failed, see gf2bv_last_error() */
+#define GF2BV_ERR_NOMEM     4
+
+#define GF2BV_MODE_SINGLE        0   /* _internal.h:25 SOLVE_MODE_SINGLE       */
+#define GF2BV_MODE_AFFINE_SPACE  1   /* _internal.h:26 SOLVE_MODE_AFFINE_SPACE */
+
+#define GF2BV_STATUS_SOLVED        0
+#define GF2BV_STATUS_INCONSISTENT  1   /* _internal.c:440-446 -> Python None */
+
+typedef struct gf2bv_result gf2bv_result;     /* owns origin / basis / pivots of one solve */
+
+typedef struct gf2bv_stats {
+	int64_t rows, cols, stride_words;
+	int64_t rank, dimension;
+	int32_t status;
+	int32_t n_panels;          /* 64-column panels processed                                  */
+	int32_t n_sweeps;          /* panels that had >= 1 pivot (= sweep launches that did work)  */
+	int32_t tables_per_sweep;  /* T: grease tables fused into one sweep                        */
+	int32_t table_bits;        /* k: index bits per table                                      */
+	int32_t tile_words;        /* 64-bit words of one row segment handled by a lane group      */
+	double  sweep_words;       /* sum over sweeps of rows_swept x active_words  (unit of work) */
+	double  row_xors;          /* sum over sweeps of rows_swept x T                            */
+	float   ms_pack;           /* digits/words -> device matrix (H2D + pack kernel)            */
+	float   ms_eliminate;      /* forward elimination, all panels (HIP events)                 */
+	float   ms_sweep;          /* of which: time inside the sweep kernel (sum of launches)     */
+	float   ms_backsub;        /* consistency check + back-substitution + kernel basis         */
+	float   ms_export;         /* D2H of origin / basis                                        */
+	float   ms_total;          /* host wall clock of the whole call                            */
+} gf2bv_stats;
+
+/* ---- library / device ------------------------------------------------------------------ */
+int         gf2bv_version(void);
+int         gf2bv_device_count(void);          /* 0 when no HIP device is visible */
+const char *gf2bv_last_error(void);            /* thread-local, never NULL */
+
+/* ---- solve: replaces the body of m4ri_solve, gf2bv/_internal.c:398-489 -------------------- */
+
+/* Equations as raw CPython `int` digit arrays (the binding memcpy's ob_digit, the device
+ * pack kernel does what _internal.c:403-426 does bit by bit under the GIL):
+ * row r occupies digits[digit_off[r] .. digit_off[r+1]), little-endian digits of
+ * `bits_per_digit` payload bits (30 on 64-bit CPython) in uint32; sign already dropped;
+ * bit 0 = affine term, bit k = coefficient of variable k-1; bits above `cols` ignored.
+ * Requires rows >= cols > 0 (_internal.c:372-395). */
+int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bits_per_digit,
+                       int64_t rows, int64_t cols, int mode, int device, gf2bv_result **out);
+
+/* Same system, already packed as augmented words in HOST memory (not modified). */
+int gf2bv_solve_words(const uint64_t *aug, int64_t rows, int64_t cols, int64_t stride_words,
+                      int mode, int device, gf2bv_result **out);
+
+/* Same, matrix resident in DEVICE memory; eliminated IN PLACE (contents destroyed).
+ * d_aug must be 16-byte aligned and stride_words a multiple of 16 (128-byte rows), so row
+ * segments map onto whole wavefront lane groups.  `stream` is a hipStream_t or NULL.
+ * `time_kernels` != 0 brackets every sweep launch with HIP events (fills ms_sweep). */
+int gf2bv_solve_device(void *d_aug, int64_t rows, int64_t cols, int64_t stride_words,
+                       int mode, int device, void *stream, int time_kernels, gf2bv_result **out);
+
+/* Batch of `nsys` independent equal-shape systems resident on one device
+ * (system s starts at d_aug + s*sys_stride_words words); out[0..nsys) receives handles.
+ * Independent systems are the unit that bench.py shards across GPUs. */
+int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words,
+                             int64_t rows, int64_t cols, int64_t stride_words,
+                             int mode, int device, gf2bv_result **out);
+
+/* ---- result accessors (AffineSpace getters, gf2bv/_internal.c:206-240) -------------------- */
+int     gf2bv_result_status(const gf2bv_result *r);      /* GF2BV_STATUS_* */
+int64_t gf2bv_result_rank(const gf2bv_result *r);
+int64_t gf2bv_result_dimension(const gf2bv_result *r);   /* cols - rank (mode 1), basis rows */
+int64_t gf2bv_result_words(const gf2bv_result *r);       /* ceil(cols/64) */
+/* origin: the solution with every free variable 0 (_internal.c:438-455) */
+int     gf2bv_result_origin(const gf2bv_result *r, uint64_t *out_words);
+/* basis: dimension x words, M4RI kernel order (_internal.c:309-357, :475-489) */
+int     gf2bv_result_basis(const gf2bv_result *r, uint64_t *out_words);
+/* pivot columns c_0 < c_1 < ... (column rank profile), `rank` entries */
+int     gf2bv_result_pivots(const gf2bv_result *r, int32_t *out);
+int     gf2bv_result_stats(const gf2bv_result *r, gf2bv_stats *out);
+void    gf2bv_result_free(gf2bv_result *r);
+
+/* ---- AffineSpace arithmetic on host word vectors (tiny; gf2bv/_internal.c:242-273, :101-122) */
+/* out = origin ^ XOR_{i: bit i of selector words set} basis[i]   (AffineSpace.get) */
+void gf2bv_space_combine(const uint64_t *origin, const uint64_t *basis, int64_t dimension,
+                         int64_t words, const uint64_t *selector, int64_t selector_words,
+                         uint64_t *out);
+
+/* ---- synthetic systems + independent residual check (bench / tests) ----------------------- */
+/* word w of row r = mix64(seed ^ ((r<<20)|w)); planted solution = pseudo-row 0xFFFFF;
+ * RHS = <row, planted>.  Writes rows x stride_words words at d_aug. */
+int gf2bv_synth_device(void *d_aug, int64_t rows, int64_t cols, int64_t stride_words,
+                       uint64_t seed, int device, void *stream);
+/* counts rows i with <A_i, x> != b_i on an (untouched) device matrix; x in host memory */
+int gf2bv_residual_device(const void *d_aug, int64_t rows, int64_t cols, int64_t stride_words,
+                          const uint64_t *x_words, int device, void *stream, int64_t *bad_rows);
+
+/* plain device buffer helpers so a host language without a HIP binding can stage data */
+int gf2bv_device_alloc(int device, int64_t bytes, void **d_ptr);
+int gf2bv_device_free(int device, void *d_ptr);
+int gf2bv_device_upload(int device, void *d_dst, const void *h_src, int64_t bytes);
+int gf2bv_device_download(int device, void *h_dst, const void *d_src, int64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GF2BV_HIP_H */
