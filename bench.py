@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: GF(2) row-XORs/s + solve wall-time, dense N x N solve_one.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 65536]
+
+One "step" = one complete solve_one of a synthetic dense N x N GF(2) system that is already
+resident in HBM (forward elimination + consistency check + back-substitution + export), through
+the C ABI (gf2bv_solve_device).  Default workload = BASELINE.json configs[1]: 65536 x 65536,
+full rank (seed committed below).  With --gpus N (launched by torch.distributed.run, one rank per
+GPU) every rank solves its own independent systems -- the path shards by system, no data-path
+collective -- and the solutions are gathered once at the end over RCCL ("scaling": "weak").
+
+Rank 0 prints ONE JSON line (see the contract in the task statement), carrying
+  roofline     : the sweep kernel (dominant): algorithmic bytes (16 B per active word per sweep)
+                 / HIP-event time of the sweep launches, against 8 TB/s HBM
+  cpu_baseline : the CPU oracle (M4RM-style "port", OpenMP) timed on this host on a bounded
+                 sample of the same generator (rank 0, N=1 only)
+torch is plumbing here: device memory, the RCCL gather, barriers.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402  (first, so its HIP runtime is the one loaded)
+import torch.distributed as dist  # noqa: E402
+
+from gf2bv_amd import hip  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# synthetic-generator seeds whose N x N matrix has full rank (found with tools/find_full_rank_seed.py)
+FULL_RANK_SEEDS = {65536: 1234, 32768: 1234}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=65536, help="system size N (rows = cols)")
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-n", type=int, default=16384, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--no-kernel-events", action="store_true",
+                    help="do not bracket sweep launches with HIP events (roofline becomes null)")
+    return ap.parse_args()
+
+
+def cpu_baseline(n: int, seed: int) -> dict:
+    """Time the CPU oracle (test infrastructure; here only as the reported baseline)."""
+    from oracle import gf2_oracle as O
+    cores = O.lib().gf2o_max_threads()
+    aug = O.gen_synthetic(n, n, seed)
+    t0 = time.perf_counter()
+    res = O.solve_words(aug, n, n, 0, algo=1)
+    dt = time.perf_counter() - t0
+    bad = O.check_solution(aug, n, n, res["origin"])
+    return {
+        "value": res["row_xors"] / dt, "unit": "row-XORs/s", "cores": cores, "kind": "port",
+        "sample": f"one {n}x{n} solve_one of the same synthetic generator (seed {seed}), "
+                  f"oracle M4RM port (8-bit tables x8, OpenMP over column tiles); M4RI itself is not installed",
+        "seconds": dt, "rank": int(res["rank"]), "residual_rows": int(bad),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.n
+    seed = args.seed if args.seed is not None else FULL_RANK_SEEDS.get(n, 1234)
+    stride = hip.padded_stride(n)
+    cw = (n + 63) // 64
+    total = args.steps + args.warmup
+    # every step gets its own pristine copy of the system (the solve is in place)
+    mats = [torch.empty(n * stride, dtype=torch.int64, device=dev) for _ in range(total)]
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for m in mats:
+        hip.synth_device(m.data_ptr(), n, n, stride, seed + rank, device=local_rank, stream=stream)
+    torch.cuda.synchronize(dev)
+
+    sols = torch.zeros(args.steps, cw, dtype=torch.int64, device=dev)
+    stats = []
+
+    def step(i: int):
+        return hip.solve_device(mats[i].data_ptr(), n, n, stride, hip.MODE_SINGLE, device=local_rank,
+                                stream=stream, time_kernels=not args.no_kernel_events)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        s = step(args.warmup + k)
+        stats.append(s)
+        sols[k].copy_(torch.from_numpy(s.origin.view(np.int64)))
+    if world > 1:
+        gathered = [torch.empty_like(sols) for _ in range(world)]
+        dist.all_gather(gathered, sols)          # the single end-of-job gather (RCCL over xGMI)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness gate on this rank: residual of the last solution on a freshly generated copy
+    hip.synth_device(mats[0].data_ptr(), n, n, stride, seed + rank, device=local_rank, stream=stream)
+    bad = hip.residual_device(mats[0].data_ptr(), n, n, stride, stats[-1].origin, device=local_rank, stream=stream)
+    ok = torch.tensor([1 if (bad == 0 and all(s.solved for s in stats)) else 0], device=dev)
+    row_xors_local = float(sum(s.stats["row_xors"] for s in stats))
+    agg = torch.tensor([row_xors_local], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(agg)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        s0 = stats[-1].stats
+        sweep_ms = float(np.mean([s.stats["ms_sweep"] for s in stats]))
+        n_sweeps = s0["n_sweeps"]
+        alg_bytes = 16.0 * s0["sweep_words"]
+        roofline = None
+        if sweep_ms > 0:
+            achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
+            roofline = {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "kernel": f"k_sweep<K={s0['table_bits']},TW={s0['tile_words']}>",
+                "launches": n_sweeps,
+                "alg_bytes_per_launch": alg_bytes / max(n_sweeps, 1),
+                "avg_launch_ms": sweep_ms / max(n_sweeps, 1),
+            }
+        out = {
+            "metric": "GF(2) row-XORs/s (solve_one, dense NxN)", "value": float(agg.item()) / elapsed,
+            "unit": "row-XORs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {
+                "workload": f"synthetic dense {n}x{n} GF(2) solve_one, planted RHS, seed {seed}"
+                            + (" (full rank)" if n in FULL_RANK_SEEDS and args.seed is None else ""),
+                "systems_per_step_per_gpu": 1, "parallelism": f"independent systems x{world}",
+                "tables_per_sweep": s0["tables_per_sweep"], "table_bits": s0["table_bits"],
+                "tile_words": s0["tile_words"], "rank": int(stats[-1].rank),
+            },
+            "solve_wall_ms": {"eliminate": float(np.mean([s.stats["ms_eliminate"] for s in stats])),
+                              "backsub": float(np.mean([s.stats["ms_backsub"] for s in stats])),
+                              "export": float(np.mean([s.stats["ms_export"] for s in stats])),
+                              "total_host": float(np.mean([s.stats["ms_total"] for s in stats]))},
+            "parity_gate": {"residual_rows": int(bad), "all_ranks_ok": bool(ok.item())},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_n, seed)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

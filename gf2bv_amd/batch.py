@@ -1,0 +1,70 @@
+"""Batch sharding of independent systems across the GPUs of a node.
+
+The reference solves one system per ``m4ri_solve`` call and has no distributed code
+(SURVEY.md 2.1 / 8e); independent systems (one per output bit / per instance in the recovery
+examples) are the natural shard unit.  One process per GPU, contiguous blocks of systems per
+rank, NO collective on the data path; a single all_gather of fixed-size solution records at
+the end (RCCL over xGMI with backend "nccl", gloo on CPU for tests).
+
+Record layout (int64 words): [status, rank, origin word 0 .. origin word cw-1].
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(nsys: int, world: int, rank: int) -> tuple:
+    """Contiguous block [lo, hi) of systems owned by `rank`; the first nsys % world ranks get one more."""
+    base, extra = divmod(nsys, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def record_words(cols: int) -> int:
+    return 2 + (cols + 63) // 64
+
+
+def make_record(status: int, rank: int, origin_words: np.ndarray) -> np.ndarray:
+    rec = np.empty(2 + len(origin_words), dtype=np.int64)
+    rec[0], rec[1] = status, rank
+    rec[2:] = np.asarray(origin_words, dtype=np.uint64).view(np.int64)
+    return rec
+
+
+def gather_records(local: torch.Tensor, nsys: int, group=None) -> torch.Tensor:
+    """local: [hi-lo, R] int64 records of this rank's block -> [nsys, R] on every rank.
+
+    Pads every block to the largest block so a single all_gather suffices."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return local
+    world = dist.get_world_size(group)
+    width = local.shape[1]
+    biggest = (nsys + world - 1) // world
+    padded = torch.zeros(biggest, width, dtype=local.dtype, device=local.device)
+    padded[: local.shape[0]] = local
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    out = torch.empty(nsys, width, dtype=local.dtype, device=local.device)
+    for r in range(world):
+        lo, hi = shard_bounds(nsys, world, r)
+        out[lo:hi] = parts[r][: hi - lo]
+    return out
+
+
+def solve_synthetic_shard(n: int, seeds: list, device_index: int, mats: torch.Tensor | None = None) -> torch.Tensor:
+    """Solve this rank's block of synthetic n x n systems on its GPU; returns [len(seeds), R] records (on GPU)."""
+    from . import hip
+    stride = hip.padded_stride(n)
+    dev = torch.device("cuda", device_index)
+    if mats is None:
+        mats = torch.empty(len(seeds), n * stride, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    for i, seed in enumerate(seeds):
+        hip.synth_device(mats[i].data_ptr(), n, n, stride, seed, device=device_index, stream=stream)
+    sols = hip.solve_batch_device(mats.data_ptr(), len(seeds), n * stride, n, n, stride, hip.MODE_SINGLE,
+                                  device=device_index) if seeds else []
+    recs = np.stack([make_record(s.status, s.rank, s.origin) for s in sols]) if sols else \
+        np.zeros((0, record_words(n)), dtype=np.int64)
+    return torch.from_numpy(recs).to(dev)
