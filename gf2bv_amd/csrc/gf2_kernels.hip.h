@@ -479,6 +479,7 @@ k_synth(u64 *__restrict__ M, i64 rows, i64 cols, i64 stride, u64 seed)
 	if (r >= rows) return;
 	const i64 cw = (cols + 63) >> 6;
 	const u64 lastmask = (cols & 63) ? ((1ull << (cols & 63)) - 1) : ~0ull;
+	seed = mix64(seed);                       // hashed seed: neighbouring seeds give unrelated matrices
 	u64 par = 0;
 	for (i64 w = lane; w < cw; w += 64) {
 		u64 a = mix64(seed ^ (((u64)r << 20) | (u64)w));

@@ -114,7 +114,7 @@ void gf2bv_space_combine(const uint64_t *origin, const uint64_t *basis, int64_t 
                          uint64_t *out);
 
 /* ---- synthetic systems + independent residual check (bench / tests) ----------------------- */
-/* word w of row r = mix64(seed ^ ((r<<20)|w)); planted solution = pseudo-row 0xFFFFF;
+/* word w of row r = mix64(mix64(seed) ^ ((r<<20)|w)); planted solution = pseudo-row 0xFFFFF;
  * RHS = <row, planted>.  Writes rows x stride_words words at d_aug. */
 int gf2bv_synth_device(void *d_aug, int64_t rows, int64_t cols, int64_t stride_words,
                        uint64_t seed, int device, void *stream);

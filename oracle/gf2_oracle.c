@@ -36,7 +36,7 @@
  * Two independent eliminations are provided and cross-checked in tests:
  *   algo 0  textbook Gauss-Jordan, one column at a time (obviously correct, slow)
  *   algo 1  Method-of-Four-Russians (M4RM-style: 64-column panels, 8-bit grease tables,
- *           column-tiled so the tables stay in cache, optional OpenMP) -- this is the
+ *           column-tiled so the tables stay in cache, OpenMP over rows) -- this is the
  *           "port" CPU baseline that bench.py times next to the GPU.
  */
 #include <stdint.h>
@@ -115,6 +115,7 @@ static int64_t rref_m4rm(u64 *M, int64_t rows, int64_t cols, int64_t stride, int
 	int64_t r = 0;
 	u64 *tmp = (u64 *)malloc((size_t)64 * wt * sizeof(u64));
 	u64 *mult = (u64 *)malloc((size_t)rows * sizeof(u64));
+	u64 *tab = (u64 *)malloc((size_t)8 * 256 * TILE_WORDS * sizeof(u64));
 	double rx = 0, sw = 0;
 
 	for (int64_t j = 0; j < npanels && r < rows; j++) {
@@ -175,54 +176,51 @@ static int64_t rref_m4rm(u64 *M, int64_t rows, int64_t cols, int64_t stride, int
 		/* multipliers (snapshot before the sweep rewrites word j) */
 		for (int64_t i = 0; i < rows; i++)
 			mult[i] = (i >= r && i < r + p) ? 0 : (M[i * stride + j] & have);
-		/* sweep, column tile by column tile */
+		/* sweep, column tile by column tile: the 8 x 256 grease tables of one tile (1 MiB) are
+		 * built by up to 8 threads and then shared read-only by all threads, which split the rows */
 		int64_t ntiles = (wt - j + TILE_WORDS - 1) / TILE_WORDS;
+		for (int64_t t = 0; t < ntiles; t++) {
+			int64_t w0 = j + t * TILE_WORDS;
+			int64_t tw = (wt - w0 < TILE_WORDS) ? (wt - w0) : TILE_WORDS;
 #ifdef _OPENMP
-#pragma omp parallel
+#pragma omp parallel for schedule(static) if (tw >= 8)
 #endif
-		{
-			u64 *tab = (u64 *)malloc((size_t)8 * 256 * TILE_WORDS * sizeof(u64));
-#ifdef _OPENMP
-#pragma omp for schedule(dynamic, 1)
-#endif
-			for (int64_t t = 0; t < ntiles; t++) {
-				int64_t w0 = j + t * TILE_WORDS;
-				int64_t tw = (wt - w0 < TILE_WORDS) ? (wt - w0) : TILE_WORDS;
-				for (int g = 0; g < 8; g++) {
-					u64 *T = tab + (size_t)g * 256 * TILE_WORDS;
-					memset(T, 0, (size_t)tw * sizeof(u64));
-					for (int l = 0; l < 8; l++) {
-						int b = 8 * g + l;
-						const u64 *src = NULL;
-						if ((have >> b) & 1) {
-							int kk = __builtin_popcountll(have & (((u64)1 << b) - 1));
-							src = M + (r + kk) * stride + w0;
-						}
-						for (int idx = 0; idx < (1 << l); idx++) {
-							u64 *dst = T + (size_t)(idx | (1 << l)) * TILE_WORDS;
-							const u64 *lo = T + (size_t)idx * TILE_WORDS;
-							if (src) for (int64_t w = 0; w < tw; w++) dst[w] = lo[w] ^ src[w];
-							else     for (int64_t w = 0; w < tw; w++) dst[w] = lo[w];
-						}
+			for (int g = 0; g < 8; g++) {
+				u64 *T = tab + (size_t)g * 256 * TILE_WORDS;
+				memset(T, 0, (size_t)tw * sizeof(u64));
+				for (int l = 0; l < 8; l++) {
+					int b = 8 * g + l;
+					const u64 *src = NULL;
+					if ((have >> b) & 1) {
+						int kk = __builtin_popcountll(have & (((u64)1 << b) - 1));
+						src = M + (r + kk) * stride + w0;
 					}
-				}
-				for (int64_t i = 0; i < rows; i++) {
-					u64 m = mult[i];
-					if (!m) continue;
-					u64 *row = M + i * stride + w0;
-					for (int g = 0; g < 8; g++) {
-						unsigned idx = (unsigned)((m >> (8 * g)) & 255);
-						if (idx) xor_words(row, tab + ((size_t)g * 256 + idx) * TILE_WORDS, tw);
+					for (int idx = 0; idx < (1 << l); idx++) {
+						u64 *dst = T + (size_t)(idx | (1 << l)) * TILE_WORDS;
+						const u64 *lo = T + (size_t)idx * TILE_WORDS;
+						if (src) for (int64_t w = 0; w < tw; w++) dst[w] = lo[w] ^ src[w];
+						else     for (int64_t w = 0; w < tw; w++) dst[w] = lo[w];
 					}
 				}
 			}
-			free(tab);
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) if (rows * tw >= 16384)
+#endif
+			for (int64_t i = 0; i < rows; i++) {
+				u64 m = mult[i];
+				if (!m) continue;
+				u64 *row = M + i * stride + w0;
+				for (int g = 0; g < 8; g++) {
+					unsigned idx = (unsigned)((m >> (8 * g)) & 255);
+					if (idx) xor_words(row, tab + ((size_t)g * 256 + idx) * TILE_WORDS, tw);
+				}
+			}
 		}
 		rx += (double)(rows - p) * 8.0;
 		sw += (double)(rows - p) * (double)(wt - j);
 		r += p;
 	}
-	free(tmp); free(mult);
+	free(tmp); free(mult); free(tab);
 	if (row_xors) *row_xors = rx;
 	if (sweep_words) *sweep_words = sw;
 	return r;
@@ -321,8 +319,10 @@ void gf2o_set_threads(int n)
 
 /* ---------------------------------------------------------------------------------- */
 /* Synthetic dense systems (DESIGN.md "synthetic generator"):     */
-/* word w of row r = mix64(seed ^ ((r << 20) | w)); planted x* lives in pseudo-row      */
-/* 0xFFFFF; RHS bit = <row, x*>.  Same definition as the HIP generator kernel.          */
+/* word w of row r = mix64(mix64(seed) ^ ((r << 20) | w)); planted x* lives in          */
+/* pseudo-row 0xFFFFF; RHS bit = <row, x*>.  Same definition as the HIP generator       */
+/* kernel.  (The seed is hashed first: XOR-ing a raw small seed into the key would only  */
+/* permute word columns, so neighbouring seeds would give column-permuted copies.)       */
 static inline u64 mix64(u64 x)
 {
 	x += 0x9E3779B97F4A7C15ull;
@@ -330,7 +330,7 @@ static inline u64 mix64(u64 x)
 	x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
 	return x ^ (x >> 31);
 }
-u64 gf2o_synth_word(u64 seed, int64_t r, int64_t w) { return mix64(seed ^ (((u64)r << 20) | (u64)w)); }
+u64 gf2o_synth_word(u64 seed, int64_t r, int64_t w) { return mix64(mix64(seed) ^ (((u64)r << 20) | (u64)w)); }
 
 void gf2o_gen_synthetic(u64 *aug, int64_t rows, int64_t cols, int64_t stride, u64 seed)
 {

@@ -90,7 +90,7 @@ def test_argument_errors():
 
 
 def test_synthetic_generator_spec():
-    """The C generator follows the written spec: word = mix64(seed ^ (r<<20 | w))."""
+    """The C generator follows the written spec: word = mix64(mix64(seed) ^ (r<<20 | w))."""
     M = (1 << 64) - 1
 
     def mix64(x):
@@ -98,13 +98,14 @@ def test_synthetic_generator_spec():
         x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & M
         x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & M
         return x ^ (x >> 31)
-    rows, cols, seed = 37, 200, 99
-    aug = O.gen_synthetic(rows, cols, seed)
+    rows, cols, seed0 = 37, 200, 99
+    aug = O.gen_synthetic(rows, cols, seed0)
+    seed = mix64(seed0)
     cw = (cols + 63) // 64
     last = (1 << (cols % 64)) - 1
     xs = [mix64(seed ^ ((0xFFFFF << 20) | w)) for w in range(cw)]
     xs[-1] &= last
-    assert [int(v) for v in O.planted_solution(cols, seed)] == xs
+    assert [int(v) for v in O.planted_solution(cols, seed0)] == xs
     for r in range(rows):
         par = 0
         for w in range(cw):
@@ -115,7 +116,7 @@ def test_synthetic_generator_spec():
             assert got == a
             par ^= a & xs[w]
         assert (int(aug[r, cols // 64]) >> (cols % 64)) & 1 == bin(par).count("1") % 2
-    assert O.check_solution(aug, rows, cols, O.planted_solution(cols, seed)) == 0
+    assert O.check_solution(aug, rows, cols, O.planted_solution(cols, seed0)) == 0
 
 
 def test_enumeration_orders():
