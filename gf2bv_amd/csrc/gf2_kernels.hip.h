@@ -2,16 +2,28 @@
 //
 // Replaces the M4RI routines gf2bv reaches from gf2bv/_internal.c (reference file:line):
 //   mzd_write_bit loop           _internal.c:403-426   -> k_pack_digits
-//   _mzd_pluq                    _internal.c:431-433   -> k_panel_scan / k_panel_select /
-//                                                         k_pivot_apply / k_gather_mult / k_sweep
-//   _mzd_pluq_solve_left         _internal.c:438-447   -> k_check_rhs + k_extract_y + k_sweep(above)
-//   _mzd_kernel_left_pluq        _internal.c:309-357   -> same back-substitution with the free
+//   _mzd_pluq                    _internal.c:431-433   -> blocked elimination:
+//        panel path  (stream A): k_win_gather, k_find, k_narrow, k_win_scatter
+//        bulk path   (stream B): k_block_trsm, k_update
+//   _mzd_pluq_solve_left         _internal.c:438-447   -> k_check_rhs + k_extract_y +
+//                                                         k_gather_mult_u + k_sweep (on Y)
+//   _mzd_kernel_left_pluq        _internal.c:309-357   -> the same back-substitution with the free
 //                                                         columns as extra right-hand sides
 //   mzd_transpose / export       _internal.c:450,486   -> k_scatter_solution
 //
 // Everything is XOR / AND / shift / ctz / popcount on 64-bit words: HBM-bound integer work,
 // no MFMA.  Wavefront = 64 lanes; a 64-column panel is one matrix word, so "one pivot bit
-// per lane" and "ballot over 64 candidate rows" both map 1:1 onto a wavefront.
+// per lane" and "ballot over 64 candidate rows" map 1:1 onto a wavefront.
+//
+// Structure (right-looking blocked LU over GF(2), PLE-style: rows are never moved):
+//   * a BLOCK is G consecutive 64-column panels = G words per row (the "window").  The window of
+//     the alive rows is copied into a compact buffer Wb; the panel path factorises it panel by
+//     panel (find pivots -> reduce -> record per-row multipliers), touching only narrow data;
+//   * the bulk path then applies all G panels of the block to the rest of the matrix in ONE
+//     pass over HBM: row[tile] ^= XOR_{g<G} XOR_t table_{g,t}[bit-field t of mult_g[row]]
+//     with the G x T grease tables of the tile staged in LDS;
+//   * the tiles that hold the NEXT block's window are updated first, so the panel path of block
+//     b+1 runs concurrently with the bulk update of block b (look-ahead on a second stream).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -19,24 +31,40 @@
 typedef unsigned long long u64;   // matches HIP's 64-bit atomics and __ballot
 typedef long long i64;
 
-// One record per 64-column panel, written by k_panel_select.
+#define GF2_GMAX 4                // max panels per block
+
+// One record per 64-column panel, written by k_find.
 struct PanelRec {
-	int start;      // first pivot row of this panel (= rank before the panel)
+	int start;      // global index of this panel's first pivot (= rank before the panel)
 	int p;          // pivots found in this panel (0..64)
 	u64 mask;       // pivot bits inside the panel word (bit b <-> column 64*j+b)
 };
 
-// Per-solve device state.  Lives in device memory; the host never reads it mid-solve, so a
-// whole elimination is one uninterrupted stream of launches.
+// Per panel: where the pivot rows come from.  Pivot k of the panel (k-th set bit of mask) is the
+// XOR of the source rows slot_row[s] for the bits s of comb[k], and is stored (in place) in
+// physical row slot_row[k].  src_mult[s][g] = multiplier of source row s with respect to panel
+// g of the same block (g earlier than this panel), recorded while that row was still alive.
+struct PanelAux {
+	int slot_row[64];
+	u64 comb[64];
+	u64 src_mult[64][GF2_GMAX];
+};
+
+// Per-solve device state.  The host never reads it mid-solve.
 struct SolveState {
 	int rank;            // pivots found so far
 	int inconsistent;    // set by k_check_rhs
-	int nd;              // rows displaced out of [start, start+p) by the current panel
-	int pad;
-	int slot_row[64];    // row that supplied basis slot s (discovery order)
-	u64 comb[64];        // comb[k]: slots XORed together to form sorted pivot row k
-	int disp_from[64];
-	int disp_to[64];
+	int first;           // lower bound of the alive rows
+	unsigned arrive;     // k_find: units that have finished (last arriver publishes)
+};
+
+// Scratch of one k_find unit (wavefront).
+struct FindUnit {
+	u64 have;
+	int cnt;
+	int first_nonsrc;    // first alive row of the unit's slice that did not become a source
+	int srow[64];        // slot -> row
+	u64 bc[64];          // pivot bit -> combination mask over slots
 };
 
 __device__ __forceinline__ u64 readlane64(u64 v, int l)
@@ -48,6 +76,7 @@ __device__ __forceinline__ u64 readlane64(u64 v, int l)
 __device__ __forceinline__ int ctz64(u64 v) { return __ffsll((long long)v) - 1; }
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ u64 lanemask_lt(int lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
+__device__ __forceinline__ uint4 xor4(uint4 a, uint4 b) { return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w); }
 
 // ------------------------------------------------------------------------------------------
 // Matrix assembly: CPython digits -> augmented words (replaces _internal.c:403-426).
@@ -81,233 +110,522 @@ __global__ void k_pack_digits(const uint32_t *__restrict__ digits, const i64 *__
 	M[r * stride + w] = val;
 }
 
-// Host words (tight stride) -> padded device layout happens with a 2D memcpy; nothing to do here.
+// ==========================================================================================
+// PANEL PATH (stream A): narrow data only.
+// ==========================================================================================
 
-// ------------------------------------------------------------------------------------------
-// Panel factorisation, step A.  Each wavefront ("unit") scans its slice of the still-active
-// rows [rank, rows), word j only, and keeps an echelon XOR-basis keyed by lowest set bit:
-// lane b owns the basis vector whose leading (lowest) bit is b.  64 candidate words are
-// tested per step with __ballot; a unit stops as soon as its basis is full.  Output: the
-// rows that supplied each unit's basis vectors (<= 64 per unit).  The union over units spans
-// the same space as all active rows, which is all step B needs.
+// Wb[i][g] = M[i][j0+g]: the block's window, compact (G words per row).
 __global__ void __launch_bounds__(256)
-k_panel_scan(const u64 *__restrict__ M, i64 stride, i64 rows, int j, u64 colmask,
-             const SolveState *__restrict__ st, int *__restrict__ cand_cnt,
-             int *__restrict__ cand_rows, int units)
+k_win_gather(const u64 *__restrict__ M, i64 stride, i64 rows, int j0, int gb, u64 *__restrict__ Wb)
+{
+	const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+	const i64 i = t / gb;
+	const int g = (int)(t % gb);
+	if (i >= rows) return;
+	Wb[i * GF2_GMAX + g] = M[i * stride + j0 + g];
+}
+
+// Alive rows get their window back (only needed for the final block: the RHS bit may live in it).
+__global__ void __launch_bounds__(256)
+k_win_scatter(u64 *__restrict__ M, i64 stride, i64 rows, int j0, int gb, const u64 *__restrict__ Wb,
+              const unsigned char *__restrict__ alive)
+{
+	const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+	const i64 i = t / gb;
+	const int g = (int)(t % gb);
+	if (i >= rows || !alive[i]) return;
+	M[i * stride + j0 + g] = Wb[i * GF2_GMAX + g];
+}
+
+// Wave-level Gauss-Jordan state of k_find: lane b owns the basis vector whose pivot is bit b
+// (bw), with the slots folded into it (bc); lane s remembers the row of slot s (srow).
+struct FindState {
+	u64 bw, bc, have;
+	int srow, nslots;
+};
+
+// Feed 64 candidate words (one per lane; w = 0 for "no candidate") into the basis.
+// Step R: reduce the candidates by the current (fully reduced) basis.  Step E: for every
+// column that has no pivot yet, in ascending order, take the first candidate that still has
+// that bit (ballot + ctz), make it the pivot vector of the column, clear the bit from every
+// other candidate AND from every existing basis vector (so the basis stays fully reduced:
+// afterwards a row's multiplier is simply `word & pivot_mask`).  Returns the lanes whose
+// candidate became a source row.
+__device__ __forceinline__ u64 find_absorb(FindState &S, u64 w, int row, u64 colmask, int lane)
+{
+	u64 c = 0, took = 0;
+	u64 hv = S.have;
+	while (hv) {
+		int b = uniform(ctz64(hv)); hv &= hv - 1;
+		u64 v = readlane64(S.bw, b), vc = readlane64(S.bc, b);
+		if ((w >> b) & 1) { w ^= v; c ^= vc; }
+	}
+	u64 todo = colmask & ~S.have;
+	while (todo) {
+		int b = uniform(ctz64(todo)); todo &= todo - 1;
+		u64 m = __ballot((w >> b) & 1);
+		if (!m) continue;
+		int L = uniform(ctz64(m));
+		u64 v = readlane64(w, L);
+		u64 vc = readlane64(c, L) | (1ull << S.nslots);
+		int r = __builtin_amdgcn_readlane(row, L);
+		if ((w >> b) & 1) { w ^= v; c ^= vc; }             // lane L itself becomes 0
+		if ((S.bw >> b) & 1) { S.bw ^= v; S.bc ^= vc; }    // keep the basis fully reduced
+		if (lane == b) { S.bw = v; S.bc = vc; }
+		if (lane == S.nslots) S.srow = r;
+		S.have |= 1ull << b;
+		S.nslots++;
+		took |= 1ull << L;
+	}
+	return took;
+}
+
+// Pivot search of panel j = j0+g.  Every wavefront ("unit") scans its own slice of the alive
+// rows and builds a basis with combination tracking; a unit stops as soon as all columns of
+// the panel have pivots.  The LAST unit to finish publishes: it adopts any unit whose basis is
+// complete (dense systems: every unit is after ~70 rows), otherwise it merges the units'
+// source rows into one basis.  Publishing = panel record, pivot columns, physical pivot rows,
+// PanelAux (sources, combinations, multipliers of the sources w.r.t. earlier panels of the
+// block), and the sources are marked dead.
+__global__ void __launch_bounds__(256)
+k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveState *__restrict__ st,
+       unsigned char *__restrict__ alive, FindUnit *__restrict__ fu, int units,
+       PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol,
+       int *__restrict__ urow, u64 *__restrict__ multset)
 {
 	const int lane = threadIdx.x & 63;
 	const int u = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	if (u >= units) return;
-	const i64 r0 = st->rank;
-	const i64 n = rows - r0;
-	if (n <= 0) { if (lane == 0) cand_cnt[u] = 0; return; }
-	i64 per = (n + units - 1) / units;
-	per = (per + 63) & ~(i64)63;
-	const i64 lo = r0 + (i64)u * per;
-	const i64 hi = (lo + per < rows) ? lo + per : rows;
+	const int first = st->first;
 	const int full = __popcll(colmask);
-
-	u64 bw = 0;            // my basis vector (lane = leading bit), 0 if none yet
-	int brow = -1;
-	u64 have = 0;          // wave-uniform: leading bits present
-	for (i64 base = lo; base < hi && __popcll(have) < full; base += 256) {
-		// 4 chunks of 64 rows in flight (word j of consecutive rows is a strided gather)
-		u64 wq[4]; i64 iq[4];
-#pragma unroll
-		for (int q = 0; q < 4; q++) {
-			iq[q] = base + 64 * q + lane;
-			wq[q] = (iq[q] < hi) ? (M[iq[q] * stride + j] & colmask) : 0ull;
-		}
-#pragma unroll
-		for (int q = 0; q < 4; q++) {
-			u64 w = wq[q];
-			u64 hv = have;
-			while (hv) {                               // reduce by the current basis, ascending
-				int b = uniform(ctz64(hv)); hv &= hv - 1;
-				u64 v = readlane64(bw, b);
-				if ((w >> b) & 1) w ^= v;
-			}
-			while (true) {                             // insert survivors one at a time
-				u64 m = __ballot(w != 0);
-				if (!m) break;
-				int L = uniform(ctz64(m));
-				u64 v = readlane64(w, L);
-				int row = __builtin_amdgcn_readlane((int)iq[q], L);
-				int b = uniform(ctz64(v));
-				if (lane == b) { bw = v; brow = row; }
-				have |= 1ull << b;
-				if ((w >> b) & 1) w ^= v;              // lane L itself becomes 0
-			}
-			if (__popcll(have) >= full) break;
-		}
-	}
-	if ((have >> lane) & 1) cand_rows[u * 64 + __popcll(have & lanemask_lt(lane))] = brow;
-	if (lane == 0) cand_cnt[u] = __popcll(have);
-}
-
-// Panel factorisation, step B (one wavefront).  Re-runs the same basis construction over the
-// candidate rows, this time remembering for every basis vector which candidate rows were
-// folded into it (a 64-bit mask over discovery "slots").  Then reduces the basis completely
-// (every vector keeps exactly its own pivot bit among the pivot bits), so that afterwards a
-// row's multiplier is simply `word & pivot_mask` -- no sequential dependency between the 64
-// columns of a panel.  Publishes: pivot mask, pivot columns, the slot rows, the per-pivot
-// combination masks, and the row moves that bring the pivot rows to [rank, rank+p).
-__global__ void __launch_bounds__(64)
-k_panel_select(const u64 *__restrict__ M, i64 stride, i64 rows, int j, u64 colmask,
-               SolveState *__restrict__ st, PanelRec *__restrict__ panels,
-               int *__restrict__ pivcol, const int *__restrict__ cand_cnt,
-               const int *__restrict__ cand_rows, int units)
-{
-	__shared__ int occ[64];
-	const int lane = threadIdx.x;
-	const int r0 = st->rank;
-	const int full = __popcll(colmask);
-	u64 bw = 0, bc = 0;
-	int srow = -1;
-	u64 have = 0;
-	int nslots = 0;
-	if ((i64)r0 < rows) {
-		for (int u = 0; u < units && nslots < full; u++) {
-			const int cnt = cand_cnt[u];
-			if (cnt == 0) continue;
-			int i = (lane < cnt) ? cand_rows[u * 64 + lane] : -1;
-			u64 w = (i >= 0) ? (M[(i64)i * stride + j] & colmask) : 0ull;
-			u64 c = 0;
-			u64 hv = have;
-			while (hv) {
-				int b = uniform(ctz64(hv)); hv &= hv - 1;
-				u64 v = readlane64(bw, b), vc = readlane64(bc, b);
-				if ((w >> b) & 1) { w ^= v; c ^= vc; }
-			}
-			while (nslots < full) {
-				u64 m = __ballot(w != 0);
-				if (!m) break;
-				int L = uniform(ctz64(m));
-				u64 v = readlane64(w, L);
-				u64 vc = readlane64(c, L) | (1ull << nslots);
-				int row = __builtin_amdgcn_readlane(i, L);
-				int b = uniform(ctz64(v));
-				if (lane == b) { bw = v; bc = vc; }
-				if (lane == nslots) srow = row;
-				have |= 1ull << b;
-				nslots++;
-				if ((w >> b) & 1) { w ^= v; c ^= vc; }
-			}
-		}
-	}
-	// full reduction, highest pivot bit first
+	FindState S;
+	S.bw = 0; S.bc = 0; S.have = 0; S.srow = -1; S.nslots = 0;
+	int first_nonsrc = -1;
 	{
-		u64 hv = have;
-		while (hv) {
-			int b = uniform(63 - __clzll((long long)hv)); hv &= ~(1ull << b);
-			u64 v = readlane64(bw, b), vc = readlane64(bc, b);
-			if (lane != b && ((have >> lane) & 1) && ((bw >> b) & 1)) { bw ^= v; bc ^= vc; }
+		const i64 n = rows - first;
+		i64 per = n > 0 ? (n + units - 1) / units : 0;
+		per = (per + 63) & ~(i64)63;
+		const i64 lo = first + (i64)u * per;
+		const i64 hi = (lo + per < rows) ? lo + per : rows;
+		i64 base = lo;
+		for (; base < hi && S.nslots < full; base += 64) {
+			const i64 i = base + lane;
+			const bool ok = (i < hi) && alive[i];
+			const u64 w = ok ? (Wb[i * GF2_GMAX + g] & colmask) : 0ull;
+			const u64 took = find_absorb(S, w, (int)i, colmask, lane);
+			if (first_nonsrc < 0) {
+				u64 m = __ballot(ok) & ~took;
+				if (m) first_nonsrc = (int)base + ctz64(m);
+			}
 		}
+		if (first_nonsrc < 0) first_nonsrc = (int)((base < rows) ? base : rows);   // lower bound
 	}
-	const int p = nslots;
-	if ((have >> lane) & 1) {
-		int k = __popcll(have & lanemask_lt(lane));
-		st->comb[k] = bc;
+	FindUnit *me = fu + u;
+	me->srow[lane] = S.srow;
+	me->bc[lane] = S.bc;
+	if (lane == 0) { me->have = S.have; me->cnt = S.nslots; me->first_nonsrc = first_nonsrc; }
+	__threadfence();
+	unsigned old = 0;
+	if (lane == 0) old = atomicAdd(&st->arrive, 1u);
+	old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+	if (old != (unsigned)(units - 1)) return;
+
+	// ---- last arriver: publish ----
+	__threadfence();
+	int pick = -1;
+	for (int v = 0; v < units; v++)
+		if (fu[v].cnt == full) { pick = v; break; }
+	int new_first;
+	if (pick >= 0 && full > 0) {
+		S.have = fu[pick].have;
+		S.nslots = fu[pick].cnt;
+		S.srow = fu[pick].srow[lane];
+		S.bc = fu[pick].bc[lane];
+		new_first = (pick == 0) ? fu[0].first_nonsrc : first;
+	} else {
+		// merge: rebuild one basis from all units' source rows
+		S.bw = 0; S.bc = 0; S.have = 0; S.srow = -1; S.nslots = 0;
+		for (int v = 0; v < units && S.nslots < full; v++) {
+			const int cnt = fu[v].cnt;
+			if (cnt == 0) continue;
+			const int i = (lane < cnt) ? fu[v].srow[lane] : -1;
+			const u64 w = (i >= 0) ? (Wb[(i64)i * GF2_GMAX + g] & colmask) : 0ull;
+			find_absorb(S, w, i, colmask, lane);
+		}
+		new_first = first;
+	}
+	const int p = S.nslots;
+	const int r0 = st->rank;
+	PanelAux *A = aux + j;
+	if ((S.have >> lane) & 1) {
+		const int k = __popcll(S.have & lanemask_lt(lane));
+		A->comb[k] = S.bc;
 		pivcol[r0 + k] = 64 * j + lane;
 	}
-	if (lane < p) st->slot_row[lane] = srow;
-	// row moves: pivot rows go to [r0, r0+p); rows sitting there that are not sources move
-	// into the holes left by sources that lived below r0+p.
-	occ[lane] = 0;
+	if (lane < p) {
+		A->slot_row[lane] = S.srow;
+		urow[r0 + lane] = S.srow;               // pivot k of the panel lives in physical row slot_row[k]
+		alive[S.srow] = 0;
+		for (int e = 0; e < g; e++) {           // multipliers of this source w.r.t. earlier panels of the block
+			u64 *me_ = multset + (i64)e * rows + S.srow;
+			A->src_mult[lane][e] = *me_;
+			*me_ = 0;                           // the bulk update must skip the block's own sources
+		}
+	}
+	// advance the lower bound of alive rows past rows that just died (cheap when pick == 0)
+	if (pick != 0) {
+		int f = new_first;
+		while (f < rows) {
+			const int i = f + lane;
+			int a = (i < rows) ? (int)alive[i] : 1;
+			for (int s = 0; s < p; s++)
+				if (i == __builtin_amdgcn_readlane(S.srow, s)) a = 0;
+			const u64 m = __ballot(a);
+			if (m) { f += ctz64(m); break; }
+			f += 64;
+		}
+		new_first = f < rows ? f : (int)rows;
+	}
+	if (lane == 0) {
+		panels[j].start = r0;
+		panels[j].p = p;
+		panels[j].mask = S.have;
+		st->rank = r0 + p;
+		st->first = new_first;
+		st->arrive = 0;
+	}
+}
+
+// Narrow elimination step of panel j = j0+g inside the window: (i) every workgroup recomputes
+// the (<= 64) reduced pivot rows' window words from the sources (tiny), workgroup 0 also
+// stores them into the matrix; (ii) every alive row records its multiplier
+// mult_g[i] = Wb[i][g] & mask and XORs the selected pivot rows into its remaining window words.
+__global__ void __launch_bounds__(256)
+k_narrow(u64 *__restrict__ M, i64 stride, i64 rows, int j0, int g, int gb, u64 *__restrict__ Wb,
+         const unsigned char *__restrict__ alive, const PanelRec *__restrict__ panels,
+         const PanelAux *__restrict__ aux, u64 *__restrict__ multset)
+{
+	__shared__ u64 Sw[64][GF2_GMAX];     // window words of the source rows
+	__shared__ u64 Pb[64][GF2_GMAX];     // reduced pivot rows' window words, indexed by pivot BIT
+	const int j = j0 + g;
+	const PanelRec rec = panels[j];
+	const PanelAux *A = aux + j;
+	const int p = rec.p;
+	u64 *mult = multset + (i64)g * rows;
+	const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (p == 0) {
+		if (i < rows) mult[i] = 0;
+		return;
+	}
+	for (int t = threadIdx.x; t < 64 * GF2_GMAX; t += blockDim.x) {
+		const int s = t / GF2_GMAX, e = t % GF2_GMAX;
+		Sw[s][e] = (s < p && e >= g && e < gb) ? Wb[(i64)A->slot_row[s] * GF2_GMAX + e] : 0ull;
+		Pb[s][e] = 0;
+	}
 	__syncthreads();
-	if (lane < p && srow < r0 + p) occ[srow - r0] = 1;
+	for (int t = threadIdx.x; t < p * GF2_GMAX; t += blockDim.x) {
+		const int k = t / GF2_GMAX, e = t % GF2_GMAX;
+		if (e < g || e >= gb) continue;
+		u64 c = A->comb[k], acc = 0;
+		while (c) { int s = ctz64(c); c &= c - 1; acc ^= Sw[s][e]; }
+		// bit of pivot k = k-th set bit of mask
+		u64 mk = rec.mask;
+		for (int q = 0; q < k; q++) mk &= mk - 1;
+		const int b = ctz64(mk);
+		Pb[b][e] = acc;
+		if (blockIdx.x == 0) M[(i64)A->slot_row[k] * stride + j0 + e] = acc;
+	}
 	__syncthreads();
+	if (i >= rows) return;
+	u64 m = 0;
+	if (alive[i]) {
+		m = Wb[i * GF2_GMAX + g] & rec.mask;
+		if (m) {
+			u64 acc[GF2_GMAX];
+#pragma unroll
+			for (int e = 0; e < GF2_GMAX; e++) acc[e] = 0;
+			u64 mm = m;
+			while (mm) {
+				const int b = ctz64(mm); mm &= mm - 1;
+#pragma unroll
+				for (int e = 0; e < GF2_GMAX; e++) acc[e] ^= Pb[b][e];
+			}
+#pragma unroll
+			for (int e = 0; e < GF2_GMAX; e++)
+				if (e >= g && e < gb) Wb[i * GF2_GMAX + e] ^= acc[e];
+		}
+	}
+	mult[i] = m;
+}
+
+// ==========================================================================================
+// BULK PATH (stream B)
+// ==========================================================================================
+
+// "TRSM" of one block on one 128-byte column tile (one workgroup per tile): brings the block's
+// source rows up to date panel by panel and forms the final pivot rows
+//   P_g[k] = XOR_{s in comb_g[k]} S_g[s]          (pivot rows of panel g)
+//   S_h[s] ^= XOR_{b in src_mult_h[s][g]} P_g[b]  (sources of later panels h > g were alive then)
+// and stores P_g[k] in place (physical row slot_row_g[k]), words >= wlo only.
+template <int TW>
+__global__ void __launch_bounds__(256)
+k_block_trsm(u64 *__restrict__ M, i64 stride, int j0, int gb, int wlo, int tile_begin,
+             const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux)
+{
+	extern __shared__ __attribute__((aligned(16))) u64 lds64[];
+	u64 *S = lds64;                          // [GMAX][64][TW]
+	u64 *P = lds64 + GF2_GMAX * 64 * TW;     // [GMAX][64][TW]
+	const i64 w0 = (i64)(tile_begin + blockIdx.x) * TW;
+	for (int g = 0; g < gb; g++) {
+		const int p = panels[j0 + g].p;
+		const PanelAux *A = aux + j0 + g;
+		for (int t = threadIdx.x; t < p * TW; t += 256) {
+			const int s = t / TW, w = t % TW;
+			S[(g * 64 + s) * TW + w] = (w0 + w >= wlo) ? M[(i64)A->slot_row[s] * stride + w0 + w] : 0ull;
+		}
+	}
+	__syncthreads();
+	for (int g = 0; g < gb; g++) {
+		const PanelRec rec = panels[j0 + g];
+		const PanelAux *A = aux + j0 + g;
+		for (int t = threadIdx.x; t < rec.p * TW; t += 256) {
+			const int k = t / TW, w = t % TW;
+			u64 c = A->comb[k], acc = 0;
+			while (c) { int s = ctz64(c); c &= c - 1; acc ^= S[(g * 64 + s) * TW + w]; }
+			P[(g * 64 + k) * TW + w] = acc;
+			if (w0 + w >= wlo) M[(i64)A->slot_row[k] * stride + w0 + w] = acc;
+		}
+		__syncthreads();
+		for (int h = g + 1; h < gb; h++) {
+			const int ph = panels[j0 + h].p;
+			const PanelAux *B = aux + j0 + h;
+			for (int t = threadIdx.x; t < ph * TW; t += 256) {
+				const int s = t / TW, w = t % TW;
+				u64 m = B->src_mult[s][g], acc = 0;
+				while (m) {
+					const int b = ctz64(m); m &= m - 1;
+					const int k = __popcll(rec.mask & ((1ull << b) - 1));
+					acc ^= P[(g * 64 + k) * TW + w];
+				}
+				S[(h * 64 + s) * TW + w] ^= acc;
+			}
+		}
+		__syncthreads();
+	}
+}
+
+// Balanced split of the 64 pivot bits of a panel into T bit-fields (grease tables).
+template <int T>
+struct Fields {
+	static constexpr int LO = 64 / T;                 // small field width
+	static constexpr int NBIG = 64 - T * LO;          // the first NBIG fields are one bit wider
+	__host__ __device__ static constexpr int width(int t) { return t < NBIG ? LO + 1 : LO; }
+	__host__ __device__ static constexpr int shift(int t) { return t < NBIG ? t * (LO + 1) : NBIG * (LO + 1) + (t - NBIG) * LO; }
+	__host__ __device__ static constexpr int offset(int t)       // first entry of table t inside a panel
 	{
-		bool is_d = (lane < p) && !occ[lane];
-		u64 md = __ballot(is_d);
-		if (is_d) st->disp_from[__popcll(md & lanemask_lt(lane))] = r0 + lane;
-		bool is_v = (lane < p) && (srow >= r0 + p);
-		u64 mv = __ballot(is_v);
-		if (is_v) st->disp_to[__popcll(mv & lanemask_lt(lane))] = srow;
-		if (lane == 0) {
-			st->nd = __popcll(md);
-			st->rank = r0 + p;
-			panels[j].start = r0;
-			panels[j].p = p;
-			panels[j].mask = have;
+		return t < NBIG ? t * (1 << (LO + 1)) : NBIG * (1 << (LO + 1)) + (t - NBIG) * (1 << LO);
+	}
+	static constexpr int ENTRIES = NBIG * (1 << (LO + 1)) + (T - NBIG) * (1 << LO);   // per panel
+};
+
+// The bulk update of one block on a set of column tiles:
+//     row[tile] ^= XOR_{g<gb} XOR_{t<T} tab[g][t][ field t of mult_g[row] ]
+// Tables ("Method of the Four Russians") of all gb panels for one 128-byte tile live in LDS.
+// Lane mapping: a row segment (TW=16 words) is covered by 8 consecutive lanes, 16 bytes each
+// (global_load_dwordx4 / ds_read_b128 / global_store_dwordx4); a wavefront covers 8 rows, so
+// HBM sees whole 128-byte segments and the 8 lanes of a row read 8 consecutive 16-byte slots of
+// ONE table entry.  Rows whose multipliers are all 0 (dead rows, the block's own sources,
+// sparse rows) are neither loaded nor stored.
+template <int G, int T>
+struct UpdateCfg {
+	static constexpr int TW = 16;
+	static constexpr int LPR = TW / 2;
+	static constexpr int E = Fields<T>::ENTRIES;
+	static constexpr int LDS_BYTES = G * E * TW * 8 + G * 64 * 4;
+};
+
+template <int G, int T, int NT>
+__global__ void __launch_bounds__(NT)
+k_update(u64 *__restrict__ M, i64 stride, i64 rows, int j0, int gb, int wlo,
+         const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
+         const u64 *__restrict__ multset, const int *__restrict__ blk_first,
+         int tile_begin, int ntiles, int nsplit)
+{
+	typedef UpdateCfg<G, T> C;
+	typedef Fields<T> F;
+	constexpr int TW = C::TW, LPR = C::LPR, E = C::E;
+	extern __shared__ __attribute__((aligned(16))) uint4 tab[];
+	int *prow = reinterpret_cast<int *>(tab + G * E * LPR);      // [G][64] physical row of pivot bit, -1 if none
+	const int ct = blockIdx.x % ntiles;
+	const int sp = blockIdx.x / ntiles;
+	const i64 w0 = (i64)(tile_begin + ct) * TW;
+	const int lr = threadIdx.x % LPR;
+	const int rr = threadIdx.x / LPR;
+	constexpr int RPP = NT / LPR;
+
+	int anyp = 0;
+	for (int g = 0; g < gb; g++) anyp |= panels[j0 + g].p;
+	if (!anyp) return;
+	// row range of this workgroup: [first alive row, rows) split evenly
+	const i64 rlo = *blk_first;
+	constexpr int ALIGN = RPP * 4;
+	i64 per = (rows - rlo + nsplit - 1) / nsplit;
+	per = (per + ALIGN - 1) / ALIGN * ALIGN;
+	const i64 rbeg = rlo + (i64)sp * per;
+	if (rbeg >= rows) return;
+	const i64 rend = (rbeg + per < rows) ? rbeg + per : rows;
+
+	// ---- tables ----
+	for (int t = threadIdx.x; t < gb * 64; t += NT) {
+		const int g = t >> 6, b = t & 63;
+		const PanelRec rec = panels[j0 + g];
+		prow[t] = ((rec.mask >> b) & 1) ? aux[j0 + g].slot_row[__popcll(rec.mask & ((1ull << b) - 1))] : -1;
+	}
+	__syncthreads();
+	// words below wlo belong to windows the panel path owns: their table slots stay zero
+	const uint4 keep = make_uint4((w0 + 2 * lr >= wlo) ? ~0u : 0u, (w0 + 2 * lr >= wlo) ? ~0u : 0u,
+	                              (w0 + 2 * lr + 1 >= wlo) ? ~0u : 0u, (w0 + 2 * lr + 1 >= wlo) ? ~0u : 0u);
+	const uint4 *Mq = reinterpret_cast<const uint4 *>(M);
+	// stage 1: entries whose index has bits only in the low half or only in the high half of
+	// the field come straight from the (L2-resident) pivot rows; stage 2: low ^ high.
+	for (int e = rr; e < gb * E; e += RPP) {
+		const int g = e / E, x = e - g * E;
+		int t = 0;
+#pragma unroll
+		for (int q = 1; q < T; q++) if (x >= F::offset(q)) t = q;
+		const int idx = x - F::offset(t);
+		const int kl = F::width(t) >> 1;
+		const int lomask = (1 << kl) - 1;
+		if ((idx & lomask) && (idx & ~lomask)) continue;
+		uint4 acc = make_uint4(0, 0, 0, 0);
+		int bits = idx;
+		while (bits) {
+			const int l = __ffs(bits) - 1; bits &= bits - 1;
+			const int pr = prow[g * 64 + F::shift(t) + l];
+			if (pr >= 0) acc = xor4(acc, Mq[((i64)pr * stride + w0) / 2 + lr]);
+		}
+		acc.x &= keep.x; acc.y &= keep.y; acc.z &= keep.z; acc.w &= keep.w;
+		tab[e * LPR + lr] = acc;
+	}
+	__syncthreads();
+	for (int e = rr; e < gb * E; e += RPP) {
+		const int g = e / E, x = e - g * E;
+		int t = 0;
+#pragma unroll
+		for (int q = 1; q < T; q++) if (x >= F::offset(q)) t = q;
+		const int idx = x - F::offset(t);
+		const int kl = F::width(t) >> 1;
+		const int lomask = (1 << kl) - 1;
+		if (!((idx & lomask) && (idx & ~lomask))) continue;
+		const int base = e - idx;
+		tab[e * LPR + lr] = xor4(tab[(base + (idx & lomask)) * LPR + lr], tab[(base + (idx & ~lomask)) * LPR + lr]);
+	}
+	__syncthreads();
+
+	// ---- stream the rows ----
+	uint4 *Mw = reinterpret_cast<uint4 *>(M);
+	constexpr int U = 4;
+	for (i64 base = rbeg; base < rend; base += (i64)RPP * U) {
+		u64 m[U][G];
+		uint4 d[U];
+		i64 q[U];
+		bool on[U];
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			const i64 row = base + (i64)u * RPP + rr;
+			u64 any = 0;
+#pragma unroll
+			for (int g = 0; g < G; g++) {
+				m[u][g] = (row < rend && g < gb) ? multset[(i64)g * rows + row] : 0ull;
+				any |= m[u][g];
+			}
+			on[u] = any != 0;
+			q[u] = (row * stride + w0) / 2 + lr;
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++)
+			if (on[u]) d[u] = Mw[q[u]];
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			if (!on[u]) continue;
+			uint4 acc = d[u];
+#pragma unroll
+			for (int g = 0; g < G; g++) {
+#pragma unroll
+				for (int t = 0; t < T; t++) {
+					const unsigned idx = (unsigned)(m[u][g] >> F::shift(t)) & ((1u << F::width(t)) - 1);
+					acc = xor4(acc, tab[(g * E + F::offset(t) + idx) * LPR + lr]);
+				}
+			}
+			Mw[q[u]] = acc;
 		}
 	}
 }
 
-// Panel factorisation, step C.  One workgroup per 128-byte column tile: stages the <= 64
-// source rows and the displaced rows of its tile in LDS, then writes (a) displaced rows into
-// the vacated positions and (b) the fully reduced pivot rows into [start, start+p).  All
-// reads of a tile precede all writes of that tile, and tiles are disjoint across workgroups.
-template <int TW>
+// ==========================================================================================
+// BACK-SUBSTITUTION
+// ==========================================================================================
+
+// After forward elimination every alive row is zero in A; the system is consistent iff their
+// RHS bits are zero too (the check inside _mzd_pluq_solve_left, _internal.c:440).
 __global__ void __launch_bounds__(256)
-k_pivot_apply(u64 *__restrict__ M, i64 stride, int j, int tile0,
-              const SolveState *__restrict__ st, const PanelRec *__restrict__ panels)
+k_check_rhs(const u64 *__restrict__ M, i64 stride, i64 rows, i64 cols,
+            const unsigned char *__restrict__ alive, SolveState *__restrict__ st)
 {
-	__shared__ u64 S[64 * TW];
-	__shared__ u64 D[64 * TW];
-	const int p = panels[j].p;
-	if (p == 0) return;
-	const int r0 = panels[j].start;
-	const int nd = st->nd;
-	const i64 w0 = (i64)(tile0 + blockIdx.x) * TW;
-	for (int idx = threadIdx.x; idx < p * TW; idx += 256) {
-		int s = idx / TW, w = idx % TW;
-		S[idx] = M[(i64)st->slot_row[s] * stride + w0 + w];
-	}
-	for (int idx = threadIdx.x; idx < nd * TW; idx += 256) {
-		int q = idx / TW, w = idx % TW;
-		D[idx] = M[(i64)st->disp_from[q] * stride + w0 + w];
-	}
-	__syncthreads();
-	for (int idx = threadIdx.x; idx < nd * TW; idx += 256) {
-		int q = idx / TW, w = idx % TW;
-		M[(i64)st->disp_to[q] * stride + w0 + w] = D[idx];
-	}
-	for (int idx = threadIdx.x; idx < p * TW; idx += 256) {
-		int k = idx / TW, w = idx % TW;
-		u64 c = st->comb[k], acc = 0;
-		while (c) { int s = ctz64(c); c &= c - 1; acc ^= S[s * TW + w]; }
-		M[(i64)(r0 + k) * stride + w0 + w] = acc;
-	}
+	int bad = 0;
+	for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (i64)gridDim.x * blockDim.x)
+		if (alive[i]) bad |= (int)((M[i * stride + (cols >> 6)] >> (cols & 63)) & 1);
+	if (__ballot(bad) && (threadIdx.x & 63) == 0) st->inconsistent = 1;
 }
 
-// Multiplier snapshot: mult[i] = word j of row i restricted to the panel's pivot bits.
-// Taken before the sweep rewrites word j (the sweep of the tile that contains word j would
-// otherwise race with the other tiles' reads).  This is the panel's column of "L".
-//   above == 0 : rows [start+p, rows)   (forward elimination)
-//   above == 1 : rows [0, start)        (back-substitution, multipliers read from U)
+// Y[k][t] = U[k][ycols[t]] for pivot k < rank: the right-hand sides of the back-substitution
+// (the RHS column, plus the free columns when a kernel basis is wanted).  Pivot row k lives in
+// physical row urow[k]; its words left of its own panel are dead storage and read as 0.
 __global__ void __launch_bounds__(256)
-k_gather_mult(const u64 *__restrict__ M, i64 stride, i64 rows, int j,
-              const PanelRec *__restrict__ rec, int above, u64 *__restrict__ mult)
+k_extract_y(const u64 *__restrict__ M, i64 stride, const SolveState *__restrict__ st,
+            const int *__restrict__ urow, const int *__restrict__ pivcol,
+            const int *__restrict__ ycols, int ny, u64 *__restrict__ Y, i64 ys)
+{
+	const int lane = threadIdx.x & 63;
+	const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const int nyw = (ny + 63) >> 6;
+	const i64 k = wave / nyw;
+	const int tw = (int)(wave % nyw);
+	if (k >= st->rank) return;
+	const int t = tw * 64 + lane;
+	int bit = 0;
+	if (t < ny) {
+		const int c = ycols[t];
+		if ((c >> 6) >= (pivcol[k] >> 6))
+			bit = (int)((M[(i64)urow[k] * stride + (c >> 6)] >> (c & 63)) & 1);
+	}
+	const u64 w = __ballot(bit);
+	if (lane == 0) Y[k * ys + tw] = w;
+}
+
+// Multipliers of the back-substitution step of panel q: for every earlier pivot k < start_q,
+// mult[k] = U[k][word j_q] & mask_q.
+__global__ void __launch_bounds__(256)
+k_gather_mult_u(const u64 *__restrict__ M, i64 stride, int j, const PanelRec *__restrict__ rec,
+                const int *__restrict__ urow, u64 *__restrict__ mult)
 {
 	const int p = rec->p;
 	if (p == 0) return;
-	const i64 lo = above ? 0 : (i64)rec->start + p;
-	const i64 hi = above ? (i64)rec->start : rows;
+	const i64 hi = rec->start;
 	const u64 mask = rec->mask;
-	for (i64 i = lo + (i64)blockIdx.x * blockDim.x + threadIdx.x; i < hi; i += (i64)gridDim.x * blockDim.x)
-		mult[i] = M[i * stride + j] & mask;
+	for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < hi; k += (i64)gridDim.x * blockDim.x)
+		mult[k] = M[(i64)urow[k] * stride + j] & mask;
 }
 
-// ------------------------------------------------------------------------------------------
-// The sweep: row[i][tile] ^= XOR_t table_t[ bits [K*t, K*t+K) of mult[i] ].
-//
-// Grease tables ("Method of the Four Russians") for one 64-pivot panel and one column tile
-// of TW words live in LDS: T = ceil(64/K) tables of 2^K entries (the last one smaller), each
-// entry TW*8 bytes.  Bits of the panel word that are not pivots index a zero row, so the
-// table index is a plain bit-field of the multiplier -- no pext.
-//
-// Lane mapping: a row segment (TW words) is covered by LPR = TW/2 consecutive lanes, 16 bytes
-// each, so one global_load_dwordx4 / ds_read_b128 / global_store_dwordx4 per lane per table;
-// a wavefront covers 64/LPR rows.  Lanes of one row read consecutive 16-byte slots of the
-// SAME table entry (conflict-free); HBM accesses are whole 128-byte (TW=16) segments.
-// Rows whose multiplier is 0 are neither loaded nor stored (sparse systems).
+// Single-panel sweep over a row-major matrix whose pivot rows are contiguous
+// (rows [start, start+p) in pivot-bit order).  Used on Y (pivot order) by the back-substitution:
+//   above == 1 : rows [0, start) ^= tables(mult[row])
 template <int K, int TW>
 struct SweepCfg {
 	static constexpr int T = (64 + K - 1) / K;
 	static constexpr int LASTBITS = 64 - K * (T - 1);
 	static constexpr int ENTRIES = (T - 1) * (1 << K) + (1 << LASTBITS);
-	static constexpr int LPR = TW / 2;                 // lanes per row segment (16 B per lane)
+	static constexpr int LPR = TW / 2;
 	static constexpr int LDS_BYTES = ENTRIES * TW * 8;
 };
 
@@ -332,12 +650,8 @@ k_sweep(u64 *__restrict__ M, i64 stride, i64 rows_total, const PanelRec *__restr
 	const i64 w0 = (i64)(tile0 + ct) * TW;
 	const int lr = threadIdx.x % C::LPR;
 	const int rr = threadIdx.x / C::LPR;
-	constexpr int RPP = NT / C::LPR;                   // rows per pass of the whole workgroup
+	constexpr int RPP = NT / C::LPR;
 
-	// ---- build the tables for this (panel, tile) ----
-	// stage 1: entries whose index has bits only in the low half or only in the high half of
-	// the table's bit-field come straight from (L2-resident) pivot rows; stage 2: the rest is
-	// low_part ^ high_part, one LDS pass.
 	const uint4 *Mq = reinterpret_cast<const uint4 *>(M);
 	for (int g = rr; g < C::ENTRIES; g += RPP) {
 		int t = g >> K; if (t > C::T - 1) t = C::T - 1;
@@ -353,8 +667,7 @@ k_sweep(u64 *__restrict__ M, i64 stride, i64 rows_total, const PanelRec *__restr
 			int b = t * K + l;
 			if ((pmask >> b) & 1) {
 				i64 prow = (i64)start + __popcll(pmask & ((1ull << b) - 1));
-				uint4 v = Mq[(prow * stride + w0) / 2 + lr];
-				acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+				acc = xor4(acc, Mq[(prow * stride + w0) / 2 + lr]);
 			}
 		}
 		tab[g * C::LPR + lr] = acc;
@@ -368,14 +681,10 @@ k_sweep(u64 *__restrict__ M, i64 stride, i64 rows_total, const PanelRec *__restr
 		const int lomask = (1 << kl) - 1;
 		if (!((idx & lomask) && (idx & ~lomask))) continue;
 		const int base = g - idx;
-		uint4 a = tab[(base + (idx & lomask)) * C::LPR + lr];
-		uint4 b = tab[(base + (idx & ~lomask)) * C::LPR + lr];
-		a.x ^= b.x; a.y ^= b.y; a.z ^= b.z; a.w ^= b.w;
-		tab[g * C::LPR + lr] = a;
+		tab[g * C::LPR + lr] = xor4(tab[(base + (idx & lomask)) * C::LPR + lr], tab[(base + (idx & ~lomask)) * C::LPR + lr]);
 	}
 	__syncthreads();
 
-	// ---- stream the rows ----
 	uint4 *Mw = reinterpret_cast<uint4 *>(M);
 	constexpr int U = 4;
 	for (i64 base = rbeg; base < rend; base += (i64)RPP * U) {
@@ -399,45 +708,11 @@ k_sweep(u64 *__restrict__ M, i64 stride, i64 rows_total, const PanelRec *__restr
 			for (int t = 0; t < C::T; t++) {
 				const int kt = (t == C::T - 1) ? C::LASTBITS : K;
 				const unsigned idx = (unsigned)(m[u] >> (K * t)) & ((1u << kt) - 1);
-				const uint4 v = tab[((t << K) + idx) * C::LPR + lr];
-				acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+				acc = xor4(acc, tab[((t << K) + idx) * C::LPR + lr]);
 			}
 			Mw[q[u]] = acc;
 		}
 	}
-}
-
-// ------------------------------------------------------------------------------------------
-// After forward elimination rows >= rank are zero in A; the system is consistent iff their
-// RHS bits are zero too (the check inside _mzd_pluq_solve_left, _internal.c:440).
-__global__ void __launch_bounds__(256)
-k_check_rhs(const u64 *__restrict__ M, i64 stride, i64 rows, i64 cols, SolveState *__restrict__ st)
-{
-	const i64 r = st->rank;
-	int bad = 0;
-	for (i64 i = r + (i64)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (i64)gridDim.x * blockDim.x)
-		bad |= (int)((M[i * stride + (cols >> 6)] >> (cols & 63)) & 1);
-	if (__ballot(bad) && (threadIdx.x & 63) == 0) st->inconsistent = 1;
-}
-
-// Y[k][t] = U[k][ycols[t]] for k < rank: the right-hand sides of the back-substitution (the
-// RHS column, plus the free columns when a kernel basis is wanted).  One wavefront packs 64
-// columns of one row with a single ballot.
-__global__ void __launch_bounds__(256)
-k_extract_y(const u64 *__restrict__ M, i64 stride, const SolveState *__restrict__ st,
-            const int *__restrict__ ycols, int ny, u64 *__restrict__ Y, i64 ys)
-{
-	const int lane = threadIdx.x & 63;
-	const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-	const int nyw = (ny + 63) >> 6;
-	const i64 k = wave / nyw;
-	const int tw = (int)(wave % nyw);
-	if (k >= st->rank) return;
-	const int t = tw * 64 + lane;
-	int bit = 0;
-	if (t < ny) { int c = ycols[t]; bit = (int)((M[k * stride + (c >> 6)] >> (c & 63)) & 1); }
-	u64 w = __ballot(bit);
-	if (lane == 0) Y[k * ys + tw] = w;
 }
 
 // out[t][pivcol[k]] = Y[k][t]: pivot-variable part of the origin (t = ny-1) and of every

@@ -39,83 +39,99 @@ int fail(int code, const char *what, hipError_t e = hipSuccess)
 
 inline i64 round_up(i64 v, i64 m) { return (v + m - 1) / m * m; }
 
-// ---- sweep configurations ------------------------------------------------------------------
-struct SweepImpl {
-	int K, TW, T, lds_bytes, threads;
-	hipError_t (*sweep)(dim3, hipStream_t, u64 *, i64, i64, const PanelRec *, int, const u64 *, int, int, int);
-	hipError_t (*apply)(dim3, hipStream_t, u64 *, i64, int, int, const SolveState *, const PanelRec *);
+// ---- kernel configurations -----------------------------------------------------------------
+// Bulk update: G panels fused per HBM pass, T grease tables per panel (balanced bit-fields).
+struct UpdateImpl {
+	int G, T, lds_bytes, threads;
+	hipError_t (*update)(dim3, hipStream_t, u64 *, i64, i64, int, int, int, const PanelRec *, const PanelAux *,
+	                     const u64 *, const int *, int, int, int);
 };
 
-template <int K, int TW, int NT>
-hipError_t launch_sweep(dim3 grid, hipStream_t s, u64 *M, i64 stride, i64 rows, const PanelRec *rec,
-                        int above, const u64 *mult, int tile0, int ntiles, int rpb)
+template <int G, int T, int NT>
+hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 stride, i64 rows, int j0, int gb, int wlo,
+                         const PanelRec *panels, const PanelAux *aux, const u64 *multset, const int *blk_first,
+                         int tile_begin, int ntiles, int nsplit)
 {
+	constexpr int lds = UpdateCfg<G, T>::LDS_BYTES;
 	static bool attr_set[16] = {};
 	int dev = 0;
 	(void)hipGetDevice(&dev);
 	if (dev < 16 && !attr_set[dev]) {
-		constexpr int lds_attr = SweepCfg<K, TW>::LDS_BYTES;
-		hipError_t e = hipFuncSetAttribute((const void *)k_sweep<K, TW, NT>,
-		                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds_attr);
+		hipError_t e = hipFuncSetAttribute((const void *)k_update<G, T, NT>,
+		                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
 		if (e != hipSuccess) return e;
 		attr_set[dev] = true;
 	}
-	constexpr int lds = SweepCfg<K, TW>::LDS_BYTES;
-	k_sweep<K, TW, NT><<<grid, dim3(NT), lds, s>>>(M, stride, rows, rec, above, mult, tile0, ntiles, rpb);
-	return hipGetLastError();
-}
-template <int TW>
-hipError_t launch_apply(dim3 grid, hipStream_t s, u64 *M, i64 stride, int j, int tile0,
-                        const SolveState *st, const PanelRec *panels)
-{
-	hipLaunchKernelGGL((k_pivot_apply<TW>), grid, dim3(256), 0, s, M, stride, j, tile0, st, panels);
+	k_update<G, T, NT><<<grid, dim3(NT), lds, s>>>(M, stride, rows, j0, gb, wlo, panels, aux, multset, blk_first,
+	                                               tile_begin, ntiles, nsplit);
 	return hipGetLastError();
 }
 
-#define SWEEP_IMPL(K, TW, NT) \
-	{ K, TW, SweepCfg<K, TW>::T, SweepCfg<K, TW>::LDS_BYTES, NT, launch_sweep<K, TW, NT>, launch_apply<TW> }
-
-const SweepImpl kImpls[] = {
-	SWEEP_IMPL(7, 16, 1024),   // default: 10 tables, 128-byte row segments, 144 KiB LDS
-	SWEEP_IMPL(8, 8, 1024),    // 8 tables, 64-byte segments, 128 KiB
-	SWEEP_IMPL(6, 16, 1024),   // 11 tables, 128-byte segments, 82 KiB
-	SWEEP_IMPL(5, 16, 1024),   // 13 tables, 128-byte segments, 50 KiB
-	SWEEP_IMPL(5, 32, 1024),   // 13 tables, 256-byte segments, 100 KiB
-	SWEEP_IMPL(4, 32, 1024),   // 16 tables, 256-byte segments, 64 KiB
-	SWEEP_IMPL(6, 16, 512),
-	SWEEP_IMPL(5, 16, 512),
+#define UPDATE_IMPL(G, T, NT) { G, T, UpdateCfg<G, T>::LDS_BYTES, NT, launch_update<G, T, NT> }
+const UpdateImpl kUpdates[] = {
+	UPDATE_IMPL(3, 13, 1024),   // default: 3 panels (192 pivots) per pass, 39 lookups, 151 KiB LDS
+	UPDATE_IMPL(2, 13, 1024),   // 2 panels, 26 lookups, 100 KiB
+	UPDATE_IMPL(2, 12, 1024),   // 2 panels, 24 lookups, 128 KiB
+	UPDATE_IMPL(4, 16, 1024),   // 4 panels, 64 lookups, 128 KiB
+	UPDATE_IMPL(1, 13, 1024),   // 1 panel, 13 lookups, 50 KiB
+	UPDATE_IMPL(1, 10, 1024),   // 1 panel, 10 lookups, 112 KiB
+	UPDATE_IMPL(3, 16, 1024),   // 3 panels, 48 lookups, 96 KiB
+	UPDATE_IMPL(2, 16, 1024),   // 2 panels, 32 lookups, 64 KiB
 };
 
-const SweepImpl *pick_impl(i64 stride)
+const UpdateImpl *pick_update()
 {
-	const SweepImpl *chosen = &kImpls[0];
-	if (const char *e = getenv("GF2BV_SWEEP")) {
-		int k = 0, tw = 0, nt = 1024;
-		if (sscanf(e, "%dx%dx%d", &k, &tw, &nt) >= 2)
-			for (const SweepImpl &c : kImpls)
-				if (c.K == k && c.TW == tw && c.threads == nt) { chosen = &c; break; }
+	const UpdateImpl *chosen = &kUpdates[0];
+	if (const char *e = getenv("GF2BV_UPDATE")) {      // "GxT", e.g. 3x13
+		int g = 0, t = 0;
+		if (sscanf(e, "%dx%d", &g, &t) == 2)
+			for (const UpdateImpl &c : kUpdates)
+				if (c.G == g && c.T == t) { chosen = &c; break; }
 	}
-	if (stride % chosen->TW != 0) chosen = &kImpls[0];     // TW=16 always divides (stride % 16 == 0)
 	return chosen;
 }
+
+// Back-substitution sweeps over Y use the single-panel kernel (5-bit tables, 128-byte segments).
+constexpr int YK = 5, YTW = 16, YNT = 1024;
+hipError_t launch_ysweep(dim3 grid, hipStream_t s, u64 *Y, i64 ys, i64 rows, const PanelRec *rec,
+                         const u64 *mult, int ntiles, int rpb)
+{
+	constexpr int lds = SweepCfg<YK, YTW>::LDS_BYTES;
+	static bool attr_set[16] = {};
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	if (dev < 16 && !attr_set[dev]) {
+		hipError_t e = hipFuncSetAttribute((const void *)k_sweep<YK, YTW, YNT>,
+		                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+		if (e != hipSuccess) return e;
+		attr_set[dev] = true;
+	}
+	k_sweep<YK, YTW, YNT><<<grid, dim3(YNT), lds, s>>>(Y, ys, rows, rec, 1, mult, 0, ntiles, rpb);
+	return hipGetLastError();
+}
+
+constexpr int TW = 16;            // words per column tile (128-byte row segments)
 
 // ---- one solve ---------------------------------------------------------------------------------
 struct Solver {
 	int device = 0;
-	hipStream_t stream = nullptr;
-	bool own_stream = false;
+	hipStream_t sA = nullptr, sB = nullptr;      // panel path / bulk path
+	bool own_sA = false;
 	u64 *M = nullptr;
 	bool own_M = false;
 	i64 rows = 0, cols = 0, stride = 0;
 	int mode = 0;
 	bool time_kernels = false;
-	const SweepImpl *impl = nullptr;
+	const UpdateImpl *impl = nullptr;
 
 	SolveState *st = nullptr;
 	PanelRec *panels = nullptr;
-	int *pivcol = nullptr;
-	u64 *mult = nullptr;
-	int *cand_cnt = nullptr, *cand_rows = nullptr;
+	PanelAux *aux = nullptr;
+	FindUnit *fu = nullptr;
+	unsigned char *alive = nullptr;
+	int *pivcol = nullptr, *urow = nullptr, *blk_first = nullptr;
+	u64 *mult = nullptr;          // 2 sets x G x rows (ping-pong between consecutive blocks)
+	u64 *Wb = nullptr;            // rows x GMAX window words
 	int units = 0;
 	u64 *Y = nullptr;
 	int *ycols = nullptr;
@@ -123,12 +139,11 @@ struct Solver {
 	i64 ys = 0;
 	int ny = 0;
 	i64 maxr = 0;
-	int npanels = 0;
+	int npanels = 0, nblocks = 0;
 	i64 wt = 0, cw = 0;
-	int rpb = 2048;
 
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
-	std::vector<hipEvent_t> kev;
+	std::vector<hipEvent_t> evA, evPrio, kev;
 	std::vector<int> free_order;     // free columns in M4RI kernel order (mode 1)
 	std::chrono::steady_clock::time_point t_begin;
 	float ms_pack = 0;
@@ -137,19 +152,21 @@ struct Solver {
 	void release()
 	{
 		(void)hipSetDevice(device);
-		for (void *p : { (void *)st, (void *)panels, (void *)pivcol, (void *)mult, (void *)cand_cnt,
-		                 (void *)cand_rows, (void *)Y, (void *)ycols, (void *)out })
+		for (void *p : { (void *)st, (void *)panels, (void *)aux, (void *)fu, (void *)alive, (void *)pivcol,
+		                 (void *)urow, (void *)blk_first, (void *)mult, (void *)Wb, (void *)Y, (void *)ycols,
+		                 (void *)out })
 			if (p) (void)hipFree(p);
-		st = nullptr; panels = nullptr; pivcol = nullptr; mult = nullptr; cand_cnt = nullptr;
-		cand_rows = nullptr; Y = nullptr; ycols = nullptr; out = nullptr;
+		st = nullptr; panels = nullptr; aux = nullptr; fu = nullptr; alive = nullptr; pivcol = nullptr;
+		urow = nullptr; blk_first = nullptr; mult = nullptr; Wb = nullptr; Y = nullptr; ycols = nullptr; out = nullptr;
 		if (own_M && M) (void)hipFree(M);
 		M = nullptr;
 		for (hipEvent_t e : { ev0, ev1, ev2, ev3 }) if (e) (void)hipEventDestroy(e);
 		ev0 = ev1 = ev2 = ev3 = nullptr;
-		for (hipEvent_t e : kev) (void)hipEventDestroy(e);
-		kev.clear();
-		if (own_stream && stream) (void)hipStreamDestroy(stream);
-		stream = nullptr;
+		for (auto *v : { &evA, &evPrio, &kev }) { for (hipEvent_t e : *v) (void)hipEventDestroy(e); v->clear(); }
+		if (sB) (void)hipStreamDestroy(sB);
+		sB = nullptr;
+		if (own_sA && sA) (void)hipStreamDestroy(sA);
+		sA = nullptr;
 	}
 };
 
@@ -182,112 +199,168 @@ int solver_alloc(Solver &S)
 	S.cw = (S.cols + 63) / 64;
 	S.npanels = (int)((S.cols + 63) / 64);
 	S.maxr = std::min(S.rows, S.cols);
-	S.impl = pick_impl(S.stride);
-	// scan units: enough wavefronts to cover the rows 256 at a time, at most 256 units
-	i64 want = (S.rows + 1023) / 1024;
-	int nA = (int)std::min<i64>(64, std::max<i64>(1, (want + 3) / 4));
-	S.units = nA * 4;
-	i64 rpb = 2048;
-	// keep >= ~2k workgroups in a full sweep when the matrix allows it
-	{
-		i64 ntiles = std::max<i64>(1, S.wt / S.impl->TW);
-		while (rpb > 512 && ntiles * ((S.rows + rpb - 1) / rpb) < 2048) rpb /= 2;
-		if (const char *e = getenv("GF2BV_RPB")) { int v = atoi(e); if (v >= 64) rpb = v; }
-	}
-	S.rpb = (int)rpb;
+	S.impl = pick_update();
+	const int G = S.impl->G;
+	S.nblocks = (S.npanels + G - 1) / G;
+	S.units = (int)std::min<i64>(256, std::max<i64>(1, (S.rows + 255) / 256));
+	HIPCHK(hipStreamCreateWithFlags(&S.sB, hipStreamNonBlocking));
 	HIPCHK(hipMalloc(&S.st, sizeof(SolveState)));
 	HIPCHK(hipMalloc(&S.panels, sizeof(PanelRec) * std::max(1, S.npanels)));
+	HIPCHK(hipMalloc(&S.aux, sizeof(PanelAux) * std::max(1, S.npanels)));
+	HIPCHK(hipMalloc(&S.fu, sizeof(FindUnit) * S.units));
+	HIPCHK(hipMalloc(&S.alive, std::max<i64>(1, S.rows)));
 	HIPCHK(hipMalloc(&S.pivcol, sizeof(int) * std::max<i64>(1, S.maxr + 64)));
-	HIPCHK(hipMalloc(&S.mult, sizeof(u64) * std::max<i64>(1, S.rows)));
-	HIPCHK(hipMalloc(&S.cand_cnt, sizeof(int) * S.units));
-	HIPCHK(hipMalloc(&S.cand_rows, sizeof(int) * S.units * 64));
-	HIPCHK(hipMemsetAsync(S.st, 0, sizeof(SolveState), S.stream));
-	HIPCHK(hipMemsetAsync(S.panels, 0, sizeof(PanelRec) * std::max(1, S.npanels), S.stream));
+	HIPCHK(hipMalloc(&S.urow, sizeof(int) * std::max<i64>(1, S.maxr + 64)));
+	HIPCHK(hipMalloc(&S.blk_first, sizeof(int) * std::max(1, S.nblocks)));
+	HIPCHK(hipMalloc(&S.mult, sizeof(u64) * 2 * G * std::max<i64>(1, S.rows)));
+	HIPCHK(hipMalloc(&S.Wb, sizeof(u64) * GF2_GMAX * std::max<i64>(1, S.rows)));
+	HIPCHK(hipMemsetAsync(S.st, 0, sizeof(SolveState), S.sA));
+	HIPCHK(hipMemsetAsync(S.panels, 0, sizeof(PanelRec) * std::max(1, S.npanels), S.sA));
+	HIPCHK(hipMemsetAsync(S.alive, 1, std::max<i64>(1, S.rows), S.sA));
+	HIPCHK(hipMemsetAsync(S.blk_first, 0, sizeof(int) * std::max(1, S.nblocks), S.sA));
+	HIPCHK(hipMemsetAsync(S.mult, 0, sizeof(u64) * 2 * G * std::max<i64>(1, S.rows), S.sA));
 	HIPCHK(hipEventCreate(&S.ev0));
 	HIPCHK(hipEventCreate(&S.ev1));
 	HIPCHK(hipEventCreate(&S.ev2));
 	HIPCHK(hipEventCreate(&S.ev3));
+	S.evA.resize(S.nblocks); S.evPrio.resize(S.nblocks);
+	for (int b = 0; b < S.nblocks; b++) {
+		HIPCHK(hipEventCreateWithFlags(&S.evA[b], hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&S.evPrio[b], hipEventDisableTiming));
+	}
 	return GF2BV_OK;
 }
 
-// forward elimination: all panels, no host synchronisation
+int pick_nsplit(i64 rows, int ntiles)
+{
+	// ~3 workgroups per CU in flight overall, each streaming at least ~512 rows
+	i64 want = (768 + ntiles - 1) / ntiles;
+	i64 cap = std::max<i64>(1, rows / 512);
+	if (const char *e = getenv("GF2BV_WGS")) { int v = atoi(e); if (v > 0) want = (v + ntiles - 1) / ntiles; }
+	return (int)std::max<i64>(1, std::min(want, cap));
+}
+
+// forward elimination: all blocks, no host synchronisation; panel path on sA, bulk path on sB
 int enqueue_forward(Solver &S)
 {
-	const SweepImpl &I = *S.impl;
-	const int TW = I.TW;
+	const UpdateImpl &I = *S.impl;
+	const int G = I.G;
 	const int tiles_total = (int)((S.wt + TW - 1) / TW);
-	const i64 nrb = (S.rows + S.rpb - 1) / S.rpb;
-	HIPCHK(hipEventRecord(S.ev0, S.stream));
-	for (int j = 0; j < S.npanels; j++) {
-		const i64 c0 = (i64)j * 64;
-		const u64 colmask = (S.cols - c0 >= 64) ? ~0ull : ((1ull << (S.cols - c0)) - 1);
-		const int tile0 = j / TW;
-		const int ntiles = tiles_total - tile0;
-		hipLaunchKernelGGL(k_panel_scan, dim3(S.units / 4), dim3(256), 0, S.stream,
-		                   S.M, S.stride, S.rows, j, colmask, S.st, S.cand_cnt, S.cand_rows, S.units);
-		hipLaunchKernelGGL(k_panel_select, dim3(1), dim3(64), 0, S.stream,
-		                   S.M, S.stride, S.rows, j, colmask, S.st, S.panels, S.pivcol,
-		                   S.cand_cnt, S.cand_rows, S.units);
-		HIPCHK(I.apply(dim3(ntiles), S.stream, S.M, S.stride, j, tile0, S.st, S.panels));
-		{
-			int g = (int)std::min<i64>(1024, (S.rows + 255) / 256);
-			hipLaunchKernelGGL(k_gather_mult, dim3(g), dim3(256), 0, S.stream,
-			                   S.M, S.stride, S.rows, j, S.panels + j, 0, S.mult);
+	const unsigned gather_blocks = (unsigned)((S.rows * GF2_GMAX + 255) / 256);
+	const unsigned row_blocks = (unsigned)((S.rows + 255) / 256);
+	HIPCHK(hipEventRecord(S.ev0, S.sA));
+	// sB starts after the setup memsets on sA
+	HIPCHK(hipStreamWaitEvent(S.sB, S.ev0, 0));
+	for (int b = 0; b < S.nblocks; b++) {
+		const int j0 = b * G;
+		const int gb = std::min(G, S.npanels - j0);
+		const int wlo = j0 + gb;
+		u64 *mset = S.mult + (i64)(b & 1) * G * S.rows;
+		// ---- panel path ----
+		if (b > 0) HIPCHK(hipStreamWaitEvent(S.sA, S.evPrio[b - 1], 0));
+		k_win_gather<<<dim3((unsigned)((S.rows * gb + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.stride, S.rows, j0, gb, S.Wb);
+		for (int g = 0; g < gb; g++) {
+			const int j = j0 + g;
+			const i64 c0 = (i64)j * 64;
+			const u64 colmask = (S.cols - c0 >= 64) ? ~0ull : ((1ull << (S.cols - c0)) - 1);
+			k_find<<<dim3((S.units + 3) / 4), dim3(256), 0, S.sA>>>(S.Wb, S.rows, j, g, colmask, S.st, S.alive, S.fu,
+			                                                       S.units, S.panels, S.aux, S.pivcol, S.urow, mset);
+			k_narrow<<<dim3(row_blocks), dim3(256), 0, S.sA>>>(S.M, S.stride, S.rows, j0, g, gb, S.Wb, S.alive,
+			                                                 S.panels, S.aux, mset);
 		}
-		if (S.time_kernels) {
-			hipEvent_t a, b;
-			HIPCHK(hipEventCreate(&a)); HIPCHK(hipEventCreate(&b));
-			S.kev.push_back(a); S.kev.push_back(b);
-			HIPCHK(hipEventRecord(a, S.stream));
+		// snapshot of the alive lower bound for the bulk update of this block
+		HIPCHK(hipMemcpyAsync(S.blk_first + b, &S.st->first, sizeof(int), hipMemcpyDeviceToDevice, S.sA));
+		if (b == S.nblocks - 1)
+			k_win_scatter<<<dim3((unsigned)((S.rows * gb + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.stride, S.rows, j0, gb, S.Wb, S.alive);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipEventRecord(S.evA[b], S.sA));
+		// ---- bulk path ----
+		HIPCHK(hipStreamWaitEvent(S.sB, S.evA[b], 0));
+		const int tb = wlo / TW;
+		if (tb < tiles_total && wlo < S.wt) {
+			const int nt_all = tiles_total - tb;
+			{
+				constexpr int trsm_lds = 2 * GF2_GMAX * 64 * TW * 8;
+				static bool trsm_attr[16] = {};
+				if (S.device < 16 && !trsm_attr[S.device]) {
+					HIPCHK(hipFuncSetAttribute((const void *)k_block_trsm<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, trsm_lds));
+					trsm_attr[S.device] = true;
+				}
+				k_block_trsm<TW><<<dim3(nt_all), dim3(256), trsm_lds, S.sB>>>(S.M, S.stride, j0, gb, wlo, tb, S.panels, S.aux);
+			}
+			int nprio = 0;
+			if (b + 1 < S.nblocks) {
+				const int gnext = std::min(G, S.npanels - (j0 + gb));
+				const int last_word = (int)std::min<i64>(wlo + gnext - 1, S.wt - 1);
+				nprio = std::min(nt_all, last_word / TW - tb + 1);
+			}
+			hipEvent_t ka = nullptr, kb = nullptr;
+			if (S.time_kernels) {
+				HIPCHK(hipEventCreate(&ka)); HIPCHK(hipEventCreate(&kb));
+				S.kev.push_back(ka); S.kev.push_back(kb);
+				HIPCHK(hipEventRecord(ka, S.sB));
+			}
+			if (nprio > 0) {
+				const int ns = pick_nsplit(S.rows, nprio);
+				HIPCHK(I.update(dim3((unsigned)(nprio * ns)), S.sB, S.M, S.stride, S.rows, j0, gb, wlo, S.panels, S.aux,
+				                mset, S.blk_first + b, tb, nprio, ns));
+			}
+			HIPCHK(hipEventRecord(S.evPrio[b], S.sB));
+			if (nt_all - nprio > 0) {
+				const int ns = pick_nsplit(S.rows, nt_all - nprio);
+				HIPCHK(I.update(dim3((unsigned)((nt_all - nprio) * ns)), S.sB, S.M, S.stride, S.rows, j0, gb, wlo, S.panels,
+				                S.aux, mset, S.blk_first + b, tb + nprio, nt_all - nprio, ns));
+			}
+			if (S.time_kernels) HIPCHK(hipEventRecord(kb, S.sB));
+		} else {
+			HIPCHK(hipEventRecord(S.evPrio[b], S.sB));
 		}
-		HIPCHK(I.sweep(dim3((unsigned)(ntiles * nrb)), S.stream, S.M, S.stride, S.rows, S.panels + j, 0,
-		               S.mult, tile0, ntiles, S.rpb));
-		if (S.time_kernels) HIPCHK(hipEventRecord(S.kev.back(), S.stream));
 	}
+	(void)gather_blocks;
+	// join: the panel stream waits for the last bulk update, then checks consistency
+	HIPCHK(hipEventRecord(S.ev3, S.sB));
+	HIPCHK(hipStreamWaitEvent(S.sA, S.ev3, 0));
 	{
 		int g = (int)std::min<i64>(1024, (S.rows + 255) / 256);
-		hipLaunchKernelGGL(k_check_rhs, dim3(g), dim3(256), 0, S.stream, S.M, S.stride, S.rows, S.cols, S.st);
+		k_check_rhs<<<dim3(g), dim3(256), 0, S.sA>>>(S.M, S.stride, S.rows, S.cols, S.alive, S.st);
 	}
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(S.ev1, S.stream));
+	HIPCHK(hipEventRecord(S.ev1, S.sA));
 	return GF2BV_OK;
 }
 
 // back-substitution on Y = selected columns of U (RHS [+ free columns]); then scatter.
 int enqueue_backward(Solver &S, const std::vector<int> &ycols_host)
 {
-	const SweepImpl &I = *S.impl;
-	const int TW = I.TW;
 	S.ny = (int)ycols_host.size();
 	const i64 nyw = (S.ny + 63) / 64;
-	S.ys = round_up(nyw, TW);
+	S.ys = round_up(nyw, YTW);
 	HIPCHK(hipMalloc(&S.ycols, sizeof(int) * S.ny));
-	HIPCHK(hipMemcpyAsync(S.ycols, ycols_host.data(), sizeof(int) * S.ny, hipMemcpyHostToDevice, S.stream));
+	HIPCHK(hipMemcpyAsync(S.ycols, ycols_host.data(), sizeof(int) * S.ny, hipMemcpyHostToDevice, S.sA));
 	HIPCHK(hipMalloc(&S.Y, sizeof(u64) * std::max<i64>(1, S.maxr) * S.ys));
-	HIPCHK(hipMemsetAsync(S.Y, 0, sizeof(u64) * std::max<i64>(1, S.maxr) * S.ys, S.stream));
+	HIPCHK(hipMemsetAsync(S.Y, 0, sizeof(u64) * std::max<i64>(1, S.maxr) * S.ys, S.sA));
 	HIPCHK(hipMalloc(&S.out, sizeof(u64) * S.ny * std::max<i64>(1, S.cw)));
-	HIPCHK(hipMemsetAsync(S.out, 0, sizeof(u64) * S.ny * std::max<i64>(1, S.cw), S.stream));
+	HIPCHK(hipMemsetAsync(S.out, 0, sizeof(u64) * S.ny * std::max<i64>(1, S.cw), S.sA));
+	u64 *bmult = S.mult;              // forward multipliers are dead by now
+	const int rpb = 2048;
 	if (S.maxr > 0) {
 		i64 waves = S.maxr * nyw;
-		hipLaunchKernelGGL(k_extract_y, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, S.stream,
-		                   S.M, S.stride, S.st, S.ycols, S.ny, S.Y, S.ys);
-		const int ytiles = (int)(S.ys / TW);
+		k_extract_y<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, S.sA>>>(S.M, S.stride, S.st, S.urow, S.pivcol,
+		                                                                      S.ycols, S.ny, S.Y, S.ys);
+		const int ytiles = (int)(S.ys / YTW);
 		for (int q = S.npanels - 1; q >= 1; q--) {
-			// rows above panel q's pivots: at most min(64*q, maxr)
-			const i64 bound = std::min<i64>((i64)64 * q, S.maxr);
+			const i64 bound = std::min<i64>((i64)64 * q, S.maxr);      // pivots before panel q
 			int g = (int)std::min<i64>(1024, (bound + 255) / 256);
-			hipLaunchKernelGGL(k_gather_mult, dim3(g), dim3(256), 0, S.stream,
-			                   S.M, S.stride, S.rows, q, S.panels + q, 1, S.mult);
-			const i64 nrb = (bound + S.rpb - 1) / S.rpb;
-			HIPCHK(I.sweep(dim3((unsigned)(ytiles * nrb)), S.stream, S.Y, S.ys, S.maxr, S.panels + q, 1,
-			               S.mult, 0, ytiles, S.rpb));
+			k_gather_mult_u<<<dim3(g), dim3(256), 0, S.sA>>>(S.M, S.stride, q, S.panels + q, S.urow, bmult);
+			const i64 nrb = (bound + rpb - 1) / rpb;
+			HIPCHK(launch_ysweep(dim3((unsigned)(ytiles * nrb)), S.sA, S.Y, S.ys, S.maxr, S.panels + q, bmult, ytiles, rpb));
 		}
 		i64 thr = S.maxr * nyw;
-		hipLaunchKernelGGL(k_scatter_solution, dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, S.stream,
-		                   S.Y, S.ys, S.st, S.pivcol, S.ny, S.out, std::max<i64>(1, S.cw));
+		k_scatter_solution<<<dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, S.sA>>>(S.Y, S.ys, S.st, S.pivcol, S.ny,
+		                                                                              S.out, std::max<i64>(1, S.cw));
 	}
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(S.ev2, S.stream));
+	HIPCHK(hipEventRecord(S.ev2, S.sA));
 	return GF2BV_OK;
 }
 
@@ -308,11 +381,13 @@ int solver_finish(Solver &S, gf2bv_result **out)
 {
 	SolveState hst;
 	std::vector<int32_t> piv;
+	hipEvent_t evx = nullptr;
+	HIPCHK(hipEventCreate(&evx));
 	if (S.mode == GF2BV_MODE_AFFINE_SPACE) {
 		// the kernel basis needs rank and pivot columns on the host (one sync) to lay out
 		// the free columns in M4RI's order (_internal.c:348)
-		HIPCHK(hipMemcpyAsync(&hst, S.st, sizeof hst, hipMemcpyDeviceToHost, S.stream));
-		HIPCHK(hipStreamSynchronize(S.stream));
+		HIPCHK(hipMemcpyAsync(&hst, S.st, sizeof hst, hipMemcpyDeviceToHost, S.sA));
+		HIPCHK(hipStreamSynchronize(S.sA));
 		piv.resize(hst.rank);
 		if (hst.rank)
 			HIPCHK(hipMemcpy(piv.data(), S.pivcol, sizeof(int) * hst.rank, hipMemcpyDeviceToHost));
@@ -326,13 +401,14 @@ int solver_finish(Solver &S, gf2bv_result **out)
 		int rc = enqueue_backward(S, yc);
 		if (rc) return rc;
 	}
-	HIPCHK(hipMemcpyAsync(&hst, S.st, sizeof hst, hipMemcpyDeviceToHost, S.stream));
+	HIPCHK(hipMemcpyAsync(&hst, S.st, sizeof hst, hipMemcpyDeviceToHost, S.sA));
 	std::vector<u64> hout((size_t)S.ny * std::max<i64>(1, S.cw));
-	HIPCHK(hipMemcpyAsync(hout.data(), S.out, sizeof(u64) * hout.size(), hipMemcpyDeviceToHost, S.stream));
+	HIPCHK(hipMemcpyAsync(hout.data(), S.out, sizeof(u64) * hout.size(), hipMemcpyDeviceToHost, S.sA));
 	std::vector<PanelRec> hp(std::max(1, S.npanels));
-	HIPCHK(hipMemcpyAsync(hp.data(), S.panels, sizeof(PanelRec) * hp.size(), hipMemcpyDeviceToHost, S.stream));
-	HIPCHK(hipEventRecord(S.ev3, S.stream));
-	HIPCHK(hipStreamSynchronize(S.stream));
+	HIPCHK(hipMemcpyAsync(hp.data(), S.panels, sizeof(PanelRec) * hp.size(), hipMemcpyDeviceToHost, S.sA));
+	HIPCHK(hipEventRecord(evx, S.sA));
+	HIPCHK(hipStreamSynchronize(S.sA));
+	HIPCHK(hipStreamSynchronize(S.sB));
 	if (piv.empty() && hst.rank) {
 		piv.resize(hst.rank);
 		HIPCHK(hipMemcpy(piv.data(), S.pivcol, sizeof(int) * hst.rank, hipMemcpyDeviceToHost));
@@ -362,23 +438,33 @@ int solver_finish(Solver &S, gf2bv_result **out)
 	st.rows = S.rows; st.cols = S.cols; st.stride_words = S.stride;
 	st.rank = R->rank; st.dimension = R->dim; st.status = R->status;
 	st.n_panels = S.npanels;
-	st.tables_per_sweep = S.impl->T; st.table_bits = S.impl->K; st.tile_words = S.impl->TW;
-	for (int j = 0; j < S.npanels; j++) {
-		if (hp[j].p <= 0) continue;
-		double rows_swept = (double)(S.rows - hp[j].start - hp[j].p);
-		st.n_sweeps++;
-		st.sweep_words += rows_swept * (double)(S.wt - j);
-		st.row_xors += rows_swept * (double)S.impl->T;
+	st.panels_per_sweep = S.impl->G;
+	st.tables_per_sweep = S.impl->G * S.impl->T;
+	st.table_bits = (64 + S.impl->T - 1) / S.impl->T;
+	st.tile_words = TW;
+	{
+		const int G = S.impl->G;
+		for (int b = 0; b < S.nblocks; b++) {
+			const int j0 = b * G, gb = std::min(G, S.npanels - j0), wlo = j0 + gb;
+			int pend = 0, any = 0;
+			for (int g = 0; g < gb; g++) { any |= hp[j0 + g].p; pend = hp[j0 + g].start + hp[j0 + g].p; }
+			if (!any || wlo >= S.wt) continue;
+			const double rows_swept = (double)(S.rows - pend);
+			st.n_sweeps++;
+			st.sweep_words += rows_swept * (double)(S.wt - wlo);
+			st.row_xors += rows_swept * (double)(S.impl->T * gb);
+		}
 	}
 	st.ms_pack = S.ms_pack;
 	(void)hipEventElapsedTime(&st.ms_eliminate, S.ev0, S.ev1);
 	(void)hipEventElapsedTime(&st.ms_backsub, S.ev1, S.ev2);
-	(void)hipEventElapsedTime(&st.ms_export, S.ev2, S.ev3);
+	(void)hipEventElapsedTime(&st.ms_export, S.ev2, evx);
 	for (size_t i = 0; i + 1 < S.kev.size(); i += 2) {
 		float ms = 0;
 		(void)hipEventElapsedTime(&ms, S.kev[i], S.kev[i + 1]);
 		st.ms_sweep += ms;
 	}
+	(void)hipEventDestroy(evx);
 	st.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - S.t_begin).count();
 	*out = R;
 	return GF2BV_OK;
@@ -425,7 +511,7 @@ int gf2bv_solve_device(void *d_aug, int64_t rows, int64_t cols, int64_t stride_w
 	Solver S;
 	S.t_begin = std::chrono::steady_clock::now();
 	S.device = device;
-	S.stream = (hipStream_t)stream;
+	S.sA = (hipStream_t)stream;
 	S.M = (u64 *)d_aug;
 	S.rows = rows; S.cols = cols; S.stride = stride_words; S.mode = mode;
 	S.time_kernels = time_kernels != 0;
@@ -459,7 +545,7 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 			Solver &S = group[i];
 			S.t_begin = std::chrono::steady_clock::now();
 			S.device = device;
-			S.stream = streams[i];
+			S.sA = streams[i];
 			S.M = (u64 *)d_aug + (s0 + i) * sys_stride_words;
 			S.rows = rows; S.cols = cols; S.stride = stride_words; S.mode = mode;
 			result = solver_enqueue(S);
@@ -485,23 +571,23 @@ int gf2bv_solve_words(const uint64_t *aug, int64_t rows, int64_t cols, int64_t s
 	Solver S;
 	S.t_begin = std::chrono::steady_clock::now();
 	S.device = device;
-	HIPCHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
-	S.own_stream = true;
+	HIPCHK(hipStreamCreateWithFlags(&S.sA, hipStreamNonBlocking));
+	S.own_sA = true;
 	S.rows = rows; S.cols = cols; S.mode = mode;
 	S.stride = round_up(wt, 32);
 	HIPCHK(hipMalloc(&S.M, sizeof(u64) * std::max<i64>(1, rows) * S.stride));
 	S.own_M = true;
 	hipEvent_t p0, p1;
 	HIPCHK(hipEventCreate(&p0)); HIPCHK(hipEventCreate(&p1));
-	HIPCHK(hipEventRecord(p0, S.stream));
-	HIPCHK(hipMemsetAsync(S.M, 0, sizeof(u64) * std::max<i64>(1, rows) * S.stride, S.stream));
+	HIPCHK(hipEventRecord(p0, S.sA));
+	HIPCHK(hipMemsetAsync(S.M, 0, sizeof(u64) * std::max<i64>(1, rows) * S.stride, S.sA));
 	if (rows > 0)
-		HIPCHK(hipMemcpy2DAsync(S.M, S.stride * 8, aug, stride_words * 8, wt * 8, rows, hipMemcpyHostToDevice, S.stream));
+		HIPCHK(hipMemcpy2DAsync(S.M, S.stride * 8, aug, stride_words * 8, wt * 8, rows, hipMemcpyHostToDevice, S.sA));
 	// bits above column `cols` are ignored by the reference (_internal.c:414): they can only sit
 	// in the last data word and are never used as pivots (colmask) nor exported; the RHS bit is
 	// read at exactly column `cols`.  A stray high bit could still leak through XORs into rows'
 	// tails, which nobody reads.  Nothing to mask.
-	HIPCHK(hipEventRecord(p1, S.stream));
+	HIPCHK(hipEventRecord(p1, S.sA));
 	rc = solver_enqueue(S);
 	if (rc == GF2BV_OK) {
 		(void)hipEventSynchronize(p1);
@@ -525,8 +611,8 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 	Solver S;
 	S.t_begin = std::chrono::steady_clock::now();
 	S.device = device;
-	HIPCHK(hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking));
-	S.own_stream = true;
+	HIPCHK(hipStreamCreateWithFlags(&S.sA, hipStreamNonBlocking));
+	S.own_sA = true;
 	S.rows = rows; S.cols = cols; S.mode = mode;
 	const i64 wt = (cols + 1 + 63) / 64;
 	S.stride = round_up(wt, 32);
@@ -539,23 +625,23 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 	HIPCHK(hipMalloc(&d_off, sizeof(i64) * (rows + 1)));
 	hipEvent_t p0, p1;
 	HIPCHK(hipEventCreate(&p0)); HIPCHK(hipEventCreate(&p1));
-	HIPCHK(hipEventRecord(p0, S.stream));
-	if (ndig) HIPCHK(hipMemcpyAsync(d_dig, digits, sizeof(uint32_t) * ndig, hipMemcpyHostToDevice, S.stream));
-	HIPCHK(hipMemcpyAsync(d_off, digit_off, sizeof(i64) * (rows + 1), hipMemcpyHostToDevice, S.stream));
+	HIPCHK(hipEventRecord(p0, S.sA));
+	if (ndig) HIPCHK(hipMemcpyAsync(d_dig, digits, sizeof(uint32_t) * ndig, hipMemcpyHostToDevice, S.sA));
+	HIPCHK(hipMemcpyAsync(d_off, digit_off, sizeof(i64) * (rows + 1), hipMemcpyHostToDevice, S.sA));
 	{
 		i64 total = rows * S.stride;
-		hipLaunchKernelGGL(k_pack_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S.stream,
+		hipLaunchKernelGGL(k_pack_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S.sA,
 		                   d_dig, d_off, bits_per_digit, (i64)rows, (i64)cols, S.stride, S.M);
 	}
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(p1, S.stream));
+	HIPCHK(hipEventRecord(p1, S.sA));
 	rc = solver_enqueue(S);
 	if (rc == GF2BV_OK) {
 		(void)hipEventSynchronize(p1);
 		(void)hipEventElapsedTime(&S.ms_pack, p0, p1);
 		rc = solver_finish(S, out);
 	}
-	(void)hipStreamSynchronize(S.stream);
+	(void)hipStreamSynchronize(S.sA);
 	(void)hipFree(d_dig); (void)hipFree(d_off);
 	(void)hipEventDestroy(p0); (void)hipEventDestroy(p1);
 	return rc;

@@ -38,7 +38,8 @@ class Stats(ctypes.Structure):
         ("rows", ctypes.c_int64), ("cols", ctypes.c_int64), ("stride_words", ctypes.c_int64),
         ("rank", ctypes.c_int64), ("dimension", ctypes.c_int64),
         ("status", ctypes.c_int32), ("n_panels", ctypes.c_int32), ("n_sweeps", ctypes.c_int32),
-        ("tables_per_sweep", ctypes.c_int32), ("table_bits", ctypes.c_int32), ("tile_words", ctypes.c_int32),
+        ("panels_per_sweep", ctypes.c_int32), ("tables_per_sweep", ctypes.c_int32), ("table_bits", ctypes.c_int32),
+        ("tile_words", ctypes.c_int32), ("reserved0", ctypes.c_int32),
         ("sweep_words", ctypes.c_double), ("row_xors", ctypes.c_double),
         ("ms_pack", ctypes.c_float), ("ms_eliminate", ctypes.c_float), ("ms_sweep", ctypes.c_float),
         ("ms_backsub", ctypes.c_float), ("ms_export", ctypes.c_float), ("ms_total", ctypes.c_float),

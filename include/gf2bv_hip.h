@@ -45,15 +45,17 @@ typedef struct gf2bv_stats {
 	int64_t rank, dimension;
 	int32_t status;
 	int32_t n_panels;          /* 64-column panels processed                                  */
-	int32_t n_sweeps;          /* panels that had >= 1 pivot (= sweep launches that did work)  */
-	int32_t tables_per_sweep;  /* T: grease tables fused into one sweep                        */
-	int32_t table_bits;        /* k: index bits per table                                      */
+	int32_t n_sweeps;          /* bulk-update passes over the trailing matrix that did work    */
+	int32_t panels_per_sweep;  /* G: 64-column panels fused into one pass                      */
+	int32_t tables_per_sweep;  /* G*T: grease tables applied per row per pass                  */
+	int32_t table_bits;        /* k: index bits of the widest table                            */
 	int32_t tile_words;        /* 64-bit words of one row segment handled by a lane group      */
+	int32_t reserved0;
 	double  sweep_words;       /* sum over sweeps of rows_swept x active_words  (unit of work) */
 	double  row_xors;          /* sum over sweeps of rows_swept x T                            */
 	float   ms_pack;           /* digits/words -> device matrix (H2D + pack kernel)            */
 	float   ms_eliminate;      /* forward elimination, all panels (HIP events)                 */
-	float   ms_sweep;          /* of which: time inside the sweep kernel (sum of launches)     */
+	float   ms_sweep;          /* time inside the bulk-update kernel (sum over passes, HIP events) */
 	float   ms_backsub;        /* consistency check + back-substitution + kernel basis         */
 	float   ms_export;         /* D2H of origin / basis                                        */
 	float   ms_total;          /* host wall clock of the whole call                            */

@@ -64,18 +64,19 @@ def test_all_zero_and_identity_systems():
     assert got.rank == 100 and got.dimension == 0 and got.origin_int() == sum((i & 1) << i for i in range(100))
 
 
-def test_sweep_configurations_agree(monkeypatch):
+def test_update_configurations_agree(monkeypatch):
+    """Every (panels-per-pass G, tables-per-panel T) instantiation of the bulk-update kernel gives the same bits."""
     rng = random.Random(77)
     rows, cols = 2600, 2500
     eqs = random_system(rng, rows, cols, .5, 2300, True, 0)
     aug = O.eqs_to_aug(eqs, cols)
     want = O.solve_words(aug, rows, cols, 1)
-    for cfg in ("7x16", "8x8", "6x16", "5x16", "5x32", "4x32", "6x16x512", "5x16x512"):
-        monkeypatch.setenv("GF2BV_SWEEP", cfg)
+    for cfg in ("3x13", "2x13", "2x12", "4x16", "1x13", "1x10", "3x16", "2x16"):
+        monkeypatch.setenv("GF2BV_UPDATE", cfg)
         got = hip.solve_words(aug, rows, cols, 1)
         assert_same(got, want, 1)
-        k, tw = int(cfg.split("x")[0]), int(cfg.split("x")[1])
-        assert (got.stats["table_bits"], got.stats["tile_words"]) == (k, tw)
+        g, t = (int(v) for v in cfg.split("x"))
+        assert (got.stats["panels_per_sweep"], got.stats["tables_per_sweep"]) == (g, g * t)
 
 
 def test_digits_path_equals_words_path():
@@ -170,7 +171,7 @@ def test_device_resident_and_batch_paths():
     hip.synth_device(buf.ptr, n, n, stride, seeds[0])
     one = hip.solve_device(buf.ptr, n, n, stride, 1, time_kernels=True)
     assert_same(one, O.solve_words(O.gen_synthetic(n, n, seeds[0]), n, n, 1), 1)
-    assert one.stats["ms_sweep"] > 0 and one.stats["n_sweeps"] == (n + 63) // 64
+    assert one.stats["ms_sweep"] > 0 and 1 <= one.stats["n_sweeps"] <= (n + 63) // 64
     with pytest.raises(ValueError):
         hip.solve_device(buf.ptr + 8, n, n, stride, 0)               # misaligned
     with pytest.raises(ValueError):

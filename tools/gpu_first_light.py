@@ -43,12 +43,12 @@ try:
 except Exception:
     traceback.print_exc()
 # timings on device-resident synthetic systems
-cfgs = os.environ.get("FL_CFGS", "7x16,8x8,6x16,5x16,5x32,4x32").split(",")
+cfgs = os.environ.get("FL_CFGS", "3x13,2x13,2x12,4x16,1x13,1x10,3x16,2x16").split(",")
 for n in [int(x) for x in os.environ.get("FL_SIZES", "8192,32768,65536").split(",")]:
     stride = hip.padded_stride(n)
     buf = hip.DeviceBuffer(n * stride * 8)
     for cfg in cfgs:
-        os.environ["GF2BV_SWEEP"] = cfg
+        os.environ["GF2BV_UPDATE"] = cfg
         hip.synth_device(buf.ptr, n, n, stride, 1234)
         t = time.time()
         sol = hip.solve_device(buf.ptr, n, n, stride, 0, time_kernels=True)
