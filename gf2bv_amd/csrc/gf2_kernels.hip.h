@@ -137,11 +137,17 @@ k_win_scatter(u64 *__restrict__ M, i64 stride, i64 rows, int j0, int gb, const u
 	M[i * stride + j0 + g] = Wb[i * GF2_GMAX + g];
 }
 
+// Cross-workgroup scratch of k_find is exchanged with relaxed AGENT-scope atomics (write-through
+// stores, L2-coherent loads): no __threadfence(), whose release half would write back the whole
+// L2 -- megabytes of lines the concurrent bulk update is dirtying.
+#define GF2_ST(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define GF2_LD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
 // Wave-level Gauss-Jordan state of k_find: lane b owns the basis vector whose pivot is bit b
-// (bw), with the slots folded into it (bc); lane s remembers the row of slot s (srow).
+// (bw) together with the slots folded into it (bc).
 struct FindState {
 	u64 bw, bc, have;
-	int srow, nslots;
+	int nslots;
 };
 
 // Feed 64 candidate words (one per lane; w = 0 for "no candidate") into the basis.
@@ -149,9 +155,9 @@ struct FindState {
 // column that has no pivot yet, in ascending order, take the first candidate that still has
 // that bit (ballot + ctz), make it the pivot vector of the column, clear the bit from every
 // other candidate AND from every existing basis vector (so the basis stays fully reduced:
-// afterwards a row's multiplier is simply `word & pivot_mask`).  Returns the lanes whose
-// candidate became a source row.
-__device__ __forceinline__ u64 find_absorb(FindState &S, u64 w, int row, u64 colmask, int lane)
+// afterwards a row's multiplier is simply `word & pivot_mask`).  The row of each new source
+// is stored to srow_out[slot].  Returns the lanes whose candidate became a source row.
+__device__ __forceinline__ u64 find_absorb(FindState &S, u64 w, int row, u64 colmask, int lane, int *srow_out)
 {
 	u64 c = 0, took = 0;
 	u64 hv = S.have;
@@ -168,11 +174,10 @@ __device__ __forceinline__ u64 find_absorb(FindState &S, u64 w, int row, u64 col
 		int L = uniform(ctz64(m));
 		u64 v = readlane64(w, L);
 		u64 vc = readlane64(c, L) | (1ull << S.nslots);
-		int r = __builtin_amdgcn_readlane(row, L);
+		if (lane == L) GF2_ST(srow_out + S.nslots, row);
 		if ((w >> b) & 1) { w ^= v; c ^= vc; }             // lane L itself becomes 0
 		if ((S.bw >> b) & 1) { S.bw ^= v; S.bc ^= vc; }    // keep the basis fully reduced
 		if (lane == b) { S.bw = v; S.bc = vc; }
-		if (lane == S.nslots) S.srow = r;
 		S.have |= 1ull << b;
 		S.nslots++;
 		took |= 1ull << L;
@@ -198,8 +203,9 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 	if (u >= units) return;
 	const int first = st->first;
 	const int full = __popcll(colmask);
+	FindUnit *me = fu + u;
 	FindState S;
-	S.bw = 0; S.bc = 0; S.have = 0; S.srow = -1; S.nslots = 0;
+	S.bw = 0; S.bc = 0; S.have = 0; S.nslots = 0;
 	int first_nonsrc = -1;
 	{
 		const i64 n = rows - first;
@@ -208,11 +214,18 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 		const i64 lo = first + (i64)u * per;
 		const i64 hi = (lo + per < rows) ? lo + per : rows;
 		i64 base = lo;
+		// two chunks in flight: the loads of chunk c+1 are issued before chunk c is absorbed
+		i64 i_n = base + lane;
+		bool ok_n = (i_n < hi) && alive[i_n];
+		u64 w_n = ok_n ? (Wb[i_n * GF2_GMAX + g] & colmask) : 0ull;
 		for (; base < hi && S.nslots < full; base += 64) {
-			const i64 i = base + lane;
-			const bool ok = (i < hi) && alive[i];
-			const u64 w = ok ? (Wb[i * GF2_GMAX + g] & colmask) : 0ull;
-			const u64 took = find_absorb(S, w, (int)i, colmask, lane);
+			const i64 i = i_n;
+			const bool ok = ok_n;
+			const u64 w = w_n;
+			i_n = base + 64 + lane;
+			ok_n = (i_n < hi) && alive[i_n];
+			w_n = ok_n ? (Wb[i_n * GF2_GMAX + g] & colmask) : 0ull;
+			const u64 took = find_absorb(S, w, (int)i, colmask, lane, me->srow);
 			if (first_nonsrc < 0) {
 				u64 m = __ballot(ok) & ~took;
 				if (m) first_nonsrc = (int)base + ctz64(m);
@@ -220,38 +233,40 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 		}
 		if (first_nonsrc < 0) first_nonsrc = (int)((base < rows) ? base : rows);   // lower bound
 	}
-	FindUnit *me = fu + u;
-	me->srow[lane] = S.srow;
-	me->bc[lane] = S.bc;
-	if (lane == 0) { me->have = S.have; me->cnt = S.nslots; me->first_nonsrc = first_nonsrc; }
-	__threadfence();
+	GF2_ST(&me->bc[lane], S.bc);
+	if (lane == 0) { GF2_ST(&me->have, S.have); GF2_ST(&me->first_nonsrc, first_nonsrc); GF2_ST(&me->cnt, S.nslots); }
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every store above has left this wave
 	unsigned old = 0;
-	if (lane == 0) old = atomicAdd(&st->arrive, 1u);
+	if (lane == 0) old = __hip_atomic_fetch_add(&st->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
 	if (old != (unsigned)(units - 1)) return;
 
 	// ---- last arriver: publish ----
-	__threadfence();
 	int pick = -1;
 	for (int v = 0; v < units; v++)
-		if (fu[v].cnt == full) { pick = v; break; }
+		if (GF2_LD(&fu[v].cnt) == full) { pick = v; break; }
 	int new_first;
+	int srow;                                   // lane s: row of slot s
 	if (pick >= 0 && full > 0) {
-		S.have = fu[pick].have;
-		S.nslots = fu[pick].cnt;
-		S.srow = fu[pick].srow[lane];
-		S.bc = fu[pick].bc[lane];
-		new_first = (pick == 0) ? fu[0].first_nonsrc : first;
+		S.have = GF2_LD(&fu[pick].have);
+		S.nslots = full;
+		srow = GF2_LD(&fu[pick].srow[lane]);
+		S.bc = GF2_LD(&fu[pick].bc[lane]);
+		new_first = (pick == 0) ? GF2_LD(&fu[0].first_nonsrc) : first;
 	} else {
-		// merge: rebuild one basis from all units' source rows
-		S.bw = 0; S.bc = 0; S.have = 0; S.srow = -1; S.nslots = 0;
+		// merge: rebuild one basis from all units' source rows (scratch: this unit's own srow list is
+		// dead by now, but other lists are still being read -> use the list of unit `units` (spare))
+		S.bw = 0; S.bc = 0; S.have = 0; S.nslots = 0;
+		FindUnit *spare = fu + units;
 		for (int v = 0; v < units && S.nslots < full; v++) {
-			const int cnt = fu[v].cnt;
+			const int cnt = GF2_LD(&fu[v].cnt);
 			if (cnt == 0) continue;
-			const int i = (lane < cnt) ? fu[v].srow[lane] : -1;
+			const int i = (lane < cnt) ? GF2_LD(&fu[v].srow[lane]) : -1;
 			const u64 w = (i >= 0) ? (Wb[(i64)i * GF2_GMAX + g] & colmask) : 0ull;
-			find_absorb(S, w, i, colmask, lane);
+			find_absorb(S, w, i, colmask, lane, spare->srow);
 		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		srow = GF2_LD(&spare->srow[lane]);
 		new_first = first;
 	}
 	const int p = S.nslots;
@@ -263,23 +278,23 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 		pivcol[r0 + k] = 64 * j + lane;
 	}
 	if (lane < p) {
-		A->slot_row[lane] = S.srow;
-		urow[r0 + lane] = S.srow;               // pivot k of the panel lives in physical row slot_row[k]
-		alive[S.srow] = 0;
+		A->slot_row[lane] = srow;
+		urow[r0 + lane] = srow;                 // pivot k of the panel lives in physical row slot_row[k]
+		alive[srow] = 0;
 		for (int e = 0; e < g; e++) {           // multipliers of this source w.r.t. earlier panels of the block
-			u64 *me_ = multset + (i64)e * rows + S.srow;
+			u64 *me_ = multset + (i64)e * rows + srow;
 			A->src_mult[lane][e] = *me_;
 			*me_ = 0;                           // the bulk update must skip the block's own sources
 		}
 	}
-	// advance the lower bound of alive rows past rows that just died (cheap when pick == 0)
+	// advance the lower bound of alive rows past rows that just died (free when pick == 0)
 	if (pick != 0) {
 		int f = new_first;
 		while (f < rows) {
 			const int i = f + lane;
 			int a = (i < rows) ? (int)alive[i] : 1;
 			for (int s = 0; s < p; s++)
-				if (i == __builtin_amdgcn_readlane(S.srow, s)) a = 0;
+				if (i == __builtin_amdgcn_readlane(srow, s)) a = 0;
 			const u64 m = __ballot(a);
 			if (m) { f += ctz64(m); break; }
 			f += 64;
@@ -292,7 +307,7 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 		panels[j].mask = S.have;
 		st->rank = r0 + p;
 		st->first = new_first;
-		st->arrive = 0;
+		GF2_ST(&st->arrive, 0u);
 	}
 }
 
@@ -305,8 +320,10 @@ k_narrow(u64 *__restrict__ M, i64 stride, i64 rows, int j0, int g, int gb, u64 *
          const unsigned char *__restrict__ alive, const PanelRec *__restrict__ panels,
          const PanelAux *__restrict__ aux, u64 *__restrict__ multset)
 {
-	__shared__ u64 Sw[64][GF2_GMAX];     // window words of the source rows
-	__shared__ u64 Pb[64][GF2_GMAX];     // reduced pivot rows' window words, indexed by pivot BIT
+	__shared__ u64 Sw[GF2_GMAX][64];     // window words of the source rows          [word][slot]
+	__shared__ u64 Pb[GF2_GMAX][64];     // reduced pivot rows' window words          [word][pivot BIT]
+	__shared__ u64 Cm[64];               // combination masks                         [pivot k]
+	__shared__ int Bk[64];               // pivot k -> pivot bit
 	const int j = j0 + g;
 	const PanelRec rec = panels[j];
 	const PanelAux *A = aux + j;
@@ -317,23 +334,26 @@ k_narrow(u64 *__restrict__ M, i64 stride, i64 rows, int j0, int g, int gb, u64 *
 		if (i < rows) mult[i] = 0;
 		return;
 	}
-	for (int t = threadIdx.x; t < 64 * GF2_GMAX; t += blockDim.x) {
-		const int s = t / GF2_GMAX, e = t % GF2_GMAX;
-		Sw[s][e] = (s < p && e >= g && e < gb) ? Wb[(i64)A->slot_row[s] * GF2_GMAX + e] : 0ull;
-		Pb[s][e] = 0;
+	{
+		const int t = threadIdx.x;               // 256 threads = 4 words x 64 slots
+		const int e = t >> 6, sl = t & 63;
+		Sw[e][sl] = (sl < p && e >= g && e < gb) ? Wb[(i64)A->slot_row[sl] * GF2_GMAX + e] : 0ull;
+		Pb[e][sl] = 0;
+		if (t < 64) {
+			Cm[t] = (t < p) ? A->comb[t] : 0ull;
+			if ((rec.mask >> t) & 1) Bk[__popcll(rec.mask & lanemask_lt(t))] = t;
+		}
 	}
 	__syncthreads();
-	for (int t = threadIdx.x; t < p * GF2_GMAX; t += blockDim.x) {
-		const int k = t / GF2_GMAX, e = t % GF2_GMAX;
-		if (e < g || e >= gb) continue;
-		u64 c = A->comb[k], acc = 0;
-		while (c) { int s = ctz64(c); c &= c - 1; acc ^= Sw[s][e]; }
-		// bit of pivot k = k-th set bit of mask
-		u64 mk = rec.mask;
-		for (int q = 0; q < k; q++) mk &= mk - 1;
-		const int b = ctz64(mk);
-		Pb[b][e] = acc;
-		if (blockIdx.x == 0) M[(i64)A->slot_row[k] * stride + j0 + e] = acc;
+	{
+		const int t = threadIdx.x;
+		const int e = t >> 6, k = t & 63;
+		if (k < p && e >= g && e < gb) {
+			u64 c = Cm[k], acc = 0;
+			while (c) { int sl = ctz64(c); c &= c - 1; acc ^= Sw[e][sl]; }
+			Pb[e][Bk[k]] = acc;
+			if (blockIdx.x == 0) M[(i64)A->slot_row[k] * stride + j0 + e] = acc;
+		}
 	}
 	__syncthreads();
 	if (i >= rows) return;
@@ -348,7 +368,7 @@ k_narrow(u64 *__restrict__ M, i64 stride, i64 rows, int j0, int g, int gb, u64 *
 			while (mm) {
 				const int b = ctz64(mm); mm &= mm - 1;
 #pragma unroll
-				for (int e = 0; e < GF2_GMAX; e++) acc[e] ^= Pb[b][e];
+				for (int e = 0; e < GF2_GMAX; e++) acc[e] ^= Pb[e][b];
 			}
 #pragma unroll
 			for (int e = 0; e < GF2_GMAX; e++)
@@ -368,7 +388,7 @@ k_narrow(u64 *__restrict__ M, i64 stride, i64 rows, int j0, int g, int gb, u64 *
 //   S_h[s] ^= XOR_{b in src_mult_h[s][g]} P_g[b]  (sources of later panels h > g were alive then)
 // and stores P_g[k] in place (physical row slot_row_g[k]), words >= wlo only.
 template <int TW>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(1024)
 k_block_trsm(u64 *__restrict__ M, i64 stride, int j0, int gb, int wlo, int tile_begin,
              const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux)
 {
@@ -379,7 +399,7 @@ k_block_trsm(u64 *__restrict__ M, i64 stride, int j0, int gb, int wlo, int tile_
 	for (int g = 0; g < gb; g++) {
 		const int p = panels[j0 + g].p;
 		const PanelAux *A = aux + j0 + g;
-		for (int t = threadIdx.x; t < p * TW; t += 256) {
+		for (int t = threadIdx.x; t < p * TW; t += 1024) {
 			const int s = t / TW, w = t % TW;
 			S[(g * 64 + s) * TW + w] = (w0 + w >= wlo) ? M[(i64)A->slot_row[s] * stride + w0 + w] : 0ull;
 		}
@@ -388,7 +408,7 @@ k_block_trsm(u64 *__restrict__ M, i64 stride, int j0, int gb, int wlo, int tile_
 	for (int g = 0; g < gb; g++) {
 		const PanelRec rec = panels[j0 + g];
 		const PanelAux *A = aux + j0 + g;
-		for (int t = threadIdx.x; t < rec.p * TW; t += 256) {
+		for (int t = threadIdx.x; t < rec.p * TW; t += 1024) {
 			const int k = t / TW, w = t % TW;
 			u64 c = A->comb[k], acc = 0;
 			while (c) { int s = ctz64(c); c &= c - 1; acc ^= S[(g * 64 + s) * TW + w]; }
@@ -399,7 +419,7 @@ k_block_trsm(u64 *__restrict__ M, i64 stride, int j0, int gb, int wlo, int tile_
 		for (int h = g + 1; h < gb; h++) {
 			const int ph = panels[j0 + h].p;
 			const PanelAux *B = aux + j0 + h;
-			for (int t = threadIdx.x; t < ph * TW; t += 256) {
+			for (int t = threadIdx.x; t < ph * TW; t += 1024) {
 				const int s = t / TW, w = t % TW;
 				u64 m = B->src_mult[s][g], acc = 0;
 				while (m) {
@@ -551,6 +571,7 @@ k_update(u64 *__restrict__ M, i64 stride, i64 rows, int j0, int gb, int wlo,
 			uint4 acc = d[u];
 #pragma unroll
 			for (int g = 0; g < G; g++) {
+				if (g >= gb) break;                 // tables of absent panels were never built (uniform branch)
 #pragma unroll
 				for (int t = 0; t < T; t++) {
 					const unsigned idx = (unsigned)(m[u][g] >> F::shift(t)) & ((1u << F::width(t)) - 1);

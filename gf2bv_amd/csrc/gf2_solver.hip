@@ -116,12 +116,13 @@ constexpr int TW = 16;            // words per column tile (128-byte row segment
 struct Solver {
 	int device = 0;
 	hipStream_t sA = nullptr, sB = nullptr;      // panel path / bulk path
-	bool own_sA = false;
+	bool own_sA = false, own_sB = false;
 	u64 *M = nullptr;
 	bool own_M = false;
 	i64 rows = 0, cols = 0, stride = 0;
 	int mode = 0;
 	bool time_kernels = false;
+	int dbg_sync = 0;
 	const UpdateImpl *impl = nullptr;
 
 	SolveState *st = nullptr;
@@ -163,7 +164,7 @@ struct Solver {
 		for (hipEvent_t e : { ev0, ev1, ev2, ev3 }) if (e) (void)hipEventDestroy(e);
 		ev0 = ev1 = ev2 = ev3 = nullptr;
 		for (auto *v : { &evA, &evPrio, &kev }) { for (hipEvent_t e : *v) (void)hipEventDestroy(e); v->clear(); }
-		if (sB) (void)hipStreamDestroy(sB);
+		if (own_sB && sB) (void)hipStreamDestroy(sB);
 		sB = nullptr;
 		if (own_sA && sA) (void)hipStreamDestroy(sA);
 		sA = nullptr;
@@ -203,11 +204,14 @@ int solver_alloc(Solver &S)
 	const int G = S.impl->G;
 	S.nblocks = (S.npanels + G - 1) / G;
 	S.units = (int)std::min<i64>(256, std::max<i64>(1, (S.rows + 255) / 256));
-	HIPCHK(hipStreamCreateWithFlags(&S.sB, hipStreamNonBlocking));
+	if (const char *e = getenv("GF2BV_DEBUG_SYNC")) S.dbg_sync = atoi(e);
+	if (getenv("GF2BV_SERIAL")) { S.sB = S.sA; S.own_sB = false; }     // ablation: no look-ahead overlap
+	else { HIPCHK(hipStreamCreateWithFlags(&S.sB, hipStreamNonBlocking)); S.own_sB = true; }
 	HIPCHK(hipMalloc(&S.st, sizeof(SolveState)));
 	HIPCHK(hipMalloc(&S.panels, sizeof(PanelRec) * std::max(1, S.npanels)));
 	HIPCHK(hipMalloc(&S.aux, sizeof(PanelAux) * std::max(1, S.npanels)));
-	HIPCHK(hipMalloc(&S.fu, sizeof(FindUnit) * S.units));
+	HIPCHK(hipMalloc(&S.fu, sizeof(FindUnit) * (S.units + 1)));     // +1: merge scratch
+	HIPCHK(hipMemsetAsync(S.fu, 0, sizeof(FindUnit) * (S.units + 1), S.sA));
 	HIPCHK(hipMalloc(&S.alive, std::max<i64>(1, S.rows)));
 	HIPCHK(hipMalloc(&S.pivcol, sizeof(int) * std::max<i64>(1, S.maxr + 64)));
 	HIPCHK(hipMalloc(&S.urow, sizeof(int) * std::max<i64>(1, S.maxr + 64)));
@@ -233,32 +237,67 @@ int solver_alloc(Solver &S)
 
 int pick_nsplit(i64 rows, int ntiles)
 {
-	// ~3 workgroups per CU in flight overall, each streaming at least ~512 rows
-	i64 want = (768 + ntiles - 1) / ntiles;
-	i64 cap = std::max<i64>(1, rows / 512);
+	// One workgroup per CU builds G x T tables (a fixed ~5-8 us) before it streams rows, so aim at
+	// ONE round of ~256 fat workgroups; go to several rounds only when each still streams >= 4096 rows.
+	i64 want = std::max<i64>(1, 256 / ntiles);
+	while (want * ntiles < 1024 && rows / (want * 2) >= 4096) want *= 2;
 	if (const char *e = getenv("GF2BV_WGS")) { int v = atoi(e); if (v > 0) want = (v + ntiles - 1) / ntiles; }
+	i64 cap = std::max<i64>(1, rows / 256);
 	return (int)std::max<i64>(1, std::min(want, cap));
 }
 
-// forward elimination: all blocks, no host synchronisation; panel path on sA, bulk path on sB
+int launch_trsm(Solver &S, hipStream_t st, int j0, int gb, int wlo, int tile_begin, int ntiles)
+{
+	constexpr int trsm_lds = 2 * GF2_GMAX * 64 * TW * 8;
+	static bool trsm_attr[16] = {};
+	if (S.device < 16 && !trsm_attr[S.device]) {
+		HIPCHK(hipFuncSetAttribute((const void *)k_block_trsm<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, trsm_lds));
+		trsm_attr[S.device] = true;
+	}
+	k_block_trsm<TW><<<dim3(ntiles), dim3(1024), trsm_lds, st>>>(S.M, S.stride, j0, gb, wlo, tile_begin, S.panels, S.aux);
+	HIPCHK(hipGetLastError());
+	return GF2BV_OK;
+}
+
+int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wlo, u64 *mset, int tile_begin, int ntiles)
+{
+	hipEvent_t ka = nullptr, kb = nullptr;
+	if (S.time_kernels) {
+		HIPCHK(hipEventCreate(&ka)); HIPCHK(hipEventCreate(&kb));
+		S.kev.push_back(ka); S.kev.push_back(kb);
+		HIPCHK(hipEventRecord(ka, st));
+	}
+	const int ns = pick_nsplit(S.rows, ntiles);
+	HIPCHK(S.impl->update(dim3((unsigned)(ntiles * ns)), st, S.M, S.stride, S.rows, j0, gb, wlo, S.panels, S.aux, mset,
+	                      S.blk_first + b, tile_begin, ntiles, ns));
+	if (S.time_kernels) HIPCHK(hipEventRecord(kb, st));
+	return GF2BV_OK;
+}
+
+// Forward elimination: all blocks, no host synchronisation.
+//   stream A (panel path): factorise block b on its compact window; then the "priority" part of
+//     block b's bulk work -- only the 1-2 column tiles that hold block b+1's window -- and gather
+//     that window.  Needs the bulk update of block b-1 (stream B) to be complete, nothing newer.
+//   stream B (bulk path): block b's TRSM + update on all remaining tiles, as soon as block b is
+//     factorised.  So A runs a whole block ahead of B and the two overlap: per-block time is
+//     max(panel path, bulk path), and B never idles when it is the longer one.
 int enqueue_forward(Solver &S)
 {
-	const UpdateImpl &I = *S.impl;
-	const int G = I.G;
+	const int G = S.impl->G;
 	const int tiles_total = (int)((S.wt + TW - 1) / TW);
-	const unsigned gather_blocks = (unsigned)((S.rows * GF2_GMAX + 255) / 256);
 	const unsigned row_blocks = (unsigned)((S.rows + 255) / 256);
 	HIPCHK(hipEventRecord(S.ev0, S.sA));
-	// sB starts after the setup memsets on sA
-	HIPCHK(hipStreamWaitEvent(S.sB, S.ev0, 0));
+	HIPCHK(hipStreamWaitEvent(S.sB, S.ev0, 0));     // sB starts after the setup memsets on sA
+	if (S.npanels > 0) {
+		const int g0 = std::min(G, S.npanels);
+		k_win_gather<<<dim3((unsigned)((S.rows * g0 + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.stride, S.rows, 0, g0, S.Wb);
+	}
 	for (int b = 0; b < S.nblocks; b++) {
 		const int j0 = b * G;
 		const int gb = std::min(G, S.npanels - j0);
 		const int wlo = j0 + gb;
 		u64 *mset = S.mult + (i64)(b & 1) * G * S.rows;
-		// ---- panel path ----
-		if (b > 0) HIPCHK(hipStreamWaitEvent(S.sA, S.evPrio[b - 1], 0));
-		k_win_gather<<<dim3((unsigned)((S.rows * gb + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.stride, S.rows, j0, gb, S.Wb);
+		// ---- stream A: factorise the block ----
 		for (int g = 0; g < gb; g++) {
 			const int j = j0 + g;
 			const i64 c0 = (i64)j * 64;
@@ -274,49 +313,39 @@ int enqueue_forward(Solver &S)
 			k_win_scatter<<<dim3((unsigned)((S.rows * gb + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.stride, S.rows, j0, gb, S.Wb, S.alive);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(S.evA[b], S.sA));
-		// ---- bulk path ----
-		HIPCHK(hipStreamWaitEvent(S.sB, S.evA[b], 0));
+		if (S.dbg_sync & 1) HIPCHK(hipDeviceSynchronize());
+		// tiles with trailing words; the first `nprio` of them hold the next block's window
 		const int tb = wlo / TW;
-		if (tb < tiles_total && wlo < S.wt) {
-			const int nt_all = tiles_total - tb;
-			{
-				constexpr int trsm_lds = 2 * GF2_GMAX * 64 * TW * 8;
-				static bool trsm_attr[16] = {};
-				if (S.device < 16 && !trsm_attr[S.device]) {
-					HIPCHK(hipFuncSetAttribute((const void *)k_block_trsm<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, trsm_lds));
-					trsm_attr[S.device] = true;
-				}
-				k_block_trsm<TW><<<dim3(nt_all), dim3(256), trsm_lds, S.sB>>>(S.M, S.stride, j0, gb, wlo, tb, S.panels, S.aux);
-			}
-			int nprio = 0;
-			if (b + 1 < S.nblocks) {
-				const int gnext = std::min(G, S.npanels - (j0 + gb));
-				const int last_word = (int)std::min<i64>(wlo + gnext - 1, S.wt - 1);
-				nprio = std::min(nt_all, last_word / TW - tb + 1);
-			}
-			hipEvent_t ka = nullptr, kb = nullptr;
-			if (S.time_kernels) {
-				HIPCHK(hipEventCreate(&ka)); HIPCHK(hipEventCreate(&kb));
-				S.kev.push_back(ka); S.kev.push_back(kb);
-				HIPCHK(hipEventRecord(ka, S.sB));
-			}
+		const int nt_all = (wlo < S.wt) ? tiles_total - tb : 0;
+		int nprio = 0, gnext = 0;
+		if (b + 1 < S.nblocks && nt_all > 0) {
+			gnext = std::min(G, S.npanels - wlo);
+			const int last_word = (int)std::min<i64>(wlo + gnext - 1, S.wt - 1);
+			nprio = std::min(nt_all, last_word / TW - tb + 1);
+		}
+		// ---- stream B: bulk of block b on the non-priority tiles ----
+		HIPCHK(hipStreamWaitEvent(S.sB, S.evA[b], 0));
+		if (nt_all - nprio > 0) {
+			int rc = launch_trsm(S, S.sB, j0, gb, wlo, tb + nprio, nt_all - nprio);
+			if (rc) return rc;
+			rc = launch_update_timed(S, S.sB, b, j0, gb, wlo, mset, tb + nprio, nt_all - nprio);
+			if (rc) return rc;
+		}
+		HIPCHK(hipEventRecord(S.evPrio[b], S.sB));          // "bulk of block b complete"
+		if (S.dbg_sync & 2) HIPCHK(hipDeviceSynchronize());
+		// ---- stream A: priority tiles of block b, then the next window ----
+		if (b + 1 < S.nblocks) {
+			if (b > 0) HIPCHK(hipStreamWaitEvent(S.sA, S.evPrio[b - 1], 0));
 			if (nprio > 0) {
-				const int ns = pick_nsplit(S.rows, nprio);
-				HIPCHK(I.update(dim3((unsigned)(nprio * ns)), S.sB, S.M, S.stride, S.rows, j0, gb, wlo, S.panels, S.aux,
-				                mset, S.blk_first + b, tb, nprio, ns));
+				int rc = launch_trsm(S, S.sA, j0, gb, wlo, tb, nprio);
+				if (rc) return rc;
+				rc = launch_update_timed(S, S.sA, b, j0, gb, wlo, mset, tb, nprio);
+				if (rc) return rc;
 			}
-			HIPCHK(hipEventRecord(S.evPrio[b], S.sB));
-			if (nt_all - nprio > 0) {
-				const int ns = pick_nsplit(S.rows, nt_all - nprio);
-				HIPCHK(I.update(dim3((unsigned)((nt_all - nprio) * ns)), S.sB, S.M, S.stride, S.rows, j0, gb, wlo, S.panels,
-				                S.aux, mset, S.blk_first + b, tb + nprio, nt_all - nprio, ns));
-			}
-			if (S.time_kernels) HIPCHK(hipEventRecord(kb, S.sB));
-		} else {
-			HIPCHK(hipEventRecord(S.evPrio[b], S.sB));
+			k_win_gather<<<dim3((unsigned)((S.rows * gnext + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.stride, S.rows, wlo,
+			                                                                                     std::max(gnext, 1), S.Wb);
 		}
 	}
-	(void)gather_blocks;
 	// join: the panel stream waits for the last bulk update, then checks consistency
 	HIPCHK(hipEventRecord(S.ev3, S.sB));
 	HIPCHK(hipStreamWaitEvent(S.sA, S.ev3, 0));
