@@ -435,33 +435,48 @@ k_block_trsm(u64 *__restrict__ M, i64 stride, int j0, int gb, int wlo, int tile_
 }
 
 // Balanced split of the 64 pivot bits of a panel into T bit-fields (grease tables).
+// T is even and so is the number of wide fields, so tables 2m and 2m+1 always have equal size
+// (they form a PAIR, see the LDS layout below).
 template <int T>
 struct Fields {
 	static constexpr int LO = 64 / T;                 // small field width
 	static constexpr int NBIG = 64 - T * LO;          // the first NBIG fields are one bit wider
+	static_assert(T % 2 == 0 && NBIG % 2 == 0, "tables must pair up");
 	__host__ __device__ static constexpr int width(int t) { return t < NBIG ? LO + 1 : LO; }
 	__host__ __device__ static constexpr int shift(int t) { return t < NBIG ? t * (LO + 1) : NBIG * (LO + 1) + (t - NBIG) * LO; }
-	__host__ __device__ static constexpr int offset(int t)       // first entry of table t inside a panel
+	// first 256-byte slot of pair m inside a panel (a slot holds entry i of table 2m and of table 2m+1)
+	__host__ __device__ static constexpr int pairoff(int m)
 	{
-		return t < NBIG ? t * (1 << (LO + 1)) : NBIG * (1 << (LO + 1)) + (t - NBIG) * (1 << LO);
+		return 2 * m < NBIG ? m * (1 << (LO + 1)) : (NBIG / 2) * (1 << (LO + 1)) + (m - NBIG / 2) * (1 << LO);
 	}
-	static constexpr int ENTRIES = NBIG * (1 << (LO + 1)) + (T - NBIG) * (1 << LO);   // per panel
+	static constexpr int SLOTS = (NBIG / 2) * (1 << (LO + 1)) + ((T - NBIG) / 2) * (1 << LO);   // per panel
 };
 
 // The bulk update of one block on a set of column tiles:
 //     row[tile] ^= XOR_{g<gb} XOR_{t<T} tab[g][t][ field t of mult_g[row] ]
 // Tables ("Method of the Four Russians") of all gb panels for one 128-byte tile live in LDS.
-// Lane mapping: a row segment (TW=16 words) is covered by 8 consecutive lanes, 16 bytes each
-// (global_load_dwordx4 / ds_read_b128 / global_store_dwordx4); a wavefront covers 8 rows, so
-// HBM sees whole 128-byte segments and the 8 lanes of a row read 8 consecutive 16-byte slots of
-// ONE table entry.  Rows whose multipliers are all 0 (dead rows, the block's own sources,
-// sparse rows) are neither loaded nor stored.
+//
+// Lane mapping: a row segment (16 words = 128 B) is covered by 8 consecutive lanes, 16 bytes each
+// (global_load_dwordx4 / ds_read_b128 / global_store_dwordx4); a wavefront covers 8 rows, so HBM
+// sees whole 128-byte segments.
+//
+// LDS layout (bank-conflict free): ds_read_b128 is serviced 16 lanes at a time, and those 16
+// lanes always belong to one EVEN and one ODD row of the wavefront (two lanes-quads each).  A
+// 128-byte table entry covers half of the 64 banks, so two different entries collide with
+// probability 1/2 -- unless even rows and odd rows are steered to opposite bank halves.  Tables
+// are therefore stored in pairs: slot i of pair m = [entry i of table 2m | entry i of table 2m+1]
+// (256 B = all 64 banks), and at every step even rows look up table 2m (low half) while odd rows
+// look up table 2m+1 (high half), then the other way round.  Every ds_read_b128 touches each
+// bank exactly once.
+//
+// Rows whose multipliers are all 0 (dead rows, the block's own sources, sparse rows) are neither
+// loaded nor stored.
 template <int G, int T>
 struct UpdateCfg {
 	static constexpr int TW = 16;
 	static constexpr int LPR = TW / 2;
-	static constexpr int E = Fields<T>::ENTRIES;
-	static constexpr int LDS_BYTES = G * E * TW * 8 + G * 64 * 4;
+	static constexpr int SLOTS = Fields<T>::SLOTS;                  // 256-byte slots per panel
+	static constexpr int LDS_BYTES = G * SLOTS * 256 + G * 64 * 4;
 };
 
 template <int G, int T, int NT>
@@ -473,9 +488,9 @@ k_update(u64 *__restrict__ M, i64 stride, i64 rows, int j0, int gb, int wlo,
 {
 	typedef UpdateCfg<G, T> C;
 	typedef Fields<T> F;
-	constexpr int TW = C::TW, LPR = C::LPR, E = C::E;
+	constexpr int TW = C::TW, LPR = C::LPR, SLOTS = C::SLOTS;
 	extern __shared__ __attribute__((aligned(16))) uint4 tab[];
-	int *prow = reinterpret_cast<int *>(tab + G * E * LPR);      // [G][64] physical row of pivot bit, -1 if none
+	int *prow = reinterpret_cast<int *>(tab + G * SLOTS * 16);     // [G][64] physical row of pivot bit, -1 if none
 	const int ct = blockIdx.x % ntiles;
 	const int sp = blockIdx.x / ntiles;
 	const i64 w0 = (i64)(tile_begin + ct) * TW;
@@ -506,44 +521,49 @@ k_update(u64 *__restrict__ M, i64 stride, i64 rows, int j0, int gb, int wlo,
 	const uint4 keep = make_uint4((w0 + 2 * lr >= wlo) ? ~0u : 0u, (w0 + 2 * lr >= wlo) ? ~0u : 0u,
 	                              (w0 + 2 * lr + 1 >= wlo) ? ~0u : 0u, (w0 + 2 * lr + 1 >= wlo) ? ~0u : 0u);
 	const uint4 *Mq = reinterpret_cast<const uint4 *>(M);
-	// stage 1: entries whose index has bits only in the low half or only in the high half of
-	// the field come straight from the (L2-resident) pivot rows; stage 2: low ^ high.
-	for (int e = rr; e < gb * E; e += RPP) {
-		const int g = e / E, x = e - g * E;
-		int t = 0;
+	// work item e = (panel g, table t, index idx); stage 1: indices with bits only in the low half or
+	// only in the high half of the field come straight from the (L2-resident) pivot rows;
+	// stage 2: low ^ high.
+	constexpr int EPP = 2 * SLOTS;                  // table entries per panel
+	for (int pass = 0; pass < 2; pass++) {
+		for (int e = rr; e < gb * EPP; e += RPP) {
+			const int g = e / EPP;
+			const int x = e - g * EPP;                // = 2 * (pairoff(m) + idx) + (t & 1)
+			const int half = x & 1, slot = x >> 1;
+			int m = 0;
 #pragma unroll
-		for (int q = 1; q < T; q++) if (x >= F::offset(q)) t = q;
-		const int idx = x - F::offset(t);
-		const int kl = F::width(t) >> 1;
-		const int lomask = (1 << kl) - 1;
-		if ((idx & lomask) && (idx & ~lomask)) continue;
-		uint4 acc = make_uint4(0, 0, 0, 0);
-		int bits = idx;
-		while (bits) {
-			const int l = __ffs(bits) - 1; bits &= bits - 1;
-			const int pr = prow[g * 64 + F::shift(t) + l];
-			if (pr >= 0) acc = xor4(acc, Mq[((i64)pr * stride + w0) / 2 + lr]);
+			for (int q = 1; q < T / 2; q++) if (slot >= F::pairoff(q)) m = q;
+			const int t = 2 * m + half;
+			const int idx = slot - F::pairoff(m);
+			const int kl = F::width(t) >> 1;
+			const int lomask = (1 << kl) - 1;
+			const bool mixed = (idx & lomask) && (idx & ~lomask);
+			const int at = ((g * SLOTS + slot) * 2 + half) * LPR + lr;
+			if (pass == 0) {
+				if (mixed) continue;
+				uint4 acc = make_uint4(0, 0, 0, 0);
+				int bits = idx;
+				while (bits) {
+					const int l = __ffs(bits) - 1; bits &= bits - 1;
+					const int pr = prow[g * 64 + F::shift(t) + l];
+					if (pr >= 0) acc = xor4(acc, Mq[((i64)pr * stride + w0) / 2 + lr]);
+				}
+				acc.x &= keep.x; acc.y &= keep.y; acc.z &= keep.z; acc.w &= keep.w;
+				tab[at] = acc;
+			} else {
+				if (!mixed) continue;
+				const int base = at - idx * 2 * LPR;
+				tab[at] = xor4(tab[base + (idx & lomask) * 2 * LPR], tab[base + (idx & ~lomask) * 2 * LPR]);
+			}
 		}
-		acc.x &= keep.x; acc.y &= keep.y; acc.z &= keep.z; acc.w &= keep.w;
-		tab[e * LPR + lr] = acc;
+		__syncthreads();
 	}
-	__syncthreads();
-	for (int e = rr; e < gb * E; e += RPP) {
-		const int g = e / E, x = e - g * E;
-		int t = 0;
-#pragma unroll
-		for (int q = 1; q < T; q++) if (x >= F::offset(q)) t = q;
-		const int idx = x - F::offset(t);
-		const int kl = F::width(t) >> 1;
-		const int lomask = (1 << kl) - 1;
-		if (!((idx & lomask) && (idx & ~lomask))) continue;
-		const int base = e - idx;
-		tab[e * LPR + lr] = xor4(tab[(base + (idx & lomask)) * LPR + lr], tab[(base + (idx & ~lomask)) * LPR + lr]);
-	}
-	__syncthreads();
 
 	// ---- stream the rows ----
 	uint4 *Mw = reinterpret_cast<uint4 *>(M);
+	const int rp = rr & 1;                          // row parity inside the wavefront
+	const int c1 = rp * LPR + lr;                   // even rows: low half first; odd rows: high half first
+	const int c2 = (1 - rp) * LPR + lr;
 	constexpr int U = 4;
 	for (i64 base = rbeg; base < rend; base += (i64)RPP * U) {
 		u64 m[U][G];
@@ -572,10 +592,19 @@ k_update(u64 *__restrict__ M, i64 stride, i64 rows, int j0, int gb, int wlo,
 #pragma unroll
 			for (int g = 0; g < G; g++) {
 				if (g >= gb) break;                 // tables of absent panels were never built (uniform branch)
+				const unsigned mlo = (unsigned)m[u][g], mhi = (unsigned)(m[u][g] >> 32);
 #pragma unroll
-				for (int t = 0; t < T; t++) {
-					const unsigned idx = (unsigned)(m[u][g] >> F::shift(t)) & ((1u << F::width(t)) - 1);
-					acc = xor4(acc, tab[(g * E + F::offset(t) + idx) * LPR + lr]);
+				for (int pm = 0; pm < T / 2; pm++) {
+					constexpr int dummy = 0; (void)dummy;
+					const int sa = F::shift(2 * pm), sb = F::shift(2 * pm + 1), wd = F::width(2 * pm);
+					const unsigned fa = (sa >= 32 ? (mhi >> (sa - 32)) : (sa + wd <= 32 ? (mlo >> sa) : __builtin_amdgcn_alignbit(mhi, mlo, sa))) & ((1u << wd) - 1);
+					const unsigned fb = (sb >= 32 ? (mhi >> (sb - 32)) : (sb + wd <= 32 ? (mlo >> sb) : __builtin_amdgcn_alignbit(mhi, mlo, sb))) & ((1u << wd) - 1);
+					const unsigned i1 = rp ? fb : fa;
+					const unsigned i2 = rp ? fa : fb;
+					const int slot0 = (g * SLOTS + F::pairoff(pm)) * 2 * LPR;
+					const uint4 v1 = tab[slot0 + i1 * 2 * LPR + c1];
+					const uint4 v2 = tab[slot0 + i2 * 2 * LPR + c2];
+					acc.x ^= v1.x ^ v2.x; acc.y ^= v1.y ^ v2.y; acc.z ^= v1.z ^ v2.z; acc.w ^= v1.w ^ v2.w;
 				}
 			}
 			Mw[q[u]] = acc;

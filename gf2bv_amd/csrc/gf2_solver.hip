@@ -69,14 +69,15 @@ hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 stride, i64 rows,
 
 #define UPDATE_IMPL(G, T, NT) { G, T, UpdateCfg<G, T>::LDS_BYTES, NT, launch_update<G, T, NT> }
 const UpdateImpl kUpdates[] = {
-	UPDATE_IMPL(3, 13, 1024),   // default: 3 panels (192 pivots) per pass, 39 lookups, 151 KiB LDS
-	UPDATE_IMPL(2, 13, 1024),   // 2 panels, 26 lookups, 100 KiB
-	UPDATE_IMPL(2, 12, 1024),   // 2 panels, 24 lookups, 128 KiB
+	UPDATE_IMPL(3, 16, 1024),   // default: 3 panels (192 pivots) per pass, 48 lookups, 96 KiB LDS
 	UPDATE_IMPL(4, 16, 1024),   // 4 panels, 64 lookups, 128 KiB
-	UPDATE_IMPL(1, 13, 1024),   // 1 panel, 13 lookups, 50 KiB
-	UPDATE_IMPL(1, 10, 1024),   // 1 panel, 10 lookups, 112 KiB
-	UPDATE_IMPL(3, 16, 1024),   // 3 panels, 48 lookups, 96 KiB
+	UPDATE_IMPL(3, 14, 1024),   // 3 panels, 42 lookups, 132 KiB
+	UPDATE_IMPL(2, 12, 1024),   // 2 panels, 24 lookups, 128 KiB
+	UPDATE_IMPL(2, 14, 1024),   // 2 panels, 28 lookups, 88 KiB
 	UPDATE_IMPL(2, 16, 1024),   // 2 panels, 32 lookups, 64 KiB
+	UPDATE_IMPL(1, 10, 1024),   // 1 panel, 10 lookups, 112 KiB
+	UPDATE_IMPL(1, 12, 1024),   // 1 panel, 12 lookups, 64 KiB
+	UPDATE_IMPL(1, 16, 1024),   // 1 panel, 16 lookups, 32 KiB
 };
 
 const UpdateImpl *pick_update()

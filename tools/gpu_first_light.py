@@ -43,7 +43,7 @@ try:
 except Exception:
     traceback.print_exc()
 # timings on device-resident synthetic systems
-cfgs = os.environ.get("FL_CFGS", "3x13,2x13,2x12,4x16,1x13,1x10,3x16,2x16").split(",")
+cfgs = os.environ.get("FL_CFGS", "3x16,4x16,3x14,2x12,2x14,2x16,1x10,1x12,1x16").split(",")
 for n in [int(x) for x in os.environ.get("FL_SIZES", "8192,32768,65536").split(",")]:
     stride = hip.padded_stride(n)
     buf = hip.DeviceBuffer(n * stride * 8)
