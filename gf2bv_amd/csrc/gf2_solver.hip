@@ -43,12 +43,12 @@ inline i64 round_up(i64 v, i64 m) { return (v + m - 1) / m * m; }
 // Bulk update: G panels fused per HBM pass, T grease tables per panel (balanced bit-fields).
 struct UpdateImpl {
 	int G, T, lds_bytes, threads;
-	hipError_t (*update)(dim3, hipStream_t, u64 *, i64, i64, int, int, int, const PanelRec *, const PanelAux *,
+	hipError_t (*update)(dim3, hipStream_t, u64 *, i64, int, int, int, const PanelRec *, const PanelAux *,
 	                     const u64 *, const int *, int, int, int);
 };
 
 template <int G, int T, int NT>
-hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 stride, i64 rows, int j0, int gb, int wlo,
+hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 rows, int j0, int gb, int wlo,
                          const PanelRec *panels, const PanelAux *aux, const u64 *multset, const int *blk_first,
                          int tile_begin, int ntiles, int nsplit)
 {
@@ -62,7 +62,7 @@ hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 stride, i64 rows,
 		if (e != hipSuccess) return e;
 		attr_set[dev] = true;
 	}
-	k_update<G, T, NT><<<grid, dim3(NT), lds, s>>>(M, stride, rows, j0, gb, wlo, panels, aux, multset, blk_first,
+	k_update<G, T, NT><<<grid, dim3(NT), lds, s>>>(M, rows, j0, gb, wlo, panels, aux, multset, blk_first,
 	                                               tile_begin, ntiles, nsplit);
 	return hipGetLastError();
 }
@@ -118,9 +118,12 @@ struct Solver {
 	int device = 0;
 	hipStream_t sA = nullptr, sB = nullptr;      // panel path / bulk path
 	bool own_sA = false, own_sB = false;
-	u64 *M = nullptr;
-	bool own_M = false;
+	u64 *M = nullptr;             // tile-major working copy (always owned)
+	const u64 *src = nullptr;     // caller's row-major matrix on the device (stride words per row)
+	u64 *tmp_src = nullptr;       // row-major staging buffer when the input came from the host
+	u64 *Ybuf = nullptr;
 	i64 rows = 0, cols = 0, stride = 0;
+	i64 ntiles = 0;
 	int mode = 0;
 	bool time_kernels = false;
 	int dbg_sync = 0;
@@ -160,8 +163,10 @@ struct Solver {
 			if (p) (void)hipFree(p);
 		st = nullptr; panels = nullptr; aux = nullptr; fu = nullptr; alive = nullptr; pivcol = nullptr;
 		urow = nullptr; blk_first = nullptr; mult = nullptr; Wb = nullptr; Y = nullptr; ycols = nullptr; out = nullptr;
-		if (own_M && M) (void)hipFree(M);
+		if (M) (void)hipFree(M);
 		M = nullptr;
+		if (tmp_src) (void)hipFree(tmp_src);
+		tmp_src = nullptr;
 		for (hipEvent_t e : { ev0, ev1, ev2, ev3 }) if (e) (void)hipEventDestroy(e);
 		ev0 = ev1 = ev2 = ev3 = nullptr;
 		for (auto *v : { &evA, &evPrio, &kev }) { for (hipEvent_t e : *v) (void)hipEventDestroy(e); v->clear(); }
@@ -202,6 +207,13 @@ int solver_alloc(Solver &S)
 	S.npanels = (int)((S.cols + 63) / 64);
 	S.maxr = std::min(S.rows, S.cols);
 	S.impl = pick_update();
+	S.ntiles = (S.wt + TW - 1) / TW;
+	if (!S.M) HIPCHK(hipMalloc(&S.M, sizeof(u64) * S.ntiles * TW * std::max<i64>(1, S.rows)));
+	if (S.src && S.rows > 0) {
+		const i64 threads = S.ntiles * S.rows * 8;
+		k_to_tiled<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, S.sA>>>(S.src, S.stride, S.rows, S.ntiles,
+		                                                                             std::min(S.wt, S.stride), S.M);
+	}
 	const int G = S.impl->G;
 	S.nblocks = (S.npanels + G - 1) / G;
 	S.units = (int)std::min<i64>(256, std::max<i64>(1, (S.rows + 255) / 256));
@@ -255,7 +267,7 @@ int launch_trsm(Solver &S, hipStream_t st, int j0, int gb, int wlo, int tile_beg
 		HIPCHK(hipFuncSetAttribute((const void *)k_block_trsm<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, trsm_lds));
 		trsm_attr[S.device] = true;
 	}
-	k_block_trsm<TW><<<dim3(ntiles), dim3(1024), trsm_lds, st>>>(S.M, S.stride, j0, gb, wlo, tile_begin, S.panels, S.aux);
+	k_block_trsm<TW><<<dim3(ntiles), dim3(1024), trsm_lds, st>>>(S.M, S.rows, j0, gb, wlo, tile_begin, S.panels, S.aux);
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
@@ -269,7 +281,7 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 		HIPCHK(hipEventRecord(ka, st));
 	}
 	const int ns = pick_nsplit(S.rows, ntiles);
-	HIPCHK(S.impl->update(dim3((unsigned)(ntiles * ns)), st, S.M, S.stride, S.rows, j0, gb, wlo, S.panels, S.aux, mset,
+	HIPCHK(S.impl->update(dim3((unsigned)(ntiles * ns)), st, S.M, S.rows, j0, gb, wlo, S.panels, S.aux, mset,
 	                      S.blk_first + b, tile_begin, ntiles, ns));
 	if (S.time_kernels) HIPCHK(hipEventRecord(kb, st));
 	return GF2BV_OK;
@@ -285,13 +297,13 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 int enqueue_forward(Solver &S)
 {
 	const int G = S.impl->G;
-	const int tiles_total = (int)((S.wt + TW - 1) / TW);
+	const int tiles_total = (int)S.ntiles;
 	const unsigned row_blocks = (unsigned)((S.rows + 255) / 256);
 	HIPCHK(hipEventRecord(S.ev0, S.sA));
 	HIPCHK(hipStreamWaitEvent(S.sB, S.ev0, 0));     // sB starts after the setup memsets on sA
 	if (S.npanels > 0) {
 		const int g0 = std::min(G, S.npanels);
-		k_win_gather<<<dim3((unsigned)((S.rows * g0 + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.stride, S.rows, 0, g0, S.Wb);
+		k_win_gather<<<dim3((unsigned)((S.rows * g0 + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.rows, 0, g0, S.Wb);
 	}
 	for (int b = 0; b < S.nblocks; b++) {
 		const int j0 = b * G;
@@ -305,13 +317,13 @@ int enqueue_forward(Solver &S)
 			const u64 colmask = (S.cols - c0 >= 64) ? ~0ull : ((1ull << (S.cols - c0)) - 1);
 			k_find<<<dim3((S.units + 3) / 4), dim3(256), 0, S.sA>>>(S.Wb, S.rows, j, g, colmask, S.st, S.alive, S.fu,
 			                                                       S.units, S.panels, S.aux, S.pivcol, S.urow, mset);
-			k_narrow<<<dim3(row_blocks), dim3(256), 0, S.sA>>>(S.M, S.stride, S.rows, j0, g, gb, S.Wb, S.alive,
+			k_narrow<<<dim3(row_blocks), dim3(256), 0, S.sA>>>(S.M, S.rows, j0, g, gb, S.Wb, S.alive,
 			                                                 S.panels, S.aux, mset);
 		}
 		// snapshot of the alive lower bound for the bulk update of this block
 		HIPCHK(hipMemcpyAsync(S.blk_first + b, &S.st->first, sizeof(int), hipMemcpyDeviceToDevice, S.sA));
 		if (b == S.nblocks - 1)
-			k_win_scatter<<<dim3((unsigned)((S.rows * gb + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.stride, S.rows, j0, gb, S.Wb, S.alive);
+			k_win_scatter<<<dim3((unsigned)((S.rows * gb + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.rows, j0, gb, S.Wb, S.alive);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(S.evA[b], S.sA));
 		if (S.dbg_sync & 1) HIPCHK(hipDeviceSynchronize());
@@ -343,7 +355,7 @@ int enqueue_forward(Solver &S)
 				rc = launch_update_timed(S, S.sA, b, j0, gb, wlo, mset, tb, nprio);
 				if (rc) return rc;
 			}
-			k_win_gather<<<dim3((unsigned)((S.rows * gnext + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.stride, S.rows, wlo,
+			k_win_gather<<<dim3((unsigned)((S.rows * gnext + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.rows, wlo,
 			                                                                                     std::max(gnext, 1), S.Wb);
 		}
 	}
@@ -352,7 +364,7 @@ int enqueue_forward(Solver &S)
 	HIPCHK(hipStreamWaitEvent(S.sA, S.ev3, 0));
 	{
 		int g = (int)std::min<i64>(1024, (S.rows + 255) / 256);
-		k_check_rhs<<<dim3(g), dim3(256), 0, S.sA>>>(S.M, S.stride, S.rows, S.cols, S.alive, S.st);
+		k_check_rhs<<<dim3(g), dim3(256), 0, S.sA>>>(S.M, S.rows, S.cols, S.alive, S.st);
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(S.ev1, S.sA));
@@ -375,13 +387,13 @@ int enqueue_backward(Solver &S, const std::vector<int> &ycols_host)
 	const int rpb = 2048;
 	if (S.maxr > 0) {
 		i64 waves = S.maxr * nyw;
-		k_extract_y<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, S.sA>>>(S.M, S.stride, S.st, S.urow, S.pivcol,
+		k_extract_y<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, S.sA>>>(S.M, S.rows, S.st, S.urow, S.pivcol,
 		                                                                      S.ycols, S.ny, S.Y, S.ys);
 		const int ytiles = (int)(S.ys / YTW);
 		for (int q = S.npanels - 1; q >= 1; q--) {
 			const i64 bound = std::min<i64>((i64)64 * q, S.maxr);      // pivots before panel q
 			int g = (int)std::min<i64>(1024, (bound + 255) / 256);
-			k_gather_mult_u<<<dim3(g), dim3(256), 0, S.sA>>>(S.M, S.stride, q, S.panels + q, S.urow, bmult);
+			k_gather_mult_u<<<dim3(g), dim3(256), 0, S.sA>>>(S.M, S.rows, q, S.panels + q, S.urow, bmult);
 			const i64 nrb = (bound + rpb - 1) / rpb;
 			HIPCHK(launch_ysweep(dim3((unsigned)(ytiles * nrb)), S.sA, S.Y, S.ys, S.maxr, S.panels + q, bmult, ytiles, rpb));
 		}
@@ -534,15 +546,15 @@ int gf2bv_solve_device(void *d_aug, int64_t rows, int64_t cols, int64_t stride_w
 	*out = nullptr;
 	int rc = check_shape(rows, cols, mode);
 	if (rc) return rc;
-	if (stride_words % 16 != 0 || stride_words < (cols + 1 + 63) / 64 || ((uintptr_t)d_aug & 15))
-		return fail(GF2BV_ERR_ARG, "device matrix needs 16-byte alignment and stride_words % 16 == 0 covering cols+1 bits");
+	if (stride_words % 2 != 0 || stride_words < (cols + 1 + 63) / 64 || ((uintptr_t)d_aug & 15))
+		return fail(GF2BV_ERR_ARG, "device matrix needs 16-byte alignment and an even stride_words covering cols+1 bits");
 	rc = check_device(device);
 	if (rc) return rc;
 	Solver S;
 	S.t_begin = std::chrono::steady_clock::now();
 	S.device = device;
 	S.sA = (hipStream_t)stream;
-	S.M = (u64 *)d_aug;
+	S.src = (const u64 *)d_aug;
 	S.rows = rows; S.cols = cols; S.stride = stride_words; S.mode = mode;
 	S.time_kernels = time_kernels != 0;
 	rc = solver_enqueue(S);
@@ -557,13 +569,13 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 	for (i64 s = 0; s < nsys; s++) out[s] = nullptr;
 	int rc = check_shape(rows, cols, mode);
 	if (rc) return rc;
-	if (stride_words % 16 != 0 || stride_words < (cols + 1 + 63) / 64 || sys_stride_words < rows * stride_words ||
+	if (stride_words % 2 != 0 || stride_words < (cols + 1 + 63) / 64 || sys_stride_words < rows * stride_words ||
 	    ((uintptr_t)d_aug & 15) || (sys_stride_words & 1))
 		return fail(GF2BV_ERR_ARG, "bad batch layout");
 	rc = check_device(device);
 	if (rc) return rc;
-	// independent systems: a few in flight on their own streams so one system's
-	// latency-bound panel steps overlap another system's sweeps
+	// independent systems: a few in flight on their own stream pairs so one system's
+	// latency-bound panel path overlaps another system's bulk updates
 	const int NS = (int)std::min<i64>(nsys, 4);
 	std::vector<hipStream_t> streams(NS);
 	for (int i = 0; i < NS; i++) HIPCHK(hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking));
@@ -576,7 +588,7 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 			S.t_begin = std::chrono::steady_clock::now();
 			S.device = device;
 			S.sA = streams[i];
-			S.M = (u64 *)d_aug + (s0 + i) * sys_stride_words;
+			S.src = (const u64 *)d_aug + (s0 + i) * sys_stride_words;
 			S.rows = rows; S.cols = cols; S.stride = stride_words; S.mode = mode;
 			result = solver_enqueue(S);
 		}
@@ -604,19 +616,16 @@ int gf2bv_solve_words(const uint64_t *aug, int64_t rows, int64_t cols, int64_t s
 	HIPCHK(hipStreamCreateWithFlags(&S.sA, hipStreamNonBlocking));
 	S.own_sA = true;
 	S.rows = rows; S.cols = cols; S.mode = mode;
-	S.stride = round_up(wt, 32);
-	HIPCHK(hipMalloc(&S.M, sizeof(u64) * std::max<i64>(1, rows) * S.stride));
-	S.own_M = true;
+	S.stride = wt;
+	HIPCHK(hipMalloc(&S.tmp_src, sizeof(u64) * std::max<i64>(1, rows) * S.stride));
+	S.src = S.tmp_src;
 	hipEvent_t p0, p1;
 	HIPCHK(hipEventCreate(&p0)); HIPCHK(hipEventCreate(&p1));
 	HIPCHK(hipEventRecord(p0, S.sA));
-	HIPCHK(hipMemsetAsync(S.M, 0, sizeof(u64) * std::max<i64>(1, rows) * S.stride, S.sA));
 	if (rows > 0)
-		HIPCHK(hipMemcpy2DAsync(S.M, S.stride * 8, aug, stride_words * 8, wt * 8, rows, hipMemcpyHostToDevice, S.sA));
-	// bits above column `cols` are ignored by the reference (_internal.c:414): they can only sit
-	// in the last data word and are never used as pivots (colmask) nor exported; the RHS bit is
-	// read at exactly column `cols`.  A stray high bit could still leak through XORs into rows'
-	// tails, which nobody reads.  Nothing to mask.
+		HIPCHK(hipMemcpy2DAsync(S.tmp_src, S.stride * 8, aug, stride_words * 8, wt * 8, rows, hipMemcpyHostToDevice, S.sA));
+	// bits above column `cols` are ignored by the reference (_internal.c:414): they are never
+	// pivot candidates (colmask), never exported, and the RHS is read at exactly column `cols`.
 	HIPCHK(hipEventRecord(p1, S.sA));
 	rc = solver_enqueue(S);
 	if (rc == GF2BV_OK) {
@@ -645,9 +654,9 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 	S.own_sA = true;
 	S.rows = rows; S.cols = cols; S.mode = mode;
 	const i64 wt = (cols + 1 + 63) / 64;
-	S.stride = round_up(wt, 32);
-	HIPCHK(hipMalloc(&S.M, sizeof(u64) * std::max<i64>(1, rows) * S.stride));
-	S.own_M = true;
+	const i64 ntiles = (wt + TW - 1) / TW;
+	S.stride = ntiles * TW;
+	HIPCHK(hipMalloc(&S.M, sizeof(u64) * ntiles * TW * std::max<i64>(1, rows)));     // packed straight into tiles
 	const i64 ndig = digit_off[rows];
 	uint32_t *d_dig = nullptr;
 	i64 *d_off = nullptr;
@@ -659,9 +668,10 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 	if (ndig) HIPCHK(hipMemcpyAsync(d_dig, digits, sizeof(uint32_t) * ndig, hipMemcpyHostToDevice, S.sA));
 	HIPCHK(hipMemcpyAsync(d_off, digit_off, sizeof(i64) * (rows + 1), hipMemcpyHostToDevice, S.sA));
 	{
-		i64 total = rows * S.stride;
-		hipLaunchKernelGGL(k_pack_digits, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S.sA,
-		                   d_dig, d_off, bits_per_digit, (i64)rows, (i64)cols, S.stride, S.M);
+		i64 total = rows * ntiles * TW;
+		if (total > 0)
+			k_pack_digits<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S.sA>>>(d_dig, d_off, bits_per_digit, (i64)rows,
+			                                                                            (i64)cols, ntiles * TW, S.M);
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(p1, S.sA));

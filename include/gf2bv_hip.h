@@ -81,10 +81,10 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 int gf2bv_solve_words(const uint64_t *aug, int64_t rows, int64_t cols, int64_t stride_words,
                       int mode, int device, gf2bv_result **out);
 
-/* Same, matrix resident in DEVICE memory; eliminated IN PLACE (contents destroyed).
- * d_aug must be 16-byte aligned and stride_words a multiple of 16 (128-byte rows), so row
- * segments map onto whole wavefront lane groups.  `stream` is a hipStream_t or NULL.
- * `time_kernels` != 0 brackets every sweep launch with HIP events (fills ms_sweep). */
+/* Same, matrix resident in DEVICE memory (row-major augmented words, left untouched: the solver
+ * first copies it into its own tile-major working layout, one extra pass over the matrix).
+ * d_aug must be 16-byte aligned and stride_words even.  `stream` is a hipStream_t or NULL.
+ * `time_kernels` != 0 brackets every bulk-update launch with HIP events (fills ms_sweep). */
 int gf2bv_solve_device(void *d_aug, int64_t rows, int64_t cols, int64_t stride_words,
                        int mode, int device, void *stream, int time_kernels, gf2bv_result **out);
 
