@@ -481,6 +481,22 @@ struct Fields {
 		return 2 * m < NBIG ? m * (1 << (LO + 1)) : (NBIG / 2) * (1 << (LO + 1)) + (m - NBIG / 2) * (1 << LO);
 	}
 	static constexpr int SLOTS = (NBIG / 2) * (1 << (LO + 1)) + ((T - NBIG) / 2) * (1 << LO);   // per panel
+	// bits of the FIRST field of every wide / narrow pair (to swap the two fields of each pair)
+	__host__ __device__ static constexpr u64 first_fields(bool wide)
+	{
+		u64 r = 0;
+		for (int m = 0; m < T / 2; m++) {
+			const bool is_wide = 2 * m < NBIG;
+			if (is_wide == wide) r |= ((1ull << width(2 * m)) - 1) << shift(2 * m);
+		}
+		return r;
+	}
+	// exchange the two fields of every pair
+	__host__ __device__ static constexpr u64 swap_pairs(u64 m)
+	{
+		constexpr u64 A1 = first_fields(true), A2 = first_fields(false);
+		return ((m & A1) << (LO + 1)) | ((m >> (LO + 1)) & A1) | ((m & A2) << LO) | ((m >> LO) & A2);
+	}
 };
 
 // The bulk update of one block on a set of column tiles:
@@ -592,55 +608,84 @@ k_update(u64 *__restrict__ M, i64 rows, int j0, int gb, int wlo,
 	}
 
 	// ---- stream the rows ----
+	// Per lane: U rows are prefetched (multipliers + 16-byte data), then handled one after the other;
+	// for each row and panel the table reads are issued in batches of 8 ds_read_b128 before the
+	// first XOR so the LDS latency overlaps, and three-input XORs (v_bitop3) fold two entries at once.
+	// Odd rows use the multiplier with the two fields of every pair exchanged: "first read of pair m"
+	// then needs no per-lookup select between the fields.
 	uint4 *Mw = reinterpret_cast<uint4 *>(M) + tile * rows * LPR;
-	const int rp = rr & 1;                          // row parity inside the wavefront
-	const int c1 = rp * LPR + lr;                   // even rows: low half first; odd rows: high half first
-	const int c2 = (1 - rp) * LPR + lr;
-	constexpr int U = 4;
-	for (i64 base = rbeg; base < rend; base += (i64)RPP * U) {
-		u64 m[U][G];
-		uint4 d[U];
-		i64 q[U];
-		bool on[U];
+	const bool odd = rr & 1;                        // row parity inside the wavefront
+	const int c1 = (odd ? LPR : 0) + lr;            // first read of a pair: even rows low half, odd rows high half
+	const int c2 = (odd ? 0 : LPR) + lr;
+	constexpr int U = 2;                            // rows per lane per half-batch
+	constexpr int NP = T / 2;                       // pairs per panel
+	constexpr int BATCH = 4;                        // pairs per batch -> 8 reads in flight
+	// Software pipeline over half-batches of U rows per lane: the global loads (multipliers + data)
+	// of half-batch h+1 are issued before half-batch h is computed and stored, so every wavefront
+	// always has HBM requests in flight while it works through its LDS lookups.
+	struct Half { u64 m[U][G]; uint4 d[U]; i64 q[U]; bool on[U]; };
+	auto load_half = [&](Half &H, i64 base) {
 #pragma unroll
 		for (int u = 0; u < U; u++) {
 			const i64 row = base + (i64)u * RPP + rr;
 			u64 any = 0;
 #pragma unroll
 			for (int g = 0; g < G; g++) {
-				m[u][g] = (row < rend && g < gb) ? multset[(i64)g * rows + row] : 0ull;
-				any |= m[u][g];
+				const u64 v = (row < rend && g < gb) ? multset[(i64)g * rows + row] : 0ull;
+				any |= v;
+				H.m[u][g] = v;
 			}
-			on[u] = any != 0;
-			q[u] = row * LPR + lr;
+			H.on[u] = any != 0;
+			H.q[u] = row * LPR + lr;
 		}
 #pragma unroll
 		for (int u = 0; u < U; u++)
-			if (on[u]) d[u] = Mw[q[u]];
+			if (H.on[u]) H.d[u] = Mw[H.q[u]];
+	};
+	auto compute_half = [&](Half &H) {
 #pragma unroll
 		for (int u = 0; u < U; u++) {
-			if (!on[u]) continue;
-			uint4 acc = d[u];
+			if (!H.on[u]) continue;
+			uint4 acc = H.d[u];
 #pragma unroll
 			for (int g = 0; g < G; g++) {
 				if (g >= gb) break;                 // tables of absent panels were never built (uniform branch)
-				const unsigned mlo = (unsigned)m[u][g], mhi = (unsigned)(m[u][g] >> 32);
+				const u64 me = odd ? F::swap_pairs(H.m[u][g]) : H.m[u][g];
+				const unsigned mlo = (unsigned)me, mhi = (unsigned)(me >> 32);
 #pragma unroll
-				for (int pm = 0; pm < T / 2; pm++) {
-					constexpr int dummy = 0; (void)dummy;
-					const int sa = F::shift(2 * pm), sb = F::shift(2 * pm + 1), wd = F::width(2 * pm);
-					const unsigned fa = (sa >= 32 ? (mhi >> (sa - 32)) : (sa + wd <= 32 ? (mlo >> sa) : __builtin_amdgcn_alignbit(mhi, mlo, sa))) & ((1u << wd) - 1);
-					const unsigned fb = (sb >= 32 ? (mhi >> (sb - 32)) : (sb + wd <= 32 ? (mlo >> sb) : __builtin_amdgcn_alignbit(mhi, mlo, sb))) & ((1u << wd) - 1);
-					const unsigned i1 = rp ? fb : fa;
-					const unsigned i2 = rp ? fa : fb;
-					const int slot0 = (g * SLOTS + F::pairoff(pm)) * 2 * LPR;
-					const uint4 v1 = tab[slot0 + i1 * 2 * LPR + c1];
-					const uint4 v2 = tab[slot0 + i2 * 2 * LPR + c2];
-					acc.x ^= v1.x ^ v2.x; acc.y ^= v1.y ^ v2.y; acc.z ^= v1.z ^ v2.z; acc.w ^= v1.w ^ v2.w;
+				for (int p0 = 0; p0 < NP; p0 += BATCH) {
+					uint4 v[2 * BATCH];
+#pragma unroll
+					for (int h = 0; h < BATCH; h++) {
+						const int pm = p0 + h;
+						if (pm >= NP) { v[2 * h] = make_uint4(0, 0, 0, 0); v[2 * h + 1] = make_uint4(0, 0, 0, 0); continue; }
+						const int sa = F::shift(2 * pm), sb = F::shift(2 * pm + 1), wd = F::width(2 * pm);
+						const unsigned fa = (sa >= 32 ? (mhi >> (sa - 32)) : (sa + wd <= 32 ? (mlo >> sa) : __builtin_amdgcn_alignbit(mhi, mlo, sa))) & ((1u << wd) - 1);
+						const unsigned fb = (sb >= 32 ? (mhi >> (sb - 32)) : (sb + wd <= 32 ? (mlo >> sb) : __builtin_amdgcn_alignbit(mhi, mlo, sb))) & ((1u << wd) - 1);
+						const int slot0 = (g * SLOTS + F::pairoff(pm)) * 2 * LPR;
+						v[2 * h] = tab[slot0 + fa * 2 * LPR + c1];
+						v[2 * h + 1] = tab[slot0 + fb * 2 * LPR + c2];
+					}
+#pragma unroll
+					for (int h = 0; h < BATCH; h++) {
+						acc.x = __builtin_amdgcn_bitop3_b32(acc.x, v[2 * h].x, v[2 * h + 1].x, 0x96);
+						acc.y = __builtin_amdgcn_bitop3_b32(acc.y, v[2 * h].y, v[2 * h + 1].y, 0x96);
+						acc.z = __builtin_amdgcn_bitop3_b32(acc.z, v[2 * h].z, v[2 * h + 1].z, 0x96);
+						acc.w = __builtin_amdgcn_bitop3_b32(acc.w, v[2 * h].w, v[2 * h + 1].w, 0x96);
+					}
 				}
 			}
-			Mw[q[u]] = acc;
+			Mw[H.q[u]] = acc;
 		}
+	};
+	constexpr i64 STEP = (i64)RPP * U;
+	Half A, B;
+	load_half(A, rbeg);
+	for (i64 base = rbeg; base < rend; base += 2 * STEP) {
+		load_half(B, base + STEP);                  // rows >= rend load nothing (on = false)
+		compute_half(A);
+		load_half(A, base + 2 * STEP);
+		compute_half(B);
 	}
 }
 
