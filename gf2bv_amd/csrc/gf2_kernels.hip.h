@@ -33,6 +33,9 @@ typedef long long i64;
 
 #define GF2_GMAX 4                // max panels per block
 #define GF2_TW 16                 // 64-bit words per column tile (128-byte row segments)
+#ifndef GF2_UROWS
+#define GF2_UROWS 2
+#endif
 
 // Working layout of the matrix in HBM: TILE-MAJOR.  Column tile c (words [16c, 16c+16)) of all
 // rows is one contiguous slab of rows x 128 bytes; inside the slab rows follow each other.  Every
@@ -40,10 +43,12 @@ typedef long long i64;
 // contiguous KiB and a workgroup streams a contiguous range -- whole-line, page-friendly HBM
 // traffic.  (With a row-major matrix the same kernel touched one 128-byte line every 4-32 KiB and
 // rocprofv3 showed 2.5x / 4x the algorithmic FETCH / WRITE bytes.)  The C ABI stays row-major;
-// k_to_tiled / k_pack_digits convert on the way in.
-__device__ __forceinline__ long long tidx(long long row, long long word, long long rows)
+// k_to_tiled / k_pack_digits convert on the way in.  A slab is `srows` rows long: rows rounded up
+// plus an odd number of 256-byte units, so that equal rows of neighbouring tiles (what concurrently
+// running workgroups touch) do not sit a power of two apart and camp on the same memory channels.
+__device__ __forceinline__ long long tidx(long long row, long long word, long long srows)
 {
-	return ((word >> 4) * rows + row) * GF2_TW + (word & 15);
+	return ((word >> 4) * srows + row) * GF2_TW + (word & 15);
 }
 
 // One record per 64-column panel, written by k_find.
@@ -96,7 +101,7 @@ __device__ __forceinline__ uint4 xor4(uint4 a, uint4 b) { return make_uint4(a.x 
 // One thread per output word.  Row r's int occupies digits[off[r]..off[r+1]); bit 0 is the
 // affine term (-> column `cols`), bit k the coefficient of variable k-1 (-> column k-1).
 __global__ void k_pack_digits(const uint32_t *__restrict__ digits, const i64 *__restrict__ off,
-                              int bpd, i64 rows, i64 cols, i64 wtot, u64 *__restrict__ M)
+                              int bpd, i64 rows, i64 cols, i64 wtot, i64 srows, u64 *__restrict__ M)
 {
 	i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
 	i64 r = g / wtot, w = g % wtot;
@@ -120,12 +125,12 @@ __global__ void k_pack_digits(const uint32_t *__restrict__ digits, const i64 *__
 		if (cols - c0 < 64) val &= (1ull << (cols - c0)) - 1;   // bits above `cols` are ignored
 	}
 	if (w == (cols >> 6) && nd > 0) val |= (u64)(d[0] & 1u) << (cols & 63);
-	M[tidx(r, w, rows)] = val;
+	M[tidx(r, w, srows)] = val;
 }
 
 // Row-major augmented words (the C ABI layout) -> tile-major working layout, 16 bytes per lane.
 __global__ void __launch_bounds__(256)
-k_to_tiled(const u64 *__restrict__ src, i64 stride, i64 rows, i64 ntiles, i64 wt, u64 *__restrict__ dst)
+k_to_tiled(const u64 *__restrict__ src, i64 stride, i64 rows, i64 ntiles, i64 wt, i64 srows, u64 *__restrict__ dst)
 {
 	const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;       // (tile, row, lr)
 	const int lr = (int)(t & 7);
@@ -135,8 +140,8 @@ k_to_tiled(const u64 *__restrict__ src, i64 stride, i64 rows, i64 ntiles, i64 wt
 	const i64 w = tile * GF2_TW + 2 * lr;
 	u64 a = (w < wt) ? src[row * stride + w] : 0ull;
 	u64 b = (w + 1 < wt) ? src[row * stride + w + 1] : 0ull;
-	dst[(tile * rows + row) * GF2_TW + 2 * lr] = a;
-	dst[(tile * rows + row) * GF2_TW + 2 * lr + 1] = b;
+	dst[(tile * srows + row) * GF2_TW + 2 * lr] = a;
+	dst[(tile * srows + row) * GF2_TW + 2 * lr + 1] = b;
 }
 
 // ==========================================================================================
@@ -145,25 +150,25 @@ k_to_tiled(const u64 *__restrict__ src, i64 stride, i64 rows, i64 ntiles, i64 wt
 
 // Wb[i][g] = M[i][j0+g]: the block's window, compact (G words per row).
 __global__ void __launch_bounds__(256)
-k_win_gather(const u64 *__restrict__ M, i64 rows, int j0, int gb, u64 *__restrict__ Wb)
+k_win_gather(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, u64 *__restrict__ Wb)
 {
 	const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
 	const i64 i = t / gb;
 	const int g = (int)(t % gb);
 	if (i >= rows) return;
-	Wb[i * GF2_GMAX + g] = M[tidx(i, j0 + g, rows)];
+	Wb[i * GF2_GMAX + g] = M[tidx(i, j0 + g, srows)];
 }
 
 // Alive rows get their window back (only needed for the final block: the RHS bit may live in it).
 __global__ void __launch_bounds__(256)
-k_win_scatter(u64 *__restrict__ M, i64 rows, int j0, int gb, const u64 *__restrict__ Wb,
+k_win_scatter(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, const u64 *__restrict__ Wb,
               const unsigned char *__restrict__ alive)
 {
 	const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
 	const i64 i = t / gb;
 	const int g = (int)(t % gb);
 	if (i >= rows || !alive[i]) return;
-	M[tidx(i, j0 + g, rows)] = Wb[i * GF2_GMAX + g];
+	M[tidx(i, j0 + g, srows)] = Wb[i * GF2_GMAX + g];
 }
 
 // Cross-workgroup scratch of k_find is exchanged with relaxed AGENT-scope atomics (write-through
@@ -345,7 +350,7 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 // stores them into the matrix; (ii) every alive row records its multiplier
 // mult_g[i] = Wb[i][g] & mask and XORs the selected pivot rows into its remaining window words.
 __global__ void __launch_bounds__(256)
-k_narrow(u64 *__restrict__ M, i64 rows, int j0, int g, int gb, u64 *__restrict__ Wb,
+k_narrow(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int g, int gb, u64 *__restrict__ Wb,
          const unsigned char *__restrict__ alive, const PanelRec *__restrict__ panels,
          const PanelAux *__restrict__ aux, u64 *__restrict__ multset)
 {
@@ -381,7 +386,7 @@ k_narrow(u64 *__restrict__ M, i64 rows, int j0, int g, int gb, u64 *__restrict__
 			u64 c = Cm[k], acc = 0;
 			while (c) { int sl = ctz64(c); c &= c - 1; acc ^= Sw[e][sl]; }
 			Pb[e][Bk[k]] = acc;
-			if (blockIdx.x == 0) M[tidx(A->slot_row[k], j0 + e, rows)] = acc;
+			if (blockIdx.x == 0) M[tidx(A->slot_row[k], j0 + e, srows)] = acc;
 		}
 	}
 	__syncthreads();
@@ -418,7 +423,7 @@ k_narrow(u64 *__restrict__ M, i64 rows, int j0, int g, int gb, u64 *__restrict__
 // and stores P_g[k] in place (physical row slot_row_g[k]), words >= wlo only.
 template <int TW>
 __global__ void __launch_bounds__(1024)
-k_block_trsm(u64 *__restrict__ M, i64 rows, int j0, int gb, int wlo, int tile_begin,
+k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int tile_begin,
              const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux)
 {
 	extern __shared__ __attribute__((aligned(16))) u64 lds64[];
@@ -426,7 +431,7 @@ k_block_trsm(u64 *__restrict__ M, i64 rows, int j0, int gb, int wlo, int tile_be
 	u64 *P = lds64 + GF2_GMAX * 64 * TW;     // [GMAX][64][TW]
 	const i64 tile = tile_begin + blockIdx.x;
 	const i64 w0 = tile * TW;
-	u64 *Mt = M + tile * rows * TW;            // this tile's slab: row r at Mt[r * TW ...]
+	u64 *Mt = M + tile * srows * TW;           // this tile's slab: row r at Mt[r * TW ...]
 	for (int g = 0; g < gb; g++) {
 		const int p = panels[j0 + g].p;
 		const PanelAux *A = aux + j0 + g;
@@ -528,7 +533,7 @@ struct UpdateCfg {
 
 template <int G, int T, int NT>
 __global__ void __launch_bounds__(NT)
-k_update(u64 *__restrict__ M, i64 rows, int j0, int gb, int wlo,
+k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
          const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
          const u64 *__restrict__ multset, const int *__restrict__ blk_first,
          int tile_begin, int ntiles, int nsplit)
@@ -553,7 +558,7 @@ k_update(u64 *__restrict__ M, i64 rows, int j0, int gb, int wlo,
 	const i64 rlo = *blk_first;
 	constexpr int ALIGN = RPP * 4;
 	i64 per = (rows - rlo + nsplit - 1) / nsplit;
-	per = (per + ALIGN - 1) / ALIGN * ALIGN;
+	per = (per + ALIGN - 1) / ALIGN * ALIGN + 2;      // +256 B: row ranges of different workgroups are not 2^k apart
 	const i64 rbeg = rlo + (i64)sp * per;
 	if (rbeg >= rows) return;
 	const i64 rend = (rbeg + per < rows) ? rbeg + per : rows;
@@ -568,7 +573,7 @@ k_update(u64 *__restrict__ M, i64 rows, int j0, int gb, int wlo,
 	// words below wlo belong to windows the panel path owns: their table slots stay zero
 	const uint4 keep = make_uint4((w0 + 2 * lr >= wlo) ? ~0u : 0u, (w0 + 2 * lr >= wlo) ? ~0u : 0u,
 	                              (w0 + 2 * lr + 1 >= wlo) ? ~0u : 0u, (w0 + 2 * lr + 1 >= wlo) ? ~0u : 0u);
-	const uint4 *Mq = reinterpret_cast<const uint4 *>(M) + tile * rows * LPR;     // this tile's slab, 8 x uint4 per row
+	const uint4 *Mq = reinterpret_cast<const uint4 *>(M) + tile * srows * LPR;    // this tile's slab, 8 x uint4 per row
 	// work item e = (panel g, table t, index idx); stage 1: indices with bits only in the low half or
 	// only in the high half of the field come straight from the (L2-resident) pivot rows;
 	// stage 2: low ^ high.
@@ -613,11 +618,11 @@ k_update(u64 *__restrict__ M, i64 rows, int j0, int gb, int wlo,
 	// first XOR so the LDS latency overlaps, and three-input XORs (v_bitop3) fold two entries at once.
 	// Odd rows use the multiplier with the two fields of every pair exchanged: "first read of pair m"
 	// then needs no per-lookup select between the fields.
-	uint4 *Mw = reinterpret_cast<uint4 *>(M) + tile * rows * LPR;
+	uint4 *Mw = reinterpret_cast<uint4 *>(M) + tile * srows * LPR;
 	const bool odd = rr & 1;                        // row parity inside the wavefront
 	const int c1 = (odd ? LPR : 0) + lr;            // first read of a pair: even rows low half, odd rows high half
 	const int c2 = (odd ? 0 : LPR) + lr;
-	constexpr int U = 2;                            // rows per lane per half-batch
+	constexpr int U = GF2_UROWS;                    // rows per lane per half-batch
 	constexpr int NP = T / 2;                       // pairs per panel
 	constexpr int BATCH = 4;                        // pairs per batch -> 8 reads in flight
 	// Software pipeline over half-batches of U rows per lane: the global loads (multipliers + data)
@@ -696,12 +701,12 @@ k_update(u64 *__restrict__ M, i64 rows, int j0, int gb, int wlo,
 // After forward elimination every alive row is zero in A; the system is consistent iff their
 // RHS bits are zero too (the check inside _mzd_pluq_solve_left, _internal.c:440).
 __global__ void __launch_bounds__(256)
-k_check_rhs(const u64 *__restrict__ M, i64 rows, i64 cols,
+k_check_rhs(const u64 *__restrict__ M, i64 rows, i64 srows, i64 cols,
             const unsigned char *__restrict__ alive, SolveState *__restrict__ st)
 {
 	int bad = 0;
 	for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (i64)gridDim.x * blockDim.x)
-		if (alive[i]) bad |= (int)((M[tidx(i, cols >> 6, rows)] >> (cols & 63)) & 1);
+		if (alive[i]) bad |= (int)((M[tidx(i, cols >> 6, srows)] >> (cols & 63)) & 1);
 	if (__ballot(bad) && (threadIdx.x & 63) == 0) st->inconsistent = 1;
 }
 
@@ -709,7 +714,7 @@ k_check_rhs(const u64 *__restrict__ M, i64 rows, i64 cols,
 // (the RHS column, plus the free columns when a kernel basis is wanted).  Pivot row k lives in
 // physical row urow[k]; its words left of its own panel are dead storage and read as 0.
 __global__ void __launch_bounds__(256)
-k_extract_y(const u64 *__restrict__ M, i64 rows, const SolveState *__restrict__ st,
+k_extract_y(const u64 *__restrict__ M, i64 srows, const SolveState *__restrict__ st,
             const int *__restrict__ urow, const int *__restrict__ pivcol,
             const int *__restrict__ ycols, int ny, u64 *__restrict__ Y, i64 ys)
 {
@@ -724,7 +729,7 @@ k_extract_y(const u64 *__restrict__ M, i64 rows, const SolveState *__restrict__ 
 	if (t < ny) {
 		const int c = ycols[t];
 		if ((c >> 6) >= (pivcol[k] >> 6))
-			bit = (int)((M[tidx(urow[k], c >> 6, rows)] >> (c & 63)) & 1);
+			bit = (int)((M[tidx(urow[k], c >> 6, srows)] >> (c & 63)) & 1);
 	}
 	const u64 w = __ballot(bit);
 	if (lane == 0) Y[k * ys + tw] = w;
@@ -733,7 +738,7 @@ k_extract_y(const u64 *__restrict__ M, i64 rows, const SolveState *__restrict__ 
 // Multipliers of the back-substitution step of panel q: for every earlier pivot k < start_q,
 // mult[k] = U[k][word j_q] & mask_q.
 __global__ void __launch_bounds__(256)
-k_gather_mult_u(const u64 *__restrict__ M, i64 rows, int j, const PanelRec *__restrict__ rec,
+k_gather_mult_u(const u64 *__restrict__ M, i64 srows, int j, const PanelRec *__restrict__ rec,
                 const int *__restrict__ urow, u64 *__restrict__ mult)
 {
 	const int p = rec->p;
@@ -741,7 +746,7 @@ k_gather_mult_u(const u64 *__restrict__ M, i64 rows, int j, const PanelRec *__re
 	const i64 hi = rec->start;
 	const u64 mask = rec->mask;
 	for (i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x; k < hi; k += (i64)gridDim.x * blockDim.x)
-		mult[k] = M[tidx(urow[k], j, rows)] & mask;
+		mult[k] = M[tidx(urow[k], j, srows)] & mask;
 }
 
 // Single-panel sweep over a row-major matrix whose pivot rows are contiguous

@@ -38,17 +38,19 @@ int fail(int code, const char *what, hipError_t e = hipSuccess)
 	} while (0)
 
 inline i64 round_up(i64 v, i64 m) { return (v + m - 1) / m * m; }
+// rows of one tile slab: slab bytes = 256 (mod 8192), so neighbouring tiles are skewed across channels
+inline i64 slab_rows(i64 rows) { return round_up(std::max<i64>(rows, 1), 64) + 2; }
 
 // ---- kernel configurations -----------------------------------------------------------------
 // Bulk update: G panels fused per HBM pass, T grease tables per panel (balanced bit-fields).
 struct UpdateImpl {
 	int G, T, lds_bytes, threads;
-	hipError_t (*update)(dim3, hipStream_t, u64 *, i64, int, int, int, const PanelRec *, const PanelAux *,
+	hipError_t (*update)(dim3, hipStream_t, u64 *, i64, i64, int, int, int, const PanelRec *, const PanelAux *,
 	                     const u64 *, const int *, int, int, int);
 };
 
 template <int G, int T, int NT>
-hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 rows, int j0, int gb, int wlo,
+hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows, int j0, int gb, int wlo,
                          const PanelRec *panels, const PanelAux *aux, const u64 *multset, const int *blk_first,
                          int tile_begin, int ntiles, int nsplit)
 {
@@ -62,7 +64,7 @@ hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 rows, int j0, int
 		if (e != hipSuccess) return e;
 		attr_set[dev] = true;
 	}
-	k_update<G, T, NT><<<grid, dim3(NT), lds, s>>>(M, rows, j0, gb, wlo, panels, aux, multset, blk_first,
+	k_update<G, T, NT><<<grid, dim3(NT), lds, s>>>(M, rows, srows, j0, gb, wlo, panels, aux, multset, blk_first,
 	                                               tile_begin, ntiles, nsplit);
 	return hipGetLastError();
 }
@@ -78,16 +80,21 @@ const UpdateImpl kUpdates[] = {
 	UPDATE_IMPL(1, 10, 1024),   // 1 panel, 10 lookups, 112 KiB
 	UPDATE_IMPL(1, 12, 1024),   // 1 panel, 12 lookups, 64 KiB
 	UPDATE_IMPL(1, 16, 1024),   // 1 panel, 16 lookups, 32 KiB
+	UPDATE_IMPL(3, 16, 512),    // 512-thread variants: two workgroups per CU when LDS allows
+	UPDATE_IMPL(2, 16, 512),
+	UPDATE_IMPL(2, 12, 512),
+	UPDATE_IMPL(1, 16, 512),
+	UPDATE_IMPL(1, 12, 512),
 };
 
 const UpdateImpl *pick_update()
 {
 	const UpdateImpl *chosen = &kUpdates[0];
-	if (const char *e = getenv("GF2BV_UPDATE")) {      // "GxT", e.g. 3x13
-		int g = 0, t = 0;
-		if (sscanf(e, "%dx%d", &g, &t) == 2)
+	if (const char *e = getenv("GF2BV_UPDATE")) {      // "GxT" or "GxTxTHREADS", e.g. 3x16 or 2x16x512
+		int g = 0, t = 0, nt = 1024;
+		if (sscanf(e, "%dx%dx%d", &g, &t, &nt) >= 2)
 			for (const UpdateImpl &c : kUpdates)
-				if (c.G == g && c.T == t) { chosen = &c; break; }
+				if (c.G == g && c.T == t && c.threads == nt) { chosen = &c; break; }
 	}
 	return chosen;
 }
@@ -123,7 +130,7 @@ struct Solver {
 	u64 *tmp_src = nullptr;       // row-major staging buffer when the input came from the host
 	u64 *Ybuf = nullptr;
 	i64 rows = 0, cols = 0, stride = 0;
-	i64 ntiles = 0;
+	i64 ntiles = 0, srows = 0;    // tiles, rows per tile slab (padded)
 	int mode = 0;
 	bool time_kernels = false;
 	int dbg_sync = 0;
@@ -208,11 +215,12 @@ int solver_alloc(Solver &S)
 	S.maxr = std::min(S.rows, S.cols);
 	S.impl = pick_update();
 	S.ntiles = (S.wt + TW - 1) / TW;
-	if (!S.M) HIPCHK(hipMalloc(&S.M, sizeof(u64) * S.ntiles * TW * std::max<i64>(1, S.rows)));
+	S.srows = slab_rows(S.rows);
+	if (!S.M) HIPCHK(hipMalloc(&S.M, sizeof(u64) * S.ntiles * TW * S.srows));
 	if (S.src && S.rows > 0) {
 		const i64 threads = S.ntiles * S.rows * 8;
 		k_to_tiled<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, S.sA>>>(S.src, S.stride, S.rows, S.ntiles,
-		                                                                             std::min(S.wt, S.stride), S.M);
+		                                                                             std::min(S.wt, S.stride), S.srows, S.M);
 	}
 	const int G = S.impl->G;
 	S.nblocks = (S.npanels + G - 1) / G;
@@ -267,7 +275,7 @@ int launch_trsm(Solver &S, hipStream_t st, int j0, int gb, int wlo, int tile_beg
 		HIPCHK(hipFuncSetAttribute((const void *)k_block_trsm<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, trsm_lds));
 		trsm_attr[S.device] = true;
 	}
-	k_block_trsm<TW><<<dim3(ntiles), dim3(1024), trsm_lds, st>>>(S.M, S.rows, j0, gb, wlo, tile_begin, S.panels, S.aux);
+	k_block_trsm<TW><<<dim3(ntiles), dim3(1024), trsm_lds, st>>>(S.M, S.srows, j0, gb, wlo, tile_begin, S.panels, S.aux);
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
@@ -281,7 +289,7 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 		HIPCHK(hipEventRecord(ka, st));
 	}
 	const int ns = pick_nsplit(S.rows, ntiles);
-	HIPCHK(S.impl->update(dim3((unsigned)(ntiles * ns)), st, S.M, S.rows, j0, gb, wlo, S.panels, S.aux, mset,
+	HIPCHK(S.impl->update(dim3((unsigned)(ntiles * ns)), st, S.M, S.rows, S.srows, j0, gb, wlo, S.panels, S.aux, mset,
 	                      S.blk_first + b, tile_begin, ntiles, ns));
 	if (S.time_kernels) HIPCHK(hipEventRecord(kb, st));
 	return GF2BV_OK;
@@ -303,7 +311,7 @@ int enqueue_forward(Solver &S)
 	HIPCHK(hipStreamWaitEvent(S.sB, S.ev0, 0));     // sB starts after the setup memsets on sA
 	if (S.npanels > 0) {
 		const int g0 = std::min(G, S.npanels);
-		k_win_gather<<<dim3((unsigned)((S.rows * g0 + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.rows, 0, g0, S.Wb);
+		k_win_gather<<<dim3((unsigned)((S.rows * g0 + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, 0, g0, S.Wb);
 	}
 	for (int b = 0; b < S.nblocks; b++) {
 		const int j0 = b * G;
@@ -317,13 +325,13 @@ int enqueue_forward(Solver &S)
 			const u64 colmask = (S.cols - c0 >= 64) ? ~0ull : ((1ull << (S.cols - c0)) - 1);
 			k_find<<<dim3((S.units + 3) / 4), dim3(256), 0, S.sA>>>(S.Wb, S.rows, j, g, colmask, S.st, S.alive, S.fu,
 			                                                       S.units, S.panels, S.aux, S.pivcol, S.urow, mset);
-			k_narrow<<<dim3(row_blocks), dim3(256), 0, S.sA>>>(S.M, S.rows, j0, g, gb, S.Wb, S.alive,
+			k_narrow<<<dim3(row_blocks), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, g, gb, S.Wb, S.alive,
 			                                                 S.panels, S.aux, mset);
 		}
 		// snapshot of the alive lower bound for the bulk update of this block
 		HIPCHK(hipMemcpyAsync(S.blk_first + b, &S.st->first, sizeof(int), hipMemcpyDeviceToDevice, S.sA));
 		if (b == S.nblocks - 1)
-			k_win_scatter<<<dim3((unsigned)((S.rows * gb + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.rows, j0, gb, S.Wb, S.alive);
+			k_win_scatter<<<dim3((unsigned)((S.rows * gb + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, gb, S.Wb, S.alive);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(S.evA[b], S.sA));
 		if (S.dbg_sync & 1) HIPCHK(hipDeviceSynchronize());
@@ -355,7 +363,7 @@ int enqueue_forward(Solver &S)
 				rc = launch_update_timed(S, S.sA, b, j0, gb, wlo, mset, tb, nprio);
 				if (rc) return rc;
 			}
-			k_win_gather<<<dim3((unsigned)((S.rows * gnext + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.rows, wlo,
+			k_win_gather<<<dim3((unsigned)((S.rows * gnext + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, wlo,
 			                                                                                     std::max(gnext, 1), S.Wb);
 		}
 	}
@@ -364,7 +372,7 @@ int enqueue_forward(Solver &S)
 	HIPCHK(hipStreamWaitEvent(S.sA, S.ev3, 0));
 	{
 		int g = (int)std::min<i64>(1024, (S.rows + 255) / 256);
-		k_check_rhs<<<dim3(g), dim3(256), 0, S.sA>>>(S.M, S.rows, S.cols, S.alive, S.st);
+		k_check_rhs<<<dim3(g), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, S.cols, S.alive, S.st);
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(S.ev1, S.sA));
@@ -387,13 +395,13 @@ int enqueue_backward(Solver &S, const std::vector<int> &ycols_host)
 	const int rpb = 2048;
 	if (S.maxr > 0) {
 		i64 waves = S.maxr * nyw;
-		k_extract_y<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, S.sA>>>(S.M, S.rows, S.st, S.urow, S.pivcol,
+		k_extract_y<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, S.sA>>>(S.M, S.srows, S.st, S.urow, S.pivcol,
 		                                                                      S.ycols, S.ny, S.Y, S.ys);
 		const int ytiles = (int)(S.ys / YTW);
 		for (int q = S.npanels - 1; q >= 1; q--) {
 			const i64 bound = std::min<i64>((i64)64 * q, S.maxr);      // pivots before panel q
 			int g = (int)std::min<i64>(1024, (bound + 255) / 256);
-			k_gather_mult_u<<<dim3(g), dim3(256), 0, S.sA>>>(S.M, S.rows, q, S.panels + q, S.urow, bmult);
+			k_gather_mult_u<<<dim3(g), dim3(256), 0, S.sA>>>(S.M, S.srows, q, S.panels + q, S.urow, bmult);
 			const i64 nrb = (bound + rpb - 1) / rpb;
 			HIPCHK(launch_ysweep(dim3((unsigned)(ytiles * nrb)), S.sA, S.Y, S.ys, S.maxr, S.panels + q, bmult, ytiles, rpb));
 		}
@@ -656,7 +664,7 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 	const i64 wt = (cols + 1 + 63) / 64;
 	const i64 ntiles = (wt + TW - 1) / TW;
 	S.stride = ntiles * TW;
-	HIPCHK(hipMalloc(&S.M, sizeof(u64) * ntiles * TW * std::max<i64>(1, rows)));     // packed straight into tiles
+	HIPCHK(hipMalloc(&S.M, sizeof(u64) * ntiles * TW * slab_rows(rows)));     // packed straight into tiles
 	const i64 ndig = digit_off[rows];
 	uint32_t *d_dig = nullptr;
 	i64 *d_off = nullptr;
@@ -671,7 +679,7 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 		i64 total = rows * ntiles * TW;
 		if (total > 0)
 			k_pack_digits<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S.sA>>>(d_dig, d_off, bits_per_digit, (i64)rows,
-			                                                                            (i64)cols, ntiles * TW, S.M);
+			                                                                            (i64)cols, ntiles * TW, slab_rows(rows), S.M);
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(p1, S.sA));
