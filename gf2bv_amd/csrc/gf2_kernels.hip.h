@@ -633,6 +633,11 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 #pragma unroll
 		for (int u = 0; u < U; u++) {
 			const i64 row = base + (i64)u * RPP + rr;
+			H.q[u] = row * LPR + lr;
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			const i64 row = base + (i64)u * RPP + rr;
 			u64 any = 0;
 #pragma unroll
 			for (int g = 0; g < G; g++) {
@@ -641,11 +646,13 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 				H.m[u][g] = v;
 			}
 			H.on[u] = any != 0;
-			H.q[u] = row * LPR + lr;
 		}
+		// the data load does NOT wait for the multipliers (no dependent second memory round trip):
+		// every row of the range is fetched; rows that turn out to have zero multipliers are
+		// simply not written back
 #pragma unroll
 		for (int u = 0; u < U; u++)
-			if (H.on[u]) H.d[u] = Mw[H.q[u]];
+			if (base + (i64)u * RPP + rr < rend) H.d[u] = Mw[H.q[u]];
 	};
 	auto compute_half = [&](Half &H) {
 #pragma unroll
@@ -708,6 +715,80 @@ k_check_rhs(const u64 *__restrict__ M, i64 rows, i64 srows, i64 cols,
 	for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (i64)gridDim.x * blockDim.x)
 		if (alive[i]) bad |= (int)((M[tidx(i, cols >> 6, srows)] >> (cols & 63)) & 1);
 	if (__ballot(bad) && (threadIdx.x & 63) == 0) st->inconsistent = 1;
+}
+
+// ---- single right-hand side (solve_one): blocked parity back-substitution --------------------
+// With every free variable 0, x[c_k] = y_k ^ parity( U[k][words right of k's panel] & X ), and the
+// pivot rows of one panel are mutually reduced, so a panel's 64 unknowns are independent of each
+// other.  Panels are handled in groups of GF2_BSG (from the last group to the first):
+//   k_bs_far : one wavefront per pivot row of the group, a coalesced dot product with the already
+//              solved part of X (all words right of the group) -- the full-chip, HBM-streaming part;
+//   k_bs_near: one workgroup walks the group's panels right to left inside the 16-word diagonal
+//              block (pre-loaded into registers, X of the group in LDS) and publishes X.
+// U is read exactly once overall.
+#define GF2_BSG 16
+
+__global__ void __launch_bounds__(256)
+k_bs_far(const u64 *__restrict__ M, i64 srows, i64 cols, int qa, int qb, const PanelRec *__restrict__ panels,
+         const int *__restrict__ urow, const u64 *__restrict__ X, unsigned char *__restrict__ accv)
+{
+	const int lane = threadIdx.x & 63;
+	const i64 wv = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const int kbeg = panels[qa].start;
+	const int kend = panels[qb - 1].start + panels[qb - 1].p;
+	const i64 k = kbeg + wv;
+	if (k >= kend) return;
+	const i64 row = urow[k];
+	const i64 cw = (cols + 63) >> 6;
+	u64 par = 0;
+	for (i64 w = qb + lane; w < cw; w += 64) par ^= M[tidx(row, w, srows)] & X[w];
+	int bit = __popcll(par) & 1;
+	bit = __popcll(__ballot(bit)) & 1;
+	const int y = (int)((M[tidx(row, cols >> 6, srows)] >> (cols & 63)) & 1);
+	if (lane == 0) accv[k] = (unsigned char)(bit ^ y);
+}
+
+__global__ void __launch_bounds__(1024)
+k_bs_near(const u64 *__restrict__ M, i64 srows, int qa, int qb, const PanelRec *__restrict__ panels,
+          const int *__restrict__ urow, const int *__restrict__ pivcol, u64 *__restrict__ X,
+          const unsigned char *__restrict__ accv)
+{
+	__shared__ u64 Xn[GF2_BSG];
+	const int t = threadIdx.x;
+	const int r = t >> 4, idx = t & 15;           // pivot r of a panel, word q+1+idx of its row
+	const int nb = qb - qa;
+	if (t < GF2_BSG) Xn[t] = 0;
+	u64 uw[GF2_BSG];
+	int kk[GF2_BSG];
+	unsigned char ac[GF2_BSG];
+#pragma unroll
+	for (int i = 0; i < GF2_BSG; i++) {
+		uw[i] = 0; kk[i] = -1; ac[i] = 0;
+		if (i < nb) {
+			const PanelRec rec = panels[qa + i];
+			if (r < rec.p) {
+				const int k = rec.start + r;
+				kk[i] = k;
+				const int w = qa + i + 1 + idx;
+				if (w < qb) uw[i] = M[tidx(urow[k], w, srows)];
+				ac[i] = accv[k];
+			}
+		}
+	}
+	__syncthreads();
+#pragma unroll
+	for (int i = GF2_BSG - 1; i >= 0; i--) {
+		if (i >= nb) continue;                       // uniform
+		const int xi = i + 1 + idx;
+		const u64 xv = (xi < nb) ? Xn[xi] : 0ull;
+		const int bit = __popcll(uw[i] & xv) & 1;
+		const u64 bal = __ballot(bit);
+		const int rowpar = __popcll((bal >> ((threadIdx.x & 48))) & 0xFFFFull) & 1;   // my row's 16 lanes
+		if (idx == 0 && kk[i] >= 0 && ((rowpar ^ ac[i]) & 1))
+			atomicOr(&Xn[i], 1ull << (pivcol[kk[i]] & 63));
+		__syncthreads();
+	}
+	if (t < nb) X[qa + t] = Xn[t];
 }
 
 // Y[k][t] = U[k][ycols[t]] for pivot k < rank: the right-hand sides of the back-substitution

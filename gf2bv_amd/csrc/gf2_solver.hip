@@ -414,6 +414,24 @@ int enqueue_backward(Solver &S, const std::vector<int> &ycols_host)
 	return GF2BV_OK;
 }
 
+// solve_one: blocked parity back-substitution straight into the solution words (no Y matrix)
+int enqueue_backward_single(Solver &S)
+{
+	S.ny = 1;
+	HIPCHK(hipMalloc(&S.out, sizeof(u64) * std::max<i64>(1, S.cw)));
+	HIPCHK(hipMemsetAsync(S.out, 0, sizeof(u64) * std::max<i64>(1, S.cw), S.sA));
+	unsigned char *accv = reinterpret_cast<unsigned char *>(S.mult);     // forward multipliers are dead by now
+	for (int qb = S.npanels; qb > 0; qb -= GF2_BSG) {
+		const int qa = std::max(0, qb - GF2_BSG);
+		const int waves = (qb - qa) * 64;
+		k_bs_far<<<dim3((waves + 3) / 4), dim3(256), 0, S.sA>>>(S.M, S.srows, S.cols, qa, qb, S.panels, S.urow, S.out, accv);
+		k_bs_near<<<dim3(1), dim3(1024), 0, S.sA>>>(S.M, S.srows, qa, qb, S.panels, S.urow, S.pivcol, S.out, accv);
+	}
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(S.ev2, S.sA));
+	return GF2BV_OK;
+}
+
 int solver_enqueue(Solver &S)
 {
 	int rc = solver_alloc(S);
@@ -421,8 +439,11 @@ int solver_enqueue(Solver &S)
 	rc = enqueue_forward(S);
 	if (rc) return rc;
 	if (S.mode == GF2BV_MODE_SINGLE) {
-		std::vector<int> yc(1, (int)S.cols);
-		return enqueue_backward(S, yc);
+		if (getenv("GF2BV_YSWEEP")) {                  // the general multi-RHS path, for cross-checking
+			std::vector<int> yc(1, (int)S.cols);
+			return enqueue_backward(S, yc);
+		}
+		return enqueue_backward_single(S);
 	}
 	return GF2BV_OK;
 }

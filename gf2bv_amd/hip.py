@@ -15,7 +15,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgf2bv_hip.so")
+LIB_PATH = os.environ.get("GF2BV_LIB") or os.path.join(_HERE, "libgf2bv_hip.so")   # env override: kernel experiments
 
 MODE_SINGLE = 0
 MODE_AFFINE_SPACE = 1
