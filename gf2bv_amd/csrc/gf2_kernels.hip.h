@@ -232,6 +232,7 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
        PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol,
        int *__restrict__ urow, u64 *__restrict__ multset)
 {
+	__builtin_amdgcn_s_setprio(3);          // panel path = critical path: win issue arbitration against bulk-update waves
 	const int lane = threadIdx.x & 63;
 	const int u = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	if (u >= units) return;
@@ -276,17 +277,26 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 	if (old != (unsigned)(units - 1)) return;
 
 	// ---- last arriver: publish ----
+	// unit 0 scans the lowest rows: adopting it keeps the alive lower bound exact for free
 	int pick = -1;
-	for (int v = 0; v < units; v++)
-		if (GF2_LD(&fu[v].cnt) == full) { pick = v; break; }
+	if (full > 0) {
+		if (u == 0 && S.nslots == full) pick = 0;
+		else if (GF2_LD(&fu[0].cnt) == full) pick = 0;
+		else if (S.nslots == full) pick = u;
+		else
+			for (int v = 1; v < units; v++)
+				if (GF2_LD(&fu[v].cnt) == full) { pick = v; break; }
+	}
 	int new_first;
 	int srow;                                   // lane s: row of slot s
-	if (pick >= 0 && full > 0) {
-		S.have = GF2_LD(&fu[pick].have);
+	if (pick >= 0) {
+		if (pick != u) {
+			S.have = GF2_LD(&fu[pick].have);
+			S.bc = GF2_LD(&fu[pick].bc[lane]);
+		}
 		S.nslots = full;
 		srow = GF2_LD(&fu[pick].srow[lane]);
-		S.bc = GF2_LD(&fu[pick].bc[lane]);
-		new_first = (pick == 0) ? GF2_LD(&fu[0].first_nonsrc) : first;
+		new_first = (pick == 0) ? ((u == 0) ? first_nonsrc : GF2_LD(&fu[0].first_nonsrc)) : first;
 	} else {
 		// merge: rebuild one basis from all units' source rows (scratch: this unit's own srow list is
 		// dead by now, but other lists are still being read -> use the list of unit `units` (spare))
@@ -354,6 +364,7 @@ k_narrow(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int g, int gb, u64 *_
          const unsigned char *__restrict__ alive, const PanelRec *__restrict__ panels,
          const PanelAux *__restrict__ aux, u64 *__restrict__ multset)
 {
+	__builtin_amdgcn_s_setprio(3);
 	__shared__ u64 Sw[GF2_GMAX][64];     // window words of the source rows          [word][slot]
 	__shared__ u64 Pb[GF2_GMAX][64];     // reduced pivot rows' window words          [word][pivot BIT]
 	__shared__ u64 Cm[64];               // combination masks                         [pivot k]
@@ -421,53 +432,53 @@ k_narrow(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int g, int gb, u64 *_
 //   P_g[k] = XOR_{s in comb_g[k]} S_g[s]          (pivot rows of panel g)
 //   S_h[s] ^= XOR_{b in src_mult_h[s][g]} P_g[b]  (sources of later panels h > g were alive then)
 // and stores P_g[k] in place (physical row slot_row_g[k]), words >= wlo only.
-template <int TW>
-__global__ void __launch_bounds__(1024)
+// One workgroup handles WPW words of one tile (16/WPW workgroups per tile) so the whole chip
+// shares this short, latency-bound step.
+template <int TW, int WPW>
+__global__ void __launch_bounds__(64 * WPW)
 k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int tile_begin,
              const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux)
 {
-	extern __shared__ __attribute__((aligned(16))) u64 lds64[];
-	u64 *S = lds64;                          // [GMAX][64][TW]
-	u64 *P = lds64 + GF2_GMAX * 64 * TW;     // [GMAX][64][TW]
-	const i64 tile = tile_begin + blockIdx.x;
-	const i64 w0 = tile * TW;
-	u64 *Mt = M + tile * srows * TW;           // this tile's slab: row r at Mt[r * TW ...]
+	__builtin_amdgcn_s_setprio(2);
+	constexpr int NT = 64 * WPW;
+	constexpr int SPLIT = TW / WPW;
+	__shared__ u64 S[GF2_GMAX * 64 * WPW];     // [panel][slot][word]
+	__shared__ u64 P[GF2_GMAX * 64 * WPW];     // [panel][pivot][word]
+	const i64 tile = tile_begin + blockIdx.x / SPLIT;
+	const int wofs = (blockIdx.x % SPLIT) * WPW;
+	const i64 w0 = tile * TW + wofs;
+	u64 *Mt = M + tile * srows * TW + wofs;    // row r, word w of this workgroup's slice at Mt[r * TW + w]
+	const int r = threadIdx.x / WPW, w = threadIdx.x % WPW;    // one (row, word) item per thread
+	const bool live = w0 + w >= wlo;
 	for (int g = 0; g < gb; g++) {
 		const int p = panels[j0 + g].p;
-		const PanelAux *A = aux + j0 + g;
-		for (int t = threadIdx.x; t < p * TW; t += 1024) {
-			const int s = t / TW, w = t % TW;
-			S[(g * 64 + s) * TW + w] = (w0 + w >= wlo) ? Mt[(i64)A->slot_row[s] * TW + w] : 0ull;
-		}
+		S[(g * 64 + r) * WPW + w] = (r < p && live) ? Mt[(i64)aux[j0 + g].slot_row[r] * TW + w] : 0ull;
 	}
 	__syncthreads();
 	for (int g = 0; g < gb; g++) {
 		const PanelRec rec = panels[j0 + g];
 		const PanelAux *A = aux + j0 + g;
-		for (int t = threadIdx.x; t < rec.p * TW; t += 1024) {
-			const int k = t / TW, w = t % TW;
-			u64 c = A->comb[k], acc = 0;
-			while (c) { int s = ctz64(c); c &= c - 1; acc ^= S[(g * 64 + s) * TW + w]; }
-			P[(g * 64 + k) * TW + w] = acc;
-			if (w0 + w >= wlo) Mt[(i64)A->slot_row[k] * TW + w] = acc;
+		if (r < rec.p) {
+			u64 c = A->comb[r], acc = 0;
+			while (c) { int sl = ctz64(c); c &= c - 1; acc ^= S[(g * 64 + sl) * WPW + w]; }
+			P[(g * 64 + r) * WPW + w] = acc;
+			if (live) Mt[(i64)A->slot_row[r] * TW + w] = acc;
 		}
 		__syncthreads();
 		for (int h = g + 1; h < gb; h++) {
-			const int ph = panels[j0 + h].p;
-			const PanelAux *B = aux + j0 + h;
-			for (int t = threadIdx.x; t < ph * TW; t += 1024) {
-				const int s = t / TW, w = t % TW;
-				u64 m = B->src_mult[s][g], acc = 0;
+			if (r < panels[j0 + h].p) {
+				u64 m = aux[j0 + h].src_mult[r][g], acc = 0;
 				while (m) {
 					const int b = ctz64(m); m &= m - 1;
 					const int k = __popcll(rec.mask & ((1ull << b) - 1));
-					acc ^= P[(g * 64 + k) * TW + w];
+					acc ^= P[(g * 64 + k) * WPW + w];
 				}
-				S[(h * 64 + s) * TW + w] ^= acc;
+				S[(h * 64 + r) * WPW + w] ^= acc;
 			}
 		}
 		__syncthreads();
 	}
+	(void)NT;
 }
 
 // Balanced split of the 64 pivot bits of a panel into T bit-fields (grease tables).

@@ -227,7 +227,13 @@ int solver_alloc(Solver &S)
 	S.units = (int)std::min<i64>(256, std::max<i64>(1, (S.rows + 255) / 256));
 	if (const char *e = getenv("GF2BV_DEBUG_SYNC")) S.dbg_sync = atoi(e);
 	if (getenv("GF2BV_SERIAL")) { S.sB = S.sA; S.own_sB = false; }     // ablation: no look-ahead overlap
-	else { HIPCHK(hipStreamCreateWithFlags(&S.sB, hipStreamNonBlocking)); S.own_sB = true; }
+	else {
+		// the bulk path yields to the (latency-critical) panel path wherever both have work queued
+		int lo = 0, hi = 0;
+		(void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+		HIPCHK(hipStreamCreateWithPriority(&S.sB, hipStreamNonBlocking, lo));
+		S.own_sB = true;
+	}
 	HIPCHK(hipMalloc(&S.st, sizeof(SolveState)));
 	HIPCHK(hipMalloc(&S.panels, sizeof(PanelRec) * std::max(1, S.npanels)));
 	HIPCHK(hipMalloc(&S.aux, sizeof(PanelAux) * std::max(1, S.npanels)));
@@ -269,13 +275,9 @@ int pick_nsplit(i64 rows, int ntiles)
 
 int launch_trsm(Solver &S, hipStream_t st, int j0, int gb, int wlo, int tile_begin, int ntiles)
 {
-	constexpr int trsm_lds = 2 * GF2_GMAX * 64 * TW * 8;
-	static bool trsm_attr[16] = {};
-	if (S.device < 16 && !trsm_attr[S.device]) {
-		HIPCHK(hipFuncSetAttribute((const void *)k_block_trsm<TW>, hipFuncAttributeMaxDynamicSharedMemorySize, trsm_lds));
-		trsm_attr[S.device] = true;
-	}
-	k_block_trsm<TW><<<dim3(ntiles), dim3(1024), trsm_lds, st>>>(S.M, S.srows, j0, gb, wlo, tile_begin, S.panels, S.aux);
+	constexpr int WPW = 4;
+	k_block_trsm<TW, WPW><<<dim3(ntiles * (TW / WPW)), dim3(64 * WPW), 0, st>>>(S.M, S.srows, j0, gb, wlo, tile_begin,
+	                                                                           S.panels, S.aux);
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
