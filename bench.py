@@ -81,6 +81,18 @@ def cpu_baseline(n: int, seed: int) -> dict:
     }
 
 
+def pmc_traffic(n: int, g: int, t: int):
+    """HBM bytes per bulk-update pass from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
+    gfx950 note in MI355X_MICROARCH.md, WRITE_SIZE as is); None when no profile of this config is committed."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None
+    for rec in json.load(open(path)):
+        if rec["n"] == n and rec["G"] == g and rec["T"] == t:
+            return rec["hbm_bytes_per_pass"]
+    return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,19 +111,18 @@ def main():
     seed = args.seed if args.seed is not None else FULL_RANK_SEEDS.get(n, 1234)
     stride = hip.padded_stride(n)
     cw = (n + 63) // 64
-    total = args.steps + args.warmup
-    # every step gets its own pristine copy of the system (the solve is in place)
-    mats = [torch.empty(n * stride, dtype=torch.int64, device=dev) for _ in range(total)]
+    # the system lives in HBM before the timed region; the solver works on its own tile-major copy
+    # (the row-major -> tile-major pass is part of every timed step), so one pristine matrix suffices
+    mat = torch.empty(n * stride, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    for m in mats:
-        hip.synth_device(m.data_ptr(), n, n, stride, seed + rank, device=local_rank, stream=stream)
+    hip.synth_device(mat.data_ptr(), n, n, stride, seed + rank, device=local_rank, stream=stream)
     torch.cuda.synchronize(dev)
 
     sols = torch.zeros(args.steps, cw, dtype=torch.int64, device=dev)
     stats = []
 
     def step(i: int):
-        return hip.solve_device(mats[i].data_ptr(), n, n, stride, hip.MODE_SINGLE, device=local_rank,
+        return hip.solve_device(mat.data_ptr(), n, n, stride, hip.MODE_SINGLE, device=local_rank,
                                 stream=stream, time_kernels=not args.no_kernel_events)
 
     for i in range(args.warmup):
@@ -138,9 +149,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # correctness gate on this rank: residual of the last solution on a freshly generated copy
-    hip.synth_device(mats[0].data_ptr(), n, n, stride, seed + rank, device=local_rank, stream=stream)
-    bad = hip.residual_device(mats[0].data_ptr(), n, n, stride, stats[-1].origin, device=local_rank, stream=stream)
+    # correctness gate on this rank: A x = b on the untouched input, by the independent residual kernel
+    bad = hip.residual_device(mat.data_ptr(), n, n, stride, stats[-1].origin, device=local_rank, stream=stream)
     ok = torch.tensor([1 if (bad == 0 and all(s.solved for s in stats)) else 0], device=dev)
     row_xors_local = float(sum(s.stats["row_xors"] for s in stats))
     agg = torch.tensor([row_xors_local], dtype=torch.float64, device=dev)
@@ -155,13 +165,20 @@ def main():
         roofline = None
         if sweep_ms > 0:
             achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
+            g = s0["panels_per_sweep"]
+            ceil = hip.stream_ceiling(2 << 30, local_rank)
             roofline = {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                "kernel": f"k_sweep<K={s0['table_bits']},TW={s0['tile_words']}>",
-                "launches": n_sweeps,
-                "alg_bytes_per_launch": alg_bytes / max(n_sweeps, 1),
-                "avg_launch_ms": sweep_ms / max(n_sweeps, 1),
+                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, g, s0["tables_per_sweep"] // g),
+                "kernel": f"k_update<G={g},T={s0['tables_per_sweep'] // g}> (bulk update, {g} panels = {64 * g} pivots per pass)",
+                "passes": n_sweeps,
+                "alg_bytes_per_pass": alg_bytes / max(n_sweeps, 1),
+                "avg_pass_ms": sweep_ms / max(n_sweeps, 1),
+                # same-run practical ceilings of this device (plain streaming kernels, 2 GiB)
+                "measured_rmw_stream_GBs": ceil["rmw_gbs"], "measured_read_stream_GBs": ceil["read_gbs"],
+                "frac_of_measured_rmw": achieved / ceil["rmw_gbs"],
+                # one pass applies G panels: HBM rate a one-panel-per-pass sweep would need for the same wall time
+                "single_panel_equivalent_GBs": achieved * g,
             }
         out = {
             "metric": "GF(2) row-XORs/s (solve_one, dense NxN)", "value": float(agg.item()) / elapsed,

@@ -1018,3 +1018,29 @@ k_residual(const u64 *__restrict__ M, i64 rows, i64 cols, i64 stride, const u64 
 	const int rhs = (int)((M[r * stride + (cols >> 6)] >> (cols & 63)) & 1);
 	if (lane == 0 && lhs != rhs) atomicAdd(bad, 1ull);
 }
+
+// ------------------------------------------------------------------------------------------
+// Practical HBM ceiling of this device for the access pattern of the bulk update (bench only):
+// every workgroup owns a contiguous range and does an in-place 16-byte read-XOR-write stream.
+__global__ void __launch_bounds__(1024)
+k_rmw_stream(uint4 *__restrict__ a, i64 per_wg, unsigned c)
+{
+	uint4 *p = a + (i64)blockIdx.x * per_wg;
+	for (i64 i = threadIdx.x; i < per_wg; i += 2048) {
+		uint4 v0 = p[i], v1;
+		const bool two = i + 1024 < per_wg;
+		if (two) v1 = p[i + 1024];
+		v0.x ^= c; v0.y ^= c; v0.z ^= c; v0.w ^= c;
+		p[i] = v0;
+		if (two) { v1.x ^= c; v1.y ^= c; v1.z ^= c; v1.w ^= c; p[i + 1024] = v1; }
+	}
+}
+__global__ void __launch_bounds__(1024)
+k_read_stream(const uint4 *__restrict__ a, i64 per_wg, unsigned *__restrict__ sink)
+{
+	const uint4 *p = a + (i64)blockIdx.x * per_wg;
+	unsigned acc = 0;
+	for (i64 i = threadIdx.x; i < per_wg; i += 1024) { uint4 v = p[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+	if (acc == 0x9E3779B9u) sink[0] = acc;
+}
+

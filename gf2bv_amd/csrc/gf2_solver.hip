@@ -797,6 +797,42 @@ int gf2bv_residual_device(const void *d_aug, int64_t rows, int64_t cols, int64_t
 	return GF2BV_OK;
 }
 
+int gf2bv_stream_ceiling_device(int device, int64_t bytes, double *rmw_gbs, double *read_gbs)
+{
+	if (!rmw_gbs || !read_gbs || bytes < (1 << 20)) return fail(GF2BV_ERR_ARG, "bad ceiling request");
+	int rc = check_device(device);
+	if (rc) return rc;
+	const int wgs = 2048;
+	const i64 per = bytes / 16 / wgs;
+	uint4 *buf = nullptr;
+	unsigned *sink = nullptr;
+	hipError_t e = hipMalloc(&buf, (size_t)per * wgs * 16);
+	if (e != hipSuccess) return fail(GF2BV_ERR_NOMEM, "hipMalloc", e);
+	HIPCHK(hipMalloc(&sink, 64));
+	HIPCHK(hipMemset(buf, 1, (size_t)per * wgs * 16));
+	hipEvent_t e0, e1;
+	HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+	const int reps = 5;
+	float ms = 0;
+	k_rmw_stream<<<dim3(wgs), dim3(1024)>>>(buf, per, 5u);
+	HIPCHK(hipEventRecord(e0, nullptr));
+	for (int r = 0; r < reps; r++) k_rmw_stream<<<dim3(wgs), dim3(1024)>>>(buf, per, 5u);
+	HIPCHK(hipEventRecord(e1, nullptr));
+	HIPCHK(hipEventSynchronize(e1));
+	HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+	*rmw_gbs = 2.0 * (double)per * wgs * 16 * reps / (ms * 1e-3) / 1e9;
+	k_read_stream<<<dim3(wgs), dim3(1024)>>>(buf, per, sink);
+	HIPCHK(hipEventRecord(e0, nullptr));
+	for (int r = 0; r < reps; r++) k_read_stream<<<dim3(wgs), dim3(1024)>>>(buf, per, sink);
+	HIPCHK(hipEventRecord(e1, nullptr));
+	HIPCHK(hipEventSynchronize(e1));
+	HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+	*read_gbs = (double)per * wgs * 16 * reps / (ms * 1e-3) / 1e9;
+	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	(void)hipFree(buf); (void)hipFree(sink);
+	return GF2BV_OK;
+}
+
 int gf2bv_device_alloc(int device, int64_t bytes, void **d_ptr)
 {
 	if (!d_ptr || bytes < 0) return fail(GF2BV_ERR_ARG, "bad alloc request");

@@ -29,6 +29,7 @@ EXPORTS = [
     "gf2bv_result_status", "gf2bv_result_rank", "gf2bv_result_dimension", "gf2bv_result_words",
     "gf2bv_result_origin", "gf2bv_result_basis", "gf2bv_result_pivots", "gf2bv_result_stats",
     "gf2bv_result_free", "gf2bv_space_combine", "gf2bv_synth_device", "gf2bv_residual_device",
+    "gf2bv_stream_ceiling_device",
     "gf2bv_device_alloc", "gf2bv_device_free", "gf2bv_device_upload", "gf2bv_device_download",
 ]
 
@@ -82,6 +83,7 @@ def lib():
         L.gf2bv_space_combine.restype = None
         L.gf2bv_synth_device.argtypes = [vp, i64, i64, i64, ctypes.c_uint64, i32, vp]
         L.gf2bv_residual_device.argtypes = [vp, i64, i64, i64, vp, i32, vp, ctypes.POINTER(i64)]
+        L.gf2bv_stream_ceiling_device.argtypes = [i32, i64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.gf2bv_device_alloc.argtypes = [i32, i64, pp]
         L.gf2bv_device_free.argtypes = [i32, vp]
         L.gf2bv_device_upload.argtypes = [i32, vp, vp, i64]
@@ -197,6 +199,13 @@ def residual_device(d_ptr: int, rows: int, cols: int, stride: int, x: np.ndarray
     _check(lib().gf2bv_residual_device(d_ptr, rows, cols, stride, x.ctypes.data, device, stream or None,
                                        ctypes.byref(bad)))
     return int(bad.value)
+
+
+def stream_ceiling(nbytes: int = 2 << 30, device: int = 0) -> dict:
+    """Measured streaming rates of this GPU (GB/s): in-place read-XOR-write and read-only."""
+    rmw, rd = ctypes.c_double(0), ctypes.c_double(0)
+    _check(lib().gf2bv_stream_ceiling_device(device, nbytes, ctypes.byref(rmw), ctypes.byref(rd)))
+    return {"rmw_gbs": rmw.value, "read_gbs": rd.value}
 
 
 class DeviceBuffer:

@@ -124,6 +124,12 @@ int gf2bv_synth_device(void *d_aug, int64_t rows, int64_t cols, int64_t stride_w
 int gf2bv_residual_device(const void *d_aug, int64_t rows, int64_t cols, int64_t stride_words,
                           const uint64_t *x_words, int device, void *stream, int64_t *bad_rows);
 
+/* Practical HBM ceilings of this device, measured with plain streaming kernels on a scratch buffer of
+ * `bytes` bytes (use >= 1 GiB, well past the 256 MiB Infinity Cache): rmw_gbs = in-place 16-byte
+ * read-XOR-write (the access pattern of the bulk update; read + written bytes per second),
+ * read_gbs = read-only.  Reported by bench.py next to the 8 TB/s spec peak. */
+int gf2bv_stream_ceiling_device(int device, int64_t bytes, double *rmw_gbs, double *read_gbs);
+
 /* plain device buffer helpers so a host language without a HIP binding can stage data */
 int gf2bv_device_alloc(int device, int64_t bytes, void **d_ptr);
 int gf2bv_device_free(int device, void *d_ptr);
