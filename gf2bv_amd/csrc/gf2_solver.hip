@@ -71,8 +71,8 @@ hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows, 
 
 #define UPDATE_IMPL(G, T, NT) { G, T, UpdateCfg<G, T>::LDS_BYTES, NT, launch_update<G, T, NT> }
 const UpdateImpl kUpdates[] = {
-	UPDATE_IMPL(3, 16, 1024),   // default: 3 panels (192 pivots) per pass, 48 lookups, 96 KiB LDS
-	UPDATE_IMPL(4, 16, 1024),   // 4 panels, 64 lookups, 128 KiB
+	UPDATE_IMPL(4, 16, 1024),   // default: 4 panels (256 pivots) per pass, 64 lookups, 128 KiB LDS
+	UPDATE_IMPL(3, 16, 1024),   // 3 panels, 48 lookups, 96 KiB
 	UPDATE_IMPL(3, 14, 1024),   // 3 panels, 42 lookups, 132 KiB
 	UPDATE_IMPL(2, 12, 1024),   // 2 panels, 24 lookups, 128 KiB
 	UPDATE_IMPL(2, 14, 1024),   // 2 panels, 28 lookups, 88 KiB

@@ -115,7 +115,7 @@ static int64_t rref_m4rm(u64 *M, int64_t rows, int64_t cols, int64_t stride, int
 	int64_t r = 0;
 	u64 *tmp = (u64 *)malloc((size_t)64 * wt * sizeof(u64));
 	u64 *mult = (u64 *)malloc((size_t)rows * sizeof(u64));
-	u64 *tab = (u64 *)malloc((size_t)8 * 256 * TILE_WORDS * sizeof(u64));
+	u64 *tab = (u64 *)malloc((size_t)((wt + TILE_WORDS - 1) / TILE_WORDS) * 8 * 256 * TILE_WORDS * sizeof(u64));
 	double rx = 0, sw = 0;
 
 	for (int64_t j = 0; j < npanels && r < rows; j++) {
@@ -176,17 +176,19 @@ static int64_t rref_m4rm(u64 *M, int64_t rows, int64_t cols, int64_t stride, int
 		/* multipliers (snapshot before the sweep rewrites word j) */
 		for (int64_t i = 0; i < rows; i++)
 			mult[i] = (i >= r && i < r + p) ? 0 : (M[i * stride + j] & have);
-		/* sweep, column tile by column tile: the 8 x 256 grease tables of one tile (1 MiB) are
-		 * built by up to 8 threads and then shared read-only by all threads, which split the rows */
-		int64_t ntiles = (wt - j + TILE_WORDS - 1) / TILE_WORDS;
-		for (int64_t t = 0; t < ntiles; t++) {
-			int64_t w0 = j + t * TILE_WORDS;
-			int64_t tw = (wt - w0 < TILE_WORDS) ? (wt - w0) : TILE_WORDS;
+		/* sweep.  Tables: 8 groups x 256 entries over all active words, built tile by tile (TILE_WORDS
+		 * words) so a thread works on one cache-sized piece; then ONE parallel loop over the rows, each
+		 * row XORs its 8 table entries tile by tile.  Two parallel regions per panel. */
+		int64_t aw = wt - j;                              /* active words */
+		int64_t ntiles = (aw + TILE_WORDS - 1) / TILE_WORDS;
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static) if (tw >= 8)
+#pragma omp parallel for collapse(2) schedule(static)
 #endif
+		for (int64_t t = 0; t < ntiles; t++) {
 			for (int g = 0; g < 8; g++) {
-				u64 *T = tab + (size_t)g * 256 * TILE_WORDS;
+				int64_t w0 = j + t * TILE_WORDS;
+				int64_t tw = (wt - w0 < TILE_WORDS) ? (wt - w0) : TILE_WORDS;
+				u64 *T = tab + ((size_t)t * 8 + g) * 256 * TILE_WORDS;
 				memset(T, 0, (size_t)tw * sizeof(u64));
 				for (int l = 0; l < 8; l++) {
 					int b = 8 * g + l;
@@ -203,16 +205,20 @@ static int64_t rref_m4rm(u64 *M, int64_t rows, int64_t cols, int64_t stride, int
 					}
 				}
 			}
+		}
 #ifdef _OPENMP
-#pragma omp parallel for schedule(static) if (rows * tw >= 16384)
+#pragma omp parallel for schedule(static) if (rows * aw >= 32768)
 #endif
-			for (int64_t i = 0; i < rows; i++) {
-				u64 m = mult[i];
-				if (!m) continue;
+		for (int64_t i = 0; i < rows; i++) {
+			u64 m = mult[i];
+			if (!m) continue;
+			for (int64_t t = 0; t < ntiles; t++) {
+				int64_t w0 = j + t * TILE_WORDS;
+				int64_t tw = (wt - w0 < TILE_WORDS) ? (wt - w0) : TILE_WORDS;
 				u64 *row = M + i * stride + w0;
 				for (int g = 0; g < 8; g++) {
 					unsigned idx = (unsigned)((m >> (8 * g)) & 255);
-					if (idx) xor_words(row, tab + ((size_t)g * 256 + idx) * TILE_WORDS, tw);
+					if (idx) xor_words(row, tab + (((size_t)t * 8 + g) * 256 + idx) * TILE_WORDS, tw);
 				}
 			}
 		}
