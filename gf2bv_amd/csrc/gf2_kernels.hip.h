@@ -33,6 +33,9 @@ typedef long long i64;
 
 #define GF2_GMAX 4                // max panels per block
 #define GF2_TW 16                 // 64-bit words per column tile (128-byte row segments)
+#ifndef GF2_BATCH
+#define GF2_BATCH 4
+#endif
 #ifndef GF2_UROWS
 #define GF2_UROWS 2
 #endif
@@ -635,7 +638,7 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	const int c2 = (odd ? 0 : LPR) + lr;
 	constexpr int U = GF2_UROWS;                    // rows per lane per half-batch
 	constexpr int NP = T / 2;                       // pairs per panel
-	constexpr int BATCH = 4;                        // pairs per batch -> 8 reads in flight
+	constexpr int BATCH = GF2_BATCH;                // pairs per batch -> 2*BATCH reads in flight
 	// Software pipeline over half-batches of U rows per lane: the global loads (multipliers + data)
 	// of half-batch h+1 are issued before half-batch h is computed and stored, so every wavefront
 	// always has HBM requests in flight while it works through its LDS lookups.

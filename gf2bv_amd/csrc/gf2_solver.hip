@@ -15,8 +15,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -39,8 +42,121 @@ int fail(int code, const char *what, hipError_t e = hipSuccess)
 	} while (0)
 
 inline i64 round_up(i64 v, i64 m) { return (v + m - 1) / m * m; }
+
+struct Trace {
+	bool on = getenv("GF2BV_TRACE") != nullptr;
+	std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+	void mark(const char *what)
+	{
+		if (!on) return;
+		auto t = std::chrono::steady_clock::now();
+		fprintf(stderr, "[gf2bv trace] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t - t0).count());
+		t0 = t;
+	}
+};
 // rows of one tile slab: slab bytes = 256 (mod 8192), so neighbouring tiles are skewed across channels
 inline i64 slab_rows(i64 rows) { return round_up(std::max<i64>(rows, 1), 64) + 2; }
+
+
+// ---- resource pool -----------------------------------------------------------------------------
+// hipMalloc / hipFree / stream and event creation cost 0.1-1 ms each; a small solve (a few hundred
+// microseconds of GPU time) would spend 5+ ms in them.  Buffers up to 64 MiB (512 MiB in total per
+// process), streams and events are therefore recycled across calls.  Thread-safe; everything handed
+// out is idle (a solve releases its resources only after synchronising its streams).
+struct Pool {
+	std::mutex mu;
+	std::unordered_map<void *, std::pair<int, size_t>> live;          // ptr -> (device, bucket bytes)
+	std::map<std::pair<int, size_t>, std::vector<void *>> free_bufs;  // (device, bucket) -> buffers
+	size_t cached_bytes = 0;
+	std::map<std::pair<int, int>, std::vector<hipEvent_t>> events;   // (device, timing?) -> events
+	std::map<std::pair<int, int>, std::vector<hipStream_t>> streams;  // (device, low priority?) -> streams
+	static constexpr size_t kMaxBucket = (size_t)64 << 20, kMaxCached = (size_t)512 << 20;
+
+	static size_t bucket(size_t bytes)
+	{
+		size_t b = 4096;
+		while (b < bytes) b <<= 1;
+		return b;
+	}
+	hipError_t alloc(void **out, size_t bytes, int device)
+	{
+		bytes = std::max<size_t>(bytes, 16);
+		if (bytes > kMaxBucket) return hipMalloc(out, bytes);
+		const size_t b = bucket(bytes);
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			auto &v = free_bufs[{device, b}];
+			if (!v.empty()) {
+				*out = v.back(); v.pop_back(); cached_bytes -= b;
+				live[*out] = {device, b};
+				return hipSuccess;
+			}
+		}
+		hipError_t e = hipMalloc(out, b);
+		if (e == hipSuccess) { std::lock_guard<std::mutex> lk(mu); live[*out] = {device, b}; }
+		return e;
+	}
+	void release(void *p)
+	{
+		if (!p) return;
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			auto it = live.find(p);
+			if (it != live.end()) {
+				const auto key = it->second;
+				live.erase(it);
+				if (cached_bytes + key.second <= kMaxCached) {
+					free_bufs[key].push_back(p); cached_bytes += key.second;
+					return;
+				}
+			}
+		}
+		(void)hipFree(p);
+	}
+	hipError_t event(hipEvent_t *e, bool timing)
+	{
+		int device = 0;
+		(void)hipGetDevice(&device);
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			auto &v = events[{device, timing ? 1 : 0}];
+			if (!v.empty()) { *e = v.back(); v.pop_back(); return hipSuccess; }
+		}
+		return timing ? hipEventCreate(e) : hipEventCreateWithFlags(e, hipEventDisableTiming);
+	}
+	void release_event(hipEvent_t e, bool timing)
+	{
+		if (!e) return;
+		int device = 0;
+		(void)hipGetDevice(&device);
+		std::lock_guard<std::mutex> lk(mu);
+		auto &v = events[{device, timing ? 1 : 0}];
+		if (v.size() < 8192) v.push_back(e); else (void)hipEventDestroy(e);
+	}
+	hipError_t stream(hipStream_t *s, int device, bool low)
+	{
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			auto &v = streams[{device, low ? 1 : 0}];
+			if (!v.empty()) { *s = v.back(); v.pop_back(); return hipSuccess; }
+		}
+		if (!low) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+		int lo = 0, hi = 0;
+		(void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+		return hipStreamCreateWithPriority(s, hipStreamNonBlocking, lo);
+	}
+	void release_stream(hipStream_t s, int device, bool low)
+	{
+		if (!s) return;
+		std::lock_guard<std::mutex> lk(mu);
+		streams[{device, low ? 1 : 0}].push_back(s);
+	}
+};
+Pool &pool()
+{
+	static Pool *p = new Pool();      // intentionally leaked: the HIP runtime may be gone at static destruction
+	return *p;
+}
 
 // ---- kernel configurations -----------------------------------------------------------------
 // Bulk update: G panels fused per HBM pass, T grease tables per panel (balanced bit-fields).
@@ -81,6 +197,7 @@ const UpdateImpl kUpdates[] = {
 	UPDATE_IMPL(1, 10, 1024),   // 1 panel, 10 lookups, 112 KiB
 	UPDATE_IMPL(1, 12, 1024),   // 1 panel, 12 lookups, 64 KiB
 	UPDATE_IMPL(1, 16, 1024),   // 1 panel, 16 lookups, 32 KiB
+	UPDATE_IMPL(4, 16, 512),
 	UPDATE_IMPL(3, 16, 512),    // 512-thread variants: two workgroups per CU when LDS allows
 	UPDATE_IMPL(2, 16, 512),
 	UPDATE_IMPL(2, 12, 512),
@@ -137,6 +254,7 @@ struct Solver {
 	int dbg_sync = 0;
 	const UpdateImpl *impl = nullptr;
 
+	void *arena = nullptr;        // st, panels, aux, fu, alive, pivcol, urow, blk_first, mult, Wb live in here
 	SolveState *st = nullptr;
 	PanelRec *panels = nullptr;
 	PanelAux *aux = nullptr;
@@ -165,22 +283,19 @@ struct Solver {
 	void release()
 	{
 		(void)hipSetDevice(device);
-		for (void *p : { (void *)st, (void *)panels, (void *)aux, (void *)fu, (void *)alive, (void *)pivcol,
-		                 (void *)urow, (void *)blk_first, (void *)mult, (void *)Wb, (void *)Y, (void *)ycols,
-		                 (void *)out })
-			if (p) (void)hipFree(p);
+		Pool &P = pool();
+		for (void *p : { arena, (void *)Y, (void *)ycols, (void *)out, (void *)M, (void *)tmp_src }) P.release(p);
+		arena = nullptr; Y = nullptr; ycols = nullptr; out = nullptr; M = nullptr; tmp_src = nullptr;
 		st = nullptr; panels = nullptr; aux = nullptr; fu = nullptr; alive = nullptr; pivcol = nullptr;
-		urow = nullptr; blk_first = nullptr; mult = nullptr; Wb = nullptr; Y = nullptr; ycols = nullptr; out = nullptr;
-		if (M) (void)hipFree(M);
-		M = nullptr;
-		if (tmp_src) (void)hipFree(tmp_src);
-		tmp_src = nullptr;
-		for (hipEvent_t e : { ev0, ev1, ev2, ev3 }) if (e) (void)hipEventDestroy(e);
-		ev0 = ev1 = ev2 = ev3 = nullptr;
-		for (auto *v : { &evA, &evPrio, &kev }) { for (hipEvent_t e : *v) (void)hipEventDestroy(e); v->clear(); }
-		if (own_sB && sB) (void)hipStreamDestroy(sB);
+		urow = nullptr; blk_first = nullptr; mult = nullptr; Wb = nullptr;
+		for (hipEvent_t *e : { &ev0, &ev1, &ev2, &ev3 }) { P.release_event(*e, true); *e = nullptr; }
+		for (hipEvent_t e : kev) P.release_event(e, true);
+		for (hipEvent_t e : evA) P.release_event(e, false);
+		for (hipEvent_t e : evPrio) P.release_event(e, false);
+		kev.clear(); evA.clear(); evPrio.clear();
+		if (own_sB && sB) P.release_stream(sB, device, true);
 		sB = nullptr;
-		if (own_sA && sA) (void)hipStreamDestroy(sA);
+		if (own_sA && sA) P.release_stream(sA, device, false);
 		sA = nullptr;
 	}
 };
@@ -217,7 +332,7 @@ int solver_alloc(Solver &S)
 	S.impl = pick_update();
 	S.ntiles = (S.wt + TW - 1) / TW;
 	S.srows = slab_rows(S.rows);
-	if (!S.M) HIPCHK(hipMalloc(&S.M, sizeof(u64) * S.ntiles * TW * S.srows));
+	if (!S.M) HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * S.ntiles * TW * S.srows, S.device));
 	if (S.src && S.rows > 0) {
 		const i64 threads = S.ntiles * S.rows * 8;
 		k_to_tiled<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, S.sA>>>(S.src, S.stride, S.rows, S.ntiles,
@@ -229,36 +344,39 @@ int solver_alloc(Solver &S)
 	if (const char *e = getenv("GF2BV_DEBUG_SYNC")) S.dbg_sync = atoi(e);
 	if (getenv("GF2BV_SERIAL")) { S.sB = S.sA; S.own_sB = false; }     // ablation: no look-ahead overlap
 	else {
-		// the bulk path yields to the (latency-critical) panel path wherever both have work queued
-		int lo = 0, hi = 0;
-		(void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-		HIPCHK(hipStreamCreateWithPriority(&S.sB, hipStreamNonBlocking, lo));
+		// the bulk path yields to the (latency-critical) panel path wherever both have work queued: lowest priority
+		HIPCHK(pool().stream(&S.sB, S.device, true));
 		S.own_sB = true;
 	}
-	HIPCHK(hipMalloc(&S.st, sizeof(SolveState)));
-	HIPCHK(hipMalloc(&S.panels, sizeof(PanelRec) * std::max(1, S.npanels)));
-	HIPCHK(hipMalloc(&S.aux, sizeof(PanelAux) * std::max(1, S.npanels)));
-	HIPCHK(hipMalloc(&S.fu, sizeof(FindUnit) * (S.units + 1)));     // +1: merge scratch
-	HIPCHK(hipMemsetAsync(S.fu, 0, sizeof(FindUnit) * (S.units + 1), S.sA));
-	HIPCHK(hipMalloc(&S.alive, std::max<i64>(1, S.rows)));
-	HIPCHK(hipMalloc(&S.pivcol, sizeof(int) * std::max<i64>(1, S.maxr + 64)));
-	HIPCHK(hipMalloc(&S.urow, sizeof(int) * std::max<i64>(1, S.maxr + 64)));
-	HIPCHK(hipMalloc(&S.blk_first, sizeof(int) * std::max(1, S.nblocks)));
-	HIPCHK(hipMalloc(&S.mult, sizeof(u64) * 2 * G * std::max<i64>(1, S.rows)));
-	HIPCHK(hipMalloc(&S.Wb, sizeof(u64) * GF2_GMAX * std::max<i64>(1, S.rows)));
-	HIPCHK(hipMemsetAsync(S.st, 0, sizeof(SolveState), S.sA));
-	HIPCHK(hipMemsetAsync(S.panels, 0, sizeof(PanelRec) * std::max(1, S.npanels), S.sA));
-	HIPCHK(hipMemsetAsync(S.alive, 1, std::max<i64>(1, S.rows), S.sA));
-	HIPCHK(hipMemsetAsync(S.blk_first, 0, sizeof(int) * std::max(1, S.nblocks), S.sA));
-	HIPCHK(hipMemsetAsync(S.mult, 0, sizeof(u64) * 2 * G * std::max<i64>(1, S.rows), S.sA));
-	HIPCHK(hipEventCreate(&S.ev0));
-	HIPCHK(hipEventCreate(&S.ev1));
-	HIPCHK(hipEventCreate(&S.ev2));
-	HIPCHK(hipEventCreate(&S.ev3));
+	// one arena for all side arrays (a dozen hipMalloc/hipFree pairs cost more than a small solve)
+	{
+		const i64 R = std::max<i64>(1, S.rows), NP = std::max(1, S.npanels);
+		size_t off = 0;
+		auto carve = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+		const size_t o_st = carve(sizeof(SolveState)), o_pan = carve(sizeof(PanelRec) * NP), o_aux = carve(sizeof(PanelAux) * NP),
+		             o_fu = carve(sizeof(FindUnit) * (S.units + 1)), o_alive = carve((size_t)R),
+		             o_piv = carve(sizeof(int) * (S.maxr + 64)), o_urow = carve(sizeof(int) * (S.maxr + 64)),
+		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * 2 * G * R),
+		             o_wb = carve(sizeof(u64) * GF2_GMAX * R);
+		HIPCHK(pool().alloc(&S.arena, off, S.device));
+		char *base = (char *)S.arena;
+		S.st = (SolveState *)(base + o_st); S.panels = (PanelRec *)(base + o_pan); S.aux = (PanelAux *)(base + o_aux);
+		S.fu = (FindUnit *)(base + o_fu); S.alive = (unsigned char *)(base + o_alive); S.pivcol = (int *)(base + o_piv);
+		S.urow = (int *)(base + o_urow); S.blk_first = (int *)(base + o_blk); S.mult = (u64 *)(base + o_mult);
+		S.Wb = (u64 *)(base + o_wb);
+		// zero everything that is read before it is written: state, panel records, unit scratch, block bounds, multipliers
+		HIPCHK(hipMemsetAsync(base + o_st, 0, o_alive - o_st, S.sA));
+		HIPCHK(hipMemsetAsync(S.alive, 1, (size_t)R, S.sA));
+		HIPCHK(hipMemsetAsync(base + o_blk, 0, o_wb - o_blk, S.sA));
+	}
+	HIPCHK(pool().event(&S.ev0, true));
+	HIPCHK(pool().event(&S.ev1, true));
+	HIPCHK(pool().event(&S.ev2, true));
+	HIPCHK(pool().event(&S.ev3, true));
 	S.evA.resize(S.nblocks); S.evPrio.resize(S.nblocks);
 	for (int b = 0; b < S.nblocks; b++) {
-		HIPCHK(hipEventCreateWithFlags(&S.evA[b], hipEventDisableTiming));
-		HIPCHK(hipEventCreateWithFlags(&S.evPrio[b], hipEventDisableTiming));
+		HIPCHK(pool().event(&S.evA[b], false));
+		HIPCHK(pool().event(&S.evPrio[b], false));
 	}
 	return GF2BV_OK;
 }
@@ -287,7 +405,7 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 {
 	hipEvent_t ka = nullptr, kb = nullptr;
 	if (S.time_kernels) {
-		HIPCHK(hipEventCreate(&ka)); HIPCHK(hipEventCreate(&kb));
+		HIPCHK(pool().event(&ka, true)); HIPCHK(pool().event(&kb, true));
 		S.kev.push_back(ka); S.kev.push_back(kb);
 		HIPCHK(hipEventRecord(ka, st));
 	}
@@ -388,11 +506,11 @@ int enqueue_backward(Solver &S, const std::vector<int> &ycols_host)
 	S.ny = (int)ycols_host.size();
 	const i64 nyw = (S.ny + 63) / 64;
 	S.ys = round_up(nyw, YTW);
-	HIPCHK(hipMalloc(&S.ycols, sizeof(int) * S.ny));
+	HIPCHK(pool().alloc((void **)&S.ycols, sizeof(int) * S.ny, S.device));
 	HIPCHK(hipMemcpyAsync(S.ycols, ycols_host.data(), sizeof(int) * S.ny, hipMemcpyHostToDevice, S.sA));
-	HIPCHK(hipMalloc(&S.Y, sizeof(u64) * std::max<i64>(1, S.maxr) * S.ys));
+	HIPCHK(pool().alloc((void **)&S.Y, sizeof(u64) * std::max<i64>(1, S.maxr) * S.ys, S.device));
 	HIPCHK(hipMemsetAsync(S.Y, 0, sizeof(u64) * std::max<i64>(1, S.maxr) * S.ys, S.sA));
-	HIPCHK(hipMalloc(&S.out, sizeof(u64) * S.ny * std::max<i64>(1, S.cw)));
+	HIPCHK(pool().alloc((void **)&S.out, sizeof(u64) * S.ny * std::max<i64>(1, S.cw), S.device));
 	HIPCHK(hipMemsetAsync(S.out, 0, sizeof(u64) * S.ny * std::max<i64>(1, S.cw), S.sA));
 	u64 *bmult = S.mult;              // forward multipliers are dead by now
 	const int rpb = 2048;
@@ -421,7 +539,7 @@ int enqueue_backward(Solver &S, const std::vector<int> &ycols_host)
 int enqueue_backward_single(Solver &S)
 {
 	S.ny = 1;
-	HIPCHK(hipMalloc(&S.out, sizeof(u64) * std::max<i64>(1, S.cw)));
+	HIPCHK(pool().alloc((void **)&S.out, sizeof(u64) * std::max<i64>(1, S.cw), S.device));
 	HIPCHK(hipMemsetAsync(S.out, 0, sizeof(u64) * std::max<i64>(1, S.cw), S.sA));
 	unsigned char *accv = reinterpret_cast<unsigned char *>(S.mult);     // forward multipliers are dead by now
 	for (int qb = S.npanels; qb > 0; qb -= GF2_BSG) {
@@ -437,9 +555,12 @@ int enqueue_backward_single(Solver &S)
 
 int solver_enqueue(Solver &S)
 {
+	Trace tr;
 	int rc = solver_alloc(S);
+	tr.mark("solver_alloc");
 	if (rc) return rc;
 	rc = enqueue_forward(S);
+	tr.mark("enqueue_forward");
 	if (rc) return rc;
 	if (S.mode == GF2BV_MODE_SINGLE) {
 		if (getenv("GF2BV_YSWEEP")) {                  // the general multi-RHS path, for cross-checking
@@ -453,10 +574,11 @@ int solver_enqueue(Solver &S)
 
 int solver_finish(Solver &S, gf2bv_result **out)
 {
+	Trace tr;
 	SolveState hst;
 	std::vector<int32_t> piv;
 	hipEvent_t evx = nullptr;
-	HIPCHK(hipEventCreate(&evx));
+	HIPCHK(pool().event(&evx, true));
 	if (S.mode == GF2BV_MODE_AFFINE_SPACE) {
 		// the kernel basis needs rank and pivot columns on the host (one sync) to lay out
 		// the free columns in M4RI's order (_internal.c:348)
@@ -481,8 +603,10 @@ int solver_finish(Solver &S, gf2bv_result **out)
 	std::vector<PanelRec> hp(std::max(1, S.npanels));
 	HIPCHK(hipMemcpyAsync(hp.data(), S.panels, sizeof(PanelRec) * hp.size(), hipMemcpyDeviceToHost, S.sA));
 	HIPCHK(hipEventRecord(evx, S.sA));
+	tr.mark("finish: enqueue tail");
 	HIPCHK(hipStreamSynchronize(S.sA));
 	HIPCHK(hipStreamSynchronize(S.sB));
+	tr.mark("finish: sync");
 	if (piv.empty() && hst.rank) {
 		piv.resize(hst.rank);
 		HIPCHK(hipMemcpy(piv.data(), S.pivcol, sizeof(int) * hst.rank, hipMemcpyDeviceToHost));
@@ -538,8 +662,9 @@ int solver_finish(Solver &S, gf2bv_result **out)
 		(void)hipEventElapsedTime(&ms, S.kev[i], S.kev[i + 1]);
 		st.ms_sweep += ms;
 	}
-	(void)hipEventDestroy(evx);
+	pool().release_event(evx, true);
 	st.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - S.t_begin).count();
+	tr.mark("finish: result");
 	*out = R;
 	return GF2BV_OK;
 }
@@ -619,7 +744,7 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 		workers.emplace_back([&, t]() {
 			if (hipSetDevice(device) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipSetDevice"; return; }
 			hipStream_t st = nullptr;
-			if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipStreamCreate"; return; }
+			if (pool().stream(&st, device, false) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipStreamCreate"; return; }
 			for (i64 s = t; s < nsys && rcs[t] == GF2BV_OK; s += NS) {
 				Solver S;
 				S.t_begin = std::chrono::steady_clock::now();
@@ -632,7 +757,7 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 				if (rc != GF2BV_OK) { rcs[t] = rc; errs[t] = g_err; }
 				(void)hipStreamSynchronize(st);
 			}
-			(void)hipStreamDestroy(st);
+			pool().release_stream(st, device, false);
 		});
 	}
 	for (auto &w : workers) w.join();
@@ -655,14 +780,14 @@ int gf2bv_solve_words(const uint64_t *aug, int64_t rows, int64_t cols, int64_t s
 	Solver S;
 	S.t_begin = std::chrono::steady_clock::now();
 	S.device = device;
-	HIPCHK(hipStreamCreateWithFlags(&S.sA, hipStreamNonBlocking));
+	HIPCHK(pool().stream(&S.sA, device, false));
 	S.own_sA = true;
 	S.rows = rows; S.cols = cols; S.mode = mode;
 	S.stride = wt;
-	HIPCHK(hipMalloc(&S.tmp_src, sizeof(u64) * std::max<i64>(1, rows) * S.stride));
+	HIPCHK(pool().alloc((void **)&S.tmp_src, sizeof(u64) * std::max<i64>(1, rows) * S.stride, device));
 	S.src = S.tmp_src;
 	hipEvent_t p0, p1;
-	HIPCHK(hipEventCreate(&p0)); HIPCHK(hipEventCreate(&p1));
+	HIPCHK(pool().event(&p0, true)); HIPCHK(pool().event(&p1, true));
 	HIPCHK(hipEventRecord(p0, S.sA));
 	if (rows > 0)
 		HIPCHK(hipMemcpy2DAsync(S.tmp_src, S.stride * 8, aug, stride_words * 8, wt * 8, rows, hipMemcpyHostToDevice, S.sA));
@@ -675,7 +800,7 @@ int gf2bv_solve_words(const uint64_t *aug, int64_t rows, int64_t cols, int64_t s
 		(void)hipEventElapsedTime(&S.ms_pack, p0, p1);
 		rc = solver_finish(S, out);
 	}
-	(void)hipEventDestroy(p0); (void)hipEventDestroy(p1);
+	pool().release_event(p0, true); pool().release_event(p1, true);
 	return rc;
 }
 
@@ -692,20 +817,20 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 	Solver S;
 	S.t_begin = std::chrono::steady_clock::now();
 	S.device = device;
-	HIPCHK(hipStreamCreateWithFlags(&S.sA, hipStreamNonBlocking));
+	HIPCHK(pool().stream(&S.sA, device, false));
 	S.own_sA = true;
 	S.rows = rows; S.cols = cols; S.mode = mode;
 	const i64 wt = (cols + 1 + 63) / 64;
 	const i64 ntiles = (wt + TW - 1) / TW;
 	S.stride = ntiles * TW;
-	HIPCHK(hipMalloc(&S.M, sizeof(u64) * ntiles * TW * slab_rows(rows)));     // packed straight into tiles
+	HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * ntiles * TW * slab_rows(rows), device));     // packed straight into tiles
 	const i64 ndig = digit_off[rows];
 	uint32_t *d_dig = nullptr;
 	i64 *d_off = nullptr;
-	HIPCHK(hipMalloc(&d_dig, sizeof(uint32_t) * std::max<i64>(1, ndig)));
-	HIPCHK(hipMalloc(&d_off, sizeof(i64) * (rows + 1)));
+	HIPCHK(pool().alloc((void **)&d_dig, sizeof(uint32_t) * std::max<i64>(1, ndig), device));
+	HIPCHK(pool().alloc((void **)&d_off, sizeof(i64) * (rows + 1), device));
 	hipEvent_t p0, p1;
-	HIPCHK(hipEventCreate(&p0)); HIPCHK(hipEventCreate(&p1));
+	HIPCHK(pool().event(&p0, true)); HIPCHK(pool().event(&p1, true));
 	HIPCHK(hipEventRecord(p0, S.sA));
 	if (ndig) HIPCHK(hipMemcpyAsync(d_dig, digits, sizeof(uint32_t) * ndig, hipMemcpyHostToDevice, S.sA));
 	HIPCHK(hipMemcpyAsync(d_off, digit_off, sizeof(i64) * (rows + 1), hipMemcpyHostToDevice, S.sA));
@@ -724,8 +849,8 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 		rc = solver_finish(S, out);
 	}
 	(void)hipStreamSynchronize(S.sA);
-	(void)hipFree(d_dig); (void)hipFree(d_off);
-	(void)hipEventDestroy(p0); (void)hipEventDestroy(p1);
+	pool().release(d_dig); pool().release(d_off);
+	pool().release_event(p0, true); pool().release_event(p1, true);
 	return rc;
 }
 

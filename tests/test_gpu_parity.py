@@ -179,6 +179,41 @@ def test_device_resident_and_batch_paths():
     buf.free()
 
 
+def test_back_substitution_paths_agree(monkeypatch):
+    """solve_one's blocked parity back-substitution vs the general multi-RHS sweep path (solve_all's)."""
+    rng = random.Random(31)
+    for rows, cols, cap in ((700, 650, 500), (2200, 2100, None), (5000, 4097, 4000)):
+        eqs = random_system(rng, rows, cols, .5, cap, True, 0)
+        aug = O.eqs_to_aug(eqs, cols)
+        want = O.solve_words(aug, rows, cols, 0)
+        monkeypatch.delenv("GF2BV_YSWEEP", raising=False)
+        a = hip.solve_words(aug, rows, cols, 0)
+        monkeypatch.setenv("GF2BV_YSWEEP", "1")
+        b = hip.solve_words(aug, rows, cols, 0)
+        monkeypatch.delenv("GF2BV_YSWEEP", raising=False)
+        assert_same(a, want, 0)
+        assert_same(b, want, 0)
+
+
+def test_device_path_strides_and_untouched_input():
+    """Row-major device input with an even but non-multiple-of-16 stride; the input must survive the solve."""
+    n, seed = 1000, 77
+    for stride in (O.words_for(n), O.words_for(n) + 2, 50):
+        stride += stride & 1
+        host = O.gen_synthetic(n, n, seed, stride)
+        buf = hip.DeviceBuffer(n * stride * 8)
+        buf.upload(host)
+        got = hip.solve_device(buf.ptr, n, n, stride, 1)
+        assert_same(got, O.solve_words(host, n, n, 1), 1)
+        assert np.array_equal(buf.download().reshape(n, stride), host)
+        buf.free()
+
+
+def test_stream_ceiling_reports_sane_rates():
+    c = hip.stream_ceiling(1 << 30)
+    assert 1000 < c["rmw_gbs"] < 8000 and 1000 < c["read_gbs"] < 8000
+
+
 def test_medium_dense_full_parity():
     """8192 x 8192 dense: full bit-for-bit comparison with the CPU oracle."""
     n, seed = 8192, 1234
