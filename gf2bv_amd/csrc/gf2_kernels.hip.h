@@ -233,7 +233,7 @@ __global__ void __launch_bounds__(256)
 k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveState *__restrict__ st,
        unsigned char *__restrict__ alive, FindUnit *__restrict__ fu, int units,
        PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol,
-       int *__restrict__ urow, u64 *__restrict__ multset)
+       int *__restrict__ urow, u64 *__restrict__ multset, int *__restrict__ blk_first_out)
 {
 	__builtin_amdgcn_s_setprio(3);          // panel path = critical path: win issue arbitration against bulk-update waves
 	const int lane = threadIdx.x & 63;
@@ -354,6 +354,7 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 		panels[j].mask = S.have;
 		st->rank = r0 + p;
 		st->first = new_first;
+		if (blk_first_out) *blk_first_out = new_first;     // last panel of a block: row bound for its bulk update
 		GF2_ST(&st->arrive, 0u);
 	}
 }
@@ -550,7 +551,7 @@ __global__ void __launch_bounds__(NT)
 k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
          const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
          const u64 *__restrict__ multset, const int *__restrict__ blk_first,
-         int tile_begin, int ntiles, int nsplit)
+         int tile_begin, int ntiles, int nsplit, u64 *__restrict__ Wb_out, int gnext)
 {
 	typedef UpdateCfg<G, T> C;
 	typedef Fields<T> F;
@@ -567,7 +568,7 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 
 	int anyp = 0;
 	for (int g = 0; g < gb; g++) anyp |= panels[j0 + g].p;
-	if (!anyp) return;
+	if (!anyp && !Wb_out) return;
 	// row range of this workgroup: [first alive row, rows) split evenly
 	const i64 rlo = *blk_first;
 	constexpr int ALIGN = RPP * 4;
@@ -576,6 +577,17 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	const i64 rbeg = rlo + (i64)sp * per;
 	if (rbeg >= rows) return;
 	const i64 rend = (rbeg + per < rows) ? rbeg + per : rows;
+	if (!anyp) {
+		// a block without pivots changes nothing, but the next block's window still has to reach Wb
+		const uint4 *Mg = reinterpret_cast<const uint4 *>(M) + tile * srows * LPR;
+		const int a0 = (int)(w0 + 2 * lr) - wlo, a1 = a0 + 1;
+		for (i64 row = rbeg + rr; row < rend; row += RPP) {
+			const uint4 v = Mg[row * LPR + lr];
+			if (a0 >= 0 && a0 < gnext) Wb_out[row * GF2_GMAX + a0] = ((u64)v.y << 32) | v.x;
+			if (a1 >= 0 && a1 < gnext) Wb_out[row * GF2_GMAX + a1] = ((u64)v.w << 32) | v.z;
+		}
+		return;
+	}
 
 	// ---- tables ----
 	for (int t = threadIdx.x; t < gb * 64; t += NT) {
@@ -668,10 +680,21 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		for (int u = 0; u < U; u++)
 			if (base + (i64)u * RPP + rr < rend) H.d[u] = Mw[H.q[u]];
 	};
-	auto compute_half = [&](Half &H) {
+	// priority launches (Wb_out != nullptr) also deposit the next block's window words [wlo, wlo+gnext)
+	// of every visited row into the compact buffer Wb -- updated or not -- which replaces a gather pass
+	const int wb0 = (int)(w0 + 2 * lr) - wlo, wb1 = wb0 + 1;       // window slots of this lane's two words
+	auto put_window = [&](i64 row, const uint4 &val) {
+		if (wb0 >= 0 && wb0 < gnext) Wb_out[row * GF2_GMAX + wb0] = ((u64)val.y << 32) | val.x;
+		if (wb1 >= 0 && wb1 < gnext) Wb_out[row * GF2_GMAX + wb1] = ((u64)val.w << 32) | val.z;
+	};
+	auto compute_half = [&](Half &H, i64 base) {
 #pragma unroll
 		for (int u = 0; u < U; u++) {
-			if (!H.on[u]) continue;
+			if (!H.on[u]) {
+				const i64 row = base + (i64)u * RPP + rr;
+				if (Wb_out && row < rend) put_window(row, H.d[u]);
+				continue;
+			}
 			uint4 acc = H.d[u];
 #pragma unroll
 			for (int g = 0; g < G; g++) {
@@ -702,6 +725,7 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 				}
 			}
 			Mw[H.q[u]] = acc;
+			if (Wb_out) put_window(base + (i64)u * RPP + rr, acc);
 		}
 	};
 	constexpr i64 STEP = (i64)RPP * U;
@@ -709,9 +733,9 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	load_half(A, rbeg);
 	for (i64 base = rbeg; base < rend; base += 2 * STEP) {
 		load_half(B, base + STEP);                  // rows >= rend load nothing (on = false)
-		compute_half(A);
+		compute_half(A, base);
 		load_half(A, base + 2 * STEP);
-		compute_half(B);
+		compute_half(B, base + STEP);
 	}
 }
 

@@ -163,13 +163,13 @@ Pool &pool()
 struct UpdateImpl {
 	int G, T, lds_bytes, threads;
 	hipError_t (*update)(dim3, hipStream_t, u64 *, i64, i64, int, int, int, const PanelRec *, const PanelAux *,
-	                     const u64 *, const int *, int, int, int);
+	                     const u64 *, const int *, int, int, int, u64 *, int);
 };
 
 template <int G, int T, int NT>
 hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows, int j0, int gb, int wlo,
                          const PanelRec *panels, const PanelAux *aux, const u64 *multset, const int *blk_first,
-                         int tile_begin, int ntiles, int nsplit)
+                         int tile_begin, int ntiles, int nsplit, u64 *wb_out, int gnext)
 {
 	constexpr int lds = UpdateCfg<G, T>::LDS_BYTES;
 	static bool attr_set[16] = {};
@@ -182,7 +182,7 @@ hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows, 
 		attr_set[dev] = true;
 	}
 	k_update<G, T, NT><<<grid, dim3(NT), lds, s>>>(M, rows, srows, j0, gb, wlo, panels, aux, multset, blk_first,
-	                                               tile_begin, ntiles, nsplit);
+	                                               tile_begin, ntiles, nsplit, wb_out, gnext);
 	return hipGetLastError();
 }
 
@@ -401,7 +401,8 @@ int launch_trsm(Solver &S, hipStream_t st, int j0, int gb, int wlo, int tile_beg
 	return GF2BV_OK;
 }
 
-int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wlo, u64 *mset, int tile_begin, int ntiles)
+int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wlo, u64 *mset, int tile_begin, int ntiles,
+                        u64 *wb_out = nullptr, int gnext = 0)
 {
 	hipEvent_t ka = nullptr, kb = nullptr;
 	if (S.time_kernels) {
@@ -411,7 +412,7 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 	}
 	const int ns = pick_nsplit(S.rows, ntiles);
 	HIPCHK(S.impl->update(dim3((unsigned)(ntiles * ns)), st, S.M, S.rows, S.srows, j0, gb, wlo, S.panels, S.aux, mset,
-	                      S.blk_first + b, tile_begin, ntiles, ns));
+	                      S.blk_first + b, tile_begin, ntiles, ns, wb_out, gnext));
 	if (S.time_kernels) HIPCHK(hipEventRecord(kb, st));
 	return GF2BV_OK;
 }
@@ -445,12 +446,11 @@ int enqueue_forward(Solver &S)
 			const i64 c0 = (i64)j * 64;
 			const u64 colmask = (S.cols - c0 >= 64) ? ~0ull : ((1ull << (S.cols - c0)) - 1);
 			k_find<<<dim3((S.units + 3) / 4), dim3(256), 0, S.sA>>>(S.Wb, S.rows, j, g, colmask, S.st, S.alive, S.fu,
-			                                                       S.units, S.panels, S.aux, S.pivcol, S.urow, mset);
+			                                                       S.units, S.panels, S.aux, S.pivcol, S.urow, mset,
+			                                                       g == gb - 1 ? S.blk_first + b : nullptr);
 			k_narrow<<<dim3(row_blocks), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, g, gb, S.Wb, S.alive,
 			                                                 S.panels, S.aux, mset);
 		}
-		// snapshot of the alive lower bound for the bulk update of this block
-		HIPCHK(hipMemcpyAsync(S.blk_first + b, &S.st->first, sizeof(int), hipMemcpyDeviceToDevice, S.sA));
 		if (b == S.nblocks - 1)
 			k_win_scatter<<<dim3((unsigned)((S.rows * gb + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, gb, S.Wb, S.alive);
 		HIPCHK(hipGetLastError());
@@ -481,11 +481,14 @@ int enqueue_forward(Solver &S)
 			if (nprio > 0) {
 				int rc = launch_trsm(S, S.sA, j0, gb, wlo, tb, nprio);
 				if (rc) return rc;
-				rc = launch_update_timed(S, S.sA, b, j0, gb, wlo, mset, tb, nprio);
+				// the priority update also writes block b+1's window into Wb (all rows >= blk_first: every
+				// alive row); rows it does not visit are dead
+				rc = launch_update_timed(S, S.sA, b, j0, gb, wlo, mset, tb, nprio, S.Wb, gnext);
 				if (rc) return rc;
+			} else {
+				k_win_gather<<<dim3((unsigned)((S.rows * gnext + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, wlo,
+				                                                                                     std::max(gnext, 1), S.Wb);
 			}
-			k_win_gather<<<dim3((unsigned)((S.rows * gnext + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, wlo,
-			                                                                                     std::max(gnext, 1), S.Wb);
 		}
 	}
 	// join: the panel stream waits for the last bulk update, then checks consistency
