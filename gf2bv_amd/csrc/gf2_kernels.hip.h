@@ -33,6 +33,7 @@ typedef long long i64;
 
 #define GF2_GMAX 4                // max panels per block
 #define GF2_TW 16                 // 64-bit words per column tile (128-byte row segments)
+#define GF2_FEW_UNITS 8           // k_find units used while panels are easy (dense systems)
 #ifndef GF2_BATCH
 #define GF2_BATCH 4
 #endif
@@ -77,6 +78,8 @@ struct SolveState {
 	int inconsistent;    // set by k_check_rhs
 	int first;           // lower bound of the alive rows
 	unsigned arrive;     // k_find: units that have finished (last arriver publishes)
+	int wide;            // k_find: 1 = the previous panel was hard (sparse / rank deficient): scan with all units
+	int pad[3];
 };
 
 // Scratch of one k_find unit (wavefront).
@@ -84,6 +87,8 @@ struct FindUnit {
 	u64 have;
 	int cnt;
 	int first_nonsrc;    // first alive row of the unit's slice that did not become a source
+	int chunks;          // 64-row steps this unit needed
+	int pad;
 	int srow[64];        // slot -> row
 	u64 bc[64];          // pivot bit -> combination mask over slots
 };
@@ -241,13 +246,18 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 	if (u >= units) return;
 	const int first = st->first;
 	const int full = __popcll(colmask);
+	// Dense panels are complete after ~70 rows, so a handful of units (each covering a long slice it
+	// will not finish) publish sooner than 256 units that all have to be dispatched and collected.
+	// Hard panels (sparse / rank deficient: a unit had to scan far) switch the NEXT panel to all units.
+	// Either way the active units' slices cover every alive row.
+	const int active = st->wide ? units : (units < GF2_FEW_UNITS ? units : GF2_FEW_UNITS);
 	FindUnit *me = fu + u;
 	FindState S;
 	S.bw = 0; S.bc = 0; S.have = 0; S.nslots = 0;
-	int first_nonsrc = -1;
-	{
+	int first_nonsrc = -1, chunks = 0;
+	if (u < active) {
 		const i64 n = rows - first;
-		i64 per = n > 0 ? (n + units - 1) / units : 0;
+		i64 per = n > 0 ? (n + active - 1) / active : 0;
 		per = (per + 63) & ~(i64)63;
 		const i64 lo = first + (i64)u * per;
 		const i64 hi = (lo + per < rows) ? lo + per : rows;
@@ -264,6 +274,7 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 			ok_n = (i_n < hi) && alive[i_n];
 			w_n = ok_n ? (Wb[i_n * GF2_GMAX + g] & colmask) : 0ull;
 			const u64 took = find_absorb(S, w, (int)i, colmask, lane, me->srow);
+			chunks++;
 			if (first_nonsrc < 0) {
 				u64 m = __ballot(ok) & ~took;
 				if (m) first_nonsrc = (int)base + ctz64(m);
@@ -272,7 +283,7 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 		if (first_nonsrc < 0) first_nonsrc = (int)((base < rows) ? base : rows);   // lower bound
 	}
 	GF2_ST(&me->bc[lane], S.bc);
-	if (lane == 0) { GF2_ST(&me->have, S.have); GF2_ST(&me->first_nonsrc, first_nonsrc); GF2_ST(&me->cnt, S.nslots); }
+	if (lane == 0) { GF2_ST(&me->have, S.have); GF2_ST(&me->first_nonsrc, first_nonsrc); GF2_ST(&me->chunks, chunks); GF2_ST(&me->cnt, S.nslots); }
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every store above has left this wave
 	unsigned old = 0;
 	if (lane == 0) old = __hip_atomic_fetch_add(&st->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -287,9 +298,10 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 		else if (GF2_LD(&fu[0].cnt) == full) pick = 0;
 		else if (S.nslots == full) pick = u;
 		else
-			for (int v = 1; v < units; v++)
+			for (int v = 1; v < active; v++)
 				if (GF2_LD(&fu[v].cnt) == full) { pick = v; break; }
 	}
+	const int hard = (pick < 0) || ((pick == u ? chunks : GF2_LD(&fu[pick].chunks)) > 8);
 	int new_first;
 	int srow;                                   // lane s: row of slot s
 	if (pick >= 0) {
@@ -305,7 +317,7 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 		// dead by now, but other lists are still being read -> use the list of unit `units` (spare))
 		S.bw = 0; S.bc = 0; S.have = 0; S.nslots = 0;
 		FindUnit *spare = fu + units;
-		for (int v = 0; v < units && S.nslots < full; v++) {
+		for (int v = 0; v < active && S.nslots < full; v++) {
 			const int cnt = GF2_LD(&fu[v].cnt);
 			if (cnt == 0) continue;
 			const int i = (lane < cnt) ? GF2_LD(&fu[v].srow[lane]) : -1;
@@ -354,6 +366,7 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 		panels[j].mask = S.have;
 		st->rank = r0 + p;
 		st->first = new_first;
+		st->wide = hard;
 		if (blk_first_out) *blk_first_out = new_first;     // last panel of a block: row bound for its bulk update
 		GF2_ST(&st->arrive, 0u);
 	}

@@ -341,6 +341,7 @@ int solver_alloc(Solver &S)
 	const int G = S.impl->G;
 	S.nblocks = (S.npanels + G - 1) / G;
 	S.units = (int)std::min<i64>(256, std::max<i64>(1, (S.rows + 255) / 256));
+	if (const char *e = getenv("GF2BV_UNITS")) { int v = atoi(e); if (v >= 1 && v <= 256) S.units = std::min(S.units, v); }
 	if (const char *e = getenv("GF2BV_DEBUG_SYNC")) S.dbg_sync = atoi(e);
 	if (getenv("GF2BV_SERIAL")) { S.sB = S.sA; S.own_sB = false; }     // ablation: no look-ahead overlap
 	else {
