@@ -209,6 +209,28 @@ def test_device_path_strides_and_untouched_input():
         buf.free()
 
 
+def test_concurrent_solves_from_python_threads():
+    """The reference drops the GIL around the solve (_internal.c:429-492); so does the shim, and every call owns
+    its streams and buffers: four Python threads solving different systems at once must all be right."""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = random.Random(404)
+    jobs = []
+    for rows, cols, cap in ((900, 800, None), (1300, 1200, 1000), (700, 650, 300), (2100, 2048, None)) * 3:
+        eqs = random_system(rng, rows, cols, .5, cap, True, 0)
+        jobs.append((eqs, cols))
+
+    def run(job):
+        eqs, cols = job
+        sp = m4ri_solve(eqs, cols, 1)
+        return sp.origin, sp.basis
+
+    with ThreadPoolExecutor(4) as ex:
+        got = list(ex.map(run, jobs))
+    for (eqs, cols), (origin, basis) in zip(jobs, got):
+        ref = O.m4ri_solve(eqs, cols, 1)
+        assert (origin, basis) == (ref.origin, ref.basis)
+
+
 def test_stream_ceiling_reports_sane_rates():
     c = hip.stream_ceiling(1 << 30)
     assert 1000 < c["rmw_gbs"] < 8000 and 1000 < c["read_gbs"] < 8000
