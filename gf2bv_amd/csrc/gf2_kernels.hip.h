@@ -672,7 +672,11 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 #pragma unroll
 		for (int u = 0; u < U; u++) {
 			const i64 row = base + (i64)u * RPP + rr;
+#ifdef GF2_MB_L2               /* tools/microbench_update.hip: keep the row data L2-resident to time the table work alone */
+			H.q[u] = (row & 1023) * LPR + lr;
+#else
 			H.q[u] = row * LPR + lr;
+#endif
 		}
 #pragma unroll
 		for (int u = 0; u < U; u++) {
@@ -709,6 +713,7 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 				continue;
 			}
 			uint4 acc = H.d[u];
+#ifndef GF2_MB_NOLOOKUP        /* tools/microbench_update.hip: time the HBM stream without the table work */
 #pragma unroll
 			for (int g = 0; g < G; g++) {
 				if (g >= gb) break;                 // tables of absent panels were never built (uniform branch)
@@ -737,6 +742,7 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 					}
 				}
 			}
+#endif
 			Mw[H.q[u]] = acc;
 			if (Wb_out) put_window(base + (i64)u * RPP + rr, acc);
 		}
