@@ -1,6 +1,7 @@
 """In-tree build of the native pieces (hipcc for gfx950, g++ for the CPython shim).
 
-    python -m gf2bv_amd.build            # or __graft_entry__.build()
+    python gf2bv_amd/build.py            # or __graft_entry__.build()
+(run it as a script: `python -m gf2bv_amd.build` would import the package, i.e. the extension it builds)
 
 Outputs land next to this file so they travel with the source tree:
   libgf2bv_hip.so                       HIP kernels + C ABI (include/gf2bv_hip.h)
