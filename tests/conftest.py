@@ -1,19 +1,16 @@
 import os
 import sys
 
-import pytest
-
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# Build the HIP library, the CPython shim and the CPU oracle BEFORE test modules are collected
+# (they import gf2bv_amd at module level; the built artefacts are git-ignored).
+import __graft_entry__  # noqa: E402
+
+__graft_entry__.build()
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
-
-
-@pytest.fixture(scope="session", autouse=True)
-def _native_built():
-    """Build the HIP library, the CPython shim and the CPU oracle if they are missing/stale."""
-    import __graft_entry__ as g
-    g.build()
