@@ -283,6 +283,9 @@ struct Solver {
 	void release()
 	{
 		(void)hipSetDevice(device);
+		// nothing goes back to the pool while work may still be in flight (error paths return early)
+		if (sB) (void)hipStreamSynchronize(sB);
+		if (arena || M) (void)hipStreamSynchronize(sA);
 		Pool &P = pool();
 		for (void *p : { arena, (void *)Y, (void *)ycols, (void *)out, (void *)M, (void *)tmp_src }) P.release(p);
 		arena = nullptr; Y = nullptr; ycols = nullptr; out = nullptr; M = nullptr; tmp_src = nullptr;
