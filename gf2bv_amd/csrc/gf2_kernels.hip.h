@@ -379,9 +379,10 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 __global__ void __launch_bounds__(256)
 k_narrow(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int g, int gb, u64 *__restrict__ Wb,
          const unsigned char *__restrict__ alive, const PanelRec *__restrict__ panels,
-         const PanelAux *__restrict__ aux, u64 *__restrict__ multset)
+         const PanelAux *__restrict__ aux, u64 *__restrict__ multset, const SolveState *__restrict__ st)
 {
 	__builtin_amdgcn_s_setprio(3);
+	const i64 first_alive = st->first;
 	__shared__ u64 Sw[GF2_GMAX][64];     // window words of the source rows          [word][slot]
 	__shared__ u64 Pb[GF2_GMAX][64];     // reduced pivot rows' window words          [word][pivot BIT]
 	__shared__ u64 Cm[64];               // combination masks                         [pivot k]
@@ -392,7 +393,8 @@ k_narrow(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int g, int gb, u64 *_
 	const int p = rec.p;
 	u64 *mult = multset + (i64)g * rows;
 	const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	if (p == 0) {
+	// no pivots in this panel, or every row of this workgroup is already dead: multipliers are 0
+	if (p == 0 || ((i64)(blockIdx.x + 1) * blockDim.x <= first_alive && blockIdx.x != 0)) {
 		if (i < rows) mult[i] = 0;
 		return;
 	}
@@ -430,7 +432,8 @@ k_narrow(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int g, int gb, u64 *_
 			while (mm) {
 				const int b = ctz64(mm); mm &= mm - 1;
 #pragma unroll
-				for (int e = 0; e < GF2_GMAX; e++) acc[e] ^= Pb[e][b];
+				for (int e = 0; e < GF2_GMAX; e++)
+					if (e >= g) acc[e] ^= Pb[e][b];        // words left of the panel are finished (uniform test)
 			}
 #pragma unroll
 			for (int e = 0; e < GF2_GMAX; e++)

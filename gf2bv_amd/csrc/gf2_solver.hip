@@ -453,7 +453,7 @@ int enqueue_forward(Solver &S)
 			                                                       S.units, S.panels, S.aux, S.pivcol, S.urow, mset,
 			                                                       g == gb - 1 ? S.blk_first + b : nullptr);
 			k_narrow<<<dim3(row_blocks), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, g, gb, S.Wb, S.alive,
-			                                                 S.panels, S.aux, mset);
+			                                                 S.panels, S.aux, mset, S.st);
 		}
 		if (b == S.nblocks - 1)
 			k_win_scatter<<<dim3((unsigned)((S.rows * gb + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, gb, S.Wb, S.alive);
