@@ -32,7 +32,13 @@ typedef unsigned long long u64;   // matches HIP's 64-bit atomics and __ballot
 typedef long long i64;
 
 #define GF2_GMAX 4                // max panels per block
-#define GF2_TW 16                 // 64-bit words per column tile (128-byte row segments)
+#ifndef GF2_TW
+#define GF2_TW 8                  // 64-bit words per column tile: 8 (64-byte row segments) or 16 (128-byte)
+#endif
+#define GF2_TW_LOG (GF2_TW == 16 ? 4 : 3)
+#define GF2_LPR (GF2_TW / 2)      // lanes per row segment, 16 bytes each
+#define GF2_IL (16 / GF2_LPR)     // table entries interleaved in one 256-byte LDS slot: 4 (TW=8) or 2 (TW=16)
+static_assert(GF2_TW == 8 || GF2_TW == 16, "tile width");
 #define GF2_FEW_UNITS 8           // k_find units used while panels are easy (dense systems)
 #ifndef GF2_BATCH
 #define GF2_BATCH 4
@@ -52,7 +58,13 @@ typedef long long i64;
 // running workgroups touch) do not sit a power of two apart and camp on the same memory channels.
 __device__ __forceinline__ long long tidx(long long row, long long word, long long srows)
 {
-	return ((word >> 4) * srows + row) * GF2_TW + (word & 15);
+	return ((word >> GF2_TW_LOG) * srows + row) * GF2_TW + (word & (GF2_TW - 1));
+}
+// Which part of a 256-byte table slot a row reads first (see k_update): a function of the row index only,
+// so the panel path can store every row's multiplier already rotated for it.
+__host__ __device__ __forceinline__ int rowq(long long row)
+{
+	return GF2_IL == 2 ? (int)(row & 1) : (int)((row >> 1) & 3);
 }
 
 // One record per 64-column panel, written by k_find.
@@ -104,6 +116,55 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 __device__ __forceinline__ u64 lanemask_lt(int lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
 __device__ __forceinline__ uint4 xor4(uint4 a, uint4 b) { return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w); }
 
+// Balanced split of the 64 pivot bits of a panel into T bit-fields (grease tables), taken in GROUPS of
+// GF2_IL consecutive tables of equal width (a group shares its 256-byte LDS slots, see k_update).
+template <int T>
+struct Fields {
+	static constexpr int IL = GF2_IL;
+	static constexpr int LO = 64 / T;                 // small field width
+	static constexpr int NBIG = 64 - T * LO;          // the first NBIG fields are one bit wider
+	static constexpr int NG = T / IL;                 // groups
+	static_assert(T % IL == 0 && NBIG % IL == 0, "tables must form equal-width groups");
+	__host__ __device__ static constexpr int width(int t) { return t < NBIG ? LO + 1 : LO; }
+	__host__ __device__ static constexpr int shift(int t) { return t < NBIG ? t * (LO + 1) : NBIG * (LO + 1) + (t - NBIG) * LO; }
+	// first 256-byte slot of group m inside a panel (slot i of a group = entry i of each of its IL tables)
+	__host__ __device__ static constexpr int groupoff(int m)
+	{
+		return IL * m < NBIG ? m * (1 << (LO + 1)) : (NBIG / IL) * (1 << (LO + 1)) + (m - NBIG / IL) * (1 << LO);
+	}
+	static constexpr int SLOTS = (NBIG / IL) * (1 << (LO + 1)) + ((T - NBIG) / IL) * (1 << LO);   // per panel
+	// Rotate the fields of every group by q positions: field s of the result = field (s+q) % IL of m.
+	// q = rowq(row).  The panel path stores multipliers in this form; rot_fields(x, (IL-q) % IL) undoes it.
+	__host__ __device__ static inline u64 rot_fields(u64 m, int q)
+	{
+		if (q == 0) return m;
+		u64 r = 0;
+#pragma unroll
+		for (int g = 0; g < NG; g++) {
+			const int w = width(IL * g), sh = shift(IL * g), gw = IL * w;
+			const u64 gm = gw >= 64 ? ~0ull : ((1ull << gw) - 1);
+			const u64 grp = (m >> sh) & gm;
+			r |= (((grp >> (q * w)) | (grp << ((IL - q) * w))) & gm) << sh;
+		}
+		return r;
+	}
+};
+
+
+// rot_fields for a table count chosen at run time (the panel path is not templated on the update config)
+__device__ __forceinline__ u64 rot_fields_rt(int T, u64 m, int q)
+{
+	switch (T) {
+	case 8: return Fields<8>::rot_fields(m, q);
+	case 12: return Fields<12>::rot_fields(m, q);
+#if GF2_IL == 2
+	case 10: return Fields<10>::rot_fields(m, q);
+	case 14: return Fields<14>::rot_fields(m, q);
+#endif
+	default: return Fields<16>::rot_fields(m, q);
+	}
+}
+
 // ------------------------------------------------------------------------------------------
 // Matrix assembly: CPython digits -> augmented words (replaces _internal.c:403-426).
 // One thread per output word.  Row r's int occupies digits[off[r]..off[r+1]); bit 0 is the
@@ -141,9 +202,9 @@ __global__ void __launch_bounds__(256)
 k_to_tiled(const u64 *__restrict__ src, i64 stride, i64 rows, i64 ntiles, i64 wt, i64 srows, u64 *__restrict__ dst)
 {
 	const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;       // (tile, row, lr)
-	const int lr = (int)(t & 7);
-	const i64 row = (t >> 3) % rows;
-	const i64 tile = (t >> 3) / rows;
+	const int lr = (int)(t % GF2_LPR);
+	const i64 row = (t / GF2_LPR) % rows;
+	const i64 tile = (t / GF2_LPR) / rows;
 	if (tile >= ntiles) return;
 	const i64 w = tile * GF2_TW + 2 * lr;
 	u64 a = (w < wt) ? src[row * stride + w] : 0ull;
@@ -238,7 +299,7 @@ __global__ void __launch_bounds__(256)
 k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveState *__restrict__ st,
        unsigned char *__restrict__ alive, FindUnit *__restrict__ fu, int units,
        PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol,
-       int *__restrict__ urow, u64 *__restrict__ multset, int *__restrict__ blk_first_out)
+       int *__restrict__ urow, u64 *__restrict__ multset, int *__restrict__ blk_first_out, int upd_T)
 {
 	__builtin_amdgcn_s_setprio(3);          // panel path = critical path: win issue arbitration against bulk-update waves
 	const int lane = threadIdx.x & 63;
@@ -342,7 +403,8 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 		alive[srow] = 0;
 		for (int e = 0; e < g; e++) {           // multipliers of this source w.r.t. earlier panels of the block
 			u64 *me_ = multset + (i64)e * rows + srow;
-			A->src_mult[lane][e] = *me_;
+			// multipliers are stored rotated for the bulk update; the TRSM wants the plain bit order
+			A->src_mult[lane][e] = rot_fields_rt(upd_T, *me_, (GF2_IL - rowq(srow)) % GF2_IL);
 			*me_ = 0;                           // the bulk update must skip the block's own sources
 		}
 	}
@@ -379,7 +441,7 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 __global__ void __launch_bounds__(256)
 k_narrow(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int g, int gb, u64 *__restrict__ Wb,
          const unsigned char *__restrict__ alive, const PanelRec *__restrict__ panels,
-         const PanelAux *__restrict__ aux, u64 *__restrict__ multset, const SolveState *__restrict__ st)
+         const PanelAux *__restrict__ aux, u64 *__restrict__ multset, const SolveState *__restrict__ st, int upd_T)
 {
 	__builtin_amdgcn_s_setprio(3);
 	const i64 first_alive = st->first;
@@ -440,7 +502,8 @@ k_narrow(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int g, int gb, u64 *_
 				if (e >= g && e < gb) Wb[i * GF2_GMAX + e] ^= acc[e];
 		}
 	}
-	mult[i] = m;
+	// stored pre-rotated for the bulk update's table layout (field s = what this row reads at step s)
+	mult[i] = rot_fields_rt(upd_T, m, rowq(i));
 }
 
 // ==========================================================================================
@@ -501,63 +564,29 @@ k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int tile_b
 	(void)NT;
 }
 
-// Balanced split of the 64 pivot bits of a panel into T bit-fields (grease tables).
-// T is even and so is the number of wide fields, so tables 2m and 2m+1 always have equal size
-// (they form a PAIR, see the LDS layout below).
-template <int T>
-struct Fields {
-	static constexpr int LO = 64 / T;                 // small field width
-	static constexpr int NBIG = 64 - T * LO;          // the first NBIG fields are one bit wider
-	static_assert(T % 2 == 0 && NBIG % 2 == 0, "tables must pair up");
-	__host__ __device__ static constexpr int width(int t) { return t < NBIG ? LO + 1 : LO; }
-	__host__ __device__ static constexpr int shift(int t) { return t < NBIG ? t * (LO + 1) : NBIG * (LO + 1) + (t - NBIG) * LO; }
-	// first 256-byte slot of pair m inside a panel (a slot holds entry i of table 2m and of table 2m+1)
-	__host__ __device__ static constexpr int pairoff(int m)
-	{
-		return 2 * m < NBIG ? m * (1 << (LO + 1)) : (NBIG / 2) * (1 << (LO + 1)) + (m - NBIG / 2) * (1 << LO);
-	}
-	static constexpr int SLOTS = (NBIG / 2) * (1 << (LO + 1)) + ((T - NBIG) / 2) * (1 << LO);   // per panel
-	// bits of the FIRST field of every wide / narrow pair (to swap the two fields of each pair)
-	__host__ __device__ static constexpr u64 first_fields(bool wide)
-	{
-		u64 r = 0;
-		for (int m = 0; m < T / 2; m++) {
-			const bool is_wide = 2 * m < NBIG;
-			if (is_wide == wide) r |= ((1ull << width(2 * m)) - 1) << shift(2 * m);
-		}
-		return r;
-	}
-	// exchange the two fields of every pair
-	__host__ __device__ static constexpr u64 swap_pairs(u64 m)
-	{
-		constexpr u64 A1 = first_fields(true), A2 = first_fields(false);
-		return ((m & A1) << (LO + 1)) | ((m >> (LO + 1)) & A1) | ((m & A2) << LO) | ((m >> LO) & A2);
-	}
-};
-
 // The bulk update of one block on a set of column tiles:
 //     row[tile] ^= XOR_{g<gb} XOR_{t<T} tab[g][t][ field t of mult_g[row] ]
-// Tables ("Method of the Four Russians") of all gb panels for one 128-byte tile live in LDS.
+// Tables ("Method of the Four Russians") of all gb panels for one tile live in LDS.
 //
-// Lane mapping: a row segment (16 words = 128 B) is covered by 8 consecutive lanes, 16 bytes each
-// (global_load_dwordx4 / ds_read_b128 / global_store_dwordx4); a wavefront covers 8 rows, so HBM
-// sees whole 128-byte segments.
+// Lane mapping: a row segment (GF2_TW words) is covered by LPR = GF2_TW/2 consecutive lanes, 16 bytes each
+// (global_load_dwordx4 / ds_read_b128 / global_store_dwordx4); a wavefront covers 64/LPR rows and, the
+// matrix being tile-major, reads/writes ONE contiguous KiB per instruction.
 //
-// LDS layout (bank-conflict free): ds_read_b128 is serviced 16 lanes at a time, and those 16
-// lanes always belong to one EVEN and one ODD row of the wavefront (two lanes-quads each).  A
-// 128-byte table entry covers half of the 64 banks, so two different entries collide with
-// probability 1/2 -- unless even rows and odd rows are steered to opposite bank halves.  Tables
-// are therefore stored in pairs: slot i of pair m = [entry i of table 2m | entry i of table 2m+1]
-// (256 B = all 64 banks), and at every step even rows look up table 2m (low half) while odd rows
-// look up table 2m+1 (high half), then the other way round.  Every ds_read_b128 touches each
-// bank exactly once.
+// LDS layout (bank-conflict free).  ds_read_b128 is serviced 16 lanes at a time; the 16 lanes of a
+// service group belong to IL = 16/LPR different rows whose rowq() values are all different (LPR = 8:
+// one even + one odd row; LPR = 4: rows {0,3,5,6} / {1,2,4,7} of each 8, rowq = (row>>1)&3).  A table
+// entry covers 1/IL of the 64 banks, so IL different entries would collide at random -- unless each of
+// those rows is steered to a different part of the bank row.  Tables are therefore stored in groups of
+// IL: slot i of a group = [entry i of table 0 | ... | entry i of table IL-1] = 256 B = all 64 banks, and
+// at step s a row with rowq = q looks up table (q+s) % IL of the group.  Every ds_read_b128 touches each
+// bank exactly once (SQ_LDS_BANK_CONFLICT ~ 0).  The multipliers arrive already rotated (field s holds
+// what the row needs at step s), so no per-lookup select is needed.
 //
-// Rows whose multipliers are all 0 (dead rows, the block's own sources, sparse rows) are neither
-// loaded nor stored.
+// Rows whose multipliers are all 0 (dead rows, the block's own sources, sparse rows) are not written back.
 template <int G, int T>
 struct UpdateCfg {
-	static constexpr int TW = 16;
-	static constexpr int LPR = TW / 2;
+	static constexpr int TW = GF2_TW;
+	static constexpr int LPR = GF2_LPR;
 	static constexpr int SLOTS = Fields<T>::SLOTS;                  // 256-byte slots per panel
 	static constexpr int LDS_BYTES = G * SLOTS * 256 + G * 64 * 4;
 };
@@ -571,7 +600,7 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 {
 	typedef UpdateCfg<G, T> C;
 	typedef Fields<T> F;
-	constexpr int TW = C::TW, LPR = C::LPR, SLOTS = C::SLOTS;
+	constexpr int TW = C::TW, LPR = C::LPR, SLOTS = C::SLOTS, IL = F::IL;
 	extern __shared__ __attribute__((aligned(16))) uint4 tab[];
 	int *prow = reinterpret_cast<int *>(tab + G * SLOTS * 16);     // [G][64] physical row of pivot bit, -1 if none
 	const int ct = blockIdx.x % ntiles;
@@ -585,11 +614,12 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	int anyp = 0;
 	for (int g = 0; g < gb; g++) anyp |= panels[j0 + g].p;
 	if (!anyp && !Wb_out) return;
-	// row range of this workgroup: [first alive row, rows) split evenly
-	const i64 rlo = *blk_first;
+	// row range of this workgroup: [first alive row, rows) split evenly; range starts are multiples of 8 so
+	// that a lane's rowq is a constant (rows just below the bound are dead: zero multipliers)
+	const i64 rlo = (i64)(*blk_first) & ~(i64)7;
 	constexpr int ALIGN = RPP * 4;
 	i64 per = (rows - rlo + nsplit - 1) / nsplit;
-	per = (per + ALIGN - 1) / ALIGN * ALIGN + 2;      // +256 B: row ranges of different workgroups are not 2^k apart
+	per = (per + ALIGN - 1) / ALIGN * ALIGN + 8;      // + a few hundred bytes: ranges of different workgroups are not 2^k apart
 	const i64 rbeg = rlo + (i64)sp * per;
 	if (rbeg >= rows) return;
 	const i64 rend = (rbeg + per < rows) ? rbeg + per : rows;
@@ -615,25 +645,25 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	// words below wlo belong to windows the panel path owns: their table slots stay zero
 	const uint4 keep = make_uint4((w0 + 2 * lr >= wlo) ? ~0u : 0u, (w0 + 2 * lr >= wlo) ? ~0u : 0u,
 	                              (w0 + 2 * lr + 1 >= wlo) ? ~0u : 0u, (w0 + 2 * lr + 1 >= wlo) ? ~0u : 0u);
-	const uint4 *Mq = reinterpret_cast<const uint4 *>(M) + tile * srows * LPR;    // this tile's slab, 8 x uint4 per row
+	const uint4 *Mq = reinterpret_cast<const uint4 *>(M) + tile * srows * LPR;    // this tile's slab, LPR x uint4 per row
 	// work item e = (panel g, table t, index idx); stage 1: indices with bits only in the low half or
 	// only in the high half of the field come straight from the (L2-resident) pivot rows;
 	// stage 2: low ^ high.
-	constexpr int EPP = 2 * SLOTS;                  // table entries per panel
+	constexpr int EPP = IL * SLOTS;                 // table entries per panel
 	for (int pass = 0; pass < 2; pass++) {
 		for (int e = rr; e < gb * EPP; e += RPP) {
 			const int g = e / EPP;
-			const int x = e - g * EPP;                // = 2 * (pairoff(m) + idx) + (t & 1)
-			const int half = x & 1, slot = x >> 1;
+			const int x = e - g * EPP;                // = IL * (groupoff(m) + idx) + part
+			const int part = x % IL, slot = x / IL;
 			int m = 0;
 #pragma unroll
-			for (int q = 1; q < T / 2; q++) if (slot >= F::pairoff(q)) m = q;
-			const int t = 2 * m + half;
-			const int idx = slot - F::pairoff(m);
+			for (int q = 1; q < F::NG; q++) if (slot >= F::groupoff(q)) m = q;
+			const int t = IL * m + part;
+			const int idx = slot - F::groupoff(m);
 			const int kl = F::width(t) >> 1;
 			const int lomask = (1 << kl) - 1;
 			const bool mixed = (idx & lomask) && (idx & ~lomask);
-			const int at = ((g * SLOTS + slot) * 2 + half) * LPR + lr;
+			const int at = (g * SLOTS + slot) * 16 + part * LPR + lr;
 			if (pass == 0) {
 				if (mixed) continue;
 				uint4 acc = make_uint4(0, 0, 0, 0);
@@ -647,38 +677,35 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 				tab[at] = acc;
 			} else {
 				if (!mixed) continue;
-				const int base = at - idx * 2 * LPR;
-				tab[at] = xor4(tab[base + (idx & lomask) * 2 * LPR], tab[base + (idx & ~lomask) * 2 * LPR]);
+				const int base = at - idx * 16;
+				tab[at] = xor4(tab[base + (idx & lomask) * 16], tab[base + (idx & ~lomask) * 16]);
 			}
 		}
 		__syncthreads();
 	}
 
 	// ---- stream the rows ----
-	// Per lane: U rows are prefetched (multipliers + 16-byte data), then handled one after the other;
-	// for each row and panel the table reads are issued in batches of 8 ds_read_b128 before the
-	// first XOR so the LDS latency overlaps, and three-input XORs (v_bitop3) fold two entries at once.
-	// Odd rows use the multiplier with the two fields of every pair exchanged: "first read of pair m"
-	// then needs no per-lookup select between the fields.
+	// Per lane: U rows per half-batch; the global loads (multipliers + data) of half-batch h+1 are issued
+	// before half-batch h is computed and stored, so every wavefront always has HBM requests in flight
+	// while it works through its LDS lookups.  Table reads go out 8 at a time before the first XOR;
+	// three-input XORs (v_bitop3) fold two entries at once.
 	uint4 *Mw = reinterpret_cast<uint4 *>(M) + tile * srows * LPR;
-	const bool odd = rr & 1;                        // row parity inside the wavefront
-	const int c1 = (odd ? LPR : 0) + lr;            // first read of a pair: even rows low half, odd rows high half
-	const int c2 = (odd ? 0 : LPR) + lr;
-	constexpr int U = GF2_UROWS;                    // rows per lane per half-batch
-	constexpr int NP = T / 2;                       // pairs per panel
-	constexpr int BATCH = GF2_BATCH;                // pairs per batch -> 2*BATCH reads in flight
-	// Software pipeline over half-batches of U rows per lane: the global loads (multipliers + data)
-	// of half-batch h+1 are issued before half-batch h is computed and stored, so every wavefront
-	// always has HBM requests in flight while it works through its LDS lookups.
-	struct Half { u64 m[U][G]; uint4 d[U]; i64 q[U]; bool on[U]; };
+	const int q = rowq(rr);                         // rbeg and the row steps are multiples of 8
+	unsigned cbyte[IL];                             // byte offset inside a 256-byte slot at step s (< 256)
+#pragma unroll
+	for (int sidx = 0; sidx < IL; sidx++) cbyte[sidx] = (unsigned)(((q + sidx) % IL) * LPR + lr) * 16u;
+	const char *tabb = reinterpret_cast<const char *>(tab);
+	constexpr int U = (G >= 4) ? 1 : GF2_UROWS;      // rows per lane per half-batch (register budget: 128 VGPRs at 1024 threads)
+	constexpr int GPB = 8 / IL;                     // groups per batch -> 8 reads in flight
+	struct Half { u64 m[U][G]; uint4 d[U]; int qx[U]; bool on[U]; };
 	auto load_half = [&](Half &H, i64 base) {
 #pragma unroll
 		for (int u = 0; u < U; u++) {
 			const i64 row = base + (i64)u * RPP + rr;
 #ifdef GF2_MB_L2               /* tools/microbench_update.hip: keep the row data L2-resident to time the table work alone */
-			H.q[u] = (row & 1023) * LPR + lr;
+			H.qx[u] = (int)((row & 1023) * LPR + lr);
 #else
-			H.q[u] = row * LPR + lr;
+			H.qx[u] = (int)(row * LPR + lr);
 #endif
 		}
 #pragma unroll
@@ -698,7 +725,7 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		// simply not written back
 #pragma unroll
 		for (int u = 0; u < U; u++)
-			if (base + (i64)u * RPP + rr < rend) H.d[u] = Mw[H.q[u]];
+			if (base + (i64)u * RPP + rr < rend) H.d[u] = Mw[H.qx[u]];
 	};
 	// priority launches (Wb_out != nullptr) also deposit the next block's window words [wlo, wlo+gnext)
 	// of every visited row into the compact buffer Wb -- updated or not -- which replaces a gather pass
@@ -720,24 +747,32 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 #pragma unroll
 			for (int g = 0; g < G; g++) {
 				if (g >= gb) break;                 // tables of absent panels were never built (uniform branch)
-				const u64 me = odd ? F::swap_pairs(H.m[u][g]) : H.m[u][g];
-				const unsigned mlo = (unsigned)me, mhi = (unsigned)(me >> 32);
+				const unsigned mlo = (unsigned)H.m[u][g], mhi = (unsigned)(H.m[u][g] >> 32);
 #pragma unroll
-				for (int p0 = 0; p0 < NP; p0 += BATCH) {
-					uint4 v[2 * BATCH];
+				for (int m0 = 0; m0 < F::NG; m0 += GPB) {
+					uint4 v[8];
 #pragma unroll
-					for (int h = 0; h < BATCH; h++) {
-						const int pm = p0 + h;
-						if (pm >= NP) { v[2 * h] = make_uint4(0, 0, 0, 0); v[2 * h + 1] = make_uint4(0, 0, 0, 0); continue; }
-						const int sa = F::shift(2 * pm), sb = F::shift(2 * pm + 1), wd = F::width(2 * pm);
-						const unsigned fa = (sa >= 32 ? (mhi >> (sa - 32)) : (sa + wd <= 32 ? (mlo >> sa) : __builtin_amdgcn_alignbit(mhi, mlo, sa))) & ((1u << wd) - 1);
-						const unsigned fb = (sb >= 32 ? (mhi >> (sb - 32)) : (sb + wd <= 32 ? (mlo >> sb) : __builtin_amdgcn_alignbit(mhi, mlo, sb))) & ((1u << wd) - 1);
-						const int slot0 = (g * SLOTS + F::pairoff(pm)) * 2 * LPR;
-						v[2 * h] = tab[slot0 + fa * 2 * LPR + c1];
-						v[2 * h + 1] = tab[slot0 + fb * 2 * LPR + c2];
+					for (int h = 0; h < GPB; h++) {
+#pragma unroll
+						for (int sidx = 0; sidx < IL; sidx++) {
+							const int gm = m0 + h;
+							if (gm >= F::NG) { v[h * IL + sidx] = make_uint4(0, 0, 0, 0); continue; }
+							// byte offset inside the group = field * 256 + (slot part, lane) * 16: the field is moved to
+							// bit 8 with ONE shift (or alignbit across the 32-bit boundary), then masked and merged with the
+							// lane constant in ONE three-operand op (v_bitop3 / v_and_or); the group base is a compile-time
+							// immediate of the ds_read
+							const int sh = F::shift(IL * gm + sidx), wd = F::width(IL * gm);
+							const unsigned fm = ((1u << wd) - 1) << 8;
+							unsigned x;
+							if (sh >= 32) x = (sh - 32 >= 8) ? (mhi >> (sh - 40)) : (mhi << (40 - sh));
+							else if (sh + wd <= 32) x = (sh >= 8) ? (mlo >> (sh - 8)) : (mlo << (8 - sh));
+							else x = __builtin_amdgcn_alignbit(mhi, mlo, sh - 8);      // sh >= 8 whenever a field straddles
+							const unsigned at = (x & fm) | cbyte[sidx];
+							v[h * IL + sidx] = *reinterpret_cast<const uint4 *>(tabb + (g * SLOTS + F::groupoff(gm)) * 256 + at);
+						}
 					}
 #pragma unroll
-					for (int h = 0; h < BATCH; h++) {
+					for (int h = 0; h < 4; h++) {
 						acc.x = __builtin_amdgcn_bitop3_b32(acc.x, v[2 * h].x, v[2 * h + 1].x, 0x96);
 						acc.y = __builtin_amdgcn_bitop3_b32(acc.y, v[2 * h].y, v[2 * h + 1].y, 0x96);
 						acc.z = __builtin_amdgcn_bitop3_b32(acc.z, v[2 * h].z, v[2 * h + 1].z, 0x96);
@@ -746,7 +781,7 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 				}
 			}
 #endif
-			Mw[H.q[u]] = acc;
+			Mw[H.qx[u]] = acc;
 			if (Wb_out) put_window(base + (i64)u * RPP + rr, acc);
 		}
 	};

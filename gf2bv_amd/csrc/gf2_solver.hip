@@ -187,6 +187,18 @@ hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows, 
 }
 
 #define UPDATE_IMPL(G, T, NT) { G, T, UpdateCfg<G, T>::LDS_BYTES, NT, launch_update<G, T, NT> }
+#if GF2_TW == 8
+const UpdateImpl kUpdates[] = {
+	UPDATE_IMPL(4, 12, 1024),   // default: 4 panels (256 pivots) per pass, 5/6-bit fields: 48 lookups, 128 KiB LDS
+	UPDATE_IMPL(4, 16, 1024),   // 4 panels, nibble fields: 64 lookups, 64 KiB
+	UPDATE_IMPL(3, 12, 1024),   // 3 panels, 36 lookups, 96 KiB
+	UPDATE_IMPL(2, 12, 1024),   // 2 panels, 24 lookups, 64 KiB
+	UPDATE_IMPL(2, 16, 1024),
+	UPDATE_IMPL(1, 12, 1024),
+	UPDATE_IMPL(1, 16, 1024),
+	UPDATE_IMPL(1, 8, 1024),    // 1 panel, byte fields: 8 lookups, 128 KiB
+};
+#else
 const UpdateImpl kUpdates[] = {
 	UPDATE_IMPL(4, 16, 1024),   // default: 4 panels (256 pivots) per pass, 64 lookups, 128 KiB LDS
 	UPDATE_IMPL(3, 16, 1024),   // 3 panels, 48 lookups, 96 KiB
@@ -197,13 +209,8 @@ const UpdateImpl kUpdates[] = {
 	UPDATE_IMPL(1, 10, 1024),   // 1 panel, 10 lookups, 112 KiB
 	UPDATE_IMPL(1, 12, 1024),   // 1 panel, 12 lookups, 64 KiB
 	UPDATE_IMPL(1, 16, 1024),   // 1 panel, 16 lookups, 32 KiB
-	UPDATE_IMPL(4, 16, 512),
-	UPDATE_IMPL(3, 16, 512),    // 512-thread variants: two workgroups per CU when LDS allows
-	UPDATE_IMPL(2, 16, 512),
-	UPDATE_IMPL(2, 12, 512),
-	UPDATE_IMPL(1, 16, 512),
-	UPDATE_IMPL(1, 12, 512),
 };
+#endif
 
 const UpdateImpl *pick_update()
 {
@@ -236,7 +243,7 @@ hipError_t launch_ysweep(dim3 grid, hipStream_t s, u64 *Y, i64 ys, i64 rows, con
 	return hipGetLastError();
 }
 
-constexpr int TW = 16;            // words per column tile (128-byte row segments)
+constexpr int TW = GF2_TW;        // words per column tile
 
 // ---- one solve ---------------------------------------------------------------------------------
 struct Solver {
@@ -451,9 +458,9 @@ int enqueue_forward(Solver &S)
 			const u64 colmask = (S.cols - c0 >= 64) ? ~0ull : ((1ull << (S.cols - c0)) - 1);
 			k_find<<<dim3((S.units + 3) / 4), dim3(256), 0, S.sA>>>(S.Wb, S.rows, j, g, colmask, S.st, S.alive, S.fu,
 			                                                       S.units, S.panels, S.aux, S.pivcol, S.urow, mset,
-			                                                       g == gb - 1 ? S.blk_first + b : nullptr);
+			                                                       g == gb - 1 ? S.blk_first + b : nullptr, S.impl->T);
 			k_narrow<<<dim3(row_blocks), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, g, gb, S.Wb, S.alive,
-			                                                 S.panels, S.aux, mset, S.st);
+			                                                 S.panels, S.aux, mset, S.st, S.impl->T);
 		}
 		if (b == S.nblocks - 1)
 			k_win_scatter<<<dim3((unsigned)((S.rows * gb + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, gb, S.Wb, S.alive);

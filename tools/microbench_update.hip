@@ -18,7 +18,7 @@ void run(const char *name, u64 *M, i64 rows, i64 srows, int ntiles, PanelRec *pa
 	const int reps = 5;
 	CK(hipEventRecord(e0)); for (int r = 0; r < reps; r++) launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
 	float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
-	double bytes = 2.0 * (double)(rows - 256) * ntiles * 128;
+	double bytes = 2.0 * (double)(rows - 256) * ntiles * GF2_TW * 8;
 	printf("%-10s G=%d T=%2d NT=%4d nsplit=%3d: %.3f ms  %.2f TB/s per pass  (x%d = %.2f TB/s single-panel equivalent)\n", name, G, T, NT, nsplit, ms,
 	       bytes / ms / 1e9, G, G * bytes / ms / 1e9);
 }
@@ -26,10 +26,10 @@ void run(const char *name, u64 *M, i64 rows, i64 srows, int ntiles, PanelRec *pa
 int main(int argc, char **argv)
 {
 	const i64 rows = argc > 1 ? atol(argv[1]) : 131072;
-	const int ntiles = argc > 2 ? atoi(argv[2]) : 64;
+	const int ntiles = argc > 2 ? atoi(argv[2]) : 1024 / GF2_TW;     // 1 KiB of row width by default
 	const i64 srows = (rows + 63) / 64 * 64 + 2;
 	u64 *M, *mult; PanelRec *panels; PanelAux *aux; int *blkf;
-	CK(hipMalloc(&M, (size_t)ntiles * srows * 128)); CK(hipMemset(M, 0x5a, (size_t)ntiles * srows * 128));
+	CK(hipMalloc(&M, (size_t)ntiles * srows * GF2_TW * 8)); CK(hipMemset(M, 0x5a, (size_t)ntiles * srows * GF2_TW * 8));
 	CK(hipMalloc(&mult, (size_t)GF2_GMAX * rows * 8));
 	std::vector<u64> hm((size_t)GF2_GMAX * rows);
 	u64 x = 88172645463325252ull;
@@ -49,13 +49,20 @@ int main(int argc, char **argv)
 	const char *name = "full";
 #endif
 	for (int ns : {16}) {
+#if GF2_TW == 8
+		run<1, 16, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
+		run<4, 16, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
+		run<1, 12, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
+		run<2, 12, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
+		run<3, 12, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
+		run<4, 12, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
+		run<1, 8, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
+#else
 		run<1, 16, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
 		run<2, 16, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
 		run<3, 16, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
 		run<4, 16, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
-		run<3, 14, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
-		run<2, 12, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
-		run<2, 14, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
+#endif
 	}
 	return 0;
 }
