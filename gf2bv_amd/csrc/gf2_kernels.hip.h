@@ -756,7 +756,7 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 #pragma unroll
 						for (int sidx = 0; sidx < IL; sidx++) {
 							const int gm = m0 + h;
-							if (gm >= F::NG) { v[h * IL + sidx] = make_uint4(0, 0, 0, 0); continue; }
+							if (gm >= F::NG) continue;
 							// byte offset inside the group = field * 256 + (slot part, lane) * 16: the field is moved to
 							// bit 8 with ONE shift (or alignbit across the 32-bit boundary), then masked and merged with the
 							// lane constant in ONE three-operand op (v_bitop3 / v_and_or); the group base is a compile-time
@@ -767,12 +767,14 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 							if (sh >= 32) x = (sh - 32 >= 8) ? (mhi >> (sh - 40)) : (mhi << (40 - sh));
 							else if (sh + wd <= 32) x = (sh >= 8) ? (mlo >> (sh - 8)) : (mlo << (8 - sh));
 							else x = __builtin_amdgcn_alignbit(mhi, mlo, sh - 8);      // sh >= 8 whenever a field straddles
-							const unsigned at = (x & fm) | cbyte[sidx];
+							const unsigned at = (x & fm) | (cbyte[sidx] & ~fm);      // bit-field insert: one v_bfi_b32
 							v[h * IL + sidx] = *reinterpret_cast<const uint4 *>(tabb + (g * SLOTS + F::groupoff(gm)) * 256 + at);
 						}
 					}
+					const int nv = ((F::NG - m0 < GPB) ? (F::NG - m0) : GPB) * IL;     // entries actually read (even; folds after unrolling)
 #pragma unroll
 					for (int h = 0; h < 4; h++) {
+						if (h >= nv / 2) break;
 						acc.x = __builtin_amdgcn_bitop3_b32(acc.x, v[2 * h].x, v[2 * h + 1].x, 0x96);
 						acc.y = __builtin_amdgcn_bitop3_b32(acc.y, v[2 * h].y, v[2 * h + 1].y, 0x96);
 						acc.z = __builtin_amdgcn_bitop3_b32(acc.z, v[2 * h].z, v[2 * h + 1].z, 0x96);
