@@ -48,10 +48,10 @@ static_assert(GF2_TW == 8 || GF2_TW == 16, "tile width");
 #endif
 
 // Working layout of the matrix in HBM: TILE-MAJOR.  Column tile c (words [16c, 16c+16)) of all
-// rows is one contiguous slab of rows x 128 bytes; inside the slab rows follow each other.  Every
-// heavy kernel works on one column tile at a time, so a wavefront's 8 rows x 128 B are ONE
+// rows is one contiguous slab of srows x GF2_TW*8 bytes; inside the slab rows follow each other.  Every
+// heavy kernel works on one column tile at a time, so the 64/GF2_LPR rows of a wavefront are ONE
 // contiguous KiB and a workgroup streams a contiguous range -- whole-line, page-friendly HBM
-// traffic.  (With a row-major matrix the same kernel touched one 128-byte line every 4-32 KiB and
+// traffic.  (With a row-major matrix the same kernel touched one short line every 4-32 KiB and
 // rocprofv3 showed 2.5x / 4x the algorithmic FETCH / WRITE bytes.)  The C ABI stays row-major;
 // k_to_tiled / k_pack_digits convert on the way in.  A slab is `srows` rows long: rows rounded up
 // plus an odd number of 256-byte units, so that equal rows of neighbouring tiles (what concurrently
@@ -510,7 +510,7 @@ k_narrow(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int g, int gb, u64 *_
 // BULK PATH (stream B)
 // ==========================================================================================
 
-// "TRSM" of one block on one 128-byte column tile (one workgroup per tile): brings the block's
+// "TRSM" of one block on one column tile: brings the block's
 // source rows up to date panel by panel and forms the final pivot rows
 //   P_g[k] = XOR_{s in comb_g[k]} S_g[s]          (pivot rows of panel g)
 //   S_h[s] ^= XOR_{b in src_mult_h[s][g]} P_g[b]  (sources of later panels h > g were alive then)
