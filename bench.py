@@ -47,7 +47,10 @@ def parse():
     ap.add_argument("--n", type=int, default=65536, help="system size N (rows = cols)")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=32768, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-n", type=int, default=65536, help="size of the bounded CPU-baseline sample")
+    ap.add_argument("--batch-systems", type=int, default=16,
+                    help="also time a gang batch of this many independent --batch-n systems (0 = skip); extra field, not `value`")
+    ap.add_argument("--batch-n", type=int, default=32768)
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket sweep launches with HIP events (roofline becomes null)")
     return ap.parse_args()
@@ -87,7 +90,29 @@ def cpu_baseline(n: int, seed: int) -> dict:
         "row_panels_per_s": n * panels / dt,          # table-count independent: (rows x 64-column panels) eliminated per second
         "single_core": {"value": res1["row_xors"] / dt1, "seconds": dt1, "n": max(n // 2, 1024)},
         "thread_probe_8192_seconds": {str(k): v for k, v in probe.items()},
+        "_origin": res["origin"], "_status": int(res["status"]),
     }
+
+
+def batch_throughput(n: int, nsys: int, device: int) -> dict:
+    """BASELINE configs[3] per-GPU share in miniature: nsys independent n x n systems resident in HBM, solved by
+    gf2bv_solve_batch_device (lock-step gangs); every solution checked by the residual kernel."""
+    stride = hip.padded_stride(n)
+    buf = hip.DeviceBuffer(nsys * n * stride * 8, device)
+    for i in range(nsys):
+        hip.synth_device(buf.ptr + i * n * stride * 8, n, n, stride, 5000 + i, device=device)
+    best, sols = None, None
+    for _ in range(2):                                   # first pass warms the allocator
+        t0 = time.perf_counter()
+        sols = hip.solve_batch_device(buf.ptr, nsys, n * stride, n, n, stride, hip.MODE_SINGLE, device)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    bad = sum(hip.residual_device(buf.ptr + i * n * stride * 8, n, n, stride, s.origin, device=device)
+              for i, s in enumerate(sols))
+    xors = float(sum(s.stats["row_xors"] for s in sols))
+    buf.free()
+    return {"n": n, "systems": nsys, "ms_per_system": best / nsys * 1e3, "row_xors_per_s": xors / best,
+            "residual_rows": int(bad), "all_solved": all(s.solved for s in sols)}
 
 
 def pmc_traffic(n: int, g: int, t: int):
@@ -210,8 +235,21 @@ def main():
             "row_panels_per_s": world * n * ((n + 63) // 64) / 2 / (elapsed / args.steps),
             "roofline": roofline,
         }
+        if world == 1 and args.batch_systems > 0:
+            out["batch_throughput"] = batch_throughput(args.batch_n, args.batch_systems, local_rank)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_n, seed)
+            cb = cpu_baseline(args.cpu_n, seed)
+            # parity gate, second half: the same sample on the GPU must give the oracle's answer word for word
+            m = args.cpu_n
+            st2 = hip.padded_stride(m)
+            buf = hip.DeviceBuffer(m * st2 * 8, local_rank)
+            hip.synth_device(buf.ptr, m, m, st2, seed, device=local_rank)
+            g = hip.solve_device(buf.ptr, m, m, st2, hip.MODE_SINGLE, device=local_rank)
+            buf.free()
+            o_status, o_origin = cb.pop("_status"), cb.pop("_origin")
+            same = g.rank == cb["rank"] and g.status == o_status and np.array_equal(g.origin, o_origin)
+            out["parity_gate"]["gpu_equals_cpu_oracle_on_sample"] = bool(same)
+            out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -197,10 +197,23 @@ __global__ void k_pack_digits(const uint32_t *__restrict__ digits, const i64 *__
 	M[tidx(r, w, srows)] = val;
 }
 
+// Gang execution: several systems of one shape are eliminated in lock-step by the same launches;
+// blockIdx.y selects the system.  A system's working matrix and its side-array arena sit at fixed
+// strides from those of system 0, so a kernel rebases its pointers once ({0, 0}: a single system).
+struct SysStride { i64 m_words, arena_bytes; };
+template <class P>
+__device__ __forceinline__ P *sys_at(P *p, i64 bytes)
+{
+	return reinterpret_cast<P *>(reinterpret_cast<uintptr_t>(p) + bytes);
+}
+
 // Row-major augmented words (the C ABI layout) -> tile-major working layout, 16 bytes per lane.
 __global__ void __launch_bounds__(256)
-k_to_tiled(const u64 *__restrict__ src, i64 stride, i64 rows, i64 ntiles, i64 wt, i64 srows, u64 *__restrict__ dst)
+k_to_tiled(const u64 *__restrict__ src, i64 stride, i64 rows, i64 ntiles, i64 wt, i64 srows, u64 *__restrict__ dst,
+           i64 src_sys_words, SysStride ss)
 {
+	src += blockIdx.y * src_sys_words;
+	dst += blockIdx.y * ss.m_words;
 	const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;       // (tile, row, lr)
 	const int lr = (int)(t % GF2_LPR);
 	const i64 row = (t / GF2_LPR) % rows;
@@ -219,8 +232,10 @@ k_to_tiled(const u64 *__restrict__ src, i64 stride, i64 rows, i64 ntiles, i64 wt
 
 // Wb[i][g] = M[i][j0+g]: the block's window, compact (G words per row).
 __global__ void __launch_bounds__(256)
-k_win_gather(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, u64 *__restrict__ Wb)
+k_win_gather(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, u64 *__restrict__ Wb, SysStride ss)
 {
+	M += blockIdx.y * ss.m_words;
+	Wb = sys_at(Wb, blockIdx.y * ss.arena_bytes);
 	const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
 	const i64 i = t / gb;
 	const int g = (int)(t % gb);
@@ -231,8 +246,11 @@ k_win_gather(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, u64
 // Alive rows get their window back (only needed for the final block: the RHS bit may live in it).
 __global__ void __launch_bounds__(256)
 k_win_scatter(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, const u64 *__restrict__ Wb,
-              const unsigned char *__restrict__ alive)
+              const unsigned char *__restrict__ alive, SysStride ss)
 {
+	M += blockIdx.y * ss.m_words;
+	Wb = sys_at(Wb, blockIdx.y * ss.arena_bytes);
+	alive = sys_at(alive, blockIdx.y * ss.arena_bytes);
 	const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
 	const i64 i = t / gb;
 	const int g = (int)(t % gb);
@@ -299,9 +317,16 @@ __global__ void __launch_bounds__(256)
 k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveState *__restrict__ st,
        unsigned char *__restrict__ alive, FindUnit *__restrict__ fu, int units,
        PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol,
-       int *__restrict__ urow, u64 *__restrict__ multset, int *__restrict__ blk_first_out, int upd_T)
+       int *__restrict__ urow, u64 *__restrict__ multset, int *__restrict__ blk_first_out, int upd_T, SysStride ss)
 {
 	__builtin_amdgcn_s_setprio(3);          // panel path = critical path: win issue arbitration against bulk-update waves
+	{
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		Wb = sys_at(Wb, ao); st = sys_at(st, ao); alive = sys_at(alive, ao); fu = sys_at(fu, ao);
+		panels = sys_at(panels, ao); aux = sys_at(aux, ao); pivcol = sys_at(pivcol, ao); urow = sys_at(urow, ao);
+		multset = sys_at(multset, ao);
+		if (blk_first_out) blk_first_out = sys_at(blk_first_out, ao);
+	}
 	const int lane = threadIdx.x & 63;
 	const int u = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
 	if (u >= units) return;
@@ -441,9 +466,16 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 __global__ void __launch_bounds__(256)
 k_narrow(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int g, int gb, u64 *__restrict__ Wb,
          const unsigned char *__restrict__ alive, const PanelRec *__restrict__ panels,
-         const PanelAux *__restrict__ aux, u64 *__restrict__ multset, const SolveState *__restrict__ st, int upd_T)
+         const PanelAux *__restrict__ aux, u64 *__restrict__ multset, const SolveState *__restrict__ st, int upd_T,
+         SysStride ss)
 {
 	__builtin_amdgcn_s_setprio(3);
+	{
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		M += blockIdx.y * ss.m_words;
+		Wb = sys_at(Wb, ao); alive = sys_at(alive, ao); panels = sys_at(panels, ao); aux = sys_at(aux, ao);
+		multset = sys_at(multset, ao); st = sys_at(st, ao);
+	}
 	const i64 first_alive = st->first;
 	__shared__ u64 Sw[GF2_GMAX][64];     // window words of the source rows          [word][slot]
 	__shared__ u64 Pb[GF2_GMAX][64];     // reduced pivot rows' window words          [word][pivot BIT]
@@ -520,9 +552,12 @@ k_narrow(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int g, int gb, u64 *_
 template <int TW, int WPW>
 __global__ void __launch_bounds__(64 * WPW)
 k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int tile_begin,
-             const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux)
+             const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux, SysStride ss)
 {
 	__builtin_amdgcn_s_setprio(2);
+	M += blockIdx.y * ss.m_words;
+	panels = sys_at(panels, blockIdx.y * ss.arena_bytes);
+	aux = sys_at(aux, blockIdx.y * ss.arena_bytes);
 	constexpr int NT = 64 * WPW;
 	constexpr int SPLIT = TW / WPW;
 	__shared__ u64 S[GF2_GMAX * 64 * WPW];     // [panel][slot][word]
@@ -596,8 +631,14 @@ __global__ void __launch_bounds__(NT)
 k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
          const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
          const u64 *__restrict__ multset, const int *__restrict__ blk_first,
-         int tile_begin, int ntiles, int nsplit, u64 *__restrict__ Wb_out, int gnext)
+         int tile_begin, int ntiles, int nsplit, u64 *__restrict__ Wb_out, int gnext, SysStride ss)
 {
+	{
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		M += blockIdx.y * ss.m_words;
+		panels = sys_at(panels, ao); aux = sys_at(aux, ao); multset = sys_at(multset, ao); blk_first = sys_at(blk_first, ao);
+		if (Wb_out) Wb_out = sys_at(Wb_out, ao);
+	}
 	typedef UpdateCfg<G, T> C;
 	typedef Fields<T> F;
 	constexpr int TW = C::TW, LPR = C::LPR, SLOTS = C::SLOTS, IL = F::IL;
@@ -806,8 +847,11 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 // RHS bits are zero too (the check inside _mzd_pluq_solve_left, _internal.c:440).
 __global__ void __launch_bounds__(256)
 k_check_rhs(const u64 *__restrict__ M, i64 rows, i64 srows, i64 cols,
-            const unsigned char *__restrict__ alive, SolveState *__restrict__ st)
+            const unsigned char *__restrict__ alive, SolveState *__restrict__ st, SysStride ss)
 {
+	M += blockIdx.y * ss.m_words;
+	alive = sys_at(alive, blockIdx.y * ss.arena_bytes);
+	st = sys_at(st, blockIdx.y * ss.arena_bytes);
 	int bad = 0;
 	for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (i64)gridDim.x * blockDim.x)
 		if (alive[i]) bad |= (int)((M[tidx(i, cols >> 6, srows)] >> (cols & 63)) & 1);

@@ -163,13 +163,13 @@ Pool &pool()
 struct UpdateImpl {
 	int G, T, lds_bytes, threads;
 	hipError_t (*update)(dim3, hipStream_t, u64 *, i64, i64, int, int, int, const PanelRec *, const PanelAux *,
-	                     const u64 *, const int *, int, int, int, u64 *, int);
+	                     const u64 *, const int *, int, int, int, u64 *, int, SysStride);
 };
 
 template <int G, int T, int NT>
 hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows, int j0, int gb, int wlo,
                          const PanelRec *panels, const PanelAux *aux, const u64 *multset, const int *blk_first,
-                         int tile_begin, int ntiles, int nsplit, u64 *wb_out, int gnext)
+                         int tile_begin, int ntiles, int nsplit, u64 *wb_out, int gnext, SysStride ss)
 {
 	constexpr int lds = UpdateCfg<G, T>::LDS_BYTES;
 	static bool attr_set[16] = {};
@@ -182,7 +182,7 @@ hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows, 
 		attr_set[dev] = true;
 	}
 	k_update<G, T, NT><<<grid, dim3(NT), lds, s>>>(M, rows, srows, j0, gb, wlo, panels, aux, multset, blk_first,
-	                                               tile_begin, ntiles, nsplit, wb_out, gnext);
+	                                               tile_begin, ntiles, nsplit, wb_out, gnext, ss);
 	return hipGetLastError();
 }
 
@@ -256,6 +256,13 @@ struct Solver {
 	u64 *Ybuf = nullptr;
 	i64 rows = 0, cols = 0, stride = 0;
 	i64 ntiles = 0, srows = 0;    // tiles, rows per tile slab (padded)
+	// gang: nsys same-shape systems eliminated in lock-step by the same launches (blockIdx.y = system);
+	// system s lives at M + s * m_stride words / arena + s * arena_stride bytes, its input at src + s * src_sys_words
+	int nsys = 1;
+	i64 m_stride = 0, src_sys_words = 0;
+	size_t arena_stride = 0;
+	bool view = false;            // a non-owning window on one system of a gang (back-substitution, export)
+	SysStride ss() const { return SysStride{ m_stride, (i64)arena_stride }; }
 	int mode = 0;
 	bool time_kernels = false;
 	int dbg_sync = 0;
@@ -283,13 +290,32 @@ struct Solver {
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
 	std::vector<hipEvent_t> evA, evPrio, kev;
 	std::vector<int> free_order;     // free columns in M4RI kernel order (mode 1)
+	// host staging of the export (filled by asynchronous copies between finish_begin and finish_end)
+	SolveState hst{};
+	std::vector<u64> hout;
+	std::vector<PanelRec> hp;
+	std::vector<int32_t> hpiv;
+	hipEvent_t evx = nullptr;
 	std::chrono::steady_clock::time_point t_begin;
 	float ms_pack = 0;
 
 	~Solver() { release(); }
 	void release()
 	{
+		if (!arena && !M && !tmp_src && !Y && !ycols && !out && !sA && !sB && !ev0) return;     // nothing held
 		(void)hipSetDevice(device);
+		if (view) {               // owns only what its own back-substitution allocated
+			if (sA && (Y || ycols || out)) (void)hipStreamSynchronize(sA);
+			Pool &P = pool();
+			for (void *p : { (void *)Y, (void *)ycols, (void *)out }) P.release(p);
+			P.release_event(ev2, true);
+			P.release_event(evx, true); evx = nullptr;
+			Y = nullptr; ycols = nullptr; out = nullptr; ev2 = nullptr;
+			arena = nullptr; M = nullptr; tmp_src = nullptr; sA = sB = nullptr;
+			ev0 = ev1 = ev3 = nullptr;
+			kev.clear(); evA.clear(); evPrio.clear();
+			return;
+		}
 		// nothing goes back to the pool while work may still be in flight (error paths return early)
 		if (sB) (void)hipStreamSynchronize(sB);
 		if (arena || M) (void)hipStreamSynchronize(sA);
@@ -298,7 +324,7 @@ struct Solver {
 		arena = nullptr; Y = nullptr; ycols = nullptr; out = nullptr; M = nullptr; tmp_src = nullptr;
 		st = nullptr; panels = nullptr; aux = nullptr; fu = nullptr; alive = nullptr; pivcol = nullptr;
 		urow = nullptr; blk_first = nullptr; mult = nullptr; Wb = nullptr;
-		for (hipEvent_t *e : { &ev0, &ev1, &ev2, &ev3 }) { P.release_event(*e, true); *e = nullptr; }
+		for (hipEvent_t *e : { &ev0, &ev1, &ev2, &ev3, &evx }) { P.release_event(*e, true); *e = nullptr; }
 		for (hipEvent_t e : kev) P.release_event(e, true);
 		for (hipEvent_t e : evA) P.release_event(e, false);
 		for (hipEvent_t e : evPrio) P.release_event(e, false);
@@ -342,11 +368,12 @@ int solver_alloc(Solver &S)
 	S.impl = pick_update();
 	S.ntiles = (S.wt + TW - 1) / TW;
 	S.srows = slab_rows(S.rows);
-	if (!S.M) HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * S.ntiles * TW * S.srows, S.device));
+	S.m_stride = S.ntiles * TW * S.srows;
+	if (!S.M) HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * S.m_stride * S.nsys, S.device));
 	if (S.src && S.rows > 0) {
 		const i64 threads = S.ntiles * S.rows * 8;
-		k_to_tiled<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, S.sA>>>(S.src, S.stride, S.rows, S.ntiles,
-		                                                                             std::min(S.wt, S.stride), S.srows, S.M);
+		k_to_tiled<<<dim3((unsigned)((threads + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(
+			S.src, S.stride, S.rows, S.ntiles, std::min(S.wt, S.stride), S.srows, S.M, S.src_sys_words, S.ss());
 	}
 	const int G = S.impl->G;
 	S.nblocks = (S.npanels + G - 1) / G;
@@ -369,16 +396,20 @@ int solver_alloc(Solver &S)
 		             o_piv = carve(sizeof(int) * (S.maxr + 64)), o_urow = carve(sizeof(int) * (S.maxr + 64)),
 		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * 2 * G * R),
 		             o_wb = carve(sizeof(u64) * GF2_GMAX * R);
-		HIPCHK(pool().alloc(&S.arena, off, S.device));
+		S.arena_stride = off;
+		HIPCHK(pool().alloc(&S.arena, off * S.nsys, S.device));
 		char *base = (char *)S.arena;
 		S.st = (SolveState *)(base + o_st); S.panels = (PanelRec *)(base + o_pan); S.aux = (PanelAux *)(base + o_aux);
 		S.fu = (FindUnit *)(base + o_fu); S.alive = (unsigned char *)(base + o_alive); S.pivcol = (int *)(base + o_piv);
 		S.urow = (int *)(base + o_urow); S.blk_first = (int *)(base + o_blk); S.mult = (u64 *)(base + o_mult);
 		S.Wb = (u64 *)(base + o_wb);
 		// zero everything that is read before it is written: state, panel records, unit scratch, block bounds, multipliers
-		HIPCHK(hipMemsetAsync(base + o_st, 0, o_alive - o_st, S.sA));
-		HIPCHK(hipMemsetAsync(S.alive, 1, (size_t)R, S.sA));
-		HIPCHK(hipMemsetAsync(base + o_blk, 0, o_wb - o_blk, S.sA));
+		for (int s = 0; s < S.nsys; s++) {
+			char *b = base + (size_t)s * off;
+			HIPCHK(hipMemsetAsync(b + o_st, 0, o_alive - o_st, S.sA));
+			HIPCHK(hipMemsetAsync(b + o_alive, 1, (size_t)R, S.sA));
+			HIPCHK(hipMemsetAsync(b + o_blk, 0, o_wb - o_blk, S.sA));
+		}
 	}
 	HIPCHK(pool().event(&S.ev0, true));
 	HIPCHK(pool().event(&S.ev1, true));
@@ -406,8 +437,8 @@ int pick_nsplit(i64 rows, int ntiles)
 int launch_trsm(Solver &S, hipStream_t st, int j0, int gb, int wlo, int tile_begin, int ntiles)
 {
 	constexpr int WPW = 4;
-	k_block_trsm<TW, WPW><<<dim3(ntiles * (TW / WPW)), dim3(64 * WPW), 0, st>>>(S.M, S.srows, j0, gb, wlo, tile_begin,
-	                                                                           S.panels, S.aux);
+	k_block_trsm<TW, WPW><<<dim3(ntiles * (TW / WPW), S.nsys), dim3(64 * WPW), 0, st>>>(S.M, S.srows, j0, gb, wlo, tile_begin,
+	                                                                                   S.panels, S.aux, S.ss());
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
@@ -421,9 +452,9 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 		S.kev.push_back(ka); S.kev.push_back(kb);
 		HIPCHK(hipEventRecord(ka, st));
 	}
-	const int ns = pick_nsplit(S.rows, ntiles);
-	HIPCHK(S.impl->update(dim3((unsigned)(ntiles * ns)), st, S.M, S.rows, S.srows, j0, gb, wlo, S.panels, S.aux, mset,
-	                      S.blk_first + b, tile_begin, ntiles, ns, wb_out, gnext));
+	const int ns = pick_nsplit(S.rows, ntiles * S.nsys);      // the gang's workgroups share the chip
+	HIPCHK(S.impl->update(dim3((unsigned)(ntiles * ns), S.nsys), st, S.M, S.rows, S.srows, j0, gb, wlo, S.panels, S.aux, mset,
+	                      S.blk_first + b, tile_begin, ntiles, ns, wb_out, gnext, S.ss()));
 	if (S.time_kernels) HIPCHK(hipEventRecord(kb, st));
 	return GF2BV_OK;
 }
@@ -444,7 +475,7 @@ int enqueue_forward(Solver &S)
 	HIPCHK(hipStreamWaitEvent(S.sB, S.ev0, 0));     // sB starts after the setup memsets on sA
 	if (S.npanels > 0) {
 		const int g0 = std::min(G, S.npanels);
-		k_win_gather<<<dim3((unsigned)((S.rows * g0 + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, 0, g0, S.Wb);
+		k_win_gather<<<dim3((unsigned)((S.rows * g0 + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, 0, g0, S.Wb, S.ss());
 	}
 	for (int b = 0; b < S.nblocks; b++) {
 		const int j0 = b * G;
@@ -456,14 +487,14 @@ int enqueue_forward(Solver &S)
 			const int j = j0 + g;
 			const i64 c0 = (i64)j * 64;
 			const u64 colmask = (S.cols - c0 >= 64) ? ~0ull : ((1ull << (S.cols - c0)) - 1);
-			k_find<<<dim3((S.units + 3) / 4), dim3(256), 0, S.sA>>>(S.Wb, S.rows, j, g, colmask, S.st, S.alive, S.fu,
-			                                                       S.units, S.panels, S.aux, S.pivcol, S.urow, mset,
-			                                                       g == gb - 1 ? S.blk_first + b : nullptr, S.impl->T);
-			k_narrow<<<dim3(row_blocks), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, g, gb, S.Wb, S.alive,
-			                                                 S.panels, S.aux, mset, S.st, S.impl->T);
+			k_find<<<dim3((S.units + 3) / 4, S.nsys), dim3(256), 0, S.sA>>>(S.Wb, S.rows, j, g, colmask, S.st, S.alive, S.fu,
+			                                                               S.units, S.panels, S.aux, S.pivcol, S.urow, mset,
+			                                                               g == gb - 1 ? S.blk_first + b : nullptr, S.impl->T, S.ss());
+			k_narrow<<<dim3(row_blocks, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, g, gb, S.Wb, S.alive,
+			                                                         S.panels, S.aux, mset, S.st, S.impl->T, S.ss());
 		}
 		if (b == S.nblocks - 1)
-			k_win_scatter<<<dim3((unsigned)((S.rows * gb + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, gb, S.Wb, S.alive);
+			k_win_scatter<<<dim3((unsigned)((S.rows * gb + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, gb, S.Wb, S.alive, S.ss());
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(S.evA[b], S.sA));
 		if (S.dbg_sync & 1) HIPCHK(hipDeviceSynchronize());
@@ -497,8 +528,8 @@ int enqueue_forward(Solver &S)
 				rc = launch_update_timed(S, S.sA, b, j0, gb, wlo, mset, tb, nprio, S.Wb, gnext);
 				if (rc) return rc;
 			} else {
-				k_win_gather<<<dim3((unsigned)((S.rows * gnext + 255) / 256)), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, wlo,
-				                                                                                     std::max(gnext, 1), S.Wb);
+				k_win_gather<<<dim3((unsigned)((S.rows * gnext + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, wlo,
+				                                                                                             std::max(gnext, 1), S.Wb, S.ss());
 			}
 		}
 	}
@@ -507,7 +538,7 @@ int enqueue_forward(Solver &S)
 	HIPCHK(hipStreamWaitEvent(S.sA, S.ev3, 0));
 	{
 		int g = (int)std::min<i64>(1024, (S.rows + 255) / 256);
-		k_check_rhs<<<dim3(g), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, S.cols, S.alive, S.st);
+		k_check_rhs<<<dim3(g, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, S.cols, S.alive, S.st, S.ss());
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(S.ev1, S.sA));
@@ -586,45 +617,53 @@ int solver_enqueue(Solver &S)
 	return GF2BV_OK;
 }
 
-int solver_finish(Solver &S, gf2bv_result **out)
+// Export, first half: (mode 1: rank and pivot columns to the host, kernel-basis back-substitution,)
+// then the asynchronous device-to-host copies of everything the result needs.
+int finish_begin(Solver &S)
 {
-	Trace tr;
-	SolveState hst;
-	std::vector<int32_t> piv;
-	hipEvent_t evx = nullptr;
-	HIPCHK(pool().event(&evx, true));
+	HIPCHK(pool().event(&S.evx, true));
 	if (S.mode == GF2BV_MODE_AFFINE_SPACE) {
 		// the kernel basis needs rank and pivot columns on the host (one sync) to lay out
 		// the free columns in M4RI's order (_internal.c:348)
-		HIPCHK(hipMemcpyAsync(&hst, S.st, sizeof hst, hipMemcpyDeviceToHost, S.sA));
+		HIPCHK(hipMemcpyAsync(&S.hst, S.st, sizeof S.hst, hipMemcpyDeviceToHost, S.sA));
 		HIPCHK(hipStreamSynchronize(S.sA));
-		piv.resize(hst.rank);
-		if (hst.rank)
-			HIPCHK(hipMemcpy(piv.data(), S.pivcol, sizeof(int) * hst.rank, hipMemcpyDeviceToHost));
+		std::vector<int32_t> piv(S.hst.rank);
+		if (S.hst.rank)
+			HIPCHK(hipMemcpy(piv.data(), S.pivcol, sizeof(int) * S.hst.rank, hipMemcpyDeviceToHost));
 		std::vector<int> order(S.cols);
 		for (i64 i = 0; i < S.cols; i++) order[i] = (int)i;
-		for (int i = 0; i < hst.rank; i++) std::swap(order[i], order[piv[i]]);
-		S.free_order.assign(order.begin() + hst.rank, order.end());
+		for (int i = 0; i < S.hst.rank; i++) std::swap(order[i], order[piv[i]]);
+		S.free_order.assign(order.begin() + S.hst.rank, order.end());
 		std::vector<int> yc;
-		if (!hst.inconsistent) yc = S.free_order;
+		if (!S.hst.inconsistent) yc = S.free_order;
 		yc.push_back((int)S.cols);
 		int rc = enqueue_backward(S, yc);
 		if (rc) return rc;
 	}
-	HIPCHK(hipMemcpyAsync(&hst, S.st, sizeof hst, hipMemcpyDeviceToHost, S.sA));
-	std::vector<u64> hout((size_t)S.ny * std::max<i64>(1, S.cw));
-	HIPCHK(hipMemcpyAsync(hout.data(), S.out, sizeof(u64) * hout.size(), hipMemcpyDeviceToHost, S.sA));
-	std::vector<PanelRec> hp(std::max(1, S.npanels));
-	HIPCHK(hipMemcpyAsync(hp.data(), S.panels, sizeof(PanelRec) * hp.size(), hipMemcpyDeviceToHost, S.sA));
-	HIPCHK(hipEventRecord(evx, S.sA));
-	tr.mark("finish: enqueue tail");
+	HIPCHK(hipMemcpyAsync(&S.hst, S.st, sizeof S.hst, hipMemcpyDeviceToHost, S.sA));
+	S.hout.resize((size_t)S.ny * std::max<i64>(1, S.cw));
+	HIPCHK(hipMemcpyAsync(S.hout.data(), S.out, sizeof(u64) * S.hout.size(), hipMemcpyDeviceToHost, S.sA));
+	S.hp.resize(std::max(1, S.npanels));
+	HIPCHK(hipMemcpyAsync(S.hp.data(), S.panels, sizeof(PanelRec) * S.hp.size(), hipMemcpyDeviceToHost, S.sA));
+	S.hpiv.resize(std::max<i64>(1, S.maxr));
+	HIPCHK(hipMemcpyAsync(S.hpiv.data(), S.pivcol, sizeof(int) * S.hpiv.size(), hipMemcpyDeviceToHost, S.sA));
+	HIPCHK(hipEventRecord(S.evx, S.sA));
+	return GF2BV_OK;
+}
+
+// Export, second half: wait for the copies and build the result object.
+int finish_end(Solver &S, gf2bv_result **out)
+{
+	Trace tr;
 	HIPCHK(hipStreamSynchronize(S.sA));
 	HIPCHK(hipStreamSynchronize(S.sB));
 	tr.mark("finish: sync");
-	if (piv.empty() && hst.rank) {
-		piv.resize(hst.rank);
-		HIPCHK(hipMemcpy(piv.data(), S.pivcol, sizeof(int) * hst.rank, hipMemcpyDeviceToHost));
-	}
+	const SolveState &hst = S.hst;
+	const std::vector<u64> &hout = S.hout;
+	const std::vector<PanelRec> &hp = S.hp;
+	S.hpiv.resize(hst.rank);
+	const std::vector<int32_t> &piv = S.hpiv;
+	hipEvent_t evx = S.evx;
 
 	gf2bv_result *R = new gf2bv_result();
 	R->status = hst.inconsistent ? GF2BV_STATUS_INCONSISTENT : GF2BV_STATUS_SOLVED;
@@ -676,10 +715,67 @@ int solver_finish(Solver &S, gf2bv_result **out)
 		(void)hipEventElapsedTime(&ms, S.kev[i], S.kev[i + 1]);
 		st.ms_sweep += ms;
 	}
-	pool().release_event(evx, true);
 	st.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - S.t_begin).count();
 	tr.mark("finish: result");
 	*out = R;
+	return GF2BV_OK;
+}
+
+int solver_finish(Solver &S, gf2bv_result **out)
+{
+	int rc = finish_begin(S);
+	if (rc) return rc;
+	return finish_end(S, out);
+}
+
+// A non-owning window on system s of a gang: same streams and events, pointers moved to that
+// system's matrix and arena.  Back-substitution and export then run per system, unchanged.
+int make_view(const Solver &S, int s, Solver &V)
+{
+	V = S;
+	V.view = true;
+	V.nsys = 1; V.m_stride = 0; V.arena_stride = 0; V.src_sys_words = 0;
+	V.own_sA = V.own_sB = false;
+	V.src = nullptr; V.tmp_src = nullptr;
+	V.kev.clear(); V.evA.clear(); V.evPrio.clear();
+	const i64 ao = (i64)S.arena_stride * s;
+	auto mv = [ao](auto *&p) { p = reinterpret_cast<decltype(+p)>(reinterpret_cast<char *>(p) + ao); };
+	V.M = S.M + S.m_stride * s;
+	V.arena = (char *)S.arena + ao;
+	mv(V.st); mv(V.panels); mv(V.aux); mv(V.fu); mv(V.alive); mv(V.pivcol); mv(V.urow); mv(V.blk_first); mv(V.mult); mv(V.Wb);
+	V.Y = nullptr; V.ycols = nullptr; V.out = nullptr;
+	V.ev2 = nullptr;
+	HIPCHK(pool().event(&V.ev2, true));
+	return GF2BV_OK;
+}
+
+// One gang: S.nsys same-shape systems, forward elimination in lock-step (one set of launches),
+// then back-substitution and export system by system.
+int solve_gang(Solver &S, gf2bv_result **out)
+{
+	int rc = solver_alloc(S);
+	if (rc) return rc;
+	rc = enqueue_forward(S);
+	if (rc) return rc;
+	std::vector<Solver> V(S.nsys);
+	for (int s = 0; s < S.nsys; s++) {
+		V[s].device = S.device;
+		rc = make_view(S, s, V[s]);
+		if (rc) return rc;
+	}
+	if (S.mode == GF2BV_MODE_SINGLE)
+		for (int s = 0; s < S.nsys; s++) {
+			rc = enqueue_backward_single(V[s]);
+			if (rc) return rc;
+		}
+	for (int s = 0; s < S.nsys; s++) {
+		rc = finish_begin(V[s]);
+		if (rc) return rc;
+	}
+	for (int s = 0; s < S.nsys; s++) {
+		rc = finish_end(V[s], &out[s]);
+		if (rc) return rc;
+	}
 	return GF2BV_OK;
 }
 
@@ -745,12 +841,27 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 		return fail(GF2BV_ERR_ARG, "bad batch layout");
 	rc = check_device(device);
 	if (rc) return rc;
-	// Independent systems: NS host threads, each solving every NS-th system on its own stream pair.
-	// One system alone leaves most of the chip idle while its latency-bound panel path runs and the
-	// host needs ~15 ms to enqueue its ~3500 launches, so several enqueuing threads are what makes
-	// the systems actually overlap on the GPU.
-	int NS = (int)std::min<i64>(nsys, 2);      // measured on MI355X at 32768^2: 2 threads 21 ms/system, 1: 33, 4: 39
-	if (const char *e = getenv("GF2BV_BATCH_THREADS")) { int v = atoi(e); if (v >= 1) NS = (int)std::min<i64>(nsys, v); }
+	// Independent systems of one shape run as GANGS: the forward elimination of `gang` systems is one set
+	// of launches (blockIdx.y = system), so the latency-bound panel path and the host's ~3500 launches
+	// per elimination are shared by the whole gang and the bulk updates of all its systems fill the chip.
+	// NS host threads each take every NS-th gang on their own stream pair (one gang's back-substitution
+	// and export then overlap the next gang's elimination).
+	// gang size: ~2 GiB of working matrices per gang (32768^2: 16 systems, 4096^2: 64), at least four gangs
+	// when there are enough systems (measured on MI355X, 48 x 32768^2: gang 4/8/16 -> 7.6/6.3/6.0 ms per
+	// system, one system at a time 15-28; 64 x 4096^2: 0.22 ms per system against 1.8)
+	const double per_sys = 1.05 * 8.0 * (double)(rows + 64) * (double)((cols + 64) / 64 + TW + 4 * GF2_GMAX);
+	i64 gang = std::max<i64>(2, std::min<i64>(64, (i64)(2147483648.0 / per_sys)));
+	gang = std::min(gang, std::max<i64>(1, (nsys + 3) / 4));
+	if (const char *e = getenv("GF2BV_GANG")) { int v = atoi(e); if (v >= 1) gang = v; }
+	gang = std::max<i64>(1, std::min<i64>(gang, nsys));
+	{
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+			gang = std::max<i64>(1, std::min<i64>(gang, (i64)(0.4 * (double)free_b / per_sys)));
+	}
+	const i64 ngangs = gang ? (nsys + gang - 1) / gang : 0;
+	int NS = (int)std::min<i64>(ngangs, 2);
+	if (const char *e = getenv("GF2BV_BATCH_THREADS")) { int v = atoi(e); if (v >= 1) NS = (int)std::min<i64>(ngangs, v); }
 	std::vector<int> rcs(NS, GF2BV_OK);
 	std::vector<std::string> errs(NS);
 	std::vector<std::thread> workers;
@@ -759,15 +870,17 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 			if (hipSetDevice(device) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipSetDevice"; return; }
 			hipStream_t st = nullptr;
 			if (pool().stream(&st, device, false) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipStreamCreate"; return; }
-			for (i64 s = t; s < nsys && rcs[t] == GF2BV_OK; s += NS) {
+			for (i64 q = t; q < ngangs && rcs[t] == GF2BV_OK; q += NS) {
+				const i64 s0 = q * gang;
 				Solver S;
 				S.t_begin = std::chrono::steady_clock::now();
 				S.device = device;
 				S.sA = st;
-				S.src = (const u64 *)d_aug + s * sys_stride_words;
+				S.nsys = (int)std::min<i64>(gang, nsys - s0);
+				S.src = (const u64 *)d_aug + s0 * sys_stride_words;
+				S.src_sys_words = sys_stride_words;
 				S.rows = rows; S.cols = cols; S.stride = stride_words; S.mode = mode;
-				int rc = solver_enqueue(S);
-				if (rc == GF2BV_OK) rc = solver_finish(S, &out[s]);
+				int rc = solve_gang(S, &out[s0]);
 				if (rc != GF2BV_OK) { rcs[t] = rc; errs[t] = g_err; }
 				(void)hipStreamSynchronize(st);
 			}

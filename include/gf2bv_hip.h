@@ -90,6 +90,10 @@ int gf2bv_solve_device(void *d_aug, int64_t rows, int64_t cols, int64_t stride_w
 
 /* Batch of `nsys` independent equal-shape systems resident on one device
  * (system s starts at d_aug + s*sys_stride_words words); out[0..nsys) receives handles.
+ * The systems run in lock-step "gangs": one set of kernel launches eliminates a whole gang
+ * (grid dimension y = system), so the latency-bound panel path is paid once per gang and the bulk
+ * updates of all its systems fill the chip; results are identical to nsys separate calls.  In the
+ * stats of a gang member ms_eliminate is the gang's elimination time and ms_sweep is 0.
  * Independent systems are the unit that bench.py shards across GPUs. */
 int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words,
                              int64_t rows, int64_t cols, int64_t stride_words,

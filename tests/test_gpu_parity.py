@@ -179,6 +179,35 @@ def test_device_resident_and_batch_paths():
     buf.free()
 
 
+@pytest.mark.parametrize("gang", ["1", "2", "3", "8"])
+def test_gang_batch_parity(monkeypatch, gang):
+    """Lock-step gangs (blockIdx.y = system): full-rank, rank-deficient, sparse, zero-row and inconsistent
+    systems side by side, a system count that is no multiple of the gang size, padded system stride, both modes."""
+    monkeypatch.setenv("GF2BV_GANG", gang)
+    rng = random.Random(4242)
+    rows, cols = 1100, 1000
+    stride = hip.padded_stride(cols, 2) + 2                    # even, not a multiple of 16 words
+    sys_stride = rows * stride + 6
+    systems = [random_system(rng, rows, cols),
+               random_system(rng, rows, cols, .5, 600),
+               random_system(rng, rows, cols, .01, None, True, 50),
+               random_system(rng, rows, cols, .5, 900, False),
+               random_system(rng, rows, cols, .5, 1),
+               [0] * rows,
+               random_system(rng, rows, cols)]
+    host = np.zeros((len(systems), sys_stride), dtype=np.uint64)
+    for i, eqs in enumerate(systems):
+        host[i, :rows * stride] = O.eqs_to_aug(eqs, cols, stride).reshape(-1)
+    buf = hip.DeviceBuffer(host.nbytes)
+    buf.upload(host)
+    for mode in (0, 1):
+        sols = hip.solve_batch_device(buf.ptr, len(systems), sys_stride, rows, cols, stride, mode)
+        for eqs, sol in zip(systems, sols):
+            assert_same(sol, O.solve_words(O.eqs_to_aug(eqs, cols), rows, cols, mode), mode)
+    assert np.array_equal(buf.download().reshape(host.shape), host)          # inputs untouched
+    buf.free()
+
+
 def test_back_substitution_paths_agree(monkeypatch):
     """solve_one's blocked parity back-substitution vs the general multi-RHS sweep path (solve_all's)."""
     rng = random.Random(31)
