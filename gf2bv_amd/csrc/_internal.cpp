@@ -202,63 +202,9 @@ PyType_Spec gray_spec = {"_internal.AffineSpaceIterator", sizeof(SpaceIterObject
 PyType_Spec slow_spec = {"_internal.AffineSpaceIteratorSlow", sizeof(SpaceIterObject), 0,
                          Py_TPFLAGS_DEFAULT | Py_TPFLAGS_DISALLOW_INSTANTIATION, slow_slots};
 
-// ------------------------------------------------------------------------------------------------
-// m4ri_solve(equations, cols, mode) -- gf2bv/_internal.c:359-502
-PyObject *py_m4ri_solve(PyObject *, PyObject *const *args, Py_ssize_t nargs)
+// Result handle -> None / int / AffineSpace (_internal.c:440-501); frees the handle.
+PyObject *result_to_py(gf2bv_result *res, long mode)
 {
-	if (nargs != 3) { PyErr_SetString(PyExc_TypeError, "m4ri_solve requires 3 arguments"); return nullptr; }
-	PyObject *list = args[0];
-	if (!PyList_Check(list)) {
-		PyErr_SetString(PyExc_TypeError, "The first argument equations must be a list");
-		return nullptr;
-	}
-	Py_ssize_t cols = PyLong_AsSsize_t(args[1]);
-	if (cols <= 0) {
-		if (cols == -1 && PyErr_Occurred()) return nullptr;
-		PyErr_SetString(PyExc_ValueError, "Number of columns must be positive");
-		return nullptr;
-	}
-	long mode = PyLong_AsLong(args[2]);
-	if (mode == -1 && PyErr_Occurred()) return nullptr;
-	if (mode != GF2BV_MODE_SINGLE && mode != GF2BV_MODE_AFFINE_SPACE) {
-		PyErr_SetString(PyExc_ValueError, "Invalid mode");
-		return nullptr;
-	}
-	const Py_ssize_t rows = PyList_GET_SIZE(list);
-	if (rows < cols) {
-		PyErr_SetString(PyExc_ValueError,
-		                "Number of rows must be greater than or equal to number of columns, try pad with zeros.");
-		return nullptr;
-	}
-	// copy the digits that can hold bits 0..cols of every equation (sign ignored, higher bits ignored)
-	const Py_ssize_t need = (cols + 1 + PyLong_SHIFT - 1) / PyLong_SHIFT;
-	std::vector<int64_t> off((size_t)rows + 1, 0);
-	for (Py_ssize_t r = 0; r < rows; r++) {
-		PyObject *item = PyList_GET_ITEM(list, r);
-		if (!PyLong_Check(item)) {
-			PyErr_SetString(PyExc_TypeError, "List items must be integers");
-			return nullptr;
-		}
-		Py_ssize_t nd = GF2_DIGIT_COUNT((PyLongObject *)item);
-		off[r + 1] = off[r] + (nd < need ? nd : need);
-	}
-	std::vector<uint32_t> digits((size_t)off[rows] + 1);
-	for (Py_ssize_t r = 0; r < rows; r++) {
-		PyLongObject *v = (PyLongObject *)PyList_GET_ITEM(list, r);
-		static_assert(sizeof(digit) == sizeof(uint32_t), "30-bit digits in uint32 expected");
-		memcpy(digits.data() + off[r], GF2_DIGITS(v), (size_t)(off[r + 1] - off[r]) * sizeof(uint32_t));
-	}
-
-	gf2bv_result *res = nullptr;
-	int rc;
-	Py_BEGIN_ALLOW_THREADS          // same place the reference drops the GIL (_internal.c:429)
-	rc = gf2bv_solve_digits(digits.data(), off.data(), PyLong_SHIFT, rows, cols, (int)mode, 0, &res);
-	Py_END_ALLOW_THREADS
-	if (rc != GF2BV_OK) {
-		PyErr_Format(rc == GF2BV_ERR_ARG ? PyExc_ValueError : PyExc_RuntimeError,
-		             "gf2bv_amd: HIP solve failed (%d): %s", rc, gf2bv_last_error());
-		return nullptr;
-	}
 	if (gf2bv_result_status(res) != GF2BV_STATUS_SOLVED) {
 		gf2bv_result_free(res);
 		Py_RETURN_NONE;              // inconsistent system -> None (_internal.c:440-446)
@@ -283,6 +229,146 @@ PyObject *py_m4ri_solve(PyObject *, PyObject *const *args, Py_ssize_t nargs)
 	}
 	gf2bv_result_free(res);
 	return ret;
+}
+
+// cols / mode checks shared by m4ri_solve and m4ri_solve_many (_internal.c:372-395)
+bool parse_cols_mode(PyObject *cols_obj, PyObject *mode_obj, Py_ssize_t *cols, long *mode)
+{
+	*cols = PyLong_AsSsize_t(cols_obj);
+	if (*cols <= 0) {
+		if (*cols == -1 && PyErr_Occurred()) return false;
+		PyErr_SetString(PyExc_ValueError, "Number of columns must be positive");
+		return false;
+	}
+	*mode = PyLong_AsLong(mode_obj);
+	if (*mode == -1 && PyErr_Occurred()) return false;
+	if (*mode != GF2BV_MODE_SINGLE && *mode != GF2BV_MODE_AFFINE_SPACE) {
+		PyErr_SetString(PyExc_ValueError, "Invalid mode");
+		return false;
+	}
+	return true;
+}
+
+// Append the digits that can hold bits 0..cols of every equation of `list` (sign ignored, higher bits
+// ignored) to `digits`, one offset per row to `off` (off.back() = running total on entry).
+bool append_digits(PyObject *list, Py_ssize_t cols, std::vector<int64_t> &off, std::vector<uint32_t> &digits)
+{
+	const Py_ssize_t need = (cols + 1 + PyLong_SHIFT - 1) / PyLong_SHIFT;
+	const Py_ssize_t rows = PyList_GET_SIZE(list);
+	const size_t first = off.size() - 1;
+	for (Py_ssize_t r = 0; r < rows; r++) {
+		PyObject *item = PyList_GET_ITEM(list, r);
+		if (!PyLong_Check(item)) {
+			PyErr_SetString(PyExc_TypeError, "List items must be integers");
+			return false;
+		}
+		Py_ssize_t nd = GF2_DIGIT_COUNT((PyLongObject *)item);
+		off.push_back(off.back() + (nd < need ? nd : need));
+	}
+	digits.resize((size_t)off.back() + 1);
+	for (Py_ssize_t r = 0; r < rows; r++) {
+		PyLongObject *v = (PyLongObject *)PyList_GET_ITEM(list, r);
+		static_assert(sizeof(digit) == sizeof(uint32_t), "30-bit digits in uint32 expected");
+		memcpy(digits.data() + off[first + r], GF2_DIGITS(v), (size_t)(off[first + r + 1] - off[first + r]) * sizeof(uint32_t));
+	}
+	return true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// m4ri_solve(equations, cols, mode) -- gf2bv/_internal.c:359-502
+PyObject *py_m4ri_solve(PyObject *, PyObject *const *args, Py_ssize_t nargs)
+{
+	if (nargs != 3) { PyErr_SetString(PyExc_TypeError, "m4ri_solve requires 3 arguments"); return nullptr; }
+	PyObject *list = args[0];
+	if (!PyList_Check(list)) {
+		PyErr_SetString(PyExc_TypeError, "The first argument equations must be a list");
+		return nullptr;
+	}
+	Py_ssize_t cols;
+	long mode;
+	if (!parse_cols_mode(args[1], args[2], &cols, &mode)) return nullptr;
+	const Py_ssize_t rows = PyList_GET_SIZE(list);
+	if (rows < cols) {
+		PyErr_SetString(PyExc_ValueError,
+		                "Number of rows must be greater than or equal to number of columns, try pad with zeros.");
+		return nullptr;
+	}
+	std::vector<int64_t> off(1, 0);
+	std::vector<uint32_t> digits;
+	off.reserve((size_t)rows + 1);
+	if (!append_digits(list, cols, off, digits)) return nullptr;
+
+	gf2bv_result *res = nullptr;
+	int rc;
+	Py_BEGIN_ALLOW_THREADS          // same place the reference drops the GIL (_internal.c:429)
+	rc = gf2bv_solve_digits(digits.data(), off.data(), PyLong_SHIFT, rows, cols, (int)mode, 0, &res);
+	Py_END_ALLOW_THREADS
+	if (rc != GF2BV_OK) {
+		PyErr_Format(rc == GF2BV_ERR_ARG ? PyExc_ValueError : PyExc_RuntimeError,
+		             "gf2bv_amd: HIP solve failed (%d): %s", rc, gf2bv_last_error());
+		return nullptr;
+	}
+	return result_to_py(res, mode);
+}
+
+// m4ri_solve_many(list_of_equation_lists, cols, mode) -> list of (None | int | AffineSpace).
+// New entry (no counterpart in the reference): independent systems of one shape -- one per output
+// bit / per instance in the recovery examples -- are solved as lock-step gangs by one call; every
+// element of the result is what m4ri_solve would return for that system.
+PyObject *py_m4ri_solve_many(PyObject *, PyObject *const *args, Py_ssize_t nargs)
+{
+	if (nargs != 3) { PyErr_SetString(PyExc_TypeError, "m4ri_solve_many requires 3 arguments"); return nullptr; }
+	PyObject *systems = args[0];
+	if (!PyList_Check(systems)) {
+		PyErr_SetString(PyExc_TypeError, "The first argument must be a list of equation lists");
+		return nullptr;
+	}
+	Py_ssize_t cols;
+	long mode;
+	if (!parse_cols_mode(args[1], args[2], &cols, &mode)) return nullptr;
+	const Py_ssize_t nsys = PyList_GET_SIZE(systems);
+	if (nsys == 0) return PyList_New(0);
+	Py_ssize_t rows = -1;
+	std::vector<int64_t> off(1, 0);
+	std::vector<uint32_t> digits;
+	for (Py_ssize_t s = 0; s < nsys; s++) {
+		PyObject *list = PyList_GET_ITEM(systems, s);
+		if (!PyList_Check(list)) {
+			PyErr_SetString(PyExc_TypeError, "The first argument must be a list of equation lists");
+			return nullptr;
+		}
+		if (rows < 0) rows = PyList_GET_SIZE(list);
+		if (PyList_GET_SIZE(list) != rows) {
+			PyErr_SetString(PyExc_ValueError, "All systems of a batch need the same number of rows, pad with zeros.");
+			return nullptr;
+		}
+		if (rows < cols) {
+			PyErr_SetString(PyExc_ValueError,
+			                "Number of rows must be greater than or equal to number of columns, try pad with zeros.");
+			return nullptr;
+		}
+		if (!append_digits(list, cols, off, digits)) return nullptr;
+	}
+	std::vector<gf2bv_result *> res((size_t)nsys, nullptr);
+	int rc;
+	Py_BEGIN_ALLOW_THREADS
+	rc = gf2bv_solve_batch_digits(digits.data(), off.data(), PyLong_SHIFT, nsys, rows, cols, (int)mode, 0, res.data());
+	Py_END_ALLOW_THREADS
+	if (rc != GF2BV_OK) {
+		for (gf2bv_result *r : res) if (r) gf2bv_result_free(r);
+		PyErr_Format(rc == GF2BV_ERR_ARG ? PyExc_ValueError : PyExc_RuntimeError,
+		             "gf2bv_amd: HIP solve failed (%d): %s", rc, gf2bv_last_error());
+		return nullptr;
+	}
+	PyObject *out = PyList_New(nsys);
+	Py_ssize_t done = 0;
+	for (; out && done < nsys; done++) {
+		PyObject *item = result_to_py(res[done], mode);      // frees res[done]
+		if (!item) { done++; Py_CLEAR(out); break; }
+		PyList_SET_ITEM(out, done, item);
+	}
+	for (Py_ssize_t t = done; t < nsys; t++) gf2bv_result_free(res[t]);
+	return out;
 }
 
 // to_bits(n, a): tuple of n bools, LSB first, zero-extended (_internal.c:504-531)
@@ -448,6 +534,8 @@ PyObject *py_device_count(PyObject *, PyObject *) { return PyLong_FromLong(gf2bv
 PyMethodDef module_methods[] = {
 	{"m4ri_solve", FAST(py_m4ri_solve), METH_FASTCALL,
 	 "m4ri_solve(equations, cols, mode)\n--\n\nSolve the linear system on the MI355X; None when inconsistent."},
+	{"m4ri_solve_many", FAST(py_m4ri_solve_many), METH_FASTCALL,
+	 "m4ri_solve_many(systems, cols, mode)\n--\n\nSolve a list of same-shape systems in one batched call; list of m4ri_solve results."},
 	{"to_bits", FAST(py_to_bits), METH_FASTCALL, "to_bits(n, a)\n--\n\nLow n bits of a, LSB first."},
 	{"mul_bit_quad", FAST(py_mul_bit_quad), METH_FASTCALL, "mul_bit_quad(n, a, b, v, basis)\n--\n\n"},
 	{"xor_tuple", FAST(py_xor_tuple), METH_FASTCALL, "xor_tuple(a, b)\n--\n\nElement-wise xor."},

@@ -165,13 +165,25 @@ __device__ __forceinline__ u64 rot_fields_rt(int T, u64 m, int q)
 	}
 }
 
+// Gang execution: several systems of one shape are eliminated in lock-step by the same launches;
+// blockIdx.y selects the system.  A system's working matrix and its side-array arena sit at fixed
+// strides from those of system 0, so a kernel rebases its pointers once ({0, 0}: a single system).
+struct SysStride { i64 m_words, arena_bytes; };
+template <class P>
+__device__ __forceinline__ P *sys_at(P *p, i64 bytes)
+{
+	return reinterpret_cast<P *>(reinterpret_cast<uintptr_t>(p) + bytes);
+}
+
 // ------------------------------------------------------------------------------------------
 // Matrix assembly: CPython digits -> augmented words (replaces _internal.c:403-426).
 // One thread per output word.  Row r's int occupies digits[off[r]..off[r+1]); bit 0 is the
 // affine term (-> column `cols`), bit k the coefficient of variable k-1 (-> column k-1).
 __global__ void k_pack_digits(const uint32_t *__restrict__ digits, const i64 *__restrict__ off,
-                              int bpd, i64 rows, i64 cols, i64 wtot, i64 srows, u64 *__restrict__ M)
+                              int bpd, i64 rows, i64 cols, i64 wtot, i64 srows, u64 *__restrict__ M, SysStride ss)
 {
+	off += blockIdx.y * rows;               // gang: system y's rows follow system y-1's in the offset table
+	M += blockIdx.y * ss.m_words;
 	i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
 	i64 r = g / wtot, w = g % wtot;
 	if (r >= rows) return;
@@ -195,16 +207,6 @@ __global__ void k_pack_digits(const uint32_t *__restrict__ digits, const i64 *__
 	}
 	if (w == (cols >> 6) && nd > 0) val |= (u64)(d[0] & 1u) << (cols & 63);
 	M[tidx(r, w, srows)] = val;
-}
-
-// Gang execution: several systems of one shape are eliminated in lock-step by the same launches;
-// blockIdx.y selects the system.  A system's working matrix and its side-array arena sit at fixed
-// strides from those of system 0, so a kernel rebases its pointers once ({0, 0}: a single system).
-struct SysStride { i64 m_words, arena_bytes; };
-template <class P>
-__device__ __forceinline__ P *sys_at(P *p, i64 bytes)
-{
-	return reinterpret_cast<P *>(reinterpret_cast<uintptr_t>(p) + bytes);
 }
 
 // Row-major augmented words (the C ABI layout) -> tile-major working layout, 16 bytes per lane.

@@ -779,6 +779,25 @@ int solve_gang(Solver &S, gf2bv_result **out)
 	return GF2BV_OK;
 }
 
+// Gang size for nsys same-shape systems.
+i64 pick_gang(i64 nsys, i64 rows, i64 cols)
+{
+	// gang size: ~2 GiB of working matrices per gang (32768^2: 16 systems, 4096^2: 64), at least four gangs
+	// when there are enough systems (measured on MI355X, 48 x 32768^2: gang 4/8/16 -> 7.6/6.3/6.0 ms per
+	// system, one system at a time 15-28; 64 x 4096^2: 0.22 ms per system against 1.8)
+	const double per_sys = 1.05 * 8.0 * (double)(rows + 64) * (double)((cols + 64) / 64 + TW + 4 * GF2_GMAX);
+	i64 gang = std::max<i64>(2, std::min<i64>(64, (i64)(2147483648.0 / per_sys)));
+	gang = std::min(gang, std::max<i64>(1, (nsys + 3) / 4));
+	if (const char *e = getenv("GF2BV_GANG")) { int v = atoi(e); if (v >= 1) gang = v; }
+	gang = std::max<i64>(1, std::min<i64>(gang, nsys));
+	{
+		size_t free_b = 0, total_b = 0;
+		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+			gang = std::max<i64>(1, std::min<i64>(gang, (i64)(0.4 * (double)free_b / per_sys)));
+	}
+	return gang;
+}
+
 int check_shape(i64 rows, i64 cols, int mode)
 {
 	// mirrors gf2bv/_internal.c:372-395
@@ -846,19 +865,7 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 	// per elimination are shared by the whole gang and the bulk updates of all its systems fill the chip.
 	// NS host threads each take every NS-th gang on their own stream pair (one gang's back-substitution
 	// and export then overlap the next gang's elimination).
-	// gang size: ~2 GiB of working matrices per gang (32768^2: 16 systems, 4096^2: 64), at least four gangs
-	// when there are enough systems (measured on MI355X, 48 x 32768^2: gang 4/8/16 -> 7.6/6.3/6.0 ms per
-	// system, one system at a time 15-28; 64 x 4096^2: 0.22 ms per system against 1.8)
-	const double per_sys = 1.05 * 8.0 * (double)(rows + 64) * (double)((cols + 64) / 64 + TW + 4 * GF2_GMAX);
-	i64 gang = std::max<i64>(2, std::min<i64>(64, (i64)(2147483648.0 / per_sys)));
-	gang = std::min(gang, std::max<i64>(1, (nsys + 3) / 4));
-	if (const char *e = getenv("GF2BV_GANG")) { int v = atoi(e); if (v >= 1) gang = v; }
-	gang = std::max<i64>(1, std::min<i64>(gang, nsys));
-	{
-		size_t free_b = 0, total_b = 0;
-		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
-			gang = std::max<i64>(1, std::min<i64>(gang, (i64)(0.4 * (double)free_b / per_sys)));
-	}
+	const i64 gang = pick_gang(nsys, rows, cols);
 	const i64 ngangs = gang ? (nsys + gang - 1) / gang : 0;
 	int NS = (int)std::min<i64>(ngangs, 2);
 	if (const char *e = getenv("GF2BV_BATCH_THREADS")) { int v = atoi(e); if (v >= 1) NS = (int)std::min<i64>(ngangs, v); }
@@ -931,6 +938,57 @@ int gf2bv_solve_words(const uint64_t *aug, int64_t rows, int64_t cols, int64_t s
 	return rc;
 }
 
+int gf2bv_solve_batch_digits(const uint32_t *digits, const int64_t *digit_off, int bits_per_digit, int64_t nsys,
+                             int64_t rows, int64_t cols, int mode, int device, gf2bv_result **out)
+{
+	if (!out || !digit_off || nsys < 0) return fail(GF2BV_ERR_ARG, "null pointer");
+	for (i64 s = 0; s < nsys; s++) out[s] = nullptr;
+	int rc = check_shape(rows, cols, mode);
+	if (rc) return rc;
+	if (bits_per_digit < 1 || bits_per_digit > 32) return fail(GF2BV_ERR_ARG, "bits_per_digit must be 1..32");
+	rc = check_device(device);
+	if (rc) return rc;
+	if (nsys == 0) return GF2BV_OK;
+	const i64 wt = (cols + 1 + 63) / 64, ntiles = (wt + TW - 1) / TW, srows = slab_rows(rows);
+	const i64 m_stride = ntiles * TW * srows;
+	const i64 nrows_all = nsys * rows, ndig = digit_off[nrows_all];
+	// all digits and offsets go up once; every gang packs its own systems straight into tile-major slabs
+	struct Staged {
+		uint32_t *dig = nullptr; i64 *off = nullptr; hipStream_t st = nullptr; int device = 0;
+		~Staged()
+		{
+			if (st) (void)hipStreamSynchronize(st);
+			pool().release(dig); pool().release(off);
+			if (st) pool().release_stream(st, device, 0);
+		}
+	} G;
+	G.device = device;
+	HIPCHK(pool().stream(&G.st, device, 0));
+	HIPCHK(pool().alloc((void **)&G.dig, sizeof(uint32_t) * std::max<i64>(1, ndig), device));
+	HIPCHK(pool().alloc((void **)&G.off, sizeof(i64) * (nrows_all + 1), device));
+	if (ndig) HIPCHK(hipMemcpyAsync(G.dig, digits, sizeof(uint32_t) * ndig, hipMemcpyHostToDevice, G.st));
+	HIPCHK(hipMemcpyAsync(G.off, digit_off, sizeof(i64) * (nrows_all + 1), hipMemcpyHostToDevice, G.st));
+	const i64 gang = pick_gang(nsys, rows, cols);
+	for (i64 s0 = 0; s0 < nsys; s0 += gang) {
+		Solver S;
+		S.t_begin = std::chrono::steady_clock::now();
+		S.device = device;
+		S.sA = G.st;
+		S.nsys = (int)std::min<i64>(gang, nsys - s0);
+		S.rows = rows; S.cols = cols; S.mode = mode;
+		S.stride = ntiles * TW;
+		HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * m_stride * S.nsys, device));
+		const i64 total = rows * ntiles * TW;
+		if (total > 0)
+			k_pack_digits<<<dim3((unsigned)((total + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(
+				G.dig, G.off + s0 * rows, bits_per_digit, (i64)rows, (i64)cols, ntiles * TW, srows, S.M, SysStride{m_stride, 0});
+		HIPCHK(hipGetLastError());
+		rc = solve_gang(S, &out[s0]);
+		if (rc) return rc;
+	}
+	return GF2BV_OK;
+}
+
 int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bits_per_digit, int64_t rows,
                        int64_t cols, int mode, int device, gf2bv_result **out)
 {
@@ -965,7 +1023,8 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 		i64 total = rows * ntiles * TW;
 		if (total > 0)
 			k_pack_digits<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S.sA>>>(d_dig, d_off, bits_per_digit, (i64)rows,
-			                                                                            (i64)cols, ntiles * TW, slab_rows(rows), S.M);
+			                                                                            (i64)cols, ntiles * TW, slab_rows(rows), S.M,
+			                                                                            SysStride{0, 0});
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(p1, S.sA));

@@ -26,6 +26,7 @@ STATUS_INCONSISTENT = 1
 EXPORTS = [
     "gf2bv_version", "gf2bv_device_count", "gf2bv_last_error",
     "gf2bv_solve_digits", "gf2bv_solve_words", "gf2bv_solve_device", "gf2bv_solve_batch_device",
+    "gf2bv_solve_batch_digits",
     "gf2bv_result_status", "gf2bv_result_rank", "gf2bv_result_dimension", "gf2bv_result_words",
     "gf2bv_result_origin", "gf2bv_result_basis", "gf2bv_result_pivots", "gf2bv_result_stats",
     "gf2bv_result_free", "gf2bv_space_combine", "gf2bv_synth_device", "gf2bv_residual_device",
@@ -70,6 +71,7 @@ def lib():
         L.gf2bv_solve_words.argtypes = [vp, i64, i64, i64, i32, i32, pp]
         L.gf2bv_solve_device.argtypes = [vp, i64, i64, i64, i32, i32, vp, i32, pp]
         L.gf2bv_solve_batch_device.argtypes = [vp, i64, i64, i64, i64, i64, i32, i32, pp]
+        L.gf2bv_solve_batch_digits.argtypes = [vp, vp, i32, i64, i64, i64, i32, i32, pp]
         for name, res in (("gf2bv_result_status", i32), ("gf2bv_result_rank", i64),
                           ("gf2bv_result_dimension", i64), ("gf2bv_result_words", i64)):
             getattr(L, name).restype = res
@@ -169,7 +171,7 @@ def solve_digits(digits: np.ndarray, offsets: np.ndarray, bits_per_digit: int, r
 
 def solve_device(d_ptr: int, rows: int, cols: int, stride: int, mode: int = MODE_SINGLE, device: int = 0,
                  stream: int = 0, time_kernels: bool = False) -> Solution:
-    """Solve in place a matrix resident in device memory (destroys it)."""
+    """Solve a row-major augmented matrix resident in device memory (the matrix is left untouched)."""
     h = ctypes.c_void_p()
     _check(lib().gf2bv_solve_device(d_ptr, rows, cols, stride, mode, device, stream or None,
                                     1 if time_kernels else 0, ctypes.byref(h)))
@@ -180,12 +182,43 @@ def solve_batch_device(d_ptr: int, nsys: int, sys_stride: int, rows: int, cols: 
                        mode: int = MODE_SINGLE, device: int = 0) -> list:
     hs = (ctypes.c_void_p * max(nsys, 1))()
     rc = lib().gf2bv_solve_batch_device(d_ptr, nsys, sys_stride, rows, cols, stride, mode, device, hs)
+    return _take_all(hs, nsys, rc, mode)
+
+
+def _take_all(hs, nsys: int, rc: int, mode: int) -> list:
     if rc != 0:
         for h in hs:
             if h:
                 lib().gf2bv_result_free(h)
         _check(rc)
     return [_take(ctypes.c_void_p(hs[i]), mode) for i in range(nsys)]
+
+
+def solve_batch_digits(digits: np.ndarray, offsets: np.ndarray, bits_per_digit: int, nsys: int, rows: int,
+                       cols: int, mode: int = MODE_SINGLE, device: int = 0) -> list:
+    """nsys equal-shape systems as digit arrays; offsets has nsys*rows + 1 entries (system-major)."""
+    digits = np.ascontiguousarray(digits, dtype=np.uint32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int64)
+    hs = (ctypes.c_void_p * max(nsys, 1))()
+    rc = lib().gf2bv_solve_batch_digits(digits.ctypes.data, offsets.ctypes.data, bits_per_digit, nsys, rows, cols,
+                                        mode, device, hs)
+    return _take_all(hs, nsys, rc, mode)
+
+
+def solve_batch_words(augs, rows: int, cols: int, mode: int = MODE_SINGLE, device: int = 0) -> list:
+    """nsys equal-shape packed systems in host memory ([nsys, rows, stride] uint64): one upload, gang solve."""
+    augs = np.ascontiguousarray(augs, dtype=np.uint64)
+    nsys, stride = augs.shape[0], augs.shape[2]
+    pad = (-stride) % 2                                   # the device entry wants an even stride
+    if pad:
+        augs = np.concatenate([augs, np.zeros((nsys, rows, pad), dtype=np.uint64)], axis=2)
+        stride += pad
+    buf = DeviceBuffer(max(augs.nbytes, 16), device)
+    try:
+        buf.upload(augs)
+        return solve_batch_device(buf.ptr, nsys, rows * stride, rows, cols, stride, mode, device)
+    finally:
+        buf.free()
 
 
 def synth_device(d_ptr: int, rows: int, cols: int, stride: int, seed: int, device: int = 0, stream: int = 0):

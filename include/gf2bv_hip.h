@@ -99,6 +99,14 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
                              int64_t rows, int64_t cols, int64_t stride_words,
                              int mode, int device, gf2bv_result **out);
 
+/* Batch of `nsys` independent equal-shape systems given as digit arrays (see gf2bv_solve_digits):
+ * row r of system s is entry s*rows + r of digit_off (nsys*rows + 1 entries).  One upload, lock-step
+ * gangs as in gf2bv_solve_batch_device.  This is what a batched m4ri_solve binds
+ * (gf2bv_amd._internal.m4ri_solve_many). */
+int gf2bv_solve_batch_digits(const uint32_t *digits, const int64_t *digit_off, int bits_per_digit,
+                             int64_t nsys, int64_t rows, int64_t cols, int mode, int device,
+                             gf2bv_result **out);
+
 /* ---- result accessors (AffineSpace getters, gf2bv/_internal.c:206-240) -------------------- */
 int     gf2bv_result_status(const gf2bv_result *r);      /* GF2BV_STATUS_* */
 int64_t gf2bv_result_rank(const gf2bv_result *r);

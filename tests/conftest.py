@@ -14,3 +14,14 @@ __graft_entry__.build()
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def pytest_collection_modifyitems(config, items):
+    # a runaway test (e.g. enumerating a 2**40-point solution space) must die long before it can exhaust the
+    # host; pytest-timeout is present in the image, the guard is skipped where it is not
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    import pytest
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(240, method="thread"))    # "thread": also ends a loop stuck in C

@@ -208,6 +208,45 @@ def test_gang_batch_parity(monkeypatch, gang):
     buf.free()
 
 
+def test_batched_list_of_int_boundary(monkeypatch):
+    """m4ri_solve_many / LinearSystem.solve_*_many == the single-system calls, element by element."""
+    monkeypatch.setenv("GF2BV_GANG", "3")
+    rng = random.Random(99)
+    cols = 130
+    systems = [random_system(rng, 200, cols), random_system(rng, 200, cols, .5, 90), random_system(rng, 200, cols, .5, 100, False),
+               [0] * 200, random_system(rng, 200, cols, .02), [-e for e in random_system(rng, 200, cols, .5, 129)],
+               [e | (rng.getrandbits(40) << (cols + 1)) for e in random_system(rng, 200, cols)]]     # junk above bit cols
+    for mode in (0, 1):
+        got = _internal.m4ri_solve_many(systems, cols, mode)
+        for eqs, g in zip(systems, got):
+            w = m4ri_solve(list(eqs), cols, mode)
+            o = O.m4ri_solve(list(eqs), cols, mode)
+            if mode == 0 or w is None:
+                assert g == w == o
+            else:
+                assert (g.dimension, g.origin, g.basis) == (w.dimension, w.origin, w.basis) == (o.dimension, o.origin, o.basis)
+                if g.dimension <= 8:              # never enumerate a big space: 2**dim Python ints
+                    assert list(g) == list(w)
+    # LinearSystem level: xoshiro-style instances with different observations, plus a contradictory one
+    lin = LinearSystem([8, 8])
+    a, b = lin.gens()
+    zlist = []
+    for k in range(5):
+        x, y = rng.getrandbits(8), rng.getrandbits(8)
+        zlist.append([(a ^ b.rotl(3)) ^ (x ^ (((y << 3) | (y >> 5)) & 255)), (a & 0xF0) ^ (x & 0xF0), b ^ y])
+    zlist.append([a ^ 1, a ^ 2])
+    zlist.append([1])
+    one = lin.solve_one_many(zlist)
+    assert one == [lin.solve_one(z) for z in zlist]
+    assert one[-1] is None and one[-2] is None and all(o is not None for o in one[:5])
+    spaces = lin.solve_raw_space_many(zlist)
+    for z, sp in zip(zlist, spaces):
+        ref = lin.solve_raw_space(z)
+        assert (sp is None) == (ref is None)
+        if sp is not None:
+            assert (sp.dimension, sp.origin, sp.basis) == (ref.dimension, ref.origin, ref.basis)
+
+
 def test_back_substitution_paths_agree(monkeypatch):
     """solve_one's blocked parity back-substitution vs the general multi-RHS sweep path (solve_all's)."""
     rng = random.Random(31)

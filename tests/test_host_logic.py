@@ -119,6 +119,29 @@ def test_m4ri_solve_argument_errors():
         m4ri_solve([1, "x"], 2, 0)
 
 
+def test_m4ri_solve_many_argument_errors():
+    many = _internal.m4ri_solve_many
+    with pytest.raises(TypeError, match="requires 3 arguments"):
+        many([[1, 2]], 2)
+    with pytest.raises(TypeError, match="list of equation lists"):
+        many([(1, 2)], 2, 0)
+    with pytest.raises(ValueError, match="columns must be positive"):
+        many([[1, 2]], 0, 0)
+    with pytest.raises(ValueError, match="Invalid mode"):
+        many([[1, 2]], 2, 2)
+    with pytest.raises(ValueError, match="same number of rows"):
+        many([[1, 2], [1, 2, 3]], 2, 0)
+    with pytest.raises(ValueError, match="greater than or equal"):
+        many([[1]], 2, 0)
+    with pytest.raises(TypeError, match="must be integers"):
+        many([[1, 2], [1, None]], 2, 0)
+    assert many([], 3, 1) == []
+    # "1 = 0" systems are decided on the host, the others would go to the GPU together
+    lin = LinearSystem([2])
+    (v,) = lin.gens()
+    assert lin.solve_one_many([[1], [v ^ v, 1]]) == [None, None]
+
+
 def test_solve_fails_loudly_without_gpu():
     if _internal.device_count() > 0:
         pytest.skip("a GPU is present")
