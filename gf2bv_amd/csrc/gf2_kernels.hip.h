@@ -82,7 +82,15 @@ struct PanelAux {
 	int slot_row[64];
 	u64 comb[64];
 	u64 src_mult[64][GF2_GMAX];
+	int first_after;     // lower bound of the alive rows once this panel's sources are dead
+	int pad;
 };
+
+// died[i] = index of the panel that made row i a pivot source, GF2_NEVER while the row is alive
+// (the byte pattern of the memset that initialises the array).  A panel index instead of a flag is
+// race-free where it matters: the launch that narrows panel j-1 also searches panel j, and
+// "died[i] > j-1" answers the same before and after the search has marked its sources.
+#define GF2_NEVER 0x7f7f7f7f
 
 // Per-solve device state.  The host never reads it mid-solve.
 struct SolveState {
@@ -248,15 +256,15 @@ k_win_gather(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, u64
 // Alive rows get their window back (only needed for the final block: the RHS bit may live in it).
 __global__ void __launch_bounds__(256)
 k_win_scatter(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, const u64 *__restrict__ Wb,
-              const unsigned char *__restrict__ alive, SysStride ss)
+              const int *__restrict__ died, SysStride ss)
 {
 	M += blockIdx.y * ss.m_words;
 	Wb = sys_at(Wb, blockIdx.y * ss.arena_bytes);
-	alive = sys_at(alive, blockIdx.y * ss.arena_bytes);
+	died = sys_at(died, blockIdx.y * ss.arena_bytes);
 	const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
 	const i64 i = t / gb;
 	const int g = (int)(t % gb);
-	if (i >= rows || !alive[i]) return;
+	if (i >= rows || died[i] != GF2_NEVER) return;
 	M[tidx(i, j0 + g, srows)] = Wb[i * GF2_GMAX + g];
 }
 
@@ -308,30 +316,147 @@ __device__ __forceinline__ u64 find_absorb(FindState &S, u64 w, int row, u64 col
 	return took;
 }
 
-// Pivot search of panel j = j0+g.  Every wavefront ("unit") scans its own slice of the alive
-// rows and builds a basis with combination tracking; a unit stops as soon as all columns of
-// the panel have pivots.  The LAST unit to finish publishes: it adopts any unit whose basis is
-// complete (dense systems: every unit is after ~70 rows), otherwise it merges the units'
-// source rows into one basis.  Publishing = panel record, pivot columns, physical pivot rows,
-// PanelAux (sources, combinations, multipliers of the sources w.r.t. earlier panels of the
-// block), and the sources are marked dead.
+// ---- one step of the panel path -------------------------------------------------------------
+// Step s of a block (s = 0..gb) is ONE launch that
+//   * narrows panel gp = s-1: every alive row records its multiplier mult_gp[i] = Wb[i][gp] & mask and
+//     XORs the selected reduced pivot rows into its remaining window words (workgroups >= find_wgs,
+//     256 rows each), reading window buffer Wb_in and writing Wb_out, and
+//   * searches panel gf = s for pivots (workgroups < find_wgs, one "unit" per wavefront).
+// The search would need the narrowed word gf of its candidate rows, which other workgroups are only
+// just producing -- so a unit derives it itself from the stable input buffer:
+//   word = Wb_in[i][gf] ^ XOR_{b in Wb_in[i][gp] & mask_gp} P_gp[b][gf]
+// (a few LDS reads per candidate).  Search and narrow step therefore overlap, and a block costs gb+1
+// launches on the critical path instead of 2*gb.  Everything a step reads from global memory was
+// written by earlier launches; what it writes is read by later ones (died[] is the one exception, see
+// GF2_NEVER).
+//
+// Search: every unit scans its own slice of the alive rows and builds a basis with combination
+// tracking; a unit stops as soon as all columns of the panel have pivots.  The LAST unit to finish
+// publishes: it adopts any unit whose basis is complete (dense systems: every unit is after ~70
+// rows), otherwise it merges the units' source rows into one basis.  Publishing = panel record, pivot
+// columns, physical pivot rows, PanelAux (sources, combinations, multipliers of the sources w.r.t.
+// earlier panels of the block), and the sources are marked dead.  The multipliers the sources
+// recorded for earlier panels are zeroed by the NEXT step (the bulk update must skip the block's
+// own sources; this step may still be writing them).
+struct StepLds {
+	u64 Sw[GF2_GMAX][64];     // window words of panel gp's source rows      [word][slot]
+	u64 Pb[GF2_GMAX][64];     // its reduced pivot rows' window words         [word][pivot BIT]
+	u64 Cm[64];               // combination masks                            [pivot k]
+	int Bk[64];               // pivot k -> pivot bit
+};
+
+// Candidate words of the search while panel gp is being narrowed by the same launch.
+struct CandWords {
+	const u64 *Wb;            // the step's input window buffer
+	const u64 *Pcol;          // LDS: P_gp[bit][word gf]
+	u64 maskp;                // pivot mask of panel gp (0: nothing to apply)
+	int gf, gp;
+	__device__ __forceinline__ u64 prev_mult(u64 wp) const { return wp & maskp; }
+	__device__ __forceinline__ u64 apply(u64 wf, u64 wp) const
+	{
+		u64 m = wp & maskp;
+		while (m) { const int b = ctz64(m); m &= m - 1; wf ^= Pcol[b]; }
+		return wf;
+	}
+};
+
 __global__ void __launch_bounds__(256)
-k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveState *__restrict__ st,
-       unsigned char *__restrict__ alive, FindUnit *__restrict__ fu, int units,
-       PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol,
-       int *__restrict__ urow, u64 *__restrict__ multset, int *__restrict__ blk_first_out, int upd_T, SysStride ss)
+k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, int gb, u64 colmask,
+             const u64 *__restrict__ Wb_in, u64 *__restrict__ Wb_out, SolveState *__restrict__ st,
+             int *__restrict__ died, FindUnit *__restrict__ fu, int units, int find_wgs,
+             PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol,
+             int *__restrict__ urow, u64 *__restrict__ multset, int *__restrict__ blk_first_out, int upd_T, SysStride ss)
 {
 	__builtin_amdgcn_s_setprio(3);          // panel path = critical path: win issue arbitration against bulk-update waves
 	{
 		const i64 ao = blockIdx.y * ss.arena_bytes;
-		Wb = sys_at(Wb, ao); st = sys_at(st, ao); alive = sys_at(alive, ao); fu = sys_at(fu, ao);
-		panels = sys_at(panels, ao); aux = sys_at(aux, ao); pivcol = sys_at(pivcol, ao); urow = sys_at(urow, ao);
-		multset = sys_at(multset, ao);
+		M += blockIdx.y * ss.m_words;
+		Wb_in = sys_at(Wb_in, ao); Wb_out = sys_at(Wb_out, ao); st = sys_at(st, ao); died = sys_at(died, ao);
+		fu = sys_at(fu, ao); panels = sys_at(panels, ao); aux = sys_at(aux, ao); pivcol = sys_at(pivcol, ao);
+		urow = sys_at(urow, ao); multset = sys_at(multset, ao);
 		if (blk_first_out) blk_first_out = sys_at(blk_first_out, ao);
 	}
-	const int lane = threadIdx.x & 63;
-	const int u = (int)((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
+	__shared__ StepLds L;
+	const int t = threadIdx.x;
+	const bool finder = (int)blockIdx.x < find_wgs;
+	const i64 rb = (i64)blockIdx.x - find_wgs;          // narrow role: row block
+	PanelRec recp;
+	recp.start = 0; recp.p = 0; recp.mask = 0;
+	const PanelAux *Ap = aux + j0 + (gp >= 0 ? gp : 0);
+	i64 bound = 0;                                      // alive lower bound after panel gp
+	if (gp >= 0) {
+		recp = panels[j0 + gp];
+		bound = Ap->first_after;
+	}
+	// a row block below the bound holds dead rows only (block 0 still stores the pivot rows)
+	const bool dead_block = !finder && rb != 0 && (rb + 1) * 256 <= bound;
+	if (recp.p > 0 && !dead_block) {
+		// reduced pivot rows of panel gp restricted to the window, from its source rows (tiny, every workgroup)
+		const int e = t >> 6, sl = t & 63;          // 256 threads = 4 words x 64 slots
+		L.Sw[e][sl] = (sl < recp.p && e >= gp && e < gb) ? Wb_in[(i64)Ap->slot_row[sl] * GF2_GMAX + e] : 0ull;
+		L.Pb[e][sl] = 0;
+		if (t < 64) {
+			L.Cm[t] = (t < recp.p) ? Ap->comb[t] : 0ull;
+			if ((recp.mask >> t) & 1) L.Bk[__popcll(recp.mask & lanemask_lt(t))] = t;
+		}
+		__syncthreads();
+		if (sl < recp.p && e >= gp && e < gb) {
+			u64 c = L.Cm[sl], acc = 0;
+			while (c) { int q = ctz64(c); c &= c - 1; acc ^= L.Sw[e][q]; }
+			L.Pb[e][L.Bk[sl]] = acc;
+			if (!finder && rb == 0) M[tidx(Ap->slot_row[sl], j0 + e, srows)] = acc;
+		}
+		__syncthreads();
+	}
+
+	if (!finder) {
+		// ---- narrow panel gp ----
+		const int p = recp.p;
+		u64 *mult = multset + (i64)gp * rows;
+		if (rb == 0 && t < p)                           // the multipliers panel gp's sources recorded for earlier panels
+			for (int e = 0; e < gp; e++) multset[(i64)e * rows + Ap->slot_row[t]] = 0;
+		const i64 i = rb * 256 + t;
+		if (i >= rows) return;
+		u64 m = 0;
+		if (!dead_block && died[i] > j0 + gp) {         // alive when panel gp was eliminated
+			const uint4 *src = reinterpret_cast<const uint4 *>(Wb_in + i * GF2_GMAX);
+			uint4 lo = src[0], hi = src[1];
+			u64 w[GF2_GMAX] = { ((u64)lo.y << 32) | lo.x, ((u64)lo.w << 32) | lo.z, ((u64)hi.y << 32) | hi.x, ((u64)hi.w << 32) | hi.z };
+			u64 wp = 0;
+#pragma unroll
+			for (int e = 0; e < GF2_GMAX; e++) if (e == gp) wp = w[e];
+			m = wp & recp.mask;
+			if (m) {
+				u64 acc[GF2_GMAX];
+#pragma unroll
+				for (int e = 0; e < GF2_GMAX; e++) acc[e] = 0;
+				u64 mm = m;
+				while (mm) {
+					const int b = ctz64(mm); mm &= mm - 1;
+#pragma unroll
+					for (int e = 0; e < GF2_GMAX; e++)
+						if (e >= gp) acc[e] ^= L.Pb[e][b];     // words left of the panel are finished (uniform test)
+				}
+#pragma unroll
+				for (int e = 0; e < GF2_GMAX; e++)
+					if (e >= gp && e < gb) w[e] ^= acc[e];
+			}
+			uint4 *dst = reinterpret_cast<uint4 *>(Wb_out + i * GF2_GMAX);
+			dst[0] = make_uint4((unsigned)w[0], (unsigned)(w[0] >> 32), (unsigned)w[1], (unsigned)(w[1] >> 32));
+			dst[1] = make_uint4((unsigned)w[2], (unsigned)(w[2] >> 32), (unsigned)w[3], (unsigned)(w[3] >> 32));
+		}
+		// stored pre-rotated for the bulk update's table layout (field s = what this row reads at step s)
+		mult[i] = rot_fields_rt(upd_T, m, rowq(i));
+		return;
+	}
+
+	// ---- search panel gf ----
+	const int lane = t & 63;
+	const int u = (int)blockIdx.x * 4 + (t >> 6);
 	if (u >= units) return;
+	const int j = j0 + gf;
+	CandWords cw;
+	cw.Wb = Wb_in; cw.Pcol = &L.Pb[gf < GF2_GMAX ? gf : 0][0]; cw.maskp = (gp >= 0) ? recp.mask : 0ull; cw.gf = gf; cw.gp = gp >= 0 ? gp : gf;
 	const int first = st->first;
 	const int full = __popcll(colmask);
 	// Dense panels are complete after ~70 rows, so a handful of units (each covering a long slice it
@@ -352,20 +477,22 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 		i64 base = lo;
 		// two chunks in flight: the loads of chunk c+1 are issued before chunk c is absorbed
 		i64 i_n = base + lane;
-		bool ok_n = (i_n < hi) && alive[i_n];
-		u64 w_n = ok_n ? (Wb[i_n * GF2_GMAX + g] & colmask) : 0ull;
+		bool ok_n = (i_n < hi) && died[i_n] >= j;
+		u64 wf_n = ok_n ? Wb_in[i_n * GF2_GMAX + cw.gf] : 0ull;
+		u64 wp_n = ok_n ? Wb_in[i_n * GF2_GMAX + cw.gp] : 0ull;
 		for (; base < hi && S.nslots < full; base += 64) {
 			const i64 i = i_n;
 			const bool ok = ok_n;
-			const u64 w = w_n;
+			const u64 w = cw.apply(wf_n, wp_n) & colmask;
 			i_n = base + 64 + lane;
-			ok_n = (i_n < hi) && alive[i_n];
-			w_n = ok_n ? (Wb[i_n * GF2_GMAX + g] & colmask) : 0ull;
+			ok_n = (i_n < hi) && died[i_n] >= j;
+			wf_n = ok_n ? Wb_in[i_n * GF2_GMAX + cw.gf] : 0ull;
+			wp_n = ok_n ? Wb_in[i_n * GF2_GMAX + cw.gp] : 0ull;
 			const u64 took = find_absorb(S, w, (int)i, colmask, lane, me->srow);
 			chunks++;
 			if (first_nonsrc < 0) {
-				u64 m = __ballot(ok) & ~took;
-				if (m) first_nonsrc = (int)base + ctz64(m);
+				u64 mk = __ballot(ok) & ~took;
+				if (mk) first_nonsrc = (int)base + ctz64(mk);
 			}
 		}
 		if (first_nonsrc < 0) first_nonsrc = (int)((base < rows) ? base : rows);   // lower bound
@@ -409,7 +536,8 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 			const int cnt = GF2_LD(&fu[v].cnt);
 			if (cnt == 0) continue;
 			const int i = (lane < cnt) ? GF2_LD(&fu[v].srow[lane]) : -1;
-			const u64 w = (i >= 0) ? (Wb[(i64)i * GF2_GMAX + g] & colmask) : 0ull;
+			u64 w = 0;
+			if (i >= 0) w = cw.apply(Wb_in[(i64)i * GF2_GMAX + cw.gf], Wb_in[(i64)i * GF2_GMAX + cw.gp]) & colmask;
 			find_absorb(S, w, i, colmask, lane, spare->srow);
 		}
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -427,12 +555,12 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 	if (lane < p) {
 		A->slot_row[lane] = srow;
 		urow[r0 + lane] = srow;                 // pivot k of the panel lives in physical row slot_row[k]
-		alive[srow] = 0;
-		for (int e = 0; e < g; e++) {           // multipliers of this source w.r.t. earlier panels of the block
-			u64 *me_ = multset + (i64)e * rows + srow;
-			// multipliers are stored rotated for the bulk update; the TRSM wants the plain bit order
-			A->src_mult[lane][e] = rot_fields_rt(upd_T, *me_, (GF2_IL - rowq(srow)) % GF2_IL);
-			*me_ = 0;                           // the bulk update must skip the block's own sources
+		died[srow] = j;
+		for (int e = 0; e < gf; e++) {          // multipliers of this source w.r.t. earlier panels of the block
+			u64 mv;
+			if (e == gp) mv = cw.prev_mult(Wb_in[(i64)srow * GF2_GMAX + gp]);      // being recorded by this very launch
+			else mv = rot_fields_rt(upd_T, multset[(i64)e * rows + srow], (GF2_IL - rowq(srow)) % GF2_IL);   // stored rotated; the TRSM wants plain bit order
+			A->src_mult[lane][e] = mv;
 		}
 	}
 	// advance the lower bound of alive rows past rows that just died (free when pick == 0)
@@ -440,11 +568,11 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 		int f = new_first;
 		while (f < rows) {
 			const int i = f + lane;
-			int a = (i < rows) ? (int)alive[i] : 1;
-			for (int s = 0; s < p; s++)
-				if (i == __builtin_amdgcn_readlane(srow, s)) a = 0;
-			const u64 m = __ballot(a);
-			if (m) { f += ctz64(m); break; }
+			int a = (i < rows) ? (int)(died[i] >= j) : 1;
+			for (int q = 0; q < p; q++)
+				if (i == __builtin_amdgcn_readlane(srow, q)) a = 0;
+			const u64 mk = __ballot(a);
+			if (mk) { f += ctz64(mk); break; }
 			f += 64;
 		}
 		new_first = f < rows ? f : (int)rows;
@@ -453,91 +581,13 @@ k_find(const u64 *__restrict__ Wb, i64 rows, int j, int g, u64 colmask, SolveSta
 		panels[j].start = r0;
 		panels[j].p = p;
 		panels[j].mask = S.have;
+		A->first_after = new_first;
 		st->rank = r0 + p;
 		st->first = new_first;
 		st->wide = hard;
 		if (blk_first_out) *blk_first_out = new_first;     // last panel of a block: row bound for its bulk update
 		GF2_ST(&st->arrive, 0u);
 	}
-}
-
-// Narrow elimination step of panel j = j0+g inside the window: (i) every workgroup recomputes
-// the (<= 64) reduced pivot rows' window words from the sources (tiny), workgroup 0 also
-// stores them into the matrix; (ii) every alive row records its multiplier
-// mult_g[i] = Wb[i][g] & mask and XORs the selected pivot rows into its remaining window words.
-__global__ void __launch_bounds__(256)
-k_narrow(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int g, int gb, u64 *__restrict__ Wb,
-         const unsigned char *__restrict__ alive, const PanelRec *__restrict__ panels,
-         const PanelAux *__restrict__ aux, u64 *__restrict__ multset, const SolveState *__restrict__ st, int upd_T,
-         SysStride ss)
-{
-	__builtin_amdgcn_s_setprio(3);
-	{
-		const i64 ao = blockIdx.y * ss.arena_bytes;
-		M += blockIdx.y * ss.m_words;
-		Wb = sys_at(Wb, ao); alive = sys_at(alive, ao); panels = sys_at(panels, ao); aux = sys_at(aux, ao);
-		multset = sys_at(multset, ao); st = sys_at(st, ao);
-	}
-	const i64 first_alive = st->first;
-	__shared__ u64 Sw[GF2_GMAX][64];     // window words of the source rows          [word][slot]
-	__shared__ u64 Pb[GF2_GMAX][64];     // reduced pivot rows' window words          [word][pivot BIT]
-	__shared__ u64 Cm[64];               // combination masks                         [pivot k]
-	__shared__ int Bk[64];               // pivot k -> pivot bit
-	const int j = j0 + g;
-	const PanelRec rec = panels[j];
-	const PanelAux *A = aux + j;
-	const int p = rec.p;
-	u64 *mult = multset + (i64)g * rows;
-	const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	// no pivots in this panel, or every row of this workgroup is already dead: multipliers are 0
-	if (p == 0 || ((i64)(blockIdx.x + 1) * blockDim.x <= first_alive && blockIdx.x != 0)) {
-		if (i < rows) mult[i] = 0;
-		return;
-	}
-	{
-		const int t = threadIdx.x;               // 256 threads = 4 words x 64 slots
-		const int e = t >> 6, sl = t & 63;
-		Sw[e][sl] = (sl < p && e >= g && e < gb) ? Wb[(i64)A->slot_row[sl] * GF2_GMAX + e] : 0ull;
-		Pb[e][sl] = 0;
-		if (t < 64) {
-			Cm[t] = (t < p) ? A->comb[t] : 0ull;
-			if ((rec.mask >> t) & 1) Bk[__popcll(rec.mask & lanemask_lt(t))] = t;
-		}
-	}
-	__syncthreads();
-	{
-		const int t = threadIdx.x;
-		const int e = t >> 6, k = t & 63;
-		if (k < p && e >= g && e < gb) {
-			u64 c = Cm[k], acc = 0;
-			while (c) { int sl = ctz64(c); c &= c - 1; acc ^= Sw[e][sl]; }
-			Pb[e][Bk[k]] = acc;
-			if (blockIdx.x == 0) M[tidx(A->slot_row[k], j0 + e, srows)] = acc;
-		}
-	}
-	__syncthreads();
-	if (i >= rows) return;
-	u64 m = 0;
-	if (alive[i]) {
-		m = Wb[i * GF2_GMAX + g] & rec.mask;
-		if (m) {
-			u64 acc[GF2_GMAX];
-#pragma unroll
-			for (int e = 0; e < GF2_GMAX; e++) acc[e] = 0;
-			u64 mm = m;
-			while (mm) {
-				const int b = ctz64(mm); mm &= mm - 1;
-#pragma unroll
-				for (int e = 0; e < GF2_GMAX; e++)
-					if (e >= g) acc[e] ^= Pb[e][b];        // words left of the panel are finished (uniform test)
-			}
-#pragma unroll
-			for (int e = 0; e < GF2_GMAX; e++)
-				if (e >= g && e < gb) Wb[i * GF2_GMAX + e] ^= acc[e];
-		}
-	}
-	// stored pre-rotated for the bulk update's table layout (field s = what this row reads at step s)
-	mult[i] = rot_fields_rt(upd_T, m, rowq(i));
 }
 
 // ==========================================================================================
@@ -849,14 +899,14 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 // RHS bits are zero too (the check inside _mzd_pluq_solve_left, _internal.c:440).
 __global__ void __launch_bounds__(256)
 k_check_rhs(const u64 *__restrict__ M, i64 rows, i64 srows, i64 cols,
-            const unsigned char *__restrict__ alive, SolveState *__restrict__ st, SysStride ss)
+            const int *__restrict__ died, SolveState *__restrict__ st, SysStride ss)
 {
 	M += blockIdx.y * ss.m_words;
-	alive = sys_at(alive, blockIdx.y * ss.arena_bytes);
+	died = sys_at(died, blockIdx.y * ss.arena_bytes);
 	st = sys_at(st, blockIdx.y * ss.arena_bytes);
 	int bad = 0;
 	for (i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (i64)gridDim.x * blockDim.x)
-		if (alive[i]) bad |= (int)((M[tidx(i, cols >> 6, srows)] >> (cols & 63)) & 1);
+		if (died[i] == GF2_NEVER) bad |= (int)((M[tidx(i, cols >> 6, srows)] >> (cols & 63)) & 1);
 	if (__ballot(bad) && (threadIdx.x & 63) == 0) st->inconsistent = 1;
 }
 

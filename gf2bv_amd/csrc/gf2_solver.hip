@@ -273,10 +273,10 @@ struct Solver {
 	PanelRec *panels = nullptr;
 	PanelAux *aux = nullptr;
 	FindUnit *fu = nullptr;
-	unsigned char *alive = nullptr;
+	int *died = nullptr;          // per row: panel that made it a pivot source, GF2_NEVER while alive
 	int *pivcol = nullptr, *urow = nullptr, *blk_first = nullptr;
 	u64 *mult = nullptr;          // 2 sets x G x rows (ping-pong between consecutive blocks)
-	u64 *Wb = nullptr;            // rows x GMAX window words
+	u64 *Wb = nullptr;            // 2 x rows x GMAX window words (the panel steps ping-pong between the halves)
 	int units = 0;
 	u64 *Y = nullptr;
 	int *ycols = nullptr;
@@ -322,7 +322,7 @@ struct Solver {
 		Pool &P = pool();
 		for (void *p : { arena, (void *)Y, (void *)ycols, (void *)out, (void *)M, (void *)tmp_src }) P.release(p);
 		arena = nullptr; Y = nullptr; ycols = nullptr; out = nullptr; M = nullptr; tmp_src = nullptr;
-		st = nullptr; panels = nullptr; aux = nullptr; fu = nullptr; alive = nullptr; pivcol = nullptr;
+		st = nullptr; panels = nullptr; aux = nullptr; fu = nullptr; died = nullptr; pivcol = nullptr;
 		urow = nullptr; blk_first = nullptr; mult = nullptr; Wb = nullptr;
 		for (hipEvent_t *e : { &ev0, &ev1, &ev2, &ev3, &evx }) { P.release_event(*e, true); *e = nullptr; }
 		for (hipEvent_t e : kev) P.release_event(e, true);
@@ -392,22 +392,22 @@ int solver_alloc(Solver &S)
 		size_t off = 0;
 		auto carve = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
 		const size_t o_st = carve(sizeof(SolveState)), o_pan = carve(sizeof(PanelRec) * NP), o_aux = carve(sizeof(PanelAux) * NP),
-		             o_fu = carve(sizeof(FindUnit) * (S.units + 1)), o_alive = carve((size_t)R),
+		             o_fu = carve(sizeof(FindUnit) * (S.units + 1)), o_alive = carve(sizeof(int) * (size_t)R),
 		             o_piv = carve(sizeof(int) * (S.maxr + 64)), o_urow = carve(sizeof(int) * (S.maxr + 64)),
 		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * 2 * G * R),
-		             o_wb = carve(sizeof(u64) * GF2_GMAX * R);
+		             o_wb = carve(sizeof(u64) * 2 * GF2_GMAX * R);
 		S.arena_stride = off;
 		HIPCHK(pool().alloc(&S.arena, off * S.nsys, S.device));
 		char *base = (char *)S.arena;
 		S.st = (SolveState *)(base + o_st); S.panels = (PanelRec *)(base + o_pan); S.aux = (PanelAux *)(base + o_aux);
-		S.fu = (FindUnit *)(base + o_fu); S.alive = (unsigned char *)(base + o_alive); S.pivcol = (int *)(base + o_piv);
+		S.fu = (FindUnit *)(base + o_fu); S.died = (int *)(base + o_alive); S.pivcol = (int *)(base + o_piv);
 		S.urow = (int *)(base + o_urow); S.blk_first = (int *)(base + o_blk); S.mult = (u64 *)(base + o_mult);
 		S.Wb = (u64 *)(base + o_wb);
 		// zero everything that is read before it is written: state, panel records, unit scratch, block bounds, multipliers
 		for (int s = 0; s < S.nsys; s++) {
 			char *b = base + (size_t)s * off;
 			HIPCHK(hipMemsetAsync(b + o_st, 0, o_alive - o_st, S.sA));
-			HIPCHK(hipMemsetAsync(b + o_alive, 1, (size_t)R, S.sA));
+			HIPCHK(hipMemsetAsync(b + o_alive, GF2_NEVER & 0xff, sizeof(int) * (size_t)R, S.sA));
 			HIPCHK(hipMemsetAsync(b + o_blk, 0, o_wb - o_blk, S.sA));
 		}
 	}
@@ -483,18 +483,21 @@ int enqueue_forward(Solver &S)
 		const int wlo = j0 + gb;
 		u64 *mset = S.mult + (i64)(b & 1) * G * S.rows;
 		// ---- stream A: factorise the block ----
-		for (int g = 0; g < gb; g++) {
-			const int j = j0 + g;
-			const i64 c0 = (i64)j * 64;
+		// step s: narrow panel s-1 (window half (s-1)&1 -> half s&1) while searching panel s; gb+1 launches
+		u64 *const half[2] = { S.Wb, S.Wb + (i64)GF2_GMAX * S.rows };
+		for (int s = 0; s <= gb; s++) {
+			const int gp = s - 1, gf = (s < gb) ? s : -1;
+			const i64 c0 = (i64)(j0 + std::max(gf, 0)) * 64;
 			const u64 colmask = (S.cols - c0 >= 64) ? ~0ull : ((1ull << (S.cols - c0)) - 1);
-			k_find<<<dim3((S.units + 3) / 4, S.nsys), dim3(256), 0, S.sA>>>(S.Wb, S.rows, j, g, colmask, S.st, S.alive, S.fu,
-			                                                               S.units, S.panels, S.aux, S.pivcol, S.urow, mset,
-			                                                               g == gb - 1 ? S.blk_first + b : nullptr, S.impl->T, S.ss());
-			k_narrow<<<dim3(row_blocks, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, g, gb, S.Wb, S.alive,
-			                                                         S.panels, S.aux, mset, S.st, S.impl->T, S.ss());
+			const int find_wgs = gf >= 0 ? (S.units + 3) / 4 : 0;
+			const unsigned wgs = (unsigned)find_wgs + (gp >= 0 ? row_blocks : 0u);
+			k_panel_step<<<dim3(wgs, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, gp, gf, gb, colmask,
+			                                                       half[s ? (s - 1) & 1 : 0], half[s & 1], S.st, S.died, S.fu, S.units, find_wgs,
+			                                                       S.panels, S.aux, S.pivcol, S.urow, mset,
+			                                                       gf == gb - 1 ? S.blk_first + b : nullptr, S.impl->T, S.ss());
 		}
 		if (b == S.nblocks - 1)
-			k_win_scatter<<<dim3((unsigned)((S.rows * gb + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, gb, S.Wb, S.alive, S.ss());
+			k_win_scatter<<<dim3((unsigned)((S.rows * gb + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, gb, half[gb & 1], S.died, S.ss());
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(S.evA[b], S.sA));
 		if (S.dbg_sync & 1) HIPCHK(hipDeviceSynchronize());
@@ -538,7 +541,7 @@ int enqueue_forward(Solver &S)
 	HIPCHK(hipStreamWaitEvent(S.sA, S.ev3, 0));
 	{
 		int g = (int)std::min<i64>(1024, (S.rows + 255) / 256);
-		k_check_rhs<<<dim3(g, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, S.cols, S.alive, S.st, S.ss());
+		k_check_rhs<<<dim3(g, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, S.cols, S.died, S.st, S.ss());
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(S.ev1, S.sA));
@@ -742,7 +745,7 @@ int make_view(const Solver &S, int s, Solver &V)
 	auto mv = [ao](auto *&p) { p = reinterpret_cast<decltype(+p)>(reinterpret_cast<char *>(p) + ao); };
 	V.M = S.M + S.m_stride * s;
 	V.arena = (char *)S.arena + ao;
-	mv(V.st); mv(V.panels); mv(V.aux); mv(V.fu); mv(V.alive); mv(V.pivcol); mv(V.urow); mv(V.blk_first); mv(V.mult); mv(V.Wb);
+	mv(V.st); mv(V.panels); mv(V.aux); mv(V.fu); mv(V.died); mv(V.pivcol); mv(V.urow); mv(V.blk_first); mv(V.mult); mv(V.Wb);
 	V.Y = nullptr; V.ycols = nullptr; V.out = nullptr;
 	V.ev2 = nullptr;
 	HIPCHK(pool().event(&V.ev2, true));
