@@ -27,6 +27,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 typedef unsigned long long u64;   // matches HIP's 64-bit atomics and __ballot
 typedef long long i64;
@@ -177,10 +178,13 @@ __device__ __forceinline__ u64 rot_fields_rt(int T, u64 m, int q)
 // blockIdx.y selects the system.  A system's working matrix and its side-array arena sit at fixed
 // strides from those of system 0, so a kernel rebases its pointers once ({0, 0}: a single system).
 struct SysStride { i64 m_words, arena_bytes; };
+// (plain pointer arithmetic, no round trip through an integer: the compiler keeps knowing that these are
+// GLOBAL pointers -- with flat loads every s_waitcnt degenerates to vmcnt(0) and the software pipelines die)
 template <class P>
 __device__ __forceinline__ P *sys_at(P *p, i64 bytes)
 {
-	return reinterpret_cast<P *>(reinterpret_cast<uintptr_t>(p) + bytes);
+	typedef typename std::remove_cv<P>::type Q;
+	return reinterpret_cast<P *>(reinterpret_cast<char *>(const_cast<Q *>(p)) + bytes);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -694,8 +698,11 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	typedef UpdateCfg<G, T> C;
 	typedef Fields<T> F;
 	constexpr int TW = C::TW, LPR = C::LPR, SLOTS = C::SLOTS, IL = F::IL;
-	extern __shared__ __attribute__((aligned(16))) uint4 tab[];
-	int *prow = reinterpret_cast<int *>(tab + G * SLOTS * 16);     // [G][64] physical row of pivot bit, -1 if none
+	// STATIC shared memory (up to 129 KiB; gfx950 has 160 KiB per CU): the tables then start at LDS address 0
+	// known to the compiler, and a lookup address is (field << 8 | lane constant) with nothing to add --
+	// two VALU instructions per lookup (shift, v_and_or) instead of three
+	__shared__ __attribute__((aligned(256))) uint4 tab[G * SLOTS * 16];
+	__shared__ int prow[G * 64];                    // [G][64] physical row of pivot bit, -1 if none
 	const int ct = blockIdx.x % ntiles;
 	const int sp = blockIdx.x / ntiles;
 	const i64 tile = tile_begin + ct;
@@ -784,14 +791,27 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	// three-input XORs (v_bitop3) fold two entries at once.
 	uint4 *Mw = reinterpret_cast<uint4 *>(M) + tile * srows * LPR;
 	const int q = rowq(rr);                         // rbeg and the row steps are multiples of 8
-	unsigned cbyte[IL];                             // byte offset inside a 256-byte slot at step s (< 256)
+	// byte offset inside a 256-byte slot at step s (< 256), plus the 64-KiB page of the group (the ds_read
+	// immediate holds 16 bits)
+	constexpr int PAGES = (G * SLOTS * 256 + 65535) / 65536;
+	unsigned cbyte[PAGES][IL];
 #pragma unroll
-	for (int sidx = 0; sidx < IL; sidx++) cbyte[sidx] = (unsigned)(((q + sidx) % IL) * LPR + lr) * 16u;
+	for (int pg = 0; pg < PAGES; pg++)
+#pragma unroll
+		for (int sidx = 0; sidx < IL; sidx++) cbyte[pg][sidx] = ((unsigned)(((q + sidx) % IL) * LPR + lr) * 16u) | ((unsigned)pg << 16);
 	const char *tabb = reinterpret_cast<const char *>(tab);
 	constexpr int U = (G >= 4) ? 1 : GF2_UROWS;      // rows per lane per half-batch (register budget: 128 VGPRs at 1024 threads)
-	constexpr int GPB = 8 / IL;                     // groups per batch -> 8 reads in flight
+	constexpr int GPB = 8 / IL;                     // groups per batch -> 8 table reads in flight per lane
 	struct Half { u64 m[U][G]; uint4 d[U]; int qx[U]; bool on[U]; };
-	auto load_half = [&](Half &H, i64 base) {
+	// FAST (compile-time tag): the half-batch lies entirely inside the row range, all G panels are present and
+	// there is no window to deposit.  Then every global load and the store are UNCONDITIONAL -- no control flow
+	// around vector-memory instructions -- which is what lets the compiler wait with vmcnt(N > 0): with loads
+	// under per-lane or per-launch conditions it cannot count what is outstanding, falls back to vmcnt(0) right
+	// after issuing the prefetch, and the software pipeline degenerates to load -> wait -> compute.
+	typedef std::integral_constant<bool, true> FastT;
+	typedef std::integral_constant<bool, false> SafeT;
+	auto load_half = [&](auto tag, Half &H, i64 base) {
+		constexpr bool FAST = decltype(tag)::value;
 #pragma unroll
 		for (int u = 0; u < U; u++) {
 			const i64 row = base + (i64)u * RPP + rr;
@@ -807,18 +827,20 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 			u64 any = 0;
 #pragma unroll
 			for (int g = 0; g < G; g++) {
-				const u64 v = (row < rend && g < gb) ? multset[(i64)g * rows + row] : 0ull;
+				u64 v;
+				if (FAST) v = multset[(i64)g * rows + row];
+				else v = (row < rend && g < gb) ? multset[(i64)g * rows + row] : 0ull;
 				any |= v;
 				H.m[u][g] = v;
 			}
 			H.on[u] = any != 0;
 		}
 		// the data load does NOT wait for the multipliers (no dependent second memory round trip):
-		// every row of the range is fetched; rows that turn out to have zero multipliers are
-		// simply not written back
+		// every row of the range is fetched; rows that turn out to have zero multipliers are written back
+		// unchanged (FAST) or not at all
 #pragma unroll
 		for (int u = 0; u < U; u++)
-			if (base + (i64)u * RPP + rr < rend) H.d[u] = Mw[H.qx[u]];
+			if (FAST || base + (i64)u * RPP + rr < rend) H.d[u] = Mw[H.qx[u]];
 	};
 	// priority launches (Wb_out != nullptr) also deposit the next block's window words [wlo, wlo+gnext)
 	// of every visited row into the compact buffer Wb -- updated or not -- which replaces a gather pass
@@ -827,19 +849,21 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		if (wb0 >= 0 && wb0 < gnext) Wb_out[row * GF2_GMAX + wb0] = ((u64)val.y << 32) | val.x;
 		if (wb1 >= 0 && wb1 < gnext) Wb_out[row * GF2_GMAX + wb1] = ((u64)val.w << 32) | val.z;
 	};
-	auto compute_half = [&](Half &H, i64 base) {
+	auto compute_half = [&](auto tag, Half &H, i64 base) {
+		constexpr bool FAST = decltype(tag)::value;
 #pragma unroll
 		for (int u = 0; u < U; u++) {
-			if (!H.on[u]) {
+			if (!FAST && !H.on[u]) {
 				const i64 row = base + (i64)u * RPP + rr;
 				if (Wb_out && row < rend) put_window(row, H.d[u]);
 				continue;
 			}
 			uint4 acc = H.d[u];
+			if (!FAST || H.on[u]) {
 #ifndef GF2_MB_NOLOOKUP        /* tools/microbench_update.hip: time the HBM stream without the table work */
 #pragma unroll
 			for (int g = 0; g < G; g++) {
-				if (g >= gb) break;                 // tables of absent panels were never built (uniform branch)
+				if (!FAST && g >= gb) break;        // tables of absent panels were never built (uniform branch)
 				const unsigned mlo = (unsigned)H.m[u][g], mhi = (unsigned)(H.m[u][g] >> 32);
 #pragma unroll
 				for (int m0 = 0; m0 < F::NG; m0 += GPB) {
@@ -860,8 +884,9 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 							if (sh >= 32) x = (sh - 32 >= 8) ? (mhi >> (sh - 40)) : (mhi << (40 - sh));
 							else if (sh + wd <= 32) x = (sh >= 8) ? (mlo >> (sh - 8)) : (mlo << (8 - sh));
 							else x = __builtin_amdgcn_alignbit(mhi, mlo, sh - 8);      // sh >= 8 whenever a field straddles
-							const unsigned at = (x & fm) | (cbyte[sidx] & ~fm);      // bit-field insert: one v_bfi_b32
-							v[h * IL + sidx] = *reinterpret_cast<const uint4 *>(tabb + (g * SLOTS + F::groupoff(gm)) * 256 + at);
+							const int goff = (g * SLOTS + F::groupoff(gm)) * 256;     // byte offset of the group (constant after unrolling)
+							const unsigned at = (x & fm) | cbyte[goff >> 16][sidx];    // one v_and_or_b32
+							v[h * IL + sidx] = *reinterpret_cast<const uint4 *>(tabb + (goff & 0xffff) + at);
 						}
 					}
 					const int nv = ((F::NG - m0 < GPB) ? (F::NG - m0) : GPB) * IL;     // entries actually read (even; folds after unrolling)
@@ -876,18 +901,27 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 				}
 			}
 #endif
+			}
 			Mw[H.qx[u]] = acc;
-			if (Wb_out) put_window(base + (i64)u * RPP + rr, acc);
+			if (!FAST && Wb_out) put_window(base + (i64)u * RPP + rr, acc);
 		}
 	};
 	constexpr i64 STEP = (i64)RPP * U;
 	Half A, B;
-	load_half(A, rbeg);
-	for (i64 base = rbeg; base < rend; base += 2 * STEP) {
-		load_half(B, base + STEP);                  // rows >= rend load nothing (on = false)
-		compute_half(A, base);
-		load_half(A, base + 2 * STEP);
-		compute_half(B, base + STEP);
+	i64 base = rbeg;
+	load_half(SafeT(), A, base);
+	if (gb == G && !Wb_out)                             // bulk launches of full blocks: the branch-free pipeline
+		for (; base + 3 * STEP <= rend; base += 2 * STEP) {
+			load_half(FastT(), B, base + STEP);
+			compute_half(FastT(), A, base);
+			load_half(FastT(), A, base + 2 * STEP);
+			compute_half(FastT(), B, base + STEP);
+		}
+	for (; base < rend; base += 2 * STEP) {                 // the range's tail, priority launches, partial blocks
+		load_half(SafeT(), B, base + STEP);             // rows >= rend load nothing (on = false)
+		compute_half(SafeT(), A, base);
+		load_half(SafeT(), A, base + 2 * STEP);
+		compute_half(SafeT(), B, base + STEP);
 	}
 }
 

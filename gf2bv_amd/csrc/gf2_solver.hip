@@ -171,18 +171,9 @@ hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows, 
                          const PanelRec *panels, const PanelAux *aux, const u64 *multset, const int *blk_first,
                          int tile_begin, int ntiles, int nsplit, u64 *wb_out, int gnext, SysStride ss)
 {
-	constexpr int lds = UpdateCfg<G, T>::LDS_BYTES;
-	static bool attr_set[16] = {};
-	int dev = 0;
-	(void)hipGetDevice(&dev);
-	if (dev < 16 && !attr_set[dev]) {
-		hipError_t e = hipFuncSetAttribute((const void *)k_update<G, T, NT>,
-		                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-		if (e != hipSuccess) return e;
-		attr_set[dev] = true;
-	}
-	k_update<G, T, NT><<<grid, dim3(NT), lds, s>>>(M, rows, srows, j0, gb, wlo, panels, aux, multset, blk_first,
-	                                               tile_begin, ntiles, nsplit, wb_out, gnext, ss);
+	// the tables are static shared memory (see k_update): no dynamic LDS, no attribute to raise
+	k_update<G, T, NT><<<grid, dim3(NT), 0, s>>>(M, rows, srows, j0, gb, wlo, panels, aux, multset, blk_first,
+	                                             tile_begin, ntiles, nsplit, wb_out, gnext, ss);
 	return hipGetLastError();
 }
 
