@@ -798,7 +798,12 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 #pragma unroll
 	for (int pg = 0; pg < PAGES; pg++)
 #pragma unroll
-		for (int sidx = 0; sidx < IL; sidx++) cbyte[pg][sidx] = ((unsigned)(((q + sidx) % IL) * LPR + lr) * 16u) | ((unsigned)pg << 16);
+		for (int sidx = 0; sidx < IL; sidx++) {
+			unsigned c = ((unsigned)(((q + sidx) % IL) * LPR + lr) * 16u) | ((unsigned)pg << 16);
+			// opaque to the optimiser: otherwise it peels the page bit off again and spends v_and + v_add per lookup
+			asm volatile("" : "+v"(c));
+			cbyte[pg][sidx] = c;
+		}
 	const char *tabb = reinterpret_cast<const char *>(tab);
 	constexpr int U = (G >= 4) ? 1 : GF2_UROWS;      // rows per lane per half-batch (register budget: 128 VGPRs at 1024 threads)
 	constexpr int GPB = 8 / IL;                     // groups per batch -> 8 table reads in flight per lane
