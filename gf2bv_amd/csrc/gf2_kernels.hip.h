@@ -3,7 +3,7 @@
 // Replaces the M4RI routines gf2bv reaches from gf2bv/_internal.c (reference file:line):
 //   mzd_write_bit loop           _internal.c:403-426   -> k_pack_digits
 //   _mzd_pluq                    _internal.c:431-433   -> blocked elimination:
-//        panel path  (stream A): k_win_gather, k_find, k_narrow, k_win_scatter
+//        panel path  (stream A): k_win_gather, k_panel_step (pivot search + narrow step), k_win_scatter
 //        bulk path   (stream B): k_block_trsm, k_update
 //   _mzd_pluq_solve_left         _internal.c:438-447   -> k_check_rhs + k_extract_y +
 //                                                         k_gather_mult_u + k_sweep (on Y)
@@ -40,7 +40,7 @@ typedef long long i64;
 #define GF2_LPR (GF2_TW / 2)      // lanes per row segment, 16 bytes each
 #define GF2_IL (16 / GF2_LPR)     // table entries interleaved in one 256-byte LDS slot: 4 (TW=8) or 2 (TW=16)
 static_assert(GF2_TW == 8 || GF2_TW == 16, "tile width");
-#define GF2_FEW_UNITS 8           // k_find units used while panels are easy (dense systems)
+#define GF2_FEW_UNITS 8           // search units used while panels are easy (dense systems)
 #ifndef GF2_BATCH
 #define GF2_BATCH 4
 #endif
@@ -68,7 +68,7 @@ __host__ __device__ __forceinline__ int rowq(long long row)
 	return GF2_IL == 2 ? (int)(row & 1) : (int)((row >> 1) & 3);
 }
 
-// One record per 64-column panel, written by k_find.
+// One record per 64-column panel, written by the search half of k_panel_step.
 struct PanelRec {
 	int start;      // global index of this panel's first pivot (= rank before the panel)
 	int p;          // pivots found in this panel (0..64)
@@ -98,12 +98,12 @@ struct SolveState {
 	int rank;            // pivots found so far
 	int inconsistent;    // set by k_check_rhs
 	int first;           // lower bound of the alive rows
-	unsigned arrive;     // k_find: units that have finished (last arriver publishes)
-	int wide;            // k_find: 1 = the previous panel was hard (sparse / rank deficient): scan with all units
+	unsigned arrive;     // search units that have finished (last arriver publishes)
+	int wide;            // search: 1 = the previous panel was hard (sparse / rank deficient): scan with all units
 	int pad[3];
 };
 
-// Scratch of one k_find unit (wavefront).
+// Scratch of one search unit (wavefront).
 struct FindUnit {
 	u64 have;
 	int cnt;
@@ -272,13 +272,13 @@ k_win_scatter(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, const u6
 	M[tidx(i, j0 + g, srows)] = Wb[i * GF2_GMAX + g];
 }
 
-// Cross-workgroup scratch of k_find is exchanged with relaxed AGENT-scope atomics (write-through
+// Cross-workgroup scratch of the search units is exchanged with relaxed AGENT-scope atomics (write-through
 // stores, L2-coherent loads): no __threadfence(), whose release half would write back the whole
 // L2 -- megabytes of lines the concurrent bulk update is dirtying.
 #define GF2_ST(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define GF2_LD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
-// Wave-level Gauss-Jordan state of k_find: lane b owns the basis vector whose pivot is bit b
+// Wave-level Gauss-Jordan state of a search unit: lane b owns the basis vector whose pivot is bit b
 // (bw) together with the slots folded into it (bc).
 struct FindState {
 	u64 bw, bc, have;
