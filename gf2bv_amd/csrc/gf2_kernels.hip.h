@@ -382,33 +382,73 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	}
 	__shared__ StepLds L;
 	const int t = threadIdx.x;
+	const int lane = t & 63;
 	const bool finder = (int)blockIdx.x < find_wgs;
 	const i64 rb = (i64)blockIdx.x - find_wgs;          // narrow role: row block
-	PanelRec recp;
-	recp.start = 0; recp.p = 0; recp.mask = 0;
-	const PanelAux *Ap = aux + j0 + (gp >= 0 ? gp : 0);
-	i64 bound = 0;                                      // alive lower bound after panel gp
-	if (gp >= 0) {
-		recp = panels[j0 + gp];
-		bound = Ap->first_after;
+
+	// Latency is what this kernel costs, so everything it needs goes out in TWO memory round trips and
+	// without control flow around the loads (indices are clamped instead): trip 1 = panel gp's record,
+	// its source list, the alive bound, this thread's own row / the search slice's start; trip 2 = the
+	// source rows' window words and the first chunk of search candidates.
+	const int gpc = gp >= 0 ? gp : 0;
+	const PanelAux *Ap = aux + j0 + gpc;
+	PanelRec recp = panels[j0 + gpc];
+	i64 bound = Ap->first_after;                        // alive lower bound after panel gp
+	const int e_ = t >> 6, sl = t & 63;                 // 256 threads = 4 words x 64 slots
+	const int sr = Ap->slot_row[sl];
+	const u64 cm = Ap->comb[sl];
+	const int first = st->first, wide = st->wide;       // (search role)
+	if (gp < 0) { recp.p = 0; recp.mask = 0; bound = 0; }
+
+	// narrow role: this thread's row
+	const i64 i = rb * 256 + t;
+	const i64 ic = (!finder && i < rows) ? i : 0;
+	const int my_died = died[ic];
+	const uint4 *src = reinterpret_cast<const uint4 *>(Wb_in + ic * GF2_GMAX);
+	const uint4 my_lo = src[0], my_hi = src[1];
+
+	// search role: this unit's slice and its first chunk
+	const int u = (int)blockIdx.x * 4 + (t >> 6);
+	const int j = j0 + (gf >= 0 ? gf : 0);
+	const int gfc = gf >= 0 ? gf : 0;
+	// Dense panels are complete after ~70 rows, so a handful of units (each covering a long slice it
+	// will not finish) publish sooner than 256 units that all have to be dispatched and collected.
+	// Hard panels (sparse / rank deficient: a unit had to scan far) switch the NEXT panel to all units.
+	// Either way the active units' slices cover every alive row.
+	const int active = wide ? units : (units < GF2_FEW_UNITS ? units : GF2_FEW_UNITS);
+	i64 lo = rows, hi = rows;
+	if (finder && u < active) {
+		const i64 n = rows - first;
+		i64 per = n > 0 ? (n + active - 1) / active : 0;
+		per = (per + 63) & ~(i64)63;
+		lo = first + (i64)u * per;
+		hi = (lo + per < rows) ? lo + per : rows;
 	}
+	const i64 rclamp = rows - 1;
+	i64 i_n = lo + lane;
+	i64 i_c = i_n < rclamp ? i_n : rclamp;
+	int d_n = died[i_c];
+	u64 wf_n = Wb_in[i_c * GF2_GMAX + gfc];
+	u64 wp_n = Wb_in[i_c * GF2_GMAX + gpc];
+
 	// a row block below the bound holds dead rows only (block 0 still stores the pivot rows)
 	const bool dead_block = !finder && rb != 0 && (rb + 1) * 256 <= bound;
 	if (recp.p > 0 && !dead_block) {
 		// reduced pivot rows of panel gp restricted to the window, from its source rows (tiny, every workgroup)
-		const int e = t >> 6, sl = t & 63;          // 256 threads = 4 words x 64 slots
-		L.Sw[e][sl] = (sl < recp.p && e >= gp && e < gb) ? Wb_in[(i64)Ap->slot_row[sl] * GF2_GMAX + e] : 0ull;
-		L.Pb[e][sl] = 0;
+		const bool use = sl < recp.p && e_ >= gp && e_ < gb;
+		const u64 sw = Wb_in[(i64)(use ? sr : 0) * GF2_GMAX + e_];
+		L.Sw[e_][sl] = use ? sw : 0ull;
+		L.Pb[e_][sl] = 0;
 		if (t < 64) {
-			L.Cm[t] = (t < recp.p) ? Ap->comb[t] : 0ull;
+			L.Cm[t] = (t < recp.p) ? cm : 0ull;
 			if ((recp.mask >> t) & 1) L.Bk[__popcll(recp.mask & lanemask_lt(t))] = t;
 		}
 		__syncthreads();
-		if (sl < recp.p && e >= gp && e < gb) {
+		if (use) {
 			u64 c = L.Cm[sl], acc = 0;
-			while (c) { int q = ctz64(c); c &= c - 1; acc ^= L.Sw[e][q]; }
-			L.Pb[e][L.Bk[sl]] = acc;
-			if (!finder && rb == 0) M[tidx(Ap->slot_row[sl], j0 + e, srows)] = acc;
+			while (c) { int q = ctz64(c); c &= c - 1; acc ^= L.Sw[e_][q]; }
+			L.Pb[e_][L.Bk[sl]] = acc;
+			if (!finder && rb == 0) M[tidx(sr, j0 + e_, srows)] = acc;
 		}
 		__syncthreads();
 	}
@@ -418,14 +458,12 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 		const int p = recp.p;
 		u64 *mult = multset + (i64)gp * rows;
 		if (rb == 0 && t < p)                           // the multipliers panel gp's sources recorded for earlier panels
-			for (int e = 0; e < gp; e++) multset[(i64)e * rows + Ap->slot_row[t]] = 0;
-		const i64 i = rb * 256 + t;
+			for (int e = 0; e < gp; e++) multset[(i64)e * rows + sr] = 0;
 		if (i >= rows) return;
 		u64 m = 0;
-		if (!dead_block && died[i] > j0 + gp) {         // alive when panel gp was eliminated
-			const uint4 *src = reinterpret_cast<const uint4 *>(Wb_in + i * GF2_GMAX);
-			uint4 lo = src[0], hi = src[1];
-			u64 w[GF2_GMAX] = { ((u64)lo.y << 32) | lo.x, ((u64)lo.w << 32) | lo.z, ((u64)hi.y << 32) | hi.x, ((u64)hi.w << 32) | hi.z };
+		if (!dead_block && my_died > j0 + gp) {         // alive when panel gp was eliminated
+			u64 w[GF2_GMAX] = { ((u64)my_lo.y << 32) | my_lo.x, ((u64)my_lo.w << 32) | my_lo.z,
+			                    ((u64)my_hi.y << 32) | my_hi.x, ((u64)my_hi.w << 32) | my_hi.z };
 			u64 wp = 0;
 #pragma unroll
 			for (int e = 0; e < GF2_GMAX; e++) if (e == gp) wp = w[e];
@@ -455,44 +493,27 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	}
 
 	// ---- search panel gf ----
-	const int lane = t & 63;
-	const int u = (int)blockIdx.x * 4 + (t >> 6);
 	if (u >= units) return;
-	const int j = j0 + gf;
 	CandWords cw;
-	cw.Wb = Wb_in; cw.Pcol = &L.Pb[gf < GF2_GMAX ? gf : 0][0]; cw.maskp = (gp >= 0) ? recp.mask : 0ull; cw.gf = gf; cw.gp = gp >= 0 ? gp : gf;
-	const int first = st->first;
+	cw.Wb = Wb_in; cw.Pcol = &L.Pb[gfc][0]; cw.maskp = recp.mask; cw.gf = gfc; cw.gp = gpc;
 	const int full = __popcll(colmask);
-	// Dense panels are complete after ~70 rows, so a handful of units (each covering a long slice it
-	// will not finish) publish sooner than 256 units that all have to be dispatched and collected.
-	// Hard panels (sparse / rank deficient: a unit had to scan far) switch the NEXT panel to all units.
-	// Either way the active units' slices cover every alive row.
-	const int active = st->wide ? units : (units < GF2_FEW_UNITS ? units : GF2_FEW_UNITS);
 	FindUnit *me = fu + u;
 	FindState S;
 	S.bw = 0; S.bc = 0; S.have = 0; S.nslots = 0;
 	int first_nonsrc = -1, chunks = 0;
 	if (u < active) {
-		const i64 n = rows - first;
-		i64 per = n > 0 ? (n + active - 1) / active : 0;
-		per = (per + 63) & ~(i64)63;
-		const i64 lo = first + (i64)u * per;
-		const i64 hi = (lo + per < rows) ? lo + per : rows;
 		i64 base = lo;
 		// two chunks in flight: the loads of chunk c+1 are issued before chunk c is absorbed
-		i64 i_n = base + lane;
-		bool ok_n = (i_n < hi) && died[i_n] >= j;
-		u64 wf_n = ok_n ? Wb_in[i_n * GF2_GMAX + cw.gf] : 0ull;
-		u64 wp_n = ok_n ? Wb_in[i_n * GF2_GMAX + cw.gp] : 0ull;
 		for (; base < hi && S.nslots < full; base += 64) {
-			const i64 i = i_n;
-			const bool ok = ok_n;
-			const u64 w = cw.apply(wf_n, wp_n) & colmask;
+			const i64 ii = i_n;
+			const bool ok = (ii < hi) && d_n >= j;
+			const u64 w = ok ? (cw.apply(wf_n, wp_n) & colmask) : 0ull;
 			i_n = base + 64 + lane;
-			ok_n = (i_n < hi) && died[i_n] >= j;
-			wf_n = ok_n ? Wb_in[i_n * GF2_GMAX + cw.gf] : 0ull;
-			wp_n = ok_n ? Wb_in[i_n * GF2_GMAX + cw.gp] : 0ull;
-			const u64 took = find_absorb(S, w, (int)i, colmask, lane, me->srow);
+			i_c = i_n < rclamp ? i_n : rclamp;
+			d_n = died[i_c];
+			wf_n = Wb_in[i_c * GF2_GMAX + gfc];
+			wp_n = Wb_in[i_c * GF2_GMAX + gpc];
+			const u64 took = find_absorb(S, w, (int)ii, colmask, lane, me->srow);
 			chunks++;
 			if (first_nonsrc < 0) {
 				u64 mk = __ballot(ok) & ~took;
@@ -510,27 +531,32 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	if (old != (unsigned)(units - 1)) return;
 
 	// ---- last arriver: publish ----
-	// unit 0 scans the lowest rows: adopting it keeps the alive lower bound exact for free
+	// unit 0 scans the lowest rows: adopting it keeps the alive lower bound exact for free.  Its record is
+	// fetched speculatively in one go (the usual case), not field by field after the decision.
+	const int cnt0 = GF2_LD(&fu[0].cnt), ch0 = GF2_LD(&fu[0].chunks), fn0 = GF2_LD(&fu[0].first_nonsrc);
+	const u64 have0 = GF2_LD(&fu[0].have), bc0 = GF2_LD(&fu[0].bc[lane]);
+	const int srow0 = GF2_LD(&fu[0].srow[lane]);
+	const int r0 = st->rank;
 	int pick = -1;
 	if (full > 0) {
 		if (u == 0 && S.nslots == full) pick = 0;
-		else if (GF2_LD(&fu[0].cnt) == full) pick = 0;
+		else if (cnt0 == full) pick = 0;
 		else if (S.nslots == full) pick = u;
 		else
 			for (int v = 1; v < active; v++)
 				if (GF2_LD(&fu[v].cnt) == full) { pick = v; break; }
 	}
-	const int hard = (pick < 0) || ((pick == u ? chunks : GF2_LD(&fu[pick].chunks)) > 8);
+	const int hard = (pick < 0) || ((pick == u ? chunks : (pick == 0 ? ch0 : GF2_LD(&fu[pick].chunks))) > 8);
 	int new_first;
 	int srow;                                   // lane s: row of slot s
 	if (pick >= 0) {
 		if (pick != u) {
-			S.have = GF2_LD(&fu[pick].have);
-			S.bc = GF2_LD(&fu[pick].bc[lane]);
+			S.have = (pick == 0) ? have0 : GF2_LD(&fu[pick].have);
+			S.bc = (pick == 0) ? bc0 : GF2_LD(&fu[pick].bc[lane]);
 		}
 		S.nslots = full;
-		srow = GF2_LD(&fu[pick].srow[lane]);
-		new_first = (pick == 0) ? ((u == 0) ? first_nonsrc : GF2_LD(&fu[0].first_nonsrc)) : first;
+		srow = (pick == 0) ? srow0 : GF2_LD(&fu[pick].srow[lane]);
+		new_first = (pick == 0) ? ((u == 0) ? first_nonsrc : fn0) : first;
 	} else {
 		// merge: rebuild one basis from all units' source rows (scratch: this unit's own srow list is
 		// dead by now, but other lists are still being read -> use the list of unit `units` (spare))
@@ -549,7 +575,6 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 		new_first = first;
 	}
 	const int p = S.nslots;
-	const int r0 = st->rank;
 	PanelAux *A = aux + j;
 	if ((S.have >> lane) & 1) {
 		const int k = __popcll(S.have & lanemask_lt(lane));
@@ -560,12 +585,15 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 		A->slot_row[lane] = srow;
 		urow[r0 + lane] = srow;                 // pivot k of the panel lives in physical row slot_row[k]
 		died[srow] = j;
-		for (int e = 0; e < gf; e++) {          // multipliers of this source w.r.t. earlier panels of the block
-			u64 mv;
-			if (e == gp) mv = cw.prev_mult(Wb_in[(i64)srow * GF2_GMAX + gp]);      // being recorded by this very launch
-			else mv = rot_fields_rt(upd_T, multset[(i64)e * rows + srow], (GF2_IL - rowq(srow)) % GF2_IL);   // stored rotated; the TRSM wants plain bit order
-			A->src_mult[lane][e] = mv;
-		}
+		// multipliers of this source w.r.t. earlier panels of the block: panel gp's is being recorded by this
+		// very launch (take it from the window), older ones are stored rotated (the TRSM wants plain bit order)
+		u64 mv[GF2_GMAX];
+#pragma unroll
+		for (int e = 0; e < GF2_GMAX; e++)      // all loads first
+			mv[e] = (e >= gf) ? 0ull : (e == gp) ? Wb_in[(i64)srow * GF2_GMAX + gpc] : multset[(i64)e * rows + srow];
+#pragma unroll
+		for (int e = 0; e < GF2_GMAX; e++)
+			if (e < gf) A->src_mult[lane][e] = (e == gp) ? cw.prev_mult(mv[e]) : rot_fields_rt(upd_T, mv[e], (GF2_IL - rowq(srow)) % GF2_IL);
 	}
 	// advance the lower bound of alive rows past rows that just died (free when pick == 0)
 	if (pick != 0) {
@@ -594,6 +622,147 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	}
 }
 
+// The next block's window, on the panel stream: every row >= blk_first gets block b's update applied to
+// its words [wlo, wlo + gnext) -- read from the matrix (complete through block b-1), written to the
+// compact buffer Wb only -- so the next block's panel steps can start while the bulk update of block b
+// is still sweeping the matrix on the other stream (look-ahead).  Only gnext <= 4 words per row are
+// involved, so this is the narrow step's method, not the table kernel's: (i) every workgroup brings the
+// block's source rows up to date on those words and forms the pivot rows (the TRSM of k_block_trsm on a
+// 4-word slice, in LDS); (ii) every row XORs in the pivot rows selected by its four multipliers, bit by
+// bit.  Neither the bulk update nor the bulk TRSM writes these words (their no-write range): the panel
+// stream owns them.  The block's pivot rows' share of them (part of U, needed by the back-substitution)
+// cannot be stored in place -- every workgroup here is still reading the source rows -- so workgroup 0
+// parks it in Uwin[pivot index][word] and k_unwind moves it into the matrix after the elimination.
+__global__ void __launch_bounds__(256)
+k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo, int gnext,
+              const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
+              const u64 *__restrict__ multset, const int *__restrict__ blk_first, u64 *__restrict__ Wb_out,
+              u64 *__restrict__ Uwin, int upd_T, SysStride ss)
+{
+	__builtin_amdgcn_s_setprio(3);
+	{
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		M += blockIdx.y * ss.m_words;
+		panels = sys_at(panels, ao); aux = sys_at(aux, ao); multset = sys_at(multset, ao); blk_first = sys_at(blk_first, ao);
+		Wb_out = sys_at(Wb_out, ao); Uwin = sys_at(Uwin, ao);
+	}
+	constexpr int W = GF2_GMAX;
+	__shared__ u64 S[GF2_GMAX * 64 * W];       // [panel][slot][word]
+	__shared__ u64 P[GF2_GMAX * 64 * W];       // [panel][pivot][word]
+	__shared__ u64 Pbit[GF2_GMAX * 64 * W];    // [panel][pivot BIT][word]
+	const int t = threadIdx.x;
+	const int r = t / W, w = t % W;            // TRSM item: (slot / pivot r, window word w)
+	const bool live = w < gnext;
+	const i64 first = *blk_first;
+	const i64 i = (i64)blockIdx.x * 256 + t;   // row of this thread
+	const i64 ic = i < rows ? i : rows - 1;
+	// trip 1: all parameters, this row's multipliers; trip 2: the source rows' and this row's window words
+	PanelRec rec[GF2_GMAX];
+	int srow[GF2_GMAX];
+	u64 comb[GF2_GMAX], smul[GF2_GMAX][GF2_GMAX], mrow[GF2_GMAX];
+#pragma unroll
+	for (int g = 0; g < GF2_GMAX; g++) {
+		const int gc = g < gb ? g : 0;
+		rec[g] = panels[j0 + gc];
+		srow[g] = aux[j0 + gc].slot_row[r];
+		comb[g] = aux[j0 + gc].comb[r];
+#pragma unroll
+		for (int e = 0; e < GF2_GMAX; e++) smul[g][e] = (e < g) ? aux[j0 + gc].src_mult[r][e] : 0ull;
+		mrow[g] = multset[(i64)gc * rows + ic];
+		if (g >= gb) { rec[g].p = 0; rec[g].mask = 0; mrow[g] = 0; }
+	}
+	u64 wv[W];
+#pragma unroll
+	for (int e = 0; e < W; e++) wv[e] = M[tidx(ic, wlo + (e < gnext ? e : 0), srows)];
+	// every row of this workgroup is dead (uniform); workgroup 0 still runs: it records the pivot rows' window words
+	if (blockIdx.x != 0 && (i64)(blockIdx.x + 1) * 256 <= first) return;
+	int anyp = 0;
+#pragma unroll
+	for (int g = 0; g < GF2_GMAX; g++) anyp |= rec[g].p;
+	if (anyp) {
+#pragma unroll
+		for (int g = 0; g < GF2_GMAX; g++) {
+			const u64 v = M[tidx(r < rec[g].p ? srow[g] : 0, wlo + (live ? w : 0), srows)];
+			S[(g * 64 + r) * W + w] = (r < rec[g].p && live) ? v : 0ull;
+			Pbit[(g * 64 + r) * W + w] = 0;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int g = 0; g < GF2_GMAX; g++) {
+			if (g >= gb) break;
+			if (r < rec[g].p) {
+				// fixed trip count, predicated: the LDS reads are independent and pipeline (a while (bits)
+				// loop pays the full LDS latency per set bit, and this step is nothing but latency)
+				const u64 c = comb[g];
+				u64 acc = 0;
+#pragma unroll 8
+				for (int sl = 0; sl < 64; sl++) acc ^= ((c >> sl) & 1) ? S[(g * 64 + sl) * W + w] : 0ull;
+				P[(g * 64 + r) * W + w] = acc;
+				if (blockIdx.x == 0 && live) Uwin[(i64)(rec[g].start + r) * GF2_GMAX + w] = acc;
+			}
+			__syncthreads();
+			if ((rec[g].mask >> r) & 1)             // thread (r, w) also files pivot bit r under its bit position
+				Pbit[(g * 64 + r) * W + w] = P[(g * 64 + __popcll(rec[g].mask & lanemask_lt(r))) * W + w];
+			int hneed = 0;
+#pragma unroll
+			for (int h = g + 1; h < GF2_GMAX; h++) {
+				if (h < gb && r < rec[h].p) hneed |= 1 << h;
+			}
+			__syncthreads();                            // Pbit[g] complete
+#pragma unroll
+			for (int h = g + 1; h < GF2_GMAX; h++) {
+				if ((hneed >> h) & 1) {
+					const u64 m = smul[h][g];
+					u64 acc = 0;
+#pragma unroll 8
+					for (int b = 0; b < 64; b++) acc ^= ((m >> b) & 1) ? Pbit[(g * 64 + b) * W + w] : 0ull;
+					S[(h * 64 + r) * W + w] ^= acc;
+				}
+			}
+			__syncthreads();
+		}
+	}
+	if (i >= rows) return;
+	if (anyp) {
+		const int unrot = (GF2_IL - rowq(i)) % GF2_IL;      // multipliers are stored rotated for the table kernel
+#pragma unroll
+		for (int g = 0; g < GF2_GMAX; g++) {
+			u64 m = mrow[g] ? rot_fields_rt(upd_T, mrow[g], unrot) : 0ull;
+			while (m) {
+				const int b = ctz64(m); m &= m - 1;
+				const u64 *pr = &Pbit[(g * 64 + b) * W];
+#pragma unroll
+				for (int e = 0; e < W; e++) wv[e] ^= pr[e];
+			}
+		}
+	}
+#pragma unroll
+	for (int e = 0; e < W; e++)
+		if (e < gnext) Wb_out[i * GF2_GMAX + e] = wv[e];
+}
+
+// After the elimination: pivot row k of block b gets its words of block b+1's window (parked in Uwin by
+// k_prio_window) written into the matrix.  One thread per (pivot, word).
+__global__ void __launch_bounds__(256)
+k_unwind(u64 *__restrict__ M, i64 srows, int G, int npanels, int nblocks, const SolveState *__restrict__ st,
+         const int *__restrict__ pivcol, const int *__restrict__ urow, const u64 *__restrict__ Uwin, SysStride ss)
+{
+	{
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		M += blockIdx.y * ss.m_words;
+		st = sys_at(st, ao); pivcol = sys_at(pivcol, ao); urow = sys_at(urow, ao); Uwin = sys_at(Uwin, ao);
+	}
+	const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+	const i64 k = t / GF2_GMAX;
+	const int e = (int)(t % GF2_GMAX);
+	if (k >= st->rank) return;
+	const int b = (pivcol[k] >> 6) / G;
+	if (b + 1 >= nblocks) return;                       // the last block has no next window
+	const int wlo = (b + 1) * G;
+	const int gnext = (npanels - wlo < G) ? npanels - wlo : G;
+	if (e < gnext) M[tidx(urow[k], wlo + e, srows)] = Uwin[k * GF2_GMAX + e];
+}
+
 // ==========================================================================================
 // BULK PATH (stream B)
 // ==========================================================================================
@@ -608,7 +777,7 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 template <int TW, int WPW>
 __global__ void __launch_bounds__(64 * WPW)
 k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int tile_begin,
-             const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux, SysStride ss)
+             const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux, int nw_lo, int nw_hi, SysStride ss)
 {
 	__builtin_amdgcn_s_setprio(2);
 	M += blockIdx.y * ss.m_words;
@@ -623,28 +792,47 @@ k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int tile_b
 	const i64 w0 = tile * TW + wofs;
 	u64 *Mt = M + tile * srows * TW + wofs;    // row r, word w of this workgroup's slice at Mt[r * TW + w]
 	const int r = threadIdx.x / WPW, w = threadIdx.x % WPW;    // one (row, word) item per thread
-	const bool live = w0 + w >= wlo;
-	for (int g = 0; g < gb; g++) {
-		const int p = panels[j0 + g].p;
-		S[(g * 64 + r) * WPW + w] = (r < p && live) ? Mt[(i64)aux[j0 + g].slot_row[r] * TW + w] : 0ull;
+	// words [nw_lo, nw_hi) = the next block's window: k_prio_window forms and stores those on the panel stream
+	const bool live = w0 + w >= wlo && !(w0 + w >= nw_lo && w0 + w < nw_hi);
+	// This step is pure latency (the chip is nearly idle while it runs), so all its parameters are fetched in
+	// ONE round trip up front -- records, this thread's source rows, combinations and multipliers of every
+	// panel -- and the source rows' words in a second one; nothing is loaded inside the panel loop.
+	PanelRec rec[GF2_GMAX];
+	int srow[GF2_GMAX];
+	u64 comb[GF2_GMAX], smul[GF2_GMAX][GF2_GMAX];
+#pragma unroll
+	for (int g = 0; g < GF2_GMAX; g++) {
+		const int gc = g < gb ? g : 0;             // clamped: no control flow around the loads
+		rec[g] = panels[j0 + gc];
+		srow[g] = aux[j0 + gc].slot_row[r];
+		comb[g] = aux[j0 + gc].comb[r];
+#pragma unroll
+		for (int e = 0; e < GF2_GMAX; e++) smul[g][e] = (e < g) ? aux[j0 + gc].src_mult[r][e] : 0ull;
+		if (g >= gb) rec[g].p = 0;
+	}
+#pragma unroll
+	for (int g = 0; g < GF2_GMAX; g++) {
+		const u64 v = Mt[(i64)(r < rec[g].p ? srow[g] : 0) * TW + w];
+		S[(g * 64 + r) * WPW + w] = (r < rec[g].p && live) ? v : 0ull;
 	}
 	__syncthreads();
-	for (int g = 0; g < gb; g++) {
-		const PanelRec rec = panels[j0 + g];
-		const PanelAux *A = aux + j0 + g;
-		if (r < rec.p) {
-			u64 c = A->comb[r], acc = 0;
+#pragma unroll
+	for (int g = 0; g < GF2_GMAX; g++) {
+		if (g >= gb) break;
+		if (r < rec[g].p) {
+			u64 c = comb[g], acc = 0;
 			while (c) { int sl = ctz64(c); c &= c - 1; acc ^= S[(g * 64 + sl) * WPW + w]; }
 			P[(g * 64 + r) * WPW + w] = acc;
-			if (live) Mt[(i64)A->slot_row[r] * TW + w] = acc;
+			if (live) Mt[(i64)srow[g] * TW + w] = acc;
 		}
 		__syncthreads();
-		for (int h = g + 1; h < gb; h++) {
-			if (r < panels[j0 + h].p) {
-				u64 m = aux[j0 + h].src_mult[r][g], acc = 0;
+#pragma unroll
+		for (int h = g + 1; h < GF2_GMAX; h++) {
+			if (h < gb && r < rec[h].p) {
+				u64 m = smul[h][g], acc = 0;
 				while (m) {
 					const int b = ctz64(m); m &= m - 1;
-					const int k = __popcll(rec.mask & ((1ull << b) - 1));
+					const int k = __popcll(rec[g].mask & ((1ull << b) - 1));
 					acc ^= P[(g * 64 + k) * WPW + w];
 				}
 				S[(h * 64 + r) * WPW + w] ^= acc;
@@ -687,13 +875,15 @@ __global__ void __launch_bounds__(NT)
 k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
          const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
          const u64 *__restrict__ multset, const int *__restrict__ blk_first,
-         int tile_begin, int ntiles, int nsplit, u64 *__restrict__ Wb_out, int gnext, SysStride ss)
+         int tile_begin, int ntiles, int nsplit, int nw_lo, int nw_hi, SysStride ss)
 {
+	// Words [nw_lo, nw_hi) -- the next block's window -- are never WRITTEN here: the panel stream owns them
+	// (k_prio_window has carried them into Wb, and the next block's panel steps store its pivot rows there
+	// while this launch is still running).
 	{
 		const i64 ao = blockIdx.y * ss.arena_bytes;
 		M += blockIdx.y * ss.m_words;
 		panels = sys_at(panels, ao); aux = sys_at(aux, ao); multset = sys_at(multset, ao); blk_first = sys_at(blk_first, ao);
-		if (Wb_out) Wb_out = sys_at(Wb_out, ao);
 	}
 	typedef UpdateCfg<G, T> C;
 	typedef Fields<T> F;
@@ -713,7 +903,7 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 
 	int anyp = 0;
 	for (int g = 0; g < gb; g++) anyp |= panels[j0 + g].p;
-	if (!anyp && !Wb_out) return;
+	if (!anyp) return;                          // a block without pivots changes nothing
 	// row range of this workgroup: [first alive row, rows) split evenly; range starts are multiples of 8 so
 	// that a lane's rowq is a constant (rows just below the bound are dead: zero multipliers)
 	const i64 rlo = (i64)(*blk_first) & ~(i64)7;
@@ -723,18 +913,6 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	const i64 rbeg = rlo + (i64)sp * per;
 	if (rbeg >= rows) return;
 	const i64 rend = (rbeg + per < rows) ? rbeg + per : rows;
-	if (!anyp) {
-		// a block without pivots changes nothing, but the next block's window still has to reach Wb
-		const uint4 *Mg = reinterpret_cast<const uint4 *>(M) + tile * srows * LPR;
-		const int a0 = (int)(w0 + 2 * lr) - wlo, a1 = a0 + 1;
-		for (i64 row = rbeg + rr; row < rend; row += RPP) {
-			const uint4 v = Mg[row * LPR + lr];
-			if (a0 >= 0 && a0 < gnext) Wb_out[row * GF2_GMAX + a0] = ((u64)v.y << 32) | v.x;
-			if (a1 >= 0 && a1 < gnext) Wb_out[row * GF2_GMAX + a1] = ((u64)v.w << 32) | v.z;
-		}
-		return;
-	}
-
 	// ---- tables ----
 	for (int t = threadIdx.x; t < gb * 64; t += NT) {
 		const int g = t >> 6, b = t & 63;
@@ -847,22 +1025,15 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		for (int u = 0; u < U; u++)
 			if (FAST || base + (i64)u * RPP + rr < rend) H.d[u] = Mw[H.qx[u]];
 	};
-	// priority launches (Wb_out != nullptr) also deposit the next block's window words [wlo, wlo+gnext)
-	// of every visited row into the compact buffer Wb -- updated or not -- which replaces a gather pass
-	const int wb0 = (int)(w0 + 2 * lr) - wlo, wb1 = wb0 + 1;       // window slots of this lane's two words
-	auto put_window = [&](i64 row, const uint4 &val) {
-		if (wb0 >= 0 && wb0 < gnext) Wb_out[row * GF2_GMAX + wb0] = ((u64)val.y << 32) | val.x;
-		if (wb1 >= 0 && wb1 < gnext) Wb_out[row * GF2_GMAX + wb1] = ((u64)val.w << 32) | val.z;
-	};
+	// this lane's two words against the no-write range (only the tile that holds the next window is affected)
+	const bool nw0 = (int)(w0 + 2 * lr) >= nw_lo && (int)(w0 + 2 * lr) < nw_hi;
+	const bool nw1 = (int)(w0 + 2 * lr + 1) >= nw_lo && (int)(w0 + 2 * lr + 1) < nw_hi;
+	const bool nw_tile = (int)w0 < nw_hi && (int)(w0 + TW) > nw_lo;        // uniform per workgroup
 	auto compute_half = [&](auto tag, Half &H, i64 base) {
 		constexpr bool FAST = decltype(tag)::value;
 #pragma unroll
 		for (int u = 0; u < U; u++) {
-			if (!FAST && !H.on[u]) {
-				const i64 row = base + (i64)u * RPP + rr;
-				if (Wb_out && row < rend) put_window(row, H.d[u]);
-				continue;
-			}
+			if (!FAST && !H.on[u]) continue;
 			uint4 acc = H.d[u];
 			if (!FAST || H.on[u]) {
 #ifndef GF2_MB_NOLOOKUP        /* tools/microbench_update.hip: time the HBM stream without the table work */
@@ -907,22 +1078,26 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 			}
 #endif
 			}
-			Mw[H.qx[u]] = acc;
-			if (!FAST && Wb_out) put_window(base + (i64)u * RPP + rr, acc);
+			if (FAST || !(nw0 | nw1)) Mw[H.qx[u]] = acc;
+			else {                                      // the window's tile: 8-byte stores of the words that may be written
+				u64 *dst = reinterpret_cast<u64 *>(Mw + H.qx[u]);
+				if (!nw0) dst[0] = ((u64)acc.y << 32) | acc.x;
+				if (!nw1) dst[1] = ((u64)acc.w << 32) | acc.z;
+			}
 		}
 	};
 	constexpr i64 STEP = (i64)RPP * U;
 	Half A, B;
 	i64 base = rbeg;
 	load_half(SafeT(), A, base);
-	if (gb == G && !Wb_out)                             // bulk launches of full blocks: the branch-free pipeline
+	if (gb == G && !nw_tile)                            // full blocks, ordinary tiles: the branch-free pipeline
 		for (; base + 3 * STEP <= rend; base += 2 * STEP) {
 			load_half(FastT(), B, base + STEP);
 			compute_half(FastT(), A, base);
 			load_half(FastT(), A, base + 2 * STEP);
 			compute_half(FastT(), B, base + STEP);
 		}
-	for (; base < rend; base += 2 * STEP) {                 // the range's tail, priority launches, partial blocks
+	for (; base < rend; base += 2 * STEP) {                 // the range's tail, the window's tile, partial blocks
 		load_half(SafeT(), B, base + STEP);             // rows >= rend load nothing (on = false)
 		compute_half(SafeT(), A, base);
 		load_half(SafeT(), A, base + 2 * STEP);

@@ -163,17 +163,17 @@ Pool &pool()
 struct UpdateImpl {
 	int G, T, lds_bytes, threads;
 	hipError_t (*update)(dim3, hipStream_t, u64 *, i64, i64, int, int, int, const PanelRec *, const PanelAux *,
-	                     const u64 *, const int *, int, int, int, u64 *, int, SysStride);
+	                     const u64 *, const int *, int, int, int, int, int, SysStride);
 };
 
 template <int G, int T, int NT>
 hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows, int j0, int gb, int wlo,
                          const PanelRec *panels, const PanelAux *aux, const u64 *multset, const int *blk_first,
-                         int tile_begin, int ntiles, int nsplit, u64 *wb_out, int gnext, SysStride ss)
+                         int tile_begin, int ntiles, int nsplit, int nw_lo, int nw_hi, SysStride ss)
 {
 	// the tables are static shared memory (see k_update): no dynamic LDS, no attribute to raise
 	k_update<G, T, NT><<<grid, dim3(NT), 0, s>>>(M, rows, srows, j0, gb, wlo, panels, aux, multset, blk_first,
-	                                             tile_begin, ntiles, nsplit, wb_out, gnext, ss);
+	                                             tile_begin, ntiles, nsplit, nw_lo, nw_hi, ss);
 	return hipGetLastError();
 }
 
@@ -268,6 +268,7 @@ struct Solver {
 	int *pivcol = nullptr, *urow = nullptr, *blk_first = nullptr;
 	u64 *mult = nullptr;          // 2 sets x G x rows (ping-pong between consecutive blocks)
 	u64 *Wb = nullptr;            // 2 x rows x GMAX window words (the panel steps ping-pong between the halves)
+	u64 *Uwin = nullptr;          // rank x GMAX: pivot rows' words of the following window (k_prio_window -> k_unwind)
 	int units = 0;
 	u64 *Y = nullptr;
 	int *ycols = nullptr;
@@ -386,14 +387,14 @@ int solver_alloc(Solver &S)
 		             o_fu = carve(sizeof(FindUnit) * (S.units + 1)), o_alive = carve(sizeof(int) * (size_t)R),
 		             o_piv = carve(sizeof(int) * (S.maxr + 64)), o_urow = carve(sizeof(int) * (S.maxr + 64)),
 		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * 2 * G * R),
-		             o_wb = carve(sizeof(u64) * 2 * GF2_GMAX * R);
+		             o_wb = carve(sizeof(u64) * 2 * GF2_GMAX * R), o_uw = carve(sizeof(u64) * GF2_GMAX * (S.maxr + 64));
 		S.arena_stride = off;
 		HIPCHK(pool().alloc(&S.arena, off * S.nsys, S.device));
 		char *base = (char *)S.arena;
 		S.st = (SolveState *)(base + o_st); S.panels = (PanelRec *)(base + o_pan); S.aux = (PanelAux *)(base + o_aux);
 		S.fu = (FindUnit *)(base + o_fu); S.died = (int *)(base + o_alive); S.pivcol = (int *)(base + o_piv);
 		S.urow = (int *)(base + o_urow); S.blk_first = (int *)(base + o_blk); S.mult = (u64 *)(base + o_mult);
-		S.Wb = (u64 *)(base + o_wb);
+		S.Wb = (u64 *)(base + o_wb); S.Uwin = (u64 *)(base + o_uw);
 		// zero everything that is read before it is written: state, panel records, unit scratch, block bounds, multipliers
 		for (int s = 0; s < S.nsys; s++) {
 			char *b = base + (size_t)s * off;
@@ -425,17 +426,17 @@ int pick_nsplit(i64 rows, int ntiles)
 	return (int)std::max<i64>(1, std::min(want, cap));
 }
 
-int launch_trsm(Solver &S, hipStream_t st, int j0, int gb, int wlo, int tile_begin, int ntiles)
+int launch_trsm(Solver &S, hipStream_t st, int j0, int gb, int wlo, int tile_begin, int ntiles, int nw_lo, int nw_hi)
 {
 	constexpr int WPW = 4;
 	k_block_trsm<TW, WPW><<<dim3(ntiles * (TW / WPW), S.nsys), dim3(64 * WPW), 0, st>>>(S.M, S.srows, j0, gb, wlo, tile_begin,
-	                                                                                   S.panels, S.aux, S.ss());
+	                                                                                   S.panels, S.aux, nw_lo, nw_hi, S.ss());
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
 
 int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wlo, u64 *mset, int tile_begin, int ntiles,
-                        u64 *wb_out = nullptr, int gnext = 0)
+                        int nw_lo, int nw_hi)
 {
 	hipEvent_t ka = nullptr, kb = nullptr;
 	if (S.time_kernels) {
@@ -445,7 +446,7 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 	}
 	const int ns = pick_nsplit(S.rows, ntiles * S.nsys);      // the gang's workgroups share the chip
 	HIPCHK(S.impl->update(dim3((unsigned)(ntiles * ns), S.nsys), st, S.M, S.rows, S.srows, j0, gb, wlo, S.panels, S.aux, mset,
-	                      S.blk_first + b, tile_begin, ntiles, ns, wb_out, gnext, S.ss()));
+	                      S.blk_first + b, tile_begin, ntiles, ns, nw_lo, nw_hi, S.ss()));
 	if (S.time_kernels) HIPCHK(hipEventRecord(kb, st));
 	return GF2BV_OK;
 }
@@ -492,44 +493,34 @@ int enqueue_forward(Solver &S)
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(S.evA[b], S.sA));
 		if (S.dbg_sync & 1) HIPCHK(hipDeviceSynchronize());
-		// tiles with trailing words; the first `nprio` of them hold the next block's window
+		// trailing tiles; the next block's window [wlo, wlo + gnext) sits in the first one or two of them
 		const int tb = wlo / TW;
 		const int nt_all = (wlo < S.wt) ? tiles_total - tb : 0;
-		int nprio = 0, gnext = 0;
-		if (b + 1 < S.nblocks && nt_all > 0) {
-			gnext = std::min(G, S.npanels - wlo);
-			const int last_word = (int)std::min<i64>(wlo + gnext - 1, S.wt - 1);
-			nprio = std::min(nt_all, last_word / TW - tb + 1);
-		}
-		// ---- stream B: bulk of block b on the non-priority tiles ----
+		const int gnext = (b + 1 < S.nblocks) ? std::min(G, S.npanels - wlo) : 0;
+		// ---- stream B: TRSM + bulk update of block b on every trailing tile (never WRITING the next window) ----
 		HIPCHK(hipStreamWaitEvent(S.sB, S.evA[b], 0));
-		if (nt_all - nprio > 0) {
-			int rc = launch_trsm(S, S.sB, j0, gb, wlo, tb + nprio, nt_all - nprio);
+		if (nt_all > 0) {
+			int rc = launch_trsm(S, S.sB, j0, gb, wlo, tb, nt_all, wlo, wlo + gnext);
 			if (rc) return rc;
-			rc = launch_update_timed(S, S.sB, b, j0, gb, wlo, mset, tb + nprio, nt_all - nprio);
+			rc = launch_update_timed(S, S.sB, b, j0, gb, wlo, mset, tb, nt_all, wlo, wlo + gnext);
 			if (rc) return rc;
 		}
 		HIPCHK(hipEventRecord(S.evPrio[b], S.sB));          // "bulk of block b complete"
 		if (S.dbg_sync & 2) HIPCHK(hipDeviceSynchronize());
-		// ---- stream A: priority tiles of block b, then the next window ----
+		// ---- stream A: the next block's window (needs the bulk update of block b-1, nothing newer) ----
 		if (b + 1 < S.nblocks) {
 			if (b > 0) HIPCHK(hipStreamWaitEvent(S.sA, S.evPrio[b - 1], 0));
-			if (nprio > 0) {
-				int rc = launch_trsm(S, S.sA, j0, gb, wlo, tb, nprio);
-				if (rc) return rc;
-				// the priority update also writes block b+1's window into Wb (all rows >= blk_first: every
-				// alive row); rows it does not visit are dead
-				rc = launch_update_timed(S, S.sA, b, j0, gb, wlo, mset, tb, nprio, S.Wb, gnext);
-				if (rc) return rc;
-			} else {
-				k_win_gather<<<dim3((unsigned)((S.rows * gnext + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, wlo,
-				                                                                                             std::max(gnext, 1), S.Wb, S.ss());
-			}
+			k_prio_window<<<dim3(row_blocks, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, gb, wlo, std::max(gnext, 1),
+			                                                             S.panels, S.aux, mset, S.blk_first + b, S.Wb, S.Uwin,
+			                                                             S.impl->T, S.ss());
 		}
 	}
 	// join: the panel stream waits for the last bulk update, then checks consistency
 	HIPCHK(hipEventRecord(S.ev3, S.sB));
 	HIPCHK(hipStreamWaitEvent(S.sA, S.ev3, 0));
+	if (S.nblocks > 1 && S.maxr > 0)
+		k_unwind<<<dim3((unsigned)((S.maxr * GF2_GMAX + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(
+			S.M, S.srows, G, S.npanels, S.nblocks, S.st, S.pivcol, S.urow, S.Uwin, S.ss());
 	{
 		int g = (int)std::min<i64>(1024, (S.rows + 255) / 256);
 		k_check_rhs<<<dim3(g, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, S.cols, S.died, S.st, S.ss());
@@ -736,7 +727,7 @@ int make_view(const Solver &S, int s, Solver &V)
 	auto mv = [ao](auto *&p) { p = reinterpret_cast<decltype(+p)>(reinterpret_cast<char *>(p) + ao); };
 	V.M = S.M + S.m_stride * s;
 	V.arena = (char *)S.arena + ao;
-	mv(V.st); mv(V.panels); mv(V.aux); mv(V.fu); mv(V.died); mv(V.pivcol); mv(V.urow); mv(V.blk_first); mv(V.mult); mv(V.Wb);
+	mv(V.st); mv(V.panels); mv(V.aux); mv(V.fu); mv(V.died); mv(V.pivcol); mv(V.urow); mv(V.blk_first); mv(V.mult); mv(V.Wb); mv(V.Uwin);
 	V.Y = nullptr; V.ycols = nullptr; V.out = nullptr;
 	V.ev2 = nullptr;
 	HIPCHK(pool().event(&V.ev2, true));
