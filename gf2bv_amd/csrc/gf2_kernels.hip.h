@@ -3,7 +3,8 @@
 // Replaces the M4RI routines gf2bv reaches from gf2bv/_internal.c (reference file:line):
 //   mzd_write_bit loop           _internal.c:403-426   -> k_pack_digits
 //   _mzd_pluq                    _internal.c:431-433   -> blocked elimination:
-//        panel path  (stream A): k_win_gather, k_panel_step (pivot search + narrow step), k_win_scatter
+//        panel path  (stream A): k_win_gather, k_panel_step (pivot search + narrow step), k_prio_window
+//                                (the next block's window), k_win_scatter, k_unwind
 //        bulk path   (stream B): k_block_trsm, k_update
 //   _mzd_pluq_solve_left         _internal.c:438-447   -> k_check_rhs + k_extract_y +
 //                                                         k_gather_mult_u + k_sweep (on Y)
@@ -22,8 +23,9 @@
 //   * the bulk path then applies all G panels of the block to the rest of the matrix in ONE
 //     pass over HBM: row[tile] ^= XOR_{g<G} XOR_t table_{g,t}[bit-field t of mult_g[row]]
 //     with the G x T grease tables of the tile staged in LDS;
-//   * the tiles that hold the NEXT block's window are updated first, so the panel path of block
-//     b+1 runs concurrently with the bulk update of block b (look-ahead on a second stream).
+//   * the NEXT block's window is carried forward on the panel stream itself (k_prio_window), so the
+//     panel path of block b+1 runs concurrently with the bulk update of block b (look-ahead on a
+//     second stream); the bulk kernels never write that window's words.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

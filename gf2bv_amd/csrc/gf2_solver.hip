@@ -71,6 +71,12 @@ struct Pool {
 	std::map<std::pair<int, int>, std::vector<hipEvent_t>> events;   // (device, timing?) -> events
 	std::map<std::pair<int, int>, std::vector<hipStream_t>> streams;  // (device, low priority?) -> streams
 	static constexpr size_t kMaxBucket = (size_t)64 << 20, kMaxCached = (size_t)512 << 20;
+	// One LARGE buffer per device (the working matrix of the last big solve) is kept as well: hipMalloc +
+	// hipFree of 2-8 GiB cost 10-100 ms per call, a visible part of a 0.3-2 s solve.  GF2BV_KEEP_BIG=0 disables.
+	struct Big { void *p = nullptr; size_t bytes = 0; };
+	std::map<int, Big> big_free;                                      // device -> idle large buffer
+	std::unordered_map<void *, std::pair<int, size_t>> big_live;      // handed-out large buffers
+	static bool keep_big() { static const bool k = !(getenv("GF2BV_KEEP_BIG") && atoi(getenv("GF2BV_KEEP_BIG")) == 0); return k; }
 
 	static size_t bucket(size_t bytes)
 	{
@@ -81,7 +87,23 @@ struct Pool {
 	hipError_t alloc(void **out, size_t bytes, int device)
 	{
 		bytes = std::max<size_t>(bytes, 16);
-		if (bytes > kMaxBucket) return hipMalloc(out, bytes);
+		if (bytes > kMaxBucket) {
+			void *stale = nullptr;
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				Big &b = big_free[device];
+				if (b.p && b.bytes >= bytes && b.bytes <= bytes + bytes / 2) {
+					*out = b.p; big_live[b.p] = {device, b.bytes};
+					b = Big();
+					return hipSuccess;
+				}
+				if (b.p) { stale = b.p; b = Big(); }              // wrong size: make room before allocating
+			}
+			if (stale) (void)hipFree(stale);
+			hipError_t e = hipMalloc(out, bytes);
+			if (e == hipSuccess && keep_big()) { std::lock_guard<std::mutex> lk(mu); big_live[*out] = {device, bytes}; }
+			return e;
+		}
 		const size_t b = bucket(bytes);
 		{
 			std::lock_guard<std::mutex> lk(mu);
@@ -101,6 +123,15 @@ struct Pool {
 		if (!p) return;
 		{
 			std::lock_guard<std::mutex> lk(mu);
+			auto bl = big_live.find(p);
+			if (bl != big_live.end()) {
+				const int device = bl->second.first;
+				const size_t bytes = bl->second.second;
+				big_live.erase(bl);
+				Big &b = big_free[device];
+				if (!b.p) { b.p = p; b.bytes = bytes; return; }
+				if (b.bytes < bytes) std::swap(b.p, p), b.bytes = bytes;     // keep the larger one, free the other
+			}
 			auto it = live.find(p);
 			if (it != live.end()) {
 				const auto key = it->second;
