@@ -483,12 +483,13 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 }
 
 // Forward elimination: all blocks, no host synchronisation.
-//   stream A (panel path): factorise block b on its compact window; then the "priority" part of
-//     block b's bulk work -- only the 1-2 column tiles that hold block b+1's window -- and gather
-//     that window.  Needs the bulk update of block b-1 (stream B) to be complete, nothing newer.
-//   stream B (bulk path): block b's TRSM + update on all remaining tiles, as soon as block b is
-//     factorised.  So A runs a whole block ahead of B and the two overlap: per-block time is
-//     max(panel path, bulk path), and B never idles when it is the longer one.
+//   stream A (panel path): factorise block b on its compact window (G+1 panel steps); then carry
+//     block b+1's window forward (k_prio_window: block b's update on those <= 4 words of every row,
+//     matrix -> Wb).  Needs the bulk update of block b-1 (stream B) to be complete, nothing newer.
+//   stream B (bulk path): block b's TRSM + update on all trailing tiles, as soon as block b is
+//     factorised, never writing the next window's words.  So A runs a whole block ahead of B and
+//     the two overlap: per-block time is max(panel path, bulk path), and B never idles when it is
+//     the longer one.
 int enqueue_forward(Solver &S)
 {
 	const int G = S.impl->G;
