@@ -294,22 +294,38 @@ struct FindState {
 // other candidate AND from every existing basis vector (so the basis stays fully reduced:
 // afterwards a row's multiplier is simply `word & pivot_mask`).  The row of each new source
 // is stored to srow_out[slot].  Returns the lanes whose candidate became a source row.
-__device__ __forceinline__ u64 find_absorb(FindState &S, u64 w, int row, u64 colmask, int lane, int *srow_out)
+// OR of a 64-bit value over the wavefront (butterfly; every lane gets the result).
+__device__ __forceinline__ u64 wave_or(u64 v)
+{
+#pragma unroll
+	for (int d = 1; d < 64; d <<= 1) v |= (u64)__shfl_xor((long long)v, d, 64);
+	return v;
+}
+
+__device__ __forceinline__ u64 find_absorb(FindState &S, u64 w, int row, u64 colmask, int lane, int *srow_out,
+                                           int sparse_mode)
 {
 	u64 c = 0, took = 0;
-	u64 hv = S.have;
+	// Only columns some candidate actually has can matter -- in sparse systems (MT19937: a handful of bits
+	// per row and panel) that is a fraction of the 64, and both loops below are serial over columns.
+	// The basis is fully reduced, so reducing by one vector never creates bits at other pivot columns.
+	// The two wave-wide ORs cost ~2 % on dense chunks, so they are taken only when fewer than a quarter of
+	// the candidates carry more than 12 bits (uniform decision; sparse_mode 0 / 1 force it off / on).
+	const bool sparse = sparse_mode == 1 || (sparse_mode == 2 && __popcll(__ballot(__popcll(w) > 12)) < 16);
+	u64 hv = S.have & (sparse ? wave_or(w) : ~0ull);
 	while (hv) {
 		int b = uniform(ctz64(hv)); hv &= hv - 1;
 		u64 v = readlane64(S.bw, b), vc = readlane64(S.bc, b);
 		if ((w >> b) & 1) { w ^= v; c ^= vc; }
 	}
-	u64 todo = colmask & ~S.have;
+	u64 todo = colmask & ~S.have & (sparse ? wave_or(w) : ~0ull);
 	while (todo) {
 		int b = uniform(ctz64(todo)); todo &= todo - 1;
 		u64 m = __ballot((w >> b) & 1);
 		if (!m) continue;
 		int L = uniform(ctz64(m));
 		u64 v = readlane64(w, L);
+		todo |= v & colmask & ~S.have & ~((2ull << b) - 1);     // columns the new pivot row spreads to (all right of b)
 		u64 vc = readlane64(c, L) | (1ull << S.nslots);
 		if (lane == L) GF2_ST(srow_out + S.nslots, row);
 		if ((w >> b) & 1) { w ^= v; c ^= vc; }             // lane L itself becomes 0
@@ -371,7 +387,8 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
              const u64 *__restrict__ Wb_in, u64 *__restrict__ Wb_out, SolveState *__restrict__ st,
              int *__restrict__ died, FindUnit *__restrict__ fu, int units, int find_wgs,
              PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol,
-             int *__restrict__ urow, u64 *__restrict__ multset, int *__restrict__ blk_first_out, int upd_T, SysStride ss)
+             int *__restrict__ urow, u64 *__restrict__ multset, int *__restrict__ blk_first_out, int upd_T,
+             int sparse_mode, SysStride ss)
 {
 	__builtin_amdgcn_s_setprio(3);          // panel path = critical path: win issue arbitration against bulk-update waves
 	{
@@ -383,6 +400,7 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 		if (blk_first_out) blk_first_out = sys_at(blk_first_out, ao);
 	}
 	__shared__ StepLds L;
+	__shared__ int pend_rows[4][128];                   // publisher's staging of source-row lists (one per wavefront)
 	const int t = threadIdx.x;
 	const int lane = t & 63;
 	const bool finder = (int)blockIdx.x < find_wgs;
@@ -515,7 +533,7 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 			d_n = died[i_c];
 			wf_n = Wb_in[i_c * GF2_GMAX + gfc];
 			wp_n = Wb_in[i_c * GF2_GMAX + gpc];
-			const u64 took = find_absorb(S, w, (int)ii, colmask, lane, me->srow);
+			const u64 took = find_absorb(S, w, (int)ii, colmask, lane, me->srow, sparse_mode);
 			chunks++;
 			if (first_nonsrc < 0) {
 				u64 mk = __ballot(ok) & ~took;
@@ -564,14 +582,28 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 		// dead by now, but other lists are still being read -> use the list of unit `units` (spare))
 		S.bw = 0; S.bc = 0; S.have = 0; S.nslots = 0;
 		FindUnit *spare = fu + units;
+		// the units' lists are short in sparse systems (a few rows each): they are packed into full 64-row
+		// chunks before being absorbed, so the merge costs sum(cnt)/64 absorb steps, not one per unit
+		int *pend = pend_rows[t >> 6];
+		int fill = 0;
+		auto absorb_rows = [&](int i) {
+			u64 w = 0;
+			if (i >= 0) w = cw.apply(Wb_in[(i64)i * GF2_GMAX + cw.gf], Wb_in[(i64)i * GF2_GMAX + cw.gp]) & colmask;
+			find_absorb(S, w, i, colmask, lane, spare->srow, sparse_mode);
+		};
 		for (int v = 0; v < active && S.nslots < full; v++) {
 			const int cnt = GF2_LD(&fu[v].cnt);
 			if (cnt == 0) continue;
-			const int i = (lane < cnt) ? GF2_LD(&fu[v].srow[lane]) : -1;
-			u64 w = 0;
-			if (i >= 0) w = cw.apply(Wb_in[(i64)i * GF2_GMAX + cw.gf], Wb_in[(i64)i * GF2_GMAX + cw.gp]) & colmask;
-			find_absorb(S, w, i, colmask, lane, spare->srow);
+			if (lane < cnt) pend[fill + lane] = GF2_LD(&fu[v].srow[lane]);
+			fill += cnt;
+			if (fill >= 64) {
+				absorb_rows(pend[lane]);
+				fill -= 64;
+				const int carry = (lane < fill) ? pend[64 + lane] : -1;
+				if (lane < fill) pend[lane] = carry;
+			}
 		}
+		if (fill > 0 && S.nslots < full) absorb_rows(lane < fill ? pend[lane] : -1);
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		srow = GF2_LD(&spare->srow[lane]);
 		new_first = first;

@@ -301,6 +301,7 @@ struct Solver {
 	u64 *Wb = nullptr;            // 2 x rows x GMAX window words (the panel steps ping-pong between the halves)
 	u64 *Uwin = nullptr;          // rank x GMAX: pivot rows' words of the following window (k_prio_window -> k_unwind)
 	int units = 0;
+	int sparse_mode = 2;          // search skips absent columns: 0 never, 1 always, 2 per chunk by density (GF2BV_SPARSE)
 	u64 *Y = nullptr;
 	int *ycols = nullptr;
 	u64 *out = nullptr;
@@ -403,6 +404,7 @@ int solver_alloc(Solver &S)
 	S.units = (int)std::min<i64>(256, std::max<i64>(1, (S.rows + 255) / 256));
 	if (const char *e = getenv("GF2BV_UNITS")) { int v = atoi(e); if (v >= 1 && v <= 256) S.units = std::min(S.units, v); }
 	if (const char *e = getenv("GF2BV_DEBUG_SYNC")) S.dbg_sync = atoi(e);
+	if (const char *e = getenv("GF2BV_SPARSE")) { int v = atoi(e); if (v >= 0 && v <= 2) S.sparse_mode = v; }
 	if (getenv("GF2BV_SERIAL")) { S.sB = S.sA; S.own_sB = false; }     // ablation: no look-ahead overlap
 	else {
 		// the bulk path yields to the (latency-critical) panel path wherever both have work queued: lowest priority
@@ -518,7 +520,7 @@ int enqueue_forward(Solver &S)
 			k_panel_step<<<dim3(wgs, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, gp, gf, gb, colmask,
 			                                                       half[s ? (s - 1) & 1 : 0], half[s & 1], S.st, S.died, S.fu, S.units, find_wgs,
 			                                                       S.panels, S.aux, S.pivcol, S.urow, mset,
-			                                                       gf == gb - 1 ? S.blk_first + b : nullptr, S.impl->T, S.ss());
+			                                                       gf == gb - 1 ? S.blk_first + b : nullptr, S.impl->T, S.sparse_mode, S.ss());
 		}
 		if (b == S.nblocks - 1)
 			k_win_scatter<<<dim3((unsigned)((S.rows * gb + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, gb, half[gb & 1], S.died, S.ss());
