@@ -436,6 +436,8 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	// Hard panels (sparse / rank deficient: a unit had to scan far) switch the NEXT panel to all units.
 	// Either way the active units' slices cover every alive row.
 	const int active = wide ? units : (units < GF2_FEW_UNITS ? units : GF2_FEW_UNITS);
+	// search workgroups without an active unit leave at once: only the active units take part in the arrival count
+	if (finder && (int)blockIdx.x * 4 >= active) return;
 	i64 lo = rows, hi = rows;
 	if (finder && u < active) {
 		const i64 n = rows - first;
@@ -513,7 +515,7 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	}
 
 	// ---- search panel gf ----
-	if (u >= units) return;
+	if (u >= active) return;
 	CandWords cw;
 	cw.Wb = Wb_in; cw.Pcol = &L.Pb[gfc][0]; cw.maskp = recp.mask; cw.gf = gfc; cw.gp = gpc;
 	const int full = __popcll(colmask);
@@ -548,7 +550,7 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	unsigned old = 0;
 	if (lane == 0) old = __hip_atomic_fetch_add(&st->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-	if (old != (unsigned)(units - 1)) return;
+	if (old != (unsigned)(active - 1)) return;
 
 	// ---- last arriver: publish ----
 	// unit 0 scans the lowest rows: adopting it keeps the alive lower bound exact for free.  Its record is
