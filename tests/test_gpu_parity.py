@@ -247,6 +247,23 @@ def test_batched_list_of_int_boundary(monkeypatch):
             assert (sp.dimension, sp.origin, sp.basis) == (ref.dimension, ref.origin, ref.basis)
 
 
+def test_randomised_shapes_and_configs(monkeypatch):
+    """A seeded sweep over shapes, densities, rank caps, zero rows, modes and k_update configurations
+    (tools/stress_parity.py runs the open-ended version of this on the GPU box)."""
+    rng = random.Random(20260928)
+    for it in range(40):
+        cols = rng.choice([rng.randint(1, 130), rng.randint(131, 600), 64 * rng.randint(1, 9), 256 * rng.randint(1, 3) + rng.choice([-1, 0, 1])])
+        rows = cols + rng.choice([0, 1, rng.randint(0, 64), rng.randint(0, cols), rng.randint(0, 2 * cols)])
+        density = rng.choice([0.5, 0.5, 0.1, 0.02])
+        cap = rng.choice([None, None, rng.randint(1, cols), max(1, cols - rng.randint(0, 5))])
+        mode = rng.randint(0, 1)
+        monkeypatch.setenv("GF2BV_UPDATE", rng.choice(["4x12", "4x16", "3x12", "2x12", "1x12", "1x8"]))
+        eqs = random_system(rng, rows, cols, density, cap, rng.random() < 0.8, min(rng.choice([0, 0, rows // 3]), rows - 1))
+        rng.shuffle(eqs)
+        aug = O.eqs_to_aug(eqs, cols)
+        assert_same(hip.solve_words(aug, rows, cols, mode), O.solve_words(aug, rows, cols, mode), mode)
+
+
 def test_back_substitution_paths_agree(monkeypatch):
     """solve_one's blocked parity back-substitution vs the general multi-RHS sweep path (solve_all's)."""
     rng = random.Random(31)
