@@ -14,8 +14,11 @@
  * Solution vectors: ceil(cols/64) words, bit j = variable j (_internal.c:32-39).
  *
  * Threading: every call owns its device buffers and stream; no global mutable state except
- * the last-error string, which is thread-local.  Matches the reference releasing the GIL
- * around the whole factor/solve/kernel section (_internal.c:429-492).
+ * the last-error string, which is thread-local, and a thread-safe pool that recycles idle
+ * device buffers, streams and events between calls (small buffers up to 512 MiB in total,
+ * plus the working matrix of the last large solve per device; GF2BV_KEEP_BIG=0 in the
+ * environment turns the latter off).  Matches the reference releasing the GIL around the
+ * whole factor/solve/kernel section (_internal.c:429-492).
  */
 #ifndef GF2BV_HIP_H
 #define GF2BV_HIP_H
