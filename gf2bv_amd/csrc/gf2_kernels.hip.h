@@ -196,11 +196,13 @@ __device__ __forceinline__ P *sys_at(P *p, i64 bytes)
 __global__ void k_pack_digits(const uint32_t *__restrict__ digits, const i64 *__restrict__ off,
                               int bpd, i64 rows, i64 cols, i64 wtot, i64 srows, u64 *__restrict__ M, SysStride ss)
 {
-	off += blockIdx.y * rows;               // gang: system y's rows follow system y-1's in the offset table
-	M += blockIdx.y * ss.m_words;
-	i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	i64 r = g / wtot, w = g % wtot;
-	if (r >= rows) return;
+	// grid: x = words of a row, y = rows (strided: a launch dimension holds at most 2^32 - 1 work-items and
+	// 65535 workgroups in y), z = system of a gang (its rows follow the previous system's in the offset table)
+	off += blockIdx.z * rows;
+	M += blockIdx.z * ss.m_words;
+	const i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= wtot) return;
+	for (i64 r = blockIdx.y; r < rows; r += gridDim.y) {
 	const uint32_t *d = digits + off[r];
 	i64 nd = off[r + 1] - off[r];
 	u64 val = 0;
@@ -221,6 +223,7 @@ __global__ void k_pack_digits(const uint32_t *__restrict__ digits, const i64 *__
 	}
 	if (w == (cols >> 6) && nd > 0) val |= (u64)(d[0] & 1u) << (cols & 63);
 	M[tidx(r, w, srows)] = val;
+	}
 }
 
 // Row-major augmented words (the C ABI layout) -> tile-major working layout, 16 bytes per lane.
@@ -228,13 +231,14 @@ __global__ void __launch_bounds__(256)
 k_to_tiled(const u64 *__restrict__ src, i64 stride, i64 rows, i64 ntiles, i64 wt, i64 srows, u64 *__restrict__ dst,
            i64 src_sys_words, SysStride ss)
 {
-	src += blockIdx.y * src_sys_words;
-	dst += blockIdx.y * ss.m_words;
-	const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;       // (tile, row, lr)
+	// grid: x = (row, lane) pairs, y = tile, z = system of a gang (one launch dimension holds < 2^32 work-items)
+	src += blockIdx.z * src_sys_words;
+	dst += blockIdx.z * ss.m_words;
+	const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
 	const int lr = (int)(t % GF2_LPR);
-	const i64 row = (t / GF2_LPR) % rows;
-	const i64 tile = (t / GF2_LPR) / rows;
-	if (tile >= ntiles) return;
+	const i64 row = t / GF2_LPR;
+	const i64 tile = blockIdx.y;
+	if (row >= rows || tile >= ntiles) return;
 	const i64 w = tile * GF2_TW + 2 * lr;
 	u64 a = (w < wt) ? src[row * stride + w] : 0ull;
 	u64 b = (w + 1 < wt) ? src[row * stride + w + 1] : 0ull;

@@ -395,8 +395,8 @@ int solver_alloc(Solver &S)
 	S.m_stride = S.ntiles * TW * S.srows;
 	if (!S.M) HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * S.m_stride * S.nsys, S.device));
 	if (S.src && S.rows > 0) {
-		const i64 threads = S.ntiles * S.rows * 8;
-		k_to_tiled<<<dim3((unsigned)((threads + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(
+		const i64 threads = S.rows * GF2_LPR;
+		k_to_tiled<<<dim3((unsigned)((threads + 255) / 256), (unsigned)S.ntiles, S.nsys), dim3(256), 0, S.sA>>>(
 			S.src, S.stride, S.rows, S.ntiles, std::min(S.wt, S.stride), S.srows, S.M, S.src_sys_words, S.ss());
 	}
 	const int G = S.impl->G;
@@ -580,6 +580,7 @@ int enqueue_backward(Solver &S, const std::vector<int> &ycols_host)
 	const int rpb = 2048;
 	if (S.maxr > 0) {
 		i64 waves = S.maxr * nyw;
+		if (waves >= (1ll << 26)) return fail(GF2BV_ERR_ARG, "kernel basis too large: rank x free columns exceeds one launch (2^32 work-items)");
 		k_extract_y<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, S.sA>>>(S.M, S.srows, S.st, S.urow, S.pivcol,
 		                                                                      S.ycols, S.ny, S.Y, S.ys);
 		const int ytiles = (int)(S.ys / YTW);
@@ -999,7 +1000,7 @@ int gf2bv_solve_batch_digits(const uint32_t *digits, const int64_t *digit_off, i
 		HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * m_stride * S.nsys, device));
 		const i64 total = rows * ntiles * TW;
 		if (total > 0)
-			k_pack_digits<<<dim3((unsigned)((total + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(
+			k_pack_digits<<<dim3((unsigned)((ntiles * TW + 255) / 256), (unsigned)std::min<i64>(rows, 65535), S.nsys), dim3(256), 0, S.sA>>>(
 				G.dig, G.off + s0 * rows, bits_per_digit, (i64)rows, (i64)cols, ntiles * TW, srows, S.M, SysStride{m_stride, 0});
 		HIPCHK(hipGetLastError());
 		rc = solve_gang(S, &out[s0]);
@@ -1041,7 +1042,7 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 	{
 		i64 total = rows * ntiles * TW;
 		if (total > 0)
-			k_pack_digits<<<dim3((unsigned)((total + 255) / 256)), dim3(256), 0, S.sA>>>(d_dig, d_off, bits_per_digit, (i64)rows,
+			k_pack_digits<<<dim3((unsigned)((ntiles * TW + 255) / 256), (unsigned)std::min<i64>(rows, 65535)), dim3(256), 0, S.sA>>>(d_dig, d_off, bits_per_digit, (i64)rows,
 			                                                                            (i64)cols, ntiles * TW, slab_rows(rows), S.M,
 			                                                                            SysStride{0, 0});
 	}
