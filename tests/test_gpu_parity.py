@@ -264,6 +264,18 @@ def test_randomised_shapes_and_configs(monkeypatch):
         assert_same(hip.solve_words(aug, rows, cols, mode), O.solve_words(aug, rows, cols, mode), mode)
 
 
+def test_batch_words_host_entry():
+    """hip.solve_batch_words: host-resident packed systems, odd stride (padded internally), both modes."""
+    rng = random.Random(5)
+    rows, cols = 400, 321                                   # 6 words per row: even; 321 + 1 bits -> stride 6
+    systems = [random_system(rng, rows, cols, .5, cap) for cap in (None, 200, 1)]
+    for stride in (6, 7):
+        augs = np.stack([O.eqs_to_aug(e, cols, stride) for e in systems])
+        for mode in (0, 1):
+            for sol, eqs in zip(hip.solve_batch_words(augs, rows, cols, mode), systems):
+                assert_same(sol, O.solve_words(O.eqs_to_aug(eqs, cols), rows, cols, mode), mode)
+
+
 def test_back_substitution_paths_agree(monkeypatch):
     """solve_one's blocked parity back-substitution vs the general multi-RHS sweep path (solve_all's)."""
     rng = random.Random(31)
