@@ -662,6 +662,24 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	}
 }
 
+// XOR of the LDS words base[idx(b)] over the set bits b of `bits`, four at a time: the four reads are
+// independent and in flight together (a one-bit-per-iteration loop pays the full LDS latency per bit,
+// and the kernels that use this are nothing but latency).
+template <class IDX>
+__device__ __forceinline__ u64 xor_over_bits(const u64 *base, u64 bits, IDX idx)
+{
+	u64 acc = 0;
+	while (bits) {
+		const int b0 = ctz64(bits); bits &= bits - 1;
+		const u64 h1 = bits ? ~0ull : 0ull; const int b1 = bits ? ctz64(bits) : b0; bits &= bits - 1;
+		const u64 h2 = bits ? ~0ull : 0ull; const int b2 = bits ? ctz64(bits) : b0; bits &= bits - 1;
+		const u64 h3 = bits ? ~0ull : 0ull; const int b3 = bits ? ctz64(bits) : b0; bits &= bits - 1;
+		const u64 v0 = base[idx(b0)], v1 = base[idx(b1)], v2 = base[idx(b2)], v3 = base[idx(b3)];
+		acc ^= v0 ^ (v1 & h1) ^ (v2 & h2) ^ (v3 & h3);
+	}
+	return acc;
+}
+
 // The next block's window, on the panel stream: every row >= blk_first gets block b's update applied to
 // its words [wlo, wlo + gnext) -- read from the matrix (complete through block b-1), written to the
 // compact buffer Wb only -- so the next block's panel steps can start while the bulk update of block b
@@ -731,12 +749,7 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 		for (int g = 0; g < GF2_GMAX; g++) {
 			if (g >= gb) break;
 			if (r < rec[g].p) {
-				// fixed trip count, predicated: the LDS reads are independent and pipeline (a while (bits)
-				// loop pays the full LDS latency per set bit, and this step is nothing but latency)
-				const u64 c = comb[g];
-				u64 acc = 0;
-#pragma unroll 8
-				for (int sl = 0; sl < 64; sl++) acc ^= ((c >> sl) & 1) ? S[(g * 64 + sl) * W + w] : 0ull;
+				const u64 acc = xor_over_bits(S, comb[g], [&](int sl) { return (g * 64 + sl) * W + w; });
 				P[(g * 64 + r) * W + w] = acc;
 				if (blockIdx.x == 0 && live) Uwin[(i64)(rec[g].start + r) * GF2_GMAX + w] = acc;
 			}
@@ -752,11 +765,7 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 #pragma unroll
 			for (int h = g + 1; h < GF2_GMAX; h++) {
 				if ((hneed >> h) & 1) {
-					const u64 m = smul[h][g];
-					u64 acc = 0;
-#pragma unroll 8
-					for (int b = 0; b < 64; b++) acc ^= ((m >> b) & 1) ? Pbit[(g * 64 + b) * W + w] : 0ull;
-					S[(h * 64 + r) * W + w] ^= acc;
+					S[(h * 64 + r) * W + w] ^= xor_over_bits(Pbit, smul[h][g], [&](int b) { return (g * 64 + b) * W + w; });
 				}
 			}
 			__syncthreads();
@@ -860,8 +869,7 @@ k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int tile_b
 	for (int g = 0; g < GF2_GMAX; g++) {
 		if (g >= gb) break;
 		if (r < rec[g].p) {
-			u64 c = comb[g], acc = 0;
-			while (c) { int sl = ctz64(c); c &= c - 1; acc ^= S[(g * 64 + sl) * WPW + w]; }
+			const u64 acc = xor_over_bits(S, comb[g], [&](int sl) { return (g * 64 + sl) * WPW + w; });
 			P[(g * 64 + r) * WPW + w] = acc;
 			if (live) Mt[(i64)srow[g] * TW + w] = acc;
 		}
@@ -869,13 +877,9 @@ k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int tile_b
 #pragma unroll
 		for (int h = g + 1; h < GF2_GMAX; h++) {
 			if (h < gb && r < rec[h].p) {
-				u64 m = smul[h][g], acc = 0;
-				while (m) {
-					const int b = ctz64(m); m &= m - 1;
-					const int k = __popcll(rec[g].mask & ((1ull << b) - 1));
-					acc ^= P[(g * 64 + k) * WPW + w];
-				}
-				S[(h * 64 + r) * WPW + w] ^= acc;
+				const u64 mk = rec[g].mask;
+				S[(h * 64 + r) * WPW + w] ^= xor_over_bits(P, smul[h][g], [&](int b) {
+					return (g * 64 + __popcll(mk & ((1ull << b) - 1))) * WPW + w; });
 			}
 		}
 		__syncthreads();
