@@ -1178,10 +1178,15 @@ k_check_rhs(const u64 *__restrict__ M, i64 rows, i64 srows, i64 cols,
 //              block (pre-loaded into registers, X of the group in LDS) and publishes X.
 // U is read exactly once overall.
 #define GF2_BSG 16
+#define GF2_BSV 8            // right-hand sides one parity back-substitution handles together (U is read once for all)
 
+// Right-hand side t of the back-substitution is column ycols[t] of U (the RHS column `cols`, or a free
+// column when a kernel basis is wanted); X holds ny solution vectors of cw words, accv ny x nacc bytes.
+// A pivot row's words left of its own panel are dead storage and read as 0.
 __global__ void __launch_bounds__(256)
-k_bs_far(const u64 *__restrict__ M, i64 srows, i64 cols, int qa, int qb, const PanelRec *__restrict__ panels,
-         const int *__restrict__ urow, const u64 *__restrict__ X, unsigned char *__restrict__ accv)
+k_bs_far(const u64 *__restrict__ M, i64 srows, i64 cw, int qa, int qb, const PanelRec *__restrict__ panels,
+         const int *__restrict__ urow, const int *__restrict__ pivcol, const int *__restrict__ ycols, int ny,
+         const u64 *__restrict__ X, unsigned char *__restrict__ accv, i64 nacc)
 {
 	const int lane = threadIdx.x & 63;
 	const i64 wv = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -1190,31 +1195,41 @@ k_bs_far(const u64 *__restrict__ M, i64 srows, i64 cols, int qa, int qb, const P
 	const i64 k = kbeg + wv;
 	if (k >= kend) return;
 	const i64 row = urow[k];
-	const i64 cw = (cols + 63) >> 6;
-	u64 par = 0;
-	for (i64 w = qb + lane; w < cw; w += 64) par ^= M[tidx(row, w, srows)] & X[w];
-	int bit = __popcll(par) & 1;
-	bit = __popcll(__ballot(bit)) & 1;
-	const int y = (int)((M[tidx(row, cols >> 6, srows)] >> (cols & 63)) & 1);
-	if (lane == 0) accv[k] = (unsigned char)(bit ^ y);
+	u64 par[GF2_BSV];
+#pragma unroll
+	for (int v = 0; v < GF2_BSV; v++) par[v] = 0;
+	for (i64 w = qb + lane; w < cw; w += 64) {
+		const u64 m = M[tidx(row, w, srows)];
+#pragma unroll
+		for (int v = 0; v < GF2_BSV; v++)
+			if (v < ny) par[v] ^= m & X[(i64)v * cw + w];
+	}
+	const int pw = pivcol[k] >> 6;
+#pragma unroll
+	for (int v = 0; v < GF2_BSV; v++) {
+		if (v >= ny) break;
+		int bit = __popcll(par[v]) & 1;
+		bit = __popcll(__ballot(bit)) & 1;
+		const int c = ycols[v];
+		const int y = ((c >> 6) >= pw) ? (int)((M[tidx(row, c >> 6, srows)] >> (c & 63)) & 1) : 0;
+		if (lane == 0) accv[(i64)v * nacc + k] = (unsigned char)(bit ^ y);
+	}
 }
 
 __global__ void __launch_bounds__(1024)
-k_bs_near(const u64 *__restrict__ M, i64 srows, int qa, int qb, const PanelRec *__restrict__ panels,
-          const int *__restrict__ urow, const int *__restrict__ pivcol, u64 *__restrict__ X,
-          const unsigned char *__restrict__ accv)
+k_bs_near(const u64 *__restrict__ M, i64 srows, i64 cw, int qa, int qb, const PanelRec *__restrict__ panels,
+          const int *__restrict__ urow, const int *__restrict__ pivcol, int ny, u64 *__restrict__ X,
+          const unsigned char *__restrict__ accv, i64 nacc)
 {
 	__shared__ u64 Xn[GF2_BSG];
 	const int t = threadIdx.x;
 	const int r = t >> 4, idx = t & 15;           // pivot r of a panel, word q+1+idx of its row
 	const int nb = qb - qa;
-	if (t < GF2_BSG) Xn[t] = 0;
 	u64 uw[GF2_BSG];
 	int kk[GF2_BSG];
-	unsigned char ac[GF2_BSG];
 #pragma unroll
 	for (int i = 0; i < GF2_BSG; i++) {
-		uw[i] = 0; kk[i] = -1; ac[i] = 0;
+		uw[i] = 0; kk[i] = -1;
 		if (i < nb) {
 			const PanelRec rec = panels[qa + i];
 			if (r < rec.p) {
@@ -1222,24 +1237,31 @@ k_bs_near(const u64 *__restrict__ M, i64 srows, int qa, int qb, const PanelRec *
 				kk[i] = k;
 				const int w = qa + i + 1 + idx;
 				if (w < qb) uw[i] = M[tidx(urow[k], w, srows)];
-				ac[i] = accv[k];
 			}
 		}
 	}
-	__syncthreads();
+	for (int v = 0; v < ny; v++) {                   // the diagonal block sits in registers for every right-hand side
+		if (t < GF2_BSG) Xn[t] = 0;
+		unsigned ac = 0;                             // bit i: parity so far of pivot (panel i, r)
 #pragma unroll
-	for (int i = GF2_BSG - 1; i >= 0; i--) {
-		if (i >= nb) continue;                       // uniform
-		const int xi = i + 1 + idx;
-		const u64 xv = (xi < nb) ? Xn[xi] : 0ull;
-		const int bit = __popcll(uw[i] & xv) & 1;
-		const u64 bal = __ballot(bit);
-		const int rowpar = __popcll((bal >> ((threadIdx.x & 48))) & 0xFFFFull) & 1;   // my row's 16 lanes
-		if (idx == 0 && kk[i] >= 0 && ((rowpar ^ ac[i]) & 1))
-			atomicOr(&Xn[i], 1ull << (pivcol[kk[i]] & 63));
+		for (int i = 0; i < GF2_BSG; i++)
+			if (kk[i] >= 0) ac |= (unsigned)(accv[(i64)v * nacc + kk[i]] & 1) << i;
+		__syncthreads();
+#pragma unroll
+		for (int i = GF2_BSG - 1; i >= 0; i--) {
+			if (i >= nb) continue;                       // uniform
+			const int xi = i + 1 + idx;
+			const u64 xv = (xi < nb) ? Xn[xi] : 0ull;
+			const int bit = __popcll(uw[i] & xv) & 1;
+			const u64 bal = __ballot(bit);
+			const int rowpar = __popcll((bal >> ((threadIdx.x & 48))) & 0xFFFFull) & 1;   // my row's 16 lanes
+			if (idx == 0 && kk[i] >= 0 && ((rowpar ^ (ac >> i)) & 1))
+				atomicOr(&Xn[i], 1ull << (pivcol[kk[i]] & 63));
+			__syncthreads();
+		}
+		if (t < nb) X[(i64)v * cw + qa + t] = Xn[t];
 		__syncthreads();
 	}
-	if (t < nb) X[qa + t] = Xn[t];
 }
 
 // Y[k][t] = U[k][ycols[t]] for pivot k < rank: the right-hand sides of the back-substitution

@@ -600,22 +600,34 @@ int enqueue_backward(Solver &S, const std::vector<int> &ycols_host)
 	return GF2BV_OK;
 }
 
-// solve_one: blocked parity back-substitution straight into the solution words (no Y matrix)
-int enqueue_backward_single(Solver &S)
+// Blocked parity back-substitution straight into the solution words (no Y matrix), for up to GF2_BSV
+// right-hand sides at once: solve_one (the RHS column) and small kernel bases (the free columns + RHS).
+// U is streamed once for all of them.
+int enqueue_backward_parity(Solver &S, const std::vector<int> &ycols_host)
 {
-	S.ny = 1;
-	HIPCHK(pool().alloc((void **)&S.out, sizeof(u64) * std::max<i64>(1, S.cw), S.device));
-	HIPCHK(hipMemsetAsync(S.out, 0, sizeof(u64) * std::max<i64>(1, S.cw), S.sA));
-	unsigned char *accv = reinterpret_cast<unsigned char *>(S.mult);     // forward multipliers are dead by now
+	S.ny = (int)ycols_host.size();
+	const i64 cw = std::max<i64>(1, S.cw);
+	HIPCHK(pool().alloc((void **)&S.ycols, sizeof(int) * S.ny, S.device));
+	HIPCHK(hipMemcpyAsync(S.ycols, ycols_host.data(), sizeof(int) * S.ny, hipMemcpyHostToDevice, S.sA));
+	HIPCHK(pool().alloc((void **)&S.out, sizeof(u64) * S.ny * cw, S.device));
+	HIPCHK(hipMemsetAsync(S.out, 0, sizeof(u64) * S.ny * cw, S.sA));
+	unsigned char *accv = reinterpret_cast<unsigned char *>(S.mult);     // forward multipliers are dead by now (2*G*8 bytes per row)
+	const i64 nacc = std::max<i64>(1, S.maxr);
 	for (int qb = S.npanels; qb > 0; qb -= GF2_BSG) {
 		const int qa = std::max(0, qb - GF2_BSG);
 		const int waves = (qb - qa) * 64;
-		k_bs_far<<<dim3((waves + 3) / 4), dim3(256), 0, S.sA>>>(S.M, S.srows, S.cols, qa, qb, S.panels, S.urow, S.out, accv);
-		k_bs_near<<<dim3(1), dim3(1024), 0, S.sA>>>(S.M, S.srows, qa, qb, S.panels, S.urow, S.pivcol, S.out, accv);
+		k_bs_far<<<dim3((waves + 3) / 4), dim3(256), 0, S.sA>>>(S.M, S.srows, cw, qa, qb, S.panels, S.urow, S.pivcol, S.ycols, S.ny,
+		                                                        S.out, accv, nacc);
+		k_bs_near<<<dim3(1), dim3(1024), 0, S.sA>>>(S.M, S.srows, cw, qa, qb, S.panels, S.urow, S.pivcol, S.ny, S.out, accv, nacc);
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(S.ev2, S.sA));
 	return GF2BV_OK;
+}
+
+int enqueue_backward_single(Solver &S)
+{
+	return enqueue_backward_parity(S, std::vector<int>(1, (int)S.cols));
 }
 
 int solver_enqueue(Solver &S)
@@ -657,7 +669,8 @@ int finish_begin(Solver &S)
 		std::vector<int> yc;
 		if (!S.hst.inconsistent) yc = S.free_order;
 		yc.push_back((int)S.cols);
-		int rc = enqueue_backward(S, yc);
+		// few right-hand sides (the usual kernel dimensions): the parity path; otherwise the sweeps over Y
+		int rc = ((int)yc.size() <= GF2_BSV && !getenv("GF2BV_YSWEEP")) ? enqueue_backward_parity(S, yc) : enqueue_backward(S, yc);
 		if (rc) return rc;
 	}
 	HIPCHK(hipMemcpyAsync(&S.hst, S.st, sizeof S.hst, hipMemcpyDeviceToHost, S.sA));

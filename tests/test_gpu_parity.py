@@ -290,6 +290,19 @@ def test_back_substitution_paths_agree(monkeypatch):
         monkeypatch.delenv("GF2BV_YSWEEP", raising=False)
         assert_same(a, want, 0)
         assert_same(b, want, 0)
+    # kernel bases of up to 7 vectors take the parity path as well (one pass over U for all right-hand sides)
+    for rows, cols, cap in ((900, 800, 797), (2300, 2200, 2193), (1500, 1029, 1028)):
+        eqs = random_system(rng, rows, cols, .5, cap, True, 0)
+        aug = O.eqs_to_aug(eqs, cols)
+        want = O.solve_words(aug, rows, cols, 1)
+        assert 1 <= want["dim"] <= 7
+        monkeypatch.delenv("GF2BV_YSWEEP", raising=False)
+        a = hip.solve_words(aug, rows, cols, 1)
+        monkeypatch.setenv("GF2BV_YSWEEP", "1")
+        b = hip.solve_words(aug, rows, cols, 1)
+        monkeypatch.delenv("GF2BV_YSWEEP", raising=False)
+        assert_same(a, want, 1)
+        assert_same(b, want, 1)
 
 
 def test_device_path_strides_and_untouched_input():
