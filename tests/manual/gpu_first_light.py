@@ -1,6 +1,6 @@
 """First-light diagnostics on a GPU box: parity on a ladder of shapes, then timings."""
 import os, sys, time, random, traceback
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import __graft_entry__ as g
 from gf2bv_amd import hip

@@ -1,7 +1,7 @@
 """Randomised differential test on the GPU box: random shapes / densities / rank caps / modes / k_update
 configurations against the CPU oracle, through the C ABI.  usage: stress_parity.py [seconds] [seed]"""
 import os, random, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from gf2bv_amd import hip
 from oracle import gf2_oracle as O

@@ -73,10 +73,18 @@ def test_space_combine_host_helper():
 
 
 def test_product_never_imports_oracle():
-    """The oracle is test infrastructure: nothing under gf2bv_amd/ may reference it."""
+    """The oracle is test infrastructure: nothing under gf2bv_amd/ may reference it, and outside tests/ only
+    __graft_entry__.smoke() and bench.py's cpu_baseline leg may import it."""
     pkg = os.path.join(ROOT, "gf2bv_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".cpp", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f), errors="replace").read()
                 assert "oracle" not in src.lower() or f == "__none__", os.path.join(dirpath, f)
+    for sub in ("tools", "examples"):
+        for f in os.listdir(os.path.join(ROOT, sub)):
+            if f.endswith((".py", ".hip")):
+                src = open(os.path.join(ROOT, sub, f), errors="replace").read()
+                assert "import gf2_oracle" not in src and "from oracle" not in src, os.path.join(sub, f)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    assert bench.count("from oracle import") == 1 and "def cpu_baseline" in bench.split("from oracle import")[0].rsplit("\ndef ", 1)[-1]

@@ -249,7 +249,7 @@ def test_batched_list_of_int_boundary(monkeypatch):
 
 def test_randomised_shapes_and_configs(monkeypatch):
     """A seeded sweep over shapes, densities, rank caps, zero rows, modes and k_update configurations
-    (tools/stress_parity.py runs the open-ended version of this on the GPU box)."""
+    (tests/manual/stress_parity.py runs the open-ended version of this on the GPU box)."""
     rng = random.Random(20260928)
     for it in range(40):
         cols = rng.choice([rng.randint(1, 130), rng.randint(131, 600), 64 * rng.randint(1, 9), 256 * rng.randint(1, 3) + rng.choice([-1, 0, 1])])
