@@ -440,8 +440,9 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	// Hard panels (sparse / rank deficient: a unit had to scan far) switch the NEXT panel to all units.
 	// Either way the active units' slices cover every alive row.
 	const int active = wide ? units : (units < GF2_FEW_UNITS ? units : GF2_FEW_UNITS);
-	// search workgroups without an active unit leave at once: only the active units take part in the arrival count
-	if (finder && (int)blockIdx.x * 4 >= active) return;
+	// EVERY unit takes part in the arrival count, active or not: publication (which rewrites st->first and
+	// st->wide, read above) must not happen while a unit of this launch has yet to start -- a workgroup that
+	// is dispatched late would derive a different `active` from the new values and arrive on the next panel's count.
 	i64 lo = rows, hi = rows;
 	if (finder && u < active) {
 		const i64 n = rows - first;
@@ -519,7 +520,7 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	}
 
 	// ---- search panel gf ----
-	if (u >= active) return;
+	if (u >= units) return;
 	CandWords cw;
 	cw.Wb = Wb_in; cw.Pcol = &L.Pb[gfc][0]; cw.maskp = recp.mask; cw.gf = gfc; cw.gp = gpc;
 	const int full = __popcll(colmask);
@@ -554,7 +555,7 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	unsigned old = 0;
 	if (lane == 0) old = __hip_atomic_fetch_add(&st->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 	old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-	if (old != (unsigned)(active - 1)) return;
+	if (old != (unsigned)(units - 1)) return;
 
 	// ---- last arriver: publish ----
 	// unit 0 scans the lowest rows: adopting it keeps the alive lower bound exact for free.  Its record is
@@ -937,10 +938,6 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	// two VALU instructions per lookup (shift, v_and_or) instead of three
 	__shared__ __attribute__((aligned(256))) uint4 tab[G * SLOTS * 16];
 	__shared__ int prow[G * 64];                    // [G][64] physical row of pivot bit, -1 if none
-	const int ct = blockIdx.x % ntiles;
-	const int sp = blockIdx.x / ntiles;
-	const i64 tile = tile_begin + ct;
-	const i64 w0 = tile * TW;
 	const int lr = threadIdx.x % LPR;
 	const int rr = threadIdx.x / LPR;
 	constexpr int RPP = NT / LPR;
@@ -948,15 +945,31 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	int anyp = 0;
 	for (int g = 0; g < gb; g++) anyp |= panels[j0 + g].p;
 	if (!anyp) return;                          // a block without pivots changes nothing
-	// row range of this workgroup: [first alive row, rows) split evenly; range starts are multiples of 8 so
-	// that a lane's rowq is a constant (rows just below the bound are dead: zero multipliers)
+	// Work = (tile, alive row) pairs, tile-major: ntiles x R of them.  Every workgroup takes ONE contiguous
+	// span of that line -- equal spans, so the launch has no tail of half-empty rounds whatever ntiles is
+	// (129 tiles x 8 row ranges were 4.03 rounds of 256 workgroups) -- and rebuilds its tables when the span
+	// crosses into the next tile (1 + span/R builds per workgroup).  Span starts are multiples of 1024 rows from
+	// a multiple of 8, so a lane's rowq is a constant (rows just below the bound are dead: zero multipliers).
 	const i64 rlo = (i64)(*blk_first) & ~(i64)7;
 	constexpr int ALIGN = RPP * 4;
-	i64 per = (rows - rlo + nsplit - 1) / nsplit;
-	per = (per + ALIGN - 1) / ALIGN * ALIGN + 8;      // + a few hundred bytes: ranges of different workgroups are not 2^k apart
-	const i64 rbeg = rlo + (i64)sp * per;
-	if (rbeg >= rows) return;
-	const i64 rend = (rbeg + per < rows) ? rbeg + per : rows;
+	const i64 R = (rows - rlo + ALIGN - 1) / ALIGN * ALIGN;
+	const i64 total = (i64)ntiles * R;
+	i64 chunk = (total + gridDim.x - 1) / gridDim.x;
+	chunk = (chunk + ALIGN - 1) / ALIGN * ALIGN;
+	i64 pos = (i64)blockIdx.x * chunk;
+	const i64 pend = (pos + chunk < total) ? pos + chunk : total;
+	(void)nsplit;
+	for (bool first_span = true; pos < pend; first_span = false) {
+	const int ct = (int)(pos / R);
+	const i64 r0 = pos - (i64)ct * R;
+	const i64 span = (R - r0 < pend - pos) ? R - r0 : pend - pos;
+	pos += span;
+	const i64 tile = tile_begin + ct;
+	const i64 w0 = tile * TW;
+	const i64 rbeg = rlo + r0;
+	if (rbeg >= rows) continue;                 // padding at the end of a tile's line
+	const i64 rend = (rbeg + span < rows) ? rbeg + span : rows;
+	if (!first_span) __syncthreads();           // the previous span's rows are done with the tables
 	// ---- tables ----
 	for (int t = threadIdx.x; t < gb * 64; t += NT) {
 		const int g = t >> 6, b = t & 63;
@@ -1147,6 +1160,7 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		load_half(SafeT(), A, base + 2 * STEP);
 		compute_half(SafeT(), B, base + STEP);
 	}
+	}       // spans
 }
 
 // ==========================================================================================

@@ -448,15 +448,17 @@ int solver_alloc(Solver &S)
 	return GF2BV_OK;
 }
 
-int pick_nsplit(i64 rows, int ntiles)
+// Workgroups of one bulk-update launch (per system).  Each takes one contiguous span of the (tile, row)
+// line (see k_update), so the count is free of the tile count: one workgroup per CU, fewer when a span
+// would fall under ~4096 rows (a table build costs as much as streaming ~800 rows), shared among the
+// systems of a gang.
+int pick_update_wgs(i64 est_rows, int ntiles, int nsys)
 {
-	// One workgroup per CU builds G x T tables (a fixed ~5-8 us) before it streams rows, so aim at
-	// ONE round of ~256 fat workgroups; go to several rounds only when each still streams >= 4096 rows.
-	i64 want = std::max<i64>(1, 256 / ntiles);
-	while (want * ntiles < 1024 && rows / (want * 2) >= 4096) want *= 2;
-	if (const char *e = getenv("GF2BV_WGS")) { int v = atoi(e); if (v > 0) want = (v + ntiles - 1) / ntiles; }
-	i64 cap = std::max<i64>(1, rows / 256);
-	return (int)std::max<i64>(1, std::min(want, cap));
+	i64 want = 256;
+	if (const char *e = getenv("GF2BV_WGS")) { int v = atoi(e); if (v > 0) want = v; }
+	want = std::max<i64>(1, want / std::max(1, nsys));
+	const i64 cap = std::max<i64>(1, (i64)ntiles * est_rows / 4096);
+	return (int)std::min(want, cap);
 }
 
 int launch_trsm(Solver &S, hipStream_t st, int j0, int gb, int wlo, int tile_begin, int ntiles, int nw_lo, int nw_hi)
@@ -477,9 +479,10 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 		S.kev.push_back(ka); S.kev.push_back(kb);
 		HIPCHK(hipEventRecord(ka, st));
 	}
-	const int ns = pick_nsplit(S.rows, ntiles * S.nsys);      // the gang's workgroups share the chip
-	HIPCHK(S.impl->update(dim3((unsigned)(ntiles * ns), S.nsys), st, S.M, S.rows, S.srows, j0, gb, wlo, S.panels, S.aux, mset,
-	                      S.blk_first + b, tile_begin, ntiles, ns, nw_lo, nw_hi, S.ss()));
+	const i64 est_rows = std::max<i64>(256, S.rows - (i64)j0 * 64);      // alive rows of a dense system (the kernel uses the true bound)
+	const int wgs = pick_update_wgs(est_rows, ntiles, S.nsys);
+	HIPCHK(S.impl->update(dim3((unsigned)wgs, S.nsys), st, S.M, S.rows, S.srows, j0, gb, wlo, S.panels, S.aux, mset,
+	                      S.blk_first + b, tile_begin, ntiles, 0, nw_lo, nw_hi, S.ss()));
 	if (S.time_kernels) HIPCHK(hipEventRecord(kb, st));
 	return GF2BV_OK;
 }

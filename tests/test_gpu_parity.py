@@ -276,6 +276,23 @@ def test_batch_words_host_entry():
                 assert_same(sol, O.solve_words(O.eqs_to_aug(eqs, cols), rows, cols, mode), mode)
 
 
+def test_concurrent_gangs_saturating_the_chip(monkeypatch):
+    """Two host threads, each driving gangs whose bulk updates fill every CU: search workgroups get dispatched
+    late, which once let a unit read the *next* panel's state (every unit must take part in the arrival count)."""
+    monkeypatch.setenv("GF2BV_GANG", "6")
+    n, nsys = 16384, 24
+    stride = hip.padded_stride(n)
+    buf = hip.DeviceBuffer(nsys * n * stride * 8)
+    for i in range(nsys):
+        hip.synth_device(buf.ptr + i * n * stride * 8, n, n, stride, 7000 + i)
+    for rep in range(3):
+        sols = hip.solve_batch_device(buf.ptr, nsys, n * stride, n, n, stride, 0)
+        for i, s in enumerate(sols):
+            assert s.solved and s.rank >= n - 8
+            assert hip.residual_device(buf.ptr + i * n * stride * 8, n, n, stride, s.origin) == 0
+    buf.free()
+
+
 def test_back_substitution_paths_agree(monkeypatch):
     """solve_one's blocked parity back-substitution vs the general multi-RHS sweep path (solve_all's)."""
     rng = random.Random(31)
