@@ -85,11 +85,14 @@ def cpu_baseline(n: int, seed: int) -> dict:
         "value": res["row_xors"] / dt, "unit": "row-XORs/s", "cores": best, "kind": "port",
         "sample": f"one {n}x{n} solve_one of the same synthetic generator (seed {seed}), "
                   f"oracle M4RM port (Gauss-Jordan, 8 byte-tables per 64-column panel, OpenMP over rows, "
-                  f"best of {sorted(probe)} threads on a {cores}-thread host); M4RI itself is not installed on this box",
+                  f"best of {sorted(probe)} threads on a {cores}-thread host); libm4ri on this host: "
+                  + str(__import__("ctypes.util").util.find_library("m4ri")),
         "seconds": dt, "rank": int(res["rank"]), "residual_rows": int(bad),
         "row_panels_per_s": n * panels / dt,          # table-count independent: (rows x 64-column panels) eliminated per second
         "single_core": {"value": res1["row_xors"] / dt1, "seconds": dt1, "n": max(n // 2, 1024)},
         "thread_probe_8192_seconds": {str(k): v for k, v in probe.items()},
+        # true M4RI would be timed as well if the box had it; checked at run time
+        "libm4ri_on_this_host": __import__("ctypes.util").util.find_library("m4ri"),
         "_origin": res["origin"], "_status": int(res["status"]),
     }
 
