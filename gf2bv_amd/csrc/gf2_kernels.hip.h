@@ -95,6 +95,9 @@ struct PanelAux {
 // "died[i] > j-1" answers the same before and after the search has marked its sources.
 #define GF2_NEVER 0x7f7f7f7f
 
+#define GF2_GROUP 16          // units per merge group on hard panels
+#define GF2_MAXGROUPS 16      // 256 units at most
+
 // Per-solve device state.  The host never reads it mid-solve.
 struct SolveState {
 	int rank;            // pivots found so far
@@ -102,6 +105,7 @@ struct SolveState {
 	int first;           // lower bound of the alive rows
 	unsigned arrive;     // search units that have finished (last arriver publishes)
 	int wide;            // search: 1 = the previous panel was hard (sparse / rank deficient): scan with all units
+	unsigned garr[GF2_MAXGROUPS];    // hard panels: arrivals per group of GF2_GROUP units (two-level merge)
 	int pad[3];
 };
 
@@ -552,56 +556,23 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	GF2_ST(&me->bc[lane], S.bc);
 	if (lane == 0) { GF2_ST(&me->have, S.have); GF2_ST(&me->first_nonsrc, first_nonsrc); GF2_ST(&me->chunks, chunks); GF2_ST(&me->cnt, S.nslots); }
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every store above has left this wave
-	unsigned old = 0;
-	if (lane == 0) old = __hip_atomic_fetch_add(&st->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
-	if (old != (unsigned)(units - 1)) return;
 
-	// ---- last arriver: publish ----
-	// unit 0 scans the lowest rows: adopting it keeps the alive lower bound exact for free.  Its record is
-	// fetched speculatively in one go (the usual case), not field by field after the decision.
-	const int cnt0 = GF2_LD(&fu[0].cnt), ch0 = GF2_LD(&fu[0].chunks), fn0 = GF2_LD(&fu[0].first_nonsrc);
-	const u64 have0 = GF2_LD(&fu[0].have), bc0 = GF2_LD(&fu[0].bc[lane]);
-	const int srow0 = GF2_LD(&fu[0].srow[lane]);
-	const int r0 = st->rank;
-	int pick = -1;
-	if (full > 0) {
-		if (u == 0 && S.nslots == full) pick = 0;
-		else if (cnt0 == full) pick = 0;
-		else if (S.nslots == full) pick = u;
-		else
-			for (int v = 1; v < active; v++)
-				if (GF2_LD(&fu[v].cnt) == full) { pick = v; break; }
-	}
-	const int hard = (pick < 0) || ((pick == u ? chunks : (pick == 0 ? ch0 : GF2_LD(&fu[pick].chunks))) > 8);
-	int new_first;
-	int srow;                                   // lane s: row of slot s
-	if (pick >= 0) {
-		if (pick != u) {
-			S.have = (pick == 0) ? have0 : GF2_LD(&fu[pick].have);
-			S.bc = (pick == 0) ? bc0 : GF2_LD(&fu[pick].bc[lane]);
-		}
-		S.nslots = full;
-		srow = (pick == 0) ? srow0 : GF2_LD(&fu[pick].srow[lane]);
-		new_first = (pick == 0) ? ((u == 0) ? first_nonsrc : fn0) : first;
-	} else {
-		// merge: rebuild one basis from all units' source rows (scratch: this unit's own srow list is
-		// dead by now, but other lists are still being read -> use the list of unit `units` (spare))
-		S.bw = 0; S.bc = 0; S.have = 0; S.nslots = 0;
-		FindUnit *spare = fu + units;
-		// the units' lists are short in sparse systems (a few rows each): they are packed into full 64-row
-		// chunks before being absorbed, so the merge costs sum(cnt)/64 absorb steps, not one per unit
-		int *pend = pend_rows[t >> 6];
+	// Rebuild one basis from the source-row lists fu[idx0 .. idx0+n) (records of units or of groups).  The lists
+	// are short in sparse systems (a few rows each): they are packed into full 64-row chunks before being
+	// absorbed, so a merge costs sum(cnt)/64 absorb steps, not one per list.
+	int *pend = pend_rows[t >> 6];
+	auto merge_lists = [&](FindState &T, int idx0, int n, int *srow_out) {
+		T.bw = 0; T.bc = 0; T.have = 0; T.nslots = 0;
 		int fill = 0;
 		auto absorb_rows = [&](int i) {
 			u64 w = 0;
 			if (i >= 0) w = cw.apply(Wb_in[(i64)i * GF2_GMAX + cw.gf], Wb_in[(i64)i * GF2_GMAX + cw.gp]) & colmask;
-			find_absorb(S, w, i, colmask, lane, spare->srow, sparse_mode);
+			find_absorb(T, w, i, colmask, lane, srow_out, sparse_mode);
 		};
-		for (int v = 0; v < active && S.nslots < full; v++) {
-			const int cnt = GF2_LD(&fu[v].cnt);
+		for (int v = 0; v < n && T.nslots < full; v++) {
+			const int cnt = GF2_LD(&fu[idx0 + v].cnt);
 			if (cnt == 0) continue;
-			if (lane < cnt) pend[fill + lane] = GF2_LD(&fu[v].srow[lane]);
+			if (lane < cnt) pend[fill + lane] = GF2_LD(&fu[idx0 + v].srow[lane]);
 			fill += cnt;
 			if (fill >= 64) {
 				absorb_rows(pend[lane]);
@@ -610,8 +581,81 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 				if (lane < fill) pend[lane] = carry;
 			}
 		}
-		if (fill > 0 && S.nslots < full) absorb_rows(lane < fill ? pend[lane] : -1);
+		if (fill > 0 && T.nslots < full) absorb_rows(lane < fill ? pend[lane] : -1);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the source list is out
+	};
+
+	// Arrival.  Easy panels: one count over all units, the last unit publishes.  Hard panels with many units: two
+	// levels -- the last unit of each group of GF2_GROUP merges its group's lists into one record (in parallel
+	// across groups), the last group leader merges those -- so the serial part is ~units/16 + 16 lists, not `units`.
+	// (`wide` was read by every unit of this launch before anything could be published: uniform.)
+	int idx0 = 0, nlists = active;              // what the publisher chooses from: fu[idx0 .. idx0+nlists)
+	unsigned old = 0;
+	if (wide && units > GF2_GROUP) {
+		const int g = u / GF2_GROUP, ng = (units + GF2_GROUP - 1) / GF2_GROUP;
+		const int gsize = (units - g * GF2_GROUP < GF2_GROUP) ? units - g * GF2_GROUP : GF2_GROUP;
+		if (lane == 0) old = __hip_atomic_fetch_add(&st->garr[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+		if (old != (unsigned)(gsize - 1)) return;
+		if (lane == 0) GF2_ST(&st->garr[g], 0u);            // every member has arrived: ready for the next panel
+		FindUnit *gu = fu + units + 1 + g;                  // the group's record
+		int fullv = -1;
+		if (full > 0)
+			for (int v = g * GF2_GROUP; v < g * GF2_GROUP + gsize; v++)
+				if (GF2_LD(&fu[v].cnt) == full) { fullv = v; break; }
+		if (fullv >= 0) {                                   // a complete unit stands for its group
+			GF2_ST(&gu->bc[lane], GF2_LD(&fu[fullv].bc[lane]));
+			GF2_ST(&gu->srow[lane], GF2_LD(&fu[fullv].srow[lane]));
+			if (lane == 0) {
+				GF2_ST(&gu->have, GF2_LD(&fu[fullv].have)); GF2_ST(&gu->chunks, GF2_LD(&fu[fullv].chunks));
+				GF2_ST(&gu->first_nonsrc, first); GF2_ST(&gu->cnt, full);
+			}
+		} else {
+			FindState T;
+			merge_lists(T, g * GF2_GROUP, gsize, gu->srow);
+			GF2_ST(&gu->bc[lane], T.bc);
+			if (lane == 0) { GF2_ST(&gu->have, T.have); GF2_ST(&gu->chunks, 1 << 20); GF2_ST(&gu->first_nonsrc, first); GF2_ST(&gu->cnt, T.nslots); }
+		}
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		old = 0;
+		if (lane == 0) old = __hip_atomic_fetch_add(&st->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+		if (old != (unsigned)(ng - 1)) return;
+		idx0 = units + 1; nlists = ng;
+	} else {
+		if (lane == 0) old = __hip_atomic_fetch_add(&st->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+		if (old != (unsigned)(units - 1)) return;
+	}
+
+	// ---- last arriver: publish ----
+	// unit 0 scans the lowest rows: adopting it keeps the alive lower bound exact for free.  Its record is
+	// fetched speculatively in one go (the usual case), not field by field after the decision.
+	const int cnt0 = GF2_LD(&fu[0].cnt), ch0 = GF2_LD(&fu[0].chunks), fn0 = GF2_LD(&fu[0].first_nonsrc);
+	const u64 have0 = GF2_LD(&fu[0].have), bc0 = GF2_LD(&fu[0].bc[lane]);
+	const int srow0 = GF2_LD(&fu[0].srow[lane]);
+	const int r0 = st->rank;
+	int pick = -1;                              // index into fu[] of the record adopted, -1: merge
+	if (full > 0) {
+		if (cnt0 == full) pick = 0;
+		else
+			for (int v = 0; v < nlists; v++)
+				if (GF2_LD(&fu[idx0 + v].cnt) == full) { pick = idx0 + v; break; }
+	}
+	const int hard = (pick < 0) || ((pick == 0 ? ch0 : GF2_LD(&fu[pick].chunks)) > 8);
+	int new_first;
+	int srow;                                   // lane s: row of slot s
+	if (pick >= 0) {
+		S.have = (pick == 0) ? have0 : GF2_LD(&fu[pick].have);
+		S.bc = (pick == 0) ? bc0 : GF2_LD(&fu[pick].bc[lane]);
+		S.nslots = full;
+		srow = (pick == 0) ? srow0 : GF2_LD(&fu[pick].srow[lane]);
+		new_first = (pick == 0) ? fn0 : first;
+	} else {
+		// (scratch: this unit's own srow list is dead by now, but other lists are still being read ->
+		// the list of unit `units` (spare) takes the merged sources)
+		FindUnit *spare = fu + units;
+		merge_lists(S, idx0, nlists, spare->srow);
 		srow = GF2_LD(&spare->srow[lane]);
 		new_first = first;
 	}

@@ -417,7 +417,7 @@ int solver_alloc(Solver &S)
 		size_t off = 0;
 		auto carve = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
 		const size_t o_st = carve(sizeof(SolveState)), o_pan = carve(sizeof(PanelRec) * NP), o_aux = carve(sizeof(PanelAux) * NP),
-		             o_fu = carve(sizeof(FindUnit) * (S.units + 1)), o_alive = carve(sizeof(int) * (size_t)R),
+		             o_fu = carve(sizeof(FindUnit) * (S.units + 1 + GF2_MAXGROUPS)), o_alive = carve(sizeof(int) * (size_t)R),
 		             o_piv = carve(sizeof(int) * (S.maxr + 64)), o_urow = carve(sizeof(int) * (S.maxr + 64)),
 		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * 2 * G * R),
 		             o_wb = carve(sizeof(u64) * 2 * GF2_GMAX * R), o_uw = carve(sizeof(u64) * GF2_GMAX * (S.maxr + 64));
