@@ -303,11 +303,21 @@ struct FindState {
 // afterwards a row's multiplier is simply `word & pivot_mask`).  The row of each new source
 // is stored to srow_out[slot].  Returns the lanes whose candidate became a source row.
 // OR of a 64-bit value over the wavefront (butterfly; every lane gets the result).
+__device__ __forceinline__ unsigned wave_or32(unsigned x)
+{
+	// DPP shifts inside rows of 16 lanes (lane 15 of a row ends up with the row's OR), then the two GFX9 row
+	// broadcasts carry it across rows into lane 63: ~7 VALU instructions instead of six LDS-speed shuffles
+	x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);      // row_shr:1
+	x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);      // row_shr:2
+	x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);      // row_shr:4
+	x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);      // row_shr:8
+	x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1, 3
+	x |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2, 3
+	return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
 __device__ __forceinline__ u64 wave_or(u64 v)
 {
-#pragma unroll
-	for (int d = 1; d < 64; d <<= 1) v |= (u64)__shfl_xor((long long)v, d, 64);
-	return v;
+	return ((u64)wave_or32((unsigned)(v >> 32)) << 32) | wave_or32((unsigned)v);
 }
 
 __device__ __forceinline__ u64 find_absorb(FindState &S, u64 w, int row, u64 colmask, int lane, int *srow_out,
