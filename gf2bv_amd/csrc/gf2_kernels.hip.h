@@ -337,6 +337,7 @@ __device__ __forceinline__ u64 find_absorb(FindState &S, u64 w, int row, u64 col
 		if ((w >> b) & 1) { w ^= v; c ^= vc; }
 	}
 	u64 todo = colmask & ~S.have & (sparse ? wave_or(w) : ~0ull);
+	int myslot = -1;                                 // slot this lane's candidate became, stored once after the loop
 	while (todo) {
 		int b = uniform(ctz64(todo)); todo &= todo - 1;
 		u64 m = __ballot((w >> b) & 1);
@@ -345,7 +346,7 @@ __device__ __forceinline__ u64 find_absorb(FindState &S, u64 w, int row, u64 col
 		u64 v = readlane64(w, L);
 		todo |= v & colmask & ~S.have & ~((2ull << b) - 1);     // columns the new pivot row spreads to (all right of b)
 		u64 vc = readlane64(c, L) | (1ull << S.nslots);
-		if (lane == L) GF2_ST(srow_out + S.nslots, row);
+		if (lane == L) myslot = S.nslots;
 		if ((w >> b) & 1) { w ^= v; c ^= vc; }             // lane L itself becomes 0
 		if ((S.bw >> b) & 1) { S.bw ^= v; S.bc ^= vc; }    // keep the basis fully reduced
 		if (lane == b) { S.bw = v; S.bc = vc; }
@@ -353,6 +354,7 @@ __device__ __forceinline__ u64 find_absorb(FindState &S, u64 w, int row, u64 col
 		S.nslots++;
 		took |= 1ull << L;
 	}
+	if (myslot >= 0) GF2_ST(srow_out + myslot, row);
 	return took;
 }
 
