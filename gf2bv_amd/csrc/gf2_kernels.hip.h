@@ -320,6 +320,20 @@ __device__ __forceinline__ u64 wave_or(u64 v)
 	return ((u64)wave_or32((unsigned)(v >> 32)) << 32) | wave_or32((unsigned)v);
 }
 
+// x ^ (v & m), one v_bitop3_b32 (truth table 0x78: bit index {x, v, m})
+__device__ __forceinline__ u64 xor_and64(u64 x, u64 v, unsigned m)
+{
+	const unsigned lo = (unsigned)__builtin_amdgcn_bitop3_b32((int)(unsigned)x, (int)(unsigned)v, (int)m, 0x78);
+	const unsigned hi = (unsigned)__builtin_amdgcn_bitop3_b32((int)(unsigned)(x >> 32), (int)(unsigned)(v >> 32), (int)m, 0x78);
+	return ((u64)hi << 32) | lo;
+}
+// bit bb (uniform, 0..31) of the HI / low half of a 64-bit lane value as an all-ones / all-zeros word: one v_bfe_i32
+template <bool HI>
+__device__ __forceinline__ unsigned halfbit_mask(u64 x, int bb)
+{
+	return (unsigned)__builtin_amdgcn_sbfe((int)(unsigned)(HI ? (x >> 32) : x), (unsigned)bb, 1u);
+}
+
 __device__ __forceinline__ u64 find_absorb(FindState &S, u64 w, int row, u64 colmask, int lane, int *srow_out,
                                            int sparse_mode)
 {
@@ -329,31 +343,51 @@ __device__ __forceinline__ u64 find_absorb(FindState &S, u64 w, int row, u64 col
 	// The basis is fully reduced, so reducing by one vector never creates bits at other pivot columns.
 	// The two wave-wide ORs cost ~2 % on dense chunks, so they are taken only when fewer than a quarter of
 	// the candidates carry more than 12 bits (uniform decision; sparse_mode 0 / 1 force it off / on).
+	// These loops are the serial core of the search, so every instruction counts: the columns are walked half
+	// by half (the bit test is then ONE v_bfe_i32 giving a 0 / ~0 word) and a conditional XOR is
+	// x ^ (v & mask) in ONE v_bitop3 per dword -- straight-line VALU, no exec juggling.
 	const bool sparse = sparse_mode == 1 || (sparse_mode == 2 && __popcll(__ballot(__popcll(w) > 12)) < 16);
 	u64 hv = S.have & (sparse ? wave_or(w) : ~0ull);
-	while (hv) {
-		int b = uniform(ctz64(hv)); hv &= hv - 1;
-		u64 v = readlane64(S.bw, b), vc = readlane64(S.bc, b);
-		if ((w >> b) & 1) { w ^= v; c ^= vc; }
-	}
+	auto reduce_half = [&](auto hi_tag) {
+		constexpr bool HI = decltype(hi_tag)::value;
+		unsigned bits = HI ? (unsigned)(hv >> 32) : (unsigned)hv;
+		while (bits) {
+			const int bb = uniform(__ffs((int)bits) - 1); bits &= bits - 1;
+			const int b = bb + (HI ? 32 : 0);
+			const u64 v = readlane64(S.bw, b), vc = readlane64(S.bc, b);
+			const unsigned mk = halfbit_mask<HI>(w, bb);
+			w = xor_and64(w, v, mk); c = xor_and64(c, vc, mk);
+		}
+	};
+	reduce_half(std::integral_constant<bool, false>());
+	reduce_half(std::integral_constant<bool, true>());
 	u64 todo = colmask & ~S.have & (sparse ? wave_or(w) : ~0ull);
 	int myslot = -1;                                 // slot this lane's candidate became, stored once after the loop
-	while (todo) {
-		int b = uniform(ctz64(todo)); todo &= todo - 1;
-		u64 m = __ballot((w >> b) & 1);
-		if (!m) continue;
-		int L = uniform(ctz64(m));
-		u64 v = readlane64(w, L);
-		todo |= v & colmask & ~S.have & ~((2ull << b) - 1);     // columns the new pivot row spreads to (all right of b)
-		u64 vc = readlane64(c, L) | (1ull << S.nslots);
-		if (lane == L) myslot = S.nslots;
-		if ((w >> b) & 1) { w ^= v; c ^= vc; }             // lane L itself becomes 0
-		if ((S.bw >> b) & 1) { S.bw ^= v; S.bc ^= vc; }    // keep the basis fully reduced
-		if (lane == b) { S.bw = v; S.bc = vc; }
-		S.have |= 1ull << b;
-		S.nslots++;
-		took |= 1ull << L;
-	}
+	auto pivots_half = [&](auto hi_tag) {
+		constexpr bool HI = decltype(hi_tag)::value;
+		while (HI ? (unsigned)(todo >> 32) : (unsigned)todo) {
+			const int bb = uniform(__ffs((int)(HI ? (unsigned)(todo >> 32) : (unsigned)todo)) - 1);
+			const int b = bb + (HI ? 32 : 0);
+			todo &= ~(1ull << b);
+			const unsigned mk = halfbit_mask<HI>(w, bb);
+			const u64 m = __ballot(mk != 0);
+			if (!m) continue;
+			const int L = uniform(ctz64(m));
+			const u64 v = readlane64(w, L);
+			todo |= v & colmask & ~S.have & ~((2ull << b) - 1);     // columns the new pivot row spreads to (all right of b)
+			const u64 vc = readlane64(c, L) | (1ull << S.nslots);
+			myslot = (lane == L) ? S.nslots : myslot;
+			w = xor_and64(w, v, mk); c = xor_and64(c, vc, mk);          // lane L itself becomes 0
+			const unsigned mb = halfbit_mask<HI>(S.bw, bb);                 // keep the basis fully reduced
+			S.bw = xor_and64(S.bw, v, mb); S.bc = xor_and64(S.bc, vc, mb);
+			if (lane == b) { S.bw = v; S.bc = vc; }
+			S.have |= 1ull << b;
+			S.nslots++;
+			took |= 1ull << L;
+		}
+	};
+	pivots_half(std::integral_constant<bool, false>());
+	pivots_half(std::integral_constant<bool, true>());
 	if (myslot >= 0) GF2_ST(srow_out + myslot, row);
 	return took;
 }
