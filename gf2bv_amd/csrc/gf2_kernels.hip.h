@@ -378,9 +378,10 @@ __device__ __forceinline__ u64 find_absorb(FindState &S, u64 w, int row, u64 col
 			const u64 vc = readlane64(c, L) | (1ull << S.nslots);
 			myslot = (lane == L) ? S.nslots : myslot;
 			w = xor_and64(w, v, mk); c = xor_and64(c, vc, mk);          // lane L itself becomes 0
-			const unsigned mb = halfbit_mask<HI>(S.bw, bb);                 // keep the basis fully reduced
+			// keep the basis fully reduced (vectors that have bit b) and install the new vector in lane b, whose
+			// bw / bc are still 0 (a lane without a pivot never changes): one masked XOR does both
+			const unsigned mb = (lane == b) ? ~0u : halfbit_mask<HI>(S.bw, bb);
 			S.bw = xor_and64(S.bw, v, mb); S.bc = xor_and64(S.bc, vc, mb);
-			if (lane == b) { S.bw = v; S.bc = vc; }
 			S.have |= 1ull << b;
 			S.nslots++;
 			took |= 1ull << L;
