@@ -393,187 +393,22 @@ __device__ __forceinline__ u64 find_absorb(FindState &S, u64 w, int row, u64 col
 	return took;
 }
 
-// ---- one step of the panel path -------------------------------------------------------------
-// Step s of a block (s = 0..gb) is ONE launch that
-//   * narrows panel gp = s-1: every alive row records its multiplier mult_gp[i] = Wb[i][gp] & mask and
-//     XORs the selected reduced pivot rows into its remaining window words (workgroups >= find_wgs,
-//     256 rows each), reading window buffer Wb_in and writing Wb_out, and
-//   * searches panel gf = s for pivots (workgroups < find_wgs, one "unit" per wavefront).
-// The search would need the narrowed word gf of its candidate rows, which other workgroups are only
-// just producing -- so a unit derives it itself from the stable input buffer:
-//   word = Wb_in[i][gf] ^ XOR_{b in Wb_in[i][gp] & mask_gp} P_gp[b][gf]
-// (a few LDS reads per candidate).  Search and narrow step therefore overlap, and a block costs gb+1
-// launches on the critical path instead of 2*gb.  Everything a step reads from global memory was
-// written by earlier launches; what it writes is read by later ones (died[] is the one exception, see
-// GF2_NEVER).
-//
-// Search: every unit scans its own slice of the alive rows and builds a basis with combination
-// tracking; a unit stops as soon as all columns of the panel have pivots.  The LAST unit to finish
-// publishes: it adopts any unit whose basis is complete (dense systems: every unit is after ~70
-// rows), otherwise it merges the units' source rows into one basis.  Publishing = panel record, pivot
-// columns, physical pivot rows, PanelAux (sources, combinations, multipliers of the sources w.r.t.
-// earlier panels of the block), and the sources are marked dead.  The multipliers the sources
-// recorded for earlier panels are zeroed by the NEXT step (the bulk update must skip the block's
-// own sources; this step may still be writing them).
-struct StepLds {
-	u64 Sw[GF2_GMAX][64];     // window words of panel gp's source rows      [word][slot]
-	u64 Pb[GF2_GMAX][64];     // its reduced pivot rows' window words         [word][pivot BIT]
-	u64 Cm[64];               // combination masks                            [pivot k]
-	int Bk[64];               // pivot k -> pivot bit
-};
-
-// Candidate words of the search while panel gp is being narrowed by the same launch.
-struct CandWords {
-	const u64 *Wb;            // the step's input window buffer
-	const u64 *Pcol;          // LDS: P_gp[bit][word gf]
-	u64 maskp;                // pivot mask of panel gp (0: nothing to apply)
-	int gf, gp;
-	__device__ __forceinline__ u64 prev_mult(u64 wp) const { return wp & maskp; }
-	__device__ __forceinline__ u64 apply(u64 wf, u64 wp) const
-	{
-		u64 m = wp & maskp;
-		while (m) { const int b = ctz64(m); m &= m - 1; wf ^= Pcol[b]; }
-		return wf;
-	}
-};
-
-__global__ void __launch_bounds__(256)
-k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, int gb, u64 colmask,
-             const u64 *__restrict__ Wb_in, u64 *__restrict__ Wb_out, SolveState *__restrict__ st,
-             int *__restrict__ died, FindUnit *__restrict__ fu, int units, int find_wgs,
-             PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol,
-             int *__restrict__ urow, u64 *__restrict__ multset, int *__restrict__ blk_first_out, int upd_T,
-             int sparse_mode, SysStride ss)
+// The pivot search of one panel (global index j, gf-th of its block) by unit u of `units`; see k_panel_step.
+// Cand supplies the candidate words: load(row) fetches what it needs for a row (unconditional loads, the
+// caller clamps the row), word(raw, row) turns that into the row's current word of the panel, and
+// src_mults(srow, gf, out) gives a source row's plain-order multipliers w.r.t. the block's earlier panels.
+// raw_n / d_n / lo / hi / active: the unit's slice and its first chunk, fetched by the caller (early, to overlap
+// with its own prologue).  pend: 128 ints of LDS per wavefront.
+template <class Cand>
+__device__ __forceinline__ void search_panel(const Cand &cand, typename Cand::Raw raw_n, int d_n, i64 lo, i64 hi, int active,
+                                             int u, int lane, i64 rows, int j, int gf, u64 colmask, int first, int wide,
+                                             int units, SolveState *__restrict__ st, int *__restrict__ died,
+                                             FindUnit *__restrict__ fu, int *pend, PanelRec *__restrict__ panels,
+                                             PanelAux *__restrict__ aux, int *__restrict__ pivcol, int *__restrict__ urow,
+                                             int *__restrict__ blk_first_out, int sparse_mode)
 {
-	__builtin_amdgcn_s_setprio(3);          // panel path = critical path: win issue arbitration against bulk-update waves
-	{
-		const i64 ao = blockIdx.y * ss.arena_bytes;
-		M += blockIdx.y * ss.m_words;
-		Wb_in = sys_at(Wb_in, ao); Wb_out = sys_at(Wb_out, ao); st = sys_at(st, ao); died = sys_at(died, ao);
-		fu = sys_at(fu, ao); panels = sys_at(panels, ao); aux = sys_at(aux, ao); pivcol = sys_at(pivcol, ao);
-		urow = sys_at(urow, ao); multset = sys_at(multset, ao);
-		if (blk_first_out) blk_first_out = sys_at(blk_first_out, ao);
-	}
-	__shared__ StepLds L;
-	__shared__ int pend_rows[4][128];                   // publisher's staging of source-row lists (one per wavefront)
-	const int t = threadIdx.x;
-	const int lane = t & 63;
-	const bool finder = (int)blockIdx.x < find_wgs;
-	const i64 rb = (i64)blockIdx.x - find_wgs;          // narrow role: row block
-
-	// Latency is what this kernel costs, so everything it needs goes out in TWO memory round trips and
-	// without control flow around the loads (indices are clamped instead): trip 1 = panel gp's record,
-	// its source list, the alive bound, this thread's own row / the search slice's start; trip 2 = the
-	// source rows' window words and the first chunk of search candidates.
-	const int gpc = gp >= 0 ? gp : 0;
-	const PanelAux *Ap = aux + j0 + gpc;
-	PanelRec recp = panels[j0 + gpc];
-	i64 bound = Ap->first_after;                        // alive lower bound after panel gp
-	const int e_ = t >> 6, sl = t & 63;                 // 256 threads = 4 words x 64 slots
-	const int sr = Ap->slot_row[sl];
-	const u64 cm = Ap->comb[sl];
-	const int first = st->first, wide = st->wide;       // (search role)
-	if (gp < 0) { recp.p = 0; recp.mask = 0; bound = 0; }
-
-	// narrow role: this thread's row
-	const i64 i = rb * 256 + t;
-	const i64 ic = (!finder && i < rows) ? i : 0;
-	const int my_died = died[ic];
-	const uint4 *src = reinterpret_cast<const uint4 *>(Wb_in + ic * GF2_GMAX);
-	const uint4 my_lo = src[0], my_hi = src[1];
-
-	// search role: this unit's slice and its first chunk
-	const int u = (int)blockIdx.x * 4 + (t >> 6);
-	const int j = j0 + (gf >= 0 ? gf : 0);
-	const int gfc = gf >= 0 ? gf : 0;
-	// Dense panels are complete after ~70 rows, so a handful of units (each covering a long slice it
-	// will not finish) publish sooner than 256 units that all have to be dispatched and collected.
-	// Hard panels (sparse / rank deficient: a unit had to scan far) switch the NEXT panel to all units.
-	// Either way the active units' slices cover every alive row.
-	const int active = wide ? units : (units < GF2_FEW_UNITS ? units : GF2_FEW_UNITS);
-	// EVERY unit takes part in the arrival count, active or not: publication (which rewrites st->first and
-	// st->wide, read above) must not happen while a unit of this launch has yet to start -- a workgroup that
-	// is dispatched late would derive a different `active` from the new values and arrive on the next panel's count.
-	i64 lo = rows, hi = rows;
-	if (finder && u < active) {
-		const i64 n = rows - first;
-		i64 per = n > 0 ? (n + active - 1) / active : 0;
-		per = (per + 63) & ~(i64)63;
-		lo = first + (i64)u * per;
-		hi = (lo + per < rows) ? lo + per : rows;
-	}
 	const i64 rclamp = rows - 1;
-	i64 i_n = lo + lane;
-	i64 i_c = i_n < rclamp ? i_n : rclamp;
-	int d_n = died[i_c];
-	u64 wf_n = Wb_in[i_c * GF2_GMAX + gfc];
-	u64 wp_n = Wb_in[i_c * GF2_GMAX + gpc];
-
-	// a row block below the bound holds dead rows only (block 0 still stores the pivot rows)
-	const bool dead_block = !finder && rb != 0 && (rb + 1) * 256 <= bound;
-	if (recp.p > 0 && !dead_block) {
-		// reduced pivot rows of panel gp restricted to the window, from its source rows (tiny, every workgroup)
-		const bool use = sl < recp.p && e_ >= gp && e_ < gb;
-		const u64 sw = Wb_in[(i64)(use ? sr : 0) * GF2_GMAX + e_];
-		L.Sw[e_][sl] = use ? sw : 0ull;
-		L.Pb[e_][sl] = 0;
-		if (t < 64) {
-			L.Cm[t] = (t < recp.p) ? cm : 0ull;
-			if ((recp.mask >> t) & 1) L.Bk[__popcll(recp.mask & lanemask_lt(t))] = t;
-		}
-		__syncthreads();
-		if (use) {
-			u64 c = L.Cm[sl], acc = 0;
-			while (c) { int q = ctz64(c); c &= c - 1; acc ^= L.Sw[e_][q]; }
-			L.Pb[e_][L.Bk[sl]] = acc;
-			if (!finder && rb == 0) M[tidx(sr, j0 + e_, srows)] = acc;
-		}
-		__syncthreads();
-	}
-
-	if (!finder) {
-		// ---- narrow panel gp ----
-		const int p = recp.p;
-		u64 *mult = multset + (i64)gp * rows;
-		if (rb == 0 && t < p)                           // the multipliers panel gp's sources recorded for earlier panels
-			for (int e = 0; e < gp; e++) multset[(i64)e * rows + sr] = 0;
-		if (i >= rows) return;
-		u64 m = 0;
-		if (!dead_block && my_died > j0 + gp) {         // alive when panel gp was eliminated
-			u64 w[GF2_GMAX] = { ((u64)my_lo.y << 32) | my_lo.x, ((u64)my_lo.w << 32) | my_lo.z,
-			                    ((u64)my_hi.y << 32) | my_hi.x, ((u64)my_hi.w << 32) | my_hi.z };
-			u64 wp = 0;
-#pragma unroll
-			for (int e = 0; e < GF2_GMAX; e++) if (e == gp) wp = w[e];
-			m = wp & recp.mask;
-			if (m) {
-				u64 acc[GF2_GMAX];
-#pragma unroll
-				for (int e = 0; e < GF2_GMAX; e++) acc[e] = 0;
-				u64 mm = m;
-				while (mm) {
-					const int b = ctz64(mm); mm &= mm - 1;
-#pragma unroll
-					for (int e = 0; e < GF2_GMAX; e++)
-						if (e >= gp) acc[e] ^= L.Pb[e][b];     // words left of the panel are finished (uniform test)
-				}
-#pragma unroll
-				for (int e = 0; e < GF2_GMAX; e++)
-					if (e >= gp && e < gb) w[e] ^= acc[e];
-			}
-			uint4 *dst = reinterpret_cast<uint4 *>(Wb_out + i * GF2_GMAX);
-			dst[0] = make_uint4((unsigned)w[0], (unsigned)(w[0] >> 32), (unsigned)w[1], (unsigned)(w[1] >> 32));
-			dst[1] = make_uint4((unsigned)w[2], (unsigned)(w[2] >> 32), (unsigned)w[3], (unsigned)(w[3] >> 32));
-		}
-		// stored pre-rotated for the bulk update's table layout (field s = what this row reads at step s)
-		mult[i] = rot_fields_rt(upd_T, m, rowq(i));
-		return;
-	}
-
-	// ---- search panel gf ----
-	if (u >= units) return;
-	CandWords cw;
-	cw.Wb = Wb_in; cw.Pcol = &L.Pb[gfc][0]; cw.maskp = recp.mask; cw.gf = gfc; cw.gp = gpc;
+	i64 i_n = lo + lane, i_c;
 	const int full = __popcll(colmask);
 	FindUnit *me = fu + u;
 	FindState S;
@@ -585,12 +420,11 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 		for (; base < hi && S.nslots < full; base += 64) {
 			const i64 ii = i_n;
 			const bool ok = (ii < hi) && d_n >= j;
-			const u64 w = ok ? (cw.apply(wf_n, wp_n) & colmask) : 0ull;
+			const u64 w = ok ? (cand.word(raw_n, ii) & colmask) : 0ull;
 			i_n = base + 64 + lane;
 			i_c = i_n < rclamp ? i_n : rclamp;
 			d_n = died[i_c];
-			wf_n = Wb_in[i_c * GF2_GMAX + gfc];
-			wp_n = Wb_in[i_c * GF2_GMAX + gpc];
+			raw_n = cand.load(i_c);
 			const u64 took = find_absorb(S, w, (int)ii, colmask, lane, me->srow, sparse_mode);
 			chunks++;
 			if (first_nonsrc < 0) {
@@ -607,13 +441,12 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	// Rebuild one basis from the source-row lists fu[idx0 .. idx0+n) (records of units or of groups).  The lists
 	// are short in sparse systems (a few rows each): they are packed into full 64-row chunks before being
 	// absorbed, so a merge costs sum(cnt)/64 absorb steps, not one per list.
-	int *pend = pend_rows[t >> 6];
 	auto merge_lists = [&](FindState &T, int idx0, int n, int *srow_out) {
 		T.bw = 0; T.bc = 0; T.have = 0; T.nslots = 0;
 		int fill = 0;
 		auto absorb_rows = [&](int i) {
 			u64 w = 0;
-			if (i >= 0) w = cw.apply(Wb_in[(i64)i * GF2_GMAX + cw.gf], Wb_in[(i64)i * GF2_GMAX + cw.gp]) & colmask;
+			if (i >= 0) w = cand.word(cand.load(i), i) & colmask;
 			find_absorb(T, w, i, colmask, lane, srow_out, sparse_mode);
 		};
 		for (int v = 0; v < n && T.nslots < full; v++) {
@@ -720,12 +553,10 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 		// multipliers of this source w.r.t. earlier panels of the block: panel gp's is being recorded by this
 		// very launch (take it from the window), older ones are stored rotated (the TRSM wants plain bit order)
 		u64 mv[GF2_GMAX];
-#pragma unroll
-		for (int e = 0; e < GF2_GMAX; e++)      // all loads first
-			mv[e] = (e >= gf) ? 0ull : (e == gp) ? Wb_in[(i64)srow * GF2_GMAX + gpc] : multset[(i64)e * rows + srow];
+		cand.src_mults(srow, gf, mv);
 #pragma unroll
 		for (int e = 0; e < GF2_GMAX; e++)
-			if (e < gf) A->src_mult[lane][e] = (e == gp) ? cw.prev_mult(mv[e]) : rot_fields_rt(upd_T, mv[e], (GF2_IL - rowq(srow)) % GF2_IL);
+			if (e < gf) A->src_mult[lane][e] = mv[e];
 	}
 	// advance the lower bound of alive rows past rows that just died (free when pick == 0)
 	if (pick != 0) {
@@ -752,6 +583,215 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 		if (blk_first_out) *blk_first_out = new_first;     // last panel of a block: row bound for its bulk update
 		GF2_ST(&st->arrive, 0u);
 	}
+}
+
+// ---- one step of the panel path -------------------------------------------------------------
+// Step s of a block (s = 0..gb) is ONE launch that
+//   * narrows panel gp = s-1: every alive row records its multiplier mult_gp[i] = Wb[i][gp] & mask and
+//     XORs the selected reduced pivot rows into its remaining window words (workgroups >= find_wgs,
+//     256 rows each), reading window buffer Wb_in and writing Wb_out, and
+//   * searches panel gf = s for pivots (workgroups < find_wgs, one "unit" per wavefront).
+// The search would need the narrowed word gf of its candidate rows, which other workgroups are only
+// just producing -- so a unit derives it itself from the stable input buffer:
+//   word = Wb_in[i][gf] ^ XOR_{b in Wb_in[i][gp] & mask_gp} P_gp[b][gf]
+// (a few LDS reads per candidate).  Search and narrow step therefore overlap, and a block costs gb+1
+// launches on the critical path instead of 2*gb.  Everything a step reads from global memory was
+// written by earlier launches; what it writes is read by later ones (died[] is the one exception, see
+// GF2_NEVER).
+//
+// Search: every unit scans its own slice of the alive rows and builds a basis with combination
+// tracking; a unit stops as soon as all columns of the panel have pivots.  The LAST unit to finish
+// publishes: it adopts any unit whose basis is complete (dense systems: every unit is after ~70
+// rows), otherwise it merges the units' source rows into one basis.  Publishing = panel record, pivot
+// columns, physical pivot rows, PanelAux (sources, combinations, multipliers of the sources w.r.t.
+// earlier panels of the block), and the sources are marked dead.  The multipliers the sources
+// recorded for earlier panels are zeroed by the NEXT step (the bulk update must skip the block's
+// own sources; this step may still be writing them).
+struct StepLds {
+	u64 Sw[GF2_GMAX][64];     // window words of panel gp's source rows      [word][slot]
+	u64 Pb[GF2_GMAX][64];     // its reduced pivot rows' window words         [word][pivot BIT]
+	u64 Cm[64];               // combination masks                            [pivot k]
+	int Bk[64];               // pivot k -> pivot bit
+};
+
+// Candidate words of the search while panel gp is being narrowed by the same launch.
+struct CandWords {
+	struct Raw { u64 wf, wp; };
+	const u64 *Wb;            // the step's input window buffer
+	const u64 *Pcol;          // LDS: P_gp[bit][word gf]
+	const u64 *multset;       // the block's multiplier sets (for the sources' older multipliers)
+	i64 rows;
+	u64 maskp;                // pivot mask of panel gp (0: nothing to apply)
+	int gf, gp, upd_T;
+	bool narrowing;           // a panel (gp) is being narrowed by the same launch; otherwise gp is a dummy and maskp = 0
+	__device__ __forceinline__ Raw load(i64 row) const
+	{
+		Raw r;
+		r.wf = Wb[row * GF2_GMAX + gf];
+		r.wp = Wb[row * GF2_GMAX + gp];
+		return r;
+	}
+	__device__ __forceinline__ u64 word(const Raw &r, i64) const
+	{
+		u64 wf = r.wf, m = r.wp & maskp;
+		while (m) { const int b = ctz64(m); m &= m - 1; wf ^= Pcol[b]; }
+		return wf;
+	}
+	// panel gp's multiplier is being recorded by this very launch (take it from the window), older ones are
+	// stored rotated for the bulk update (the TRSM wants plain bit order)
+	__device__ __forceinline__ void src_mults(int srow, int gfl, u64 *out) const
+	{
+		u64 mv[GF2_GMAX];
+#pragma unroll
+		for (int e = 0; e < GF2_GMAX; e++)      // all loads first
+			mv[e] = (e >= gfl) ? 0ull : (narrowing && e == gp) ? Wb[(i64)srow * GF2_GMAX + gp] : multset[(i64)e * rows + srow];
+#pragma unroll
+		for (int e = 0; e < GF2_GMAX; e++)
+			out[e] = (e >= gfl) ? 0ull : (narrowing && e == gp) ? (mv[e] & maskp) : rot_fields_rt(upd_T, mv[e], (GF2_IL - rowq(srow)) % GF2_IL);
+	}
+};
+
+__global__ void __launch_bounds__(256)
+k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, int gb, u64 colmask,
+             const u64 *__restrict__ Wb_in, u64 *__restrict__ Wb_out, SolveState *__restrict__ st,
+             int *__restrict__ died, FindUnit *__restrict__ fu, int units, int find_wgs,
+             PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol,
+             int *__restrict__ urow, u64 *__restrict__ multset, int *__restrict__ blk_first_out, int upd_T,
+             int sparse_mode, SysStride ss)
+{
+	__builtin_amdgcn_s_setprio(3);          // panel path = critical path: win issue arbitration against bulk-update waves
+	{
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		M += blockIdx.y * ss.m_words;
+		Wb_in = sys_at(Wb_in, ao); Wb_out = sys_at(Wb_out, ao); st = sys_at(st, ao); died = sys_at(died, ao);
+		fu = sys_at(fu, ao); panels = sys_at(panels, ao); aux = sys_at(aux, ao); pivcol = sys_at(pivcol, ao);
+		urow = sys_at(urow, ao); multset = sys_at(multset, ao);
+		if (blk_first_out) blk_first_out = sys_at(blk_first_out, ao);
+	}
+	__shared__ StepLds L;
+	__shared__ int pend_rows[4][128];                   // publisher's staging of source-row lists (one per wavefront)
+	const int t = threadIdx.x;
+	const int lane = t & 63;
+	const bool finder = (int)blockIdx.x < find_wgs;
+	const i64 rb = (i64)blockIdx.x - find_wgs;          // narrow role: row block
+
+	// Latency is what this kernel costs, so everything it needs goes out in TWO memory round trips and
+	// without control flow around the loads (indices are clamped instead): trip 1 = panel gp's record,
+	// its source list, the alive bound, this thread's own row / the search slice's start; trip 2 = the
+	// source rows' window words and the first chunk of search candidates.
+	const int gpc = gp >= 0 ? gp : 0;
+	const PanelAux *Ap = aux + j0 + gpc;
+	PanelRec recp = panels[j0 + gpc];
+	i64 bound = Ap->first_after;                        // alive lower bound after panel gp
+	const int e_ = t >> 6, sl = t & 63;                 // 256 threads = 4 words x 64 slots
+	const int sr = Ap->slot_row[sl];
+	const u64 cm = Ap->comb[sl];
+	const int first = st->first, wide = st->wide;       // (search role)
+	if (gp < 0) { recp.p = 0; recp.mask = 0; bound = 0; }
+
+	// narrow role: this thread's row
+	const i64 i = rb * 256 + t;
+	const i64 ic = (!finder && i < rows) ? i : 0;
+	const int my_died = died[ic];
+	const uint4 *src = reinterpret_cast<const uint4 *>(Wb_in + ic * GF2_GMAX);
+	const uint4 my_lo = src[0], my_hi = src[1];
+
+	// search role: this unit's slice and its first chunk
+	const int u = (int)blockIdx.x * 4 + (t >> 6);
+	const int j = j0 + (gf >= 0 ? gf : 0);
+	const int gfc = gf >= 0 ? gf : 0;
+	// Dense panels are complete after ~70 rows, so a handful of units (each covering a long slice it
+	// will not finish) publish sooner than 256 units that all have to be dispatched and collected.
+	// Hard panels (sparse / rank deficient: a unit had to scan far) switch the NEXT panel to all units.
+	// Either way the active units' slices cover every alive row.
+	const int active = wide ? units : (units < GF2_FEW_UNITS ? units : GF2_FEW_UNITS);
+	// EVERY unit takes part in the arrival count, active or not: publication (which rewrites st->first and
+	// st->wide, read above) must not happen while a unit of this launch has yet to start -- a workgroup that
+	// is dispatched late would derive a different `active` from the new values and arrive on the next panel's count.
+	i64 lo = rows, hi = rows;
+	if (finder && u < active) {
+		const i64 n = rows - first;
+		i64 per = n > 0 ? (n + active - 1) / active : 0;
+		per = (per + 63) & ~(i64)63;
+		lo = first + (i64)u * per;
+		hi = (lo + per < rows) ? lo + per : rows;
+	}
+	const i64 rclamp = rows - 1;
+	i64 i_n = lo + lane;
+	i64 i_c = i_n < rclamp ? i_n : rclamp;
+	int d_n = died[i_c];
+	CandWords::Raw raw0;
+	raw0.wf = Wb_in[i_c * GF2_GMAX + gfc];
+	raw0.wp = Wb_in[i_c * GF2_GMAX + gpc];
+
+	// a row block below the bound holds dead rows only (block 0 still stores the pivot rows)
+	const bool dead_block = !finder && rb != 0 && (rb + 1) * 256 <= bound;
+	if (recp.p > 0 && !dead_block) {
+		// reduced pivot rows of panel gp restricted to the window, from its source rows (tiny, every workgroup)
+		const bool use = sl < recp.p && e_ >= gp && e_ < gb;
+		const u64 sw = Wb_in[(i64)(use ? sr : 0) * GF2_GMAX + e_];
+		L.Sw[e_][sl] = use ? sw : 0ull;
+		L.Pb[e_][sl] = 0;
+		if (t < 64) {
+			L.Cm[t] = (t < recp.p) ? cm : 0ull;
+			if ((recp.mask >> t) & 1) L.Bk[__popcll(recp.mask & lanemask_lt(t))] = t;
+		}
+		__syncthreads();
+		if (use) {
+			u64 c = L.Cm[sl], acc = 0;
+			while (c) { int q = ctz64(c); c &= c - 1; acc ^= L.Sw[e_][q]; }
+			L.Pb[e_][L.Bk[sl]] = acc;
+			if (!finder && rb == 0) M[tidx(sr, j0 + e_, srows)] = acc;
+		}
+		__syncthreads();
+	}
+
+	if (!finder) {
+		// ---- narrow panel gp ----
+		const int p = recp.p;
+		u64 *mult = multset + (i64)gp * rows;
+		if (rb == 0 && t < p)                           // the multipliers panel gp's sources recorded for earlier panels
+			for (int e = 0; e < gp; e++) multset[(i64)e * rows + sr] = 0;
+		if (i >= rows) return;
+		u64 m = 0;
+		if (!dead_block && my_died > j0 + gp) {         // alive when panel gp was eliminated
+			u64 w[GF2_GMAX] = { ((u64)my_lo.y << 32) | my_lo.x, ((u64)my_lo.w << 32) | my_lo.z,
+			                    ((u64)my_hi.y << 32) | my_hi.x, ((u64)my_hi.w << 32) | my_hi.z };
+			u64 wp = 0;
+#pragma unroll
+			for (int e = 0; e < GF2_GMAX; e++) if (e == gp) wp = w[e];
+			m = wp & recp.mask;
+			if (m) {
+				u64 acc[GF2_GMAX];
+#pragma unroll
+				for (int e = 0; e < GF2_GMAX; e++) acc[e] = 0;
+				u64 mm = m;
+				while (mm) {
+					const int b = ctz64(mm); mm &= mm - 1;
+#pragma unroll
+					for (int e = 0; e < GF2_GMAX; e++)
+						if (e >= gp) acc[e] ^= L.Pb[e][b];     // words left of the panel are finished (uniform test)
+				}
+#pragma unroll
+				for (int e = 0; e < GF2_GMAX; e++)
+					if (e >= gp && e < gb) w[e] ^= acc[e];
+			}
+			uint4 *dst = reinterpret_cast<uint4 *>(Wb_out + i * GF2_GMAX);
+			dst[0] = make_uint4((unsigned)w[0], (unsigned)(w[0] >> 32), (unsigned)w[1], (unsigned)(w[1] >> 32));
+			dst[1] = make_uint4((unsigned)w[2], (unsigned)(w[2] >> 32), (unsigned)w[3], (unsigned)(w[3] >> 32));
+		}
+		// stored pre-rotated for the bulk update's table layout (field s = what this row reads at step s)
+		mult[i] = rot_fields_rt(upd_T, m, rowq(i));
+		return;
+	}
+
+	// ---- search panel gf ----
+	if (u >= units) return;
+	CandWords cw;
+	cw.Wb = Wb_in; cw.Pcol = &L.Pb[gfc][0]; cw.maskp = recp.mask; cw.gf = gfc; cw.gp = gpc;
+	cw.multset = multset; cw.rows = rows; cw.upd_T = upd_T; cw.narrowing = gp >= 0;
+	search_panel(cw, raw0, d_n, lo, hi, active, u, lane, rows, j, gf, colmask, first, wide, units, st, died, fu,
+	             pend_rows[t >> 6], panels, aux, pivcol, urow, blk_first_out, sparse_mode);
 }
 
 // XOR of the LDS words base[idx(b)] over the set bits b of `bits`, four at a time: the four reads are
