@@ -320,6 +320,24 @@ __device__ __forceinline__ u64 wave_or(u64 v)
 	return ((u64)wave_or32((unsigned)(v >> 32)) << 32) | wave_or32((unsigned)v);
 }
 
+// XOR of the LDS words base[idx(b)] over the set bits b of `bits`, four at a time: the four reads are
+// independent and in flight together (a one-bit-per-iteration loop pays the full LDS latency per bit,
+// and the kernels that use this are nothing but latency).
+template <class IDX>
+__device__ __forceinline__ u64 xor_over_bits(const u64 *base, u64 bits, IDX idx)
+{
+	u64 acc = 0;
+	while (bits) {
+		const int b0 = ctz64(bits); bits &= bits - 1;
+		const u64 h1 = bits ? ~0ull : 0ull; const int b1 = bits ? ctz64(bits) : b0; bits &= bits - 1;
+		const u64 h2 = bits ? ~0ull : 0ull; const int b2 = bits ? ctz64(bits) : b0; bits &= bits - 1;
+		const u64 h3 = bits ? ~0ull : 0ull; const int b3 = bits ? ctz64(bits) : b0; bits &= bits - 1;
+		const u64 v0 = base[idx(b0)], v1 = base[idx(b1)], v2 = base[idx(b2)], v3 = base[idx(b3)];
+		acc ^= v0 ^ (v1 & h1) ^ (v2 & h2) ^ (v3 & h3);
+	}
+	return acc;
+}
+
 // x ^ (v & m), one v_bitop3_b32 (truth table 0x78: bit index {x, v, m})
 __device__ __forceinline__ u64 xor_and64(u64 x, u64 v, unsigned m)
 {
@@ -633,9 +651,7 @@ struct CandWords {
 	}
 	__device__ __forceinline__ u64 word(const Raw &r, i64) const
 	{
-		u64 wf = r.wf, m = r.wp & maskp;
-		while (m) { const int b = ctz64(m); m &= m - 1; wf ^= Pcol[b]; }
-		return wf;
+		return r.wf ^ xor_over_bits(Pcol, r.wp & maskp, [](int b) { return b; });
 	}
 	// panel gp's multiplier is being recorded by this very launch (take it from the window), older ones are
 	// stored rotated for the bulk update (the TRSM wants plain bit order)
@@ -765,13 +781,9 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 				u64 acc[GF2_GMAX];
 #pragma unroll
 				for (int e = 0; e < GF2_GMAX; e++) acc[e] = 0;
-				u64 mm = m;
-				while (mm) {
-					const int b = ctz64(mm); mm &= mm - 1;
 #pragma unroll
-					for (int e = 0; e < GF2_GMAX; e++)
-						if (e >= gp) acc[e] ^= L.Pb[e][b];     // words left of the panel are finished (uniform test)
-				}
+				for (int e = 0; e < GF2_GMAX; e++)
+					if (e >= gp) acc[e] = xor_over_bits(&L.Pb[e][0], m, [](int b) { return b; });    // words left of the panel are finished (uniform test)
 #pragma unroll
 				for (int e = 0; e < GF2_GMAX; e++)
 					if (e >= gp && e < gb) w[e] ^= acc[e];
@@ -792,24 +804,6 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	cw.multset = multset; cw.rows = rows; cw.upd_T = upd_T; cw.narrowing = gp >= 0;
 	search_panel(cw, raw0, d_n, lo, hi, active, u, lane, rows, j, gf, colmask, first, wide, units, st, died, fu,
 	             pend_rows[t >> 6], panels, aux, pivcol, urow, blk_first_out, sparse_mode);
-}
-
-// XOR of the LDS words base[idx(b)] over the set bits b of `bits`, four at a time: the four reads are
-// independent and in flight together (a one-bit-per-iteration loop pays the full LDS latency per bit,
-// and the kernels that use this are nothing but latency).
-template <class IDX>
-__device__ __forceinline__ u64 xor_over_bits(const u64 *base, u64 bits, IDX idx)
-{
-	u64 acc = 0;
-	while (bits) {
-		const int b0 = ctz64(bits); bits &= bits - 1;
-		const u64 h1 = bits ? ~0ull : 0ull; const int b1 = bits ? ctz64(bits) : b0; bits &= bits - 1;
-		const u64 h2 = bits ? ~0ull : 0ull; const int b2 = bits ? ctz64(bits) : b0; bits &= bits - 1;
-		const u64 h3 = bits ? ~0ull : 0ull; const int b3 = bits ? ctz64(bits) : b0; bits &= bits - 1;
-		const u64 v0 = base[idx(b0)], v1 = base[idx(b1)], v2 = base[idx(b2)], v3 = base[idx(b3)];
-		acc ^= v0 ^ (v1 & h1) ^ (v2 & h2) ^ (v3 & h3);
-	}
-	return acc;
 }
 
 // The next block's window, on the panel stream: every row >= blk_first gets block b's update applied to
