@@ -903,11 +903,15 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 #pragma unroll
 		for (int g = 0; g < GF2_GMAX; g++) {
 			u64 m = mrow[g] ? rot_fields_rt(upd_T, mrow[g], unrot) : 0ull;
-			while (m) {
-				const int b = ctz64(m); m &= m - 1;
-				const u64 *pr = &Pbit[(g * 64 + b) * W];
+			while (m) {                                 // two pivot rows (2 x 32 bytes) in flight per step
+				const int b0 = ctz64(m); m &= m - 1;
+				const u64 h1 = m ? ~0ull : 0ull; const int b1 = m ? ctz64(m) : b0; m &= m - 1;
+				const u64 *p0 = &Pbit[(g * 64 + b0) * W], *p1 = &Pbit[(g * 64 + b1) * W];
+				u64 v0[W], v1[W];
 #pragma unroll
-				for (int e = 0; e < W; e++) wv[e] ^= pr[e];
+				for (int e = 0; e < W; e++) { v0[e] = p0[e]; v1[e] = p1[e]; }
+#pragma unroll
+				for (int e = 0; e < W; e++) wv[e] ^= v0[e] ^ (v1[e] & h1);
 			}
 		}
 	}
