@@ -8,6 +8,7 @@
 // There is deliberately NO CPU fallback: without a HIP device every solve entry point
 // returns GF2BV_ERR_NODEVICE.
 #include "gf2_kernels.hip.h"
+#include <hip/hip_ext.h>
 #include "../../include/gf2bv_hip.h"
 
 #include <algorithm>
@@ -194,17 +195,20 @@ Pool &pool()
 struct UpdateImpl {
 	int G, T, lds_bytes, threads;
 	hipError_t (*update)(dim3, hipStream_t, u64 *, i64, i64, int, int, int, const PanelRec *, const PanelAux *,
-	                     const u64 *, const int *, int, int, int, int, int, SysStride);
+	                     const u64 *, const int *, int, int, int, int, int, SysStride, hipEvent_t, hipEvent_t);
 };
 
 template <int G, int T, int NT>
 hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows, int j0, int gb, int wlo,
                          const PanelRec *panels, const PanelAux *aux, const u64 *multset, const int *blk_first,
-                         int tile_begin, int ntiles, int nsplit, int nw_lo, int nw_hi, SysStride ss)
+                         int tile_begin, int ntiles, int nsplit, int nw_lo, int nw_hi, SysStride ss, hipEvent_t begun,
+                         hipEvent_t done)
 {
 	// the tables are static shared memory (see k_update): no dynamic LDS, no attribute to raise
-	k_update<G, T, NT><<<grid, dim3(NT), 0, s>>>(M, rows, srows, j0, gb, wlo, panels, aux, multset, blk_first,
-	                                             tile_begin, ntiles, nsplit, nw_lo, nw_hi, ss);
+	// `begun` / `done` (optional): timing and hand-off events ride on this kernel's own start / completion signals
+	// instead of marker packets around it
+	hipExtLaunchKernelGGL((k_update<G, T, NT>), grid, dim3(NT), 0, s, begun, done, 0, M, rows, srows, j0, gb, wlo, panels, aux,
+	                      multset, blk_first, tile_begin, ntiles, nsplit, nw_lo, nw_hi, ss);
 	return hipGetLastError();
 }
 
@@ -301,6 +305,8 @@ struct Solver {
 	u64 *Wb = nullptr;            // 2 x rows x GMAX window words (the panel steps ping-pong between the halves)
 	u64 *Uwin = nullptr;          // rank x GMAX: pivot rows' words of the following window (k_prio_window -> k_unwind)
 	int units = 0;
+	bool ext_events = true;       // hand-off and timing events ride on kernel start / completion signals (hipExtLaunchKernel)
+	                              // instead of marker packets: ~1 % at every size; GF2BV_EXT_EVENTS=0 restores hipEventRecord
 	int sparse_mode = 2;          // search skips absent columns: 0 never, 1 always, 2 per chunk by density (GF2BV_SPARSE)
 	u64 *Y = nullptr;
 	int *ycols = nullptr;
@@ -312,7 +318,7 @@ struct Solver {
 	i64 wt = 0, cw = 0;
 
 	hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
-	std::vector<hipEvent_t> evA, evPrio, kev;
+	std::vector<hipEvent_t> evA, evPrio, kev, waitPrio;     // waitPrio[b]: the event that means "bulk of block b complete"
 	std::vector<int> free_order;     // free columns in M4RI kernel order (mode 1)
 	// host staging of the export (filled by asynchronous copies between finish_begin and finish_end)
 	SolveState hst{};
@@ -404,6 +410,7 @@ int solver_alloc(Solver &S)
 	S.units = (int)std::min<i64>(256, std::max<i64>(1, (S.rows + 255) / 256));
 	if (const char *e = getenv("GF2BV_UNITS")) { int v = atoi(e); if (v >= 1 && v <= 256) S.units = std::min(S.units, v); }
 	if (const char *e = getenv("GF2BV_DEBUG_SYNC")) S.dbg_sync = atoi(e);
+	if (const char *e = getenv("GF2BV_EXT_EVENTS")) S.ext_events = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_SPARSE")) { int v = atoi(e); if (v >= 0 && v <= 2) S.sparse_mode = v; }
 	if (getenv("GF2BV_SERIAL")) { S.sB = S.sA; S.own_sB = false; }     // ablation: no look-ahead overlap
 	else {
@@ -440,7 +447,7 @@ int solver_alloc(Solver &S)
 	HIPCHK(pool().event(&S.ev1, true));
 	HIPCHK(pool().event(&S.ev2, true));
 	HIPCHK(pool().event(&S.ev3, true));
-	S.evA.resize(S.nblocks); S.evPrio.resize(S.nblocks);
+	S.evA.resize(S.nblocks); S.evPrio.resize(S.nblocks); S.waitPrio.assign(S.nblocks, nullptr);
 	for (int b = 0; b < S.nblocks; b++) {
 		HIPCHK(pool().event(&S.evA[b], false));
 		HIPCHK(pool().event(&S.evPrio[b], false));
@@ -470,20 +477,25 @@ int launch_trsm(Solver &S, hipStream_t st, int j0, int gb, int wlo, int tile_beg
 	return GF2BV_OK;
 }
 
+// Bulk update of block b; *handoff receives the event that means "bulk of block b complete".
 int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wlo, u64 *mset, int tile_begin, int ntiles,
-                        int nw_lo, int nw_hi)
+                        int nw_lo, int nw_hi, hipEvent_t *handoff)
 {
 	hipEvent_t ka = nullptr, kb = nullptr;
 	if (S.time_kernels) {
 		HIPCHK(pool().event(&ka, true)); HIPCHK(pool().event(&kb, true));
 		S.kev.push_back(ka); S.kev.push_back(kb);
-		HIPCHK(hipEventRecord(ka, st));
+		if (!S.ext_events) HIPCHK(hipEventRecord(ka, st));
 	}
 	const i64 est_rows = std::max<i64>(256, S.rows - (i64)j0 * 64);      // alive rows of a dense system (the kernel uses the true bound)
 	const int wgs = pick_update_wgs(est_rows, ntiles, S.nsys);
+	hipEvent_t begun = nullptr, done = nullptr;
+	if (S.ext_events) { begun = ka; done = S.time_kernels ? kb : S.evPrio[b]; }
 	HIPCHK(S.impl->update(dim3((unsigned)wgs, S.nsys), st, S.M, S.rows, S.srows, j0, gb, wlo, S.panels, S.aux, mset,
-	                      S.blk_first + b, tile_begin, ntiles, 0, nw_lo, nw_hi, S.ss()));
-	if (S.time_kernels) HIPCHK(hipEventRecord(kb, st));
+	                      S.blk_first + b, tile_begin, ntiles, 0, nw_lo, nw_hi, S.ss(), begun, done));
+	if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, st));
+	if (S.ext_events) *handoff = done;
+	else { HIPCHK(hipEventRecord(S.evPrio[b], st)); *handoff = S.evPrio[b]; }
 	return GF2BV_OK;
 }
 
@@ -520,15 +532,18 @@ int enqueue_forward(Solver &S)
 			const u64 colmask = (S.cols - c0 >= 64) ? ~0ull : ((1ull << (S.cols - c0)) - 1);
 			const int find_wgs = gf >= 0 ? (S.units + 3) / 4 : 0;
 			const unsigned wgs = (unsigned)find_wgs + (gp >= 0 ? row_blocks : 0u);
-			k_panel_step<<<dim3(wgs, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, gp, gf, gb, colmask,
-			                                                       half[s ? (s - 1) & 1 : 0], half[s & 1], S.st, S.died, S.fu, S.units, find_wgs,
-			                                                       S.panels, S.aux, S.pivcol, S.urow, mset,
-			                                                       gf == gb - 1 ? S.blk_first + b : nullptr, S.impl->T, S.sparse_mode, S.ss());
+			// the block's last step carries the hand-off event as its own completion signal (no marker packet)
+			const bool ext = S.ext_events && s == gb && b != S.nblocks - 1;
+			hipExtLaunchKernelGGL(k_panel_step, dim3(wgs, S.nsys), dim3(256), 0, S.sA, nullptr, ext ? S.evA[b] : nullptr, 0,
+			                      S.M, S.rows, S.srows, j0, gp, gf, gb, colmask,
+			                      (const u64 *)half[s ? (s - 1) & 1 : 0], half[s & 1], S.st, S.died, S.fu, S.units, find_wgs,
+			                      S.panels, S.aux, S.pivcol, S.urow, mset,
+			                      gf == gb - 1 ? S.blk_first + b : (int *)nullptr, S.impl->T, S.sparse_mode, S.ss());
 		}
 		if (b == S.nblocks - 1)
 			k_win_scatter<<<dim3((unsigned)((S.rows * gb + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, gb, half[gb & 1], S.died, S.ss());
 		HIPCHK(hipGetLastError());
-		HIPCHK(hipEventRecord(S.evA[b], S.sA));
+		if (!(S.ext_events && b != S.nblocks - 1)) HIPCHK(hipEventRecord(S.evA[b], S.sA));
 		if (S.dbg_sync & 1) HIPCHK(hipDeviceSynchronize());
 		// trailing tiles; the next block's window [wlo, wlo + gnext) sits in the first one or two of them
 		const int tb = wlo / TW;
@@ -539,14 +554,16 @@ int enqueue_forward(Solver &S)
 		if (nt_all > 0) {
 			int rc = launch_trsm(S, S.sB, j0, gb, wlo, tb, nt_all, wlo, wlo + gnext);
 			if (rc) return rc;
-			rc = launch_update_timed(S, S.sB, b, j0, gb, wlo, mset, tb, nt_all, wlo, wlo + gnext);
+			rc = launch_update_timed(S, S.sB, b, j0, gb, wlo, mset, tb, nt_all, wlo, wlo + gnext, &S.waitPrio[b]);
 			if (rc) return rc;
+		} else {
+			HIPCHK(hipEventRecord(S.evPrio[b], S.sB));      // "bulk of block b complete" (nothing to do)
+			S.waitPrio[b] = S.evPrio[b];
 		}
-		HIPCHK(hipEventRecord(S.evPrio[b], S.sB));          // "bulk of block b complete"
 		if (S.dbg_sync & 2) HIPCHK(hipDeviceSynchronize());
 		// ---- stream A: the next block's window (needs the bulk update of block b-1, nothing newer) ----
 		if (b + 1 < S.nblocks) {
-			if (b > 0) HIPCHK(hipStreamWaitEvent(S.sA, S.evPrio[b - 1], 0));
+			if (b > 0) HIPCHK(hipStreamWaitEvent(S.sA, S.waitPrio[b - 1], 0));
 			k_prio_window<<<dim3(row_blocks, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, gb, wlo, std::max(gnext, 1),
 			                                                             S.panels, S.aux, mset, S.blk_first + b, S.Wb, S.Uwin,
 			                                                             S.impl->T, S.ss());
