@@ -95,6 +95,7 @@ struct PanelAux {
 // "died[i] > j-1" answers the same before and after the search has marked its sources.
 #define GF2_NEVER 0x7f7f7f7f
 
+#define GF2_FEW_MISSING 8         // search: at most this many columns without a pivot -> targeted path of find_absorb
 #define GF2_GROUP 16          // units per merge group on hard panels
 #define GF2_MAXGROUPS 16      // 256 units at most
 
@@ -126,6 +127,16 @@ __device__ __forceinline__ u64 readlane64(u64 v, int l)
 	unsigned hi = __builtin_amdgcn_readlane((unsigned)(v >> 32), l);
 	return ((u64)hi << 32) | lo;
 }
+// Lane l (scalar) of three registers takes three scalar values.  (This compiler has no builtin for v_writelane_b32;
+// one scalar register per VALU instruction on this target, so the lane select travels in M0.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"          // "clobber list contains reserved registers: m0" -- that is the point
+__device__ __forceinline__ void writelane3(unsigned &d0, unsigned s0, unsigned &d1, unsigned s1, int &d2, int s2, int l)
+{
+	asm volatile("s_mov_b32 m0, %6\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\tv_writelane_b32 %2, %5, m0"
+	             : "+v"(d0), "+v"(d1), "+v"(d2) : "s"(s0), "s"(s1), "s"(s2), "s"(l) : "m0");
+}
+#pragma clang diagnostic pop
 __device__ __forceinline__ int ctz64(u64 v) { return __ffsll((long long)v) - 1; }
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ u64 lanemask_lt(int lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
@@ -288,11 +299,31 @@ k_win_scatter(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, const u6
 #define GF2_ST(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define GF2_LD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 
+// -DGF2_STEP_PROBE (tools/probe_step.py builds a separate library with it): wall-clock (100 MHz) timestamps of
+// the phases of the panel steps of ONE block, per workgroup and per search unit.  Not compiled into the product.
+#ifdef GF2_STEP_PROBE
+#define GF2_PROBE_WGS 384
+#define GF2_PROBE_UNITS 256
+__device__ int gf2_probe_j0 = -1;                                        // block (first panel index) to record
+__device__ unsigned long long gf2_probe_wg[GF2_GMAX + 1][GF2_PROBE_WGS][4];     // [step][workgroup][entry, params in, P built, end]
+__device__ unsigned long long gf2_probe_un[GF2_GMAX + 1][GF2_PROBE_UNITS][6];   // [step][unit][loop start, loop end, arrived, decided, published, chunks]
+__device__ int gf2_probe_step_now;
+#define GF2_PROBE_WG(k) do { if (probe_on && threadIdx.x == 0 && blockIdx.x < GF2_PROBE_WGS) gf2_probe_wg[probe_step][blockIdx.x][k] = wall_clock64(); } while (0)
+#define GF2_PROBE_UN(k) do { if (gf2_probe_on_u && lane == 0 && u < GF2_PROBE_UNITS) gf2_probe_un[gf2_probe_step_u][u][k] = wall_clock64(); } while (0)
+#define GF2_PROBE_UNV(k, v) do { if (gf2_probe_on_u && lane == 0 && u < GF2_PROBE_UNITS) gf2_probe_un[gf2_probe_step_u][u][k] = (v); } while (0)
+#else
+#define GF2_PROBE_WG(k) do { } while (0)
+#define GF2_PROBE_UN(k) do { } while (0)
+#define GF2_PROBE_UNV(k, v) do { } while (0)
+#endif
+
 // Wave-level Gauss-Jordan state of a search unit: lane b owns the basis vector whose pivot is bit b
 // (bw) together with the slots folded into it (bc).
 struct FindState {
 	u64 bw, bc, have;
 	int nslots;
+	bool colslots;       // slot of a pivot = its column (set by gj_columns); otherwise slots count up in order of discovery
+	int srow;            // colslots: lane b = the source row of pivot column b (stored by the caller at the end)
 };
 
 // Feed 64 candidate words (one per lane; w = 0 for "no candidate") into the basis.
@@ -318,6 +349,22 @@ __device__ __forceinline__ unsigned wave_or32(unsigned x)
 __device__ __forceinline__ u64 wave_or(u64 v)
 {
 	return ((u64)wave_or32((unsigned)(v >> 32)) << 32) | wave_or32((unsigned)v);
+}
+// XOR of a value over the wavefront (same DPP ladder: an inclusive scan inside each row of 16, then the row
+// broadcasts fold the row totals into lane 63 -- every lane counted exactly once).
+__device__ __forceinline__ unsigned wave_xor32(unsigned x)
+{
+	x ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+	x ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+	x ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+	x ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+	x ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+	x ^= (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+	return (unsigned)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ u64 wave_xor(u64 v)
+{
+	return ((u64)wave_xor32((unsigned)(v >> 32)) << 32) | wave_xor32((unsigned)v);
 }
 
 // XOR of the LDS words base[idx(b)] over the set bits b of `bits`, four at a time: the four reads are
@@ -352,6 +399,66 @@ __device__ __forceinline__ unsigned halfbit_mask(u64 x, int bb)
 	return (unsigned)__builtin_amdgcn_sbfe((int)(unsigned)(HI ? (x >> 32) : x), (unsigned)bb, 1u);
 }
 
+// 64 x 64 bit-matrix transpose across the wavefront: lane i holds row i (bit j = column j) on entry, column i
+// (bit j = row j) on return.  Six block-swap stages with the partner lane i ^ k.
+template <int K>
+__device__ __forceinline__ u64 transpose_stage(u64 x, int lane)
+{
+	constexpr u64 mk = K == 32 ? 0x00000000ffffffffull : K == 16 ? 0x0000ffff0000ffffull : K == 8 ? 0x00ff00ff00ff00ffull
+	                 : K == 4 ? 0x0f0f0f0f0f0f0f0full : K == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
+	const unsigned plo = (unsigned)__builtin_amdgcn_ds_bpermute((lane ^ K) << 2, (int)(unsigned)x);
+	const unsigned phi = (unsigned)__builtin_amdgcn_ds_bpermute((lane ^ K) << 2, (int)(unsigned)(x >> 32));
+	const u64 pv = ((u64)phi << 32) | plo;
+	return (lane & K) ? ((x & ~mk) | ((pv >> K) & mk)) : ((x & mk) | ((pv << K) & ~mk));
+}
+__device__ __forceinline__ u64 wave_transpose64(u64 x, int lane)
+{
+	x = transpose_stage<32>(x, lane); x = transpose_stage<16>(x, lane); x = transpose_stage<8>(x, lane);
+	x = transpose_stage<4>(x, lane); x = transpose_stage<2>(x, lane); x = transpose_stage<1>(x, lane);
+	return x;
+}
+
+// The first chunk of a dense panel, column-wise: Gauss-Jordan on the TRANSPOSED 64 x 64 candidate block (lane c =
+// column c, bit r = candidate r), in place.  The row-wise loop of find_absorb needs ~40 instructions and three
+// branches per pivot on one wavefront (ballot -> scalar -> readlane -> masked XORs of the candidate, its
+// combination, and the basis with ITS combinations); here a pivot is: read column b into scalars, pick its first
+// unused row L (scalar ff1), and every lane with bit L XORs the column in -- and because the eliminated column is
+// left in place it IS the combination record (the classic in-place inversion), so nothing else is tracked.
+// Same pivot choice as the row-wise loop (first candidate that still has the bit), hence the same sources.
+// Returns the candidates taken; fills S in column-slot mode (slot of a pivot = its column).
+__device__ __forceinline__ u64 gj_columns(FindState &S, u64 w, int row, int lane)
+{
+	u64 col = wave_transpose64(w, lane);
+	u64 used = 0, have = 0;
+	int Lv = 0;                                             // lane b: the candidate that became pivot of column b
+	for (int b = 0; b < 64; b++) {
+		const u64 v = readlane64(col, b);
+		const u64 a = v & ~used;
+		if (!a) continue;
+		const int L = ctz64(a);                             // scalar
+		used |= 1ull << L; have |= 1ull << b;
+		const u64 vm = v & ~(1ull << L);
+		const unsigned mk = 0u - (unsigned)((col >> L) & 1);
+		col = xor_and64(col, vm, mk);
+		// lane b itself has bit L: put its column back (it keeps recording which rows took the pivot row)
+		unsigned clo = (unsigned)col, chi = (unsigned)(col >> 32);
+		writelane3(clo, (unsigned)v, chi, (unsigned)(v >> 32), Lv, L, b);
+		col = ((u64)chi << 32) | clo;
+	}
+	// row L_b of the tableau: pivot columns = combination (bit b' = the source of pivot b'), others = the reduced row
+	const u64 rows_t = wave_transpose64(col, lane);
+	const u64 x = ((u64)(unsigned)__builtin_amdgcn_ds_bpermute(Lv << 2, (int)(unsigned)(rows_t >> 32)) << 32)
+	            | (unsigned)__builtin_amdgcn_ds_bpermute(Lv << 2, (int)(unsigned)rows_t);
+	const bool piv = (have >> lane) & 1;
+	S.bw = piv ? ((x & ~have) | (1ull << lane)) : 0ull;
+	S.bc = piv ? (x & have) : 0ull;
+	S.have = have;
+	S.nslots = __popcll(have);
+	S.colslots = true;
+	S.srow = __builtin_amdgcn_ds_bpermute(Lv << 2, row);
+	return used;
+}
+
 __device__ __forceinline__ u64 find_absorb(FindState &S, u64 w, int row, u64 colmask, int lane, int *srow_out,
                                            int sparse_mode)
 {
@@ -364,6 +471,36 @@ __device__ __forceinline__ u64 find_absorb(FindState &S, u64 w, int row, u64 col
 	// These loops are the serial core of the search, so every instruction counts: the columns are walked half
 	// by half (the bit test is then ONE v_bfe_i32 giving a 0 / ~0 word) and a conditional XOR is
 	// x ^ (v & mask) in ONE v_bitop3 per dword -- straight-line VALU, no exec juggling.
+	// Nearly complete basis (the second chunk of a dense panel: 64 random rows give 62-63 pivots; every further
+	// chunk of a rank-deficient one): only the few missing columns matter, so the candidates are NOT reduced
+	// (one step per basis vector).  The basis is fully reduced, hence the reduced candidate's bit at a missing
+	// column c is w[c] ^ parity(w & z_c), z_c = the lanes whose basis vector has bit c -- one ballot and a
+	// popcount per missing column; only a row that becomes a pivot is reduced in full, as an XOR over the
+	// wavefront (lane b contributes its vector if the row has bit b).
+	if (S.have && __popcll(colmask & ~S.have) <= GF2_FEW_MISSING) {
+		u64 todo = colmask & ~S.have;
+		int myslot = -1;
+		while (todo) {
+			const int b = uniform(ctz64(todo)); todo &= todo - 1;
+			const u64 z = __ballot((S.bw >> b) & 1);
+			const u64 m = __ballot(((w >> b) ^ (u64)__popcll(w & z)) & 1);
+			if (!m) continue;
+			const int L = uniform(ctz64(m));
+			const u64 wL = readlane64(w, L);
+			const bool mine = (wL >> lane) & 1;                 // lanes without a pivot hold bw = bc = 0
+			const u64 v = wL ^ wave_xor(mine ? S.bw : 0ull);
+			const u64 vc = wave_xor(mine ? S.bc : 0ull) | (1ull << (S.colslots ? b : S.nslots));
+			myslot = (lane == L) ? S.nslots : myslot;
+			if (S.colslots) S.srow = (lane == b) ? __builtin_amdgcn_readlane(row, L) : S.srow;
+			const bool mb = (lane == b) || ((S.bw >> b) & 1);
+			S.bw ^= mb ? v : 0ull; S.bc ^= mb ? vc : 0ull;
+			S.have |= 1ull << b;
+			S.nslots++;
+			took |= 1ull << L;
+		}
+		if (myslot >= 0 && !S.colslots) GF2_ST(srow_out + myslot, row);
+		return took;
+	}
 	const bool sparse = sparse_mode == 1 || (sparse_mode == 2 && __popcll(__ballot(__popcll(w) > 12)) < 16);
 	u64 hv = S.have & (sparse ? wave_or(w) : ~0ull);
 	auto reduce_half = [&](auto hi_tag) {
@@ -430,8 +567,13 @@ __device__ __forceinline__ void search_panel(const Cand &cand, typename Cand::Ra
 	const int full = __popcll(colmask);
 	FindUnit *me = fu + u;
 	FindState S;
-	S.bw = 0; S.bc = 0; S.have = 0; S.nslots = 0;
+	S.bw = 0; S.bc = 0; S.have = 0; S.nslots = 0; S.colslots = false; S.srow = 0;
 	int first_nonsrc = -1, chunks = 0;
+#ifdef GF2_STEP_PROBE
+	const bool gf2_probe_on_u = (j - gf) == gf2_probe_j0 && blockIdx.y == 0;
+	const int gf2_probe_step_u = gf;
+#endif
+	GF2_PROBE_UN(0);
 	if (u < active) {
 		i64 base = lo;
 		// two chunks in flight: the loads of chunk c+1 are issued before chunk c is absorbed
@@ -443,7 +585,16 @@ __device__ __forceinline__ void search_panel(const Cand &cand, typename Cand::Ra
 			i_c = i_n < rclamp ? i_n : rclamp;
 			d_n = died[i_c];
 			raw_n = cand.load(i_c);
-			const u64 took = find_absorb(S, w, (int)ii, colmask, lane, me->srow, sparse_mode);
+			u64 took;
+			// dense first chunk of a full panel: column-wise (gj_columns); kept if it leaves few enough columns for
+			// the targeted path of find_absorb to finish, redone row-wise otherwise
+			bool done = false;
+			if (chunks == 0 && full == 64 && !wide && sparse_mode != 1 && __popcll(__ballot(__popcll(w) > 12)) >= 48) {
+				took = gj_columns(S, w, (int)ii, lane);
+				done = S.nslots >= 64 - GF2_FEW_MISSING;
+				if (!done) { S.bw = 0; S.bc = 0; S.have = 0; S.nslots = 0; S.colslots = false; }
+			}
+			if (!done) took = find_absorb(S, w, (int)ii, colmask, lane, me->srow, sparse_mode);
 			chunks++;
 			if (first_nonsrc < 0) {
 				u64 mk = __ballot(ok) & ~took;
@@ -451,6 +602,12 @@ __device__ __forceinline__ void search_panel(const Cand &cand, typename Cand::Ra
 			}
 		}
 		if (first_nonsrc < 0) first_nonsrc = (int)((base < rows) ? base : rows);   // lower bound
+	}
+	GF2_PROBE_UN(1);
+	GF2_PROBE_UNV(5, (unsigned long long)chunks);
+	if (S.colslots) {                       // slot = column; an incomplete list is packed (the merge reads srow[0 .. cnt))
+		const int k = S.nslots == 64 ? lane : __popcll(S.have & lanemask_lt(lane));
+		if ((S.have >> lane) & 1) GF2_ST(&me->srow[k], S.srow);
 	}
 	GF2_ST(&me->bc[lane], S.bc);
 	if (lane == 0) { GF2_ST(&me->have, S.have); GF2_ST(&me->first_nonsrc, first_nonsrc); GF2_ST(&me->chunks, chunks); GF2_ST(&me->cnt, S.nslots); }
@@ -460,7 +617,7 @@ __device__ __forceinline__ void search_panel(const Cand &cand, typename Cand::Ra
 	// are short in sparse systems (a few rows each): they are packed into full 64-row chunks before being
 	// absorbed, so a merge costs sum(cnt)/64 absorb steps, not one per list.
 	auto merge_lists = [&](FindState &T, int idx0, int n, int *srow_out) {
-		T.bw = 0; T.bc = 0; T.have = 0; T.nslots = 0;
+		T.bw = 0; T.bc = 0; T.have = 0; T.nslots = 0; T.colslots = false; T.srow = 0;
 		int fill = 0;
 		auto absorb_rows = [&](int i) {
 			u64 w = 0;
@@ -523,6 +680,7 @@ __device__ __forceinline__ void search_panel(const Cand &cand, typename Cand::Ra
 	} else {
 		if (lane == 0) old = __hip_atomic_fetch_add(&st->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
+		GF2_PROBE_UN(2);
 		if (old != (unsigned)(units - 1)) return;
 	}
 
@@ -541,6 +699,7 @@ __device__ __forceinline__ void search_panel(const Cand &cand, typename Cand::Ra
 				if (GF2_LD(&fu[idx0 + v].cnt) == full) { pick = idx0 + v; break; }
 	}
 	const int hard = (pick < 0) || ((pick == 0 ? ch0 : GF2_LD(&fu[pick].chunks)) > 8);
+	GF2_PROBE_UN(3);
 	int new_first;
 	int srow;                                   // lane s: row of slot s
 	if (pick >= 0) {
@@ -601,6 +760,7 @@ __device__ __forceinline__ void search_panel(const Cand &cand, typename Cand::Ra
 		if (blk_first_out) *blk_first_out = new_first;     // last panel of a block: row bound for its bulk update
 		GF2_ST(&st->arrive, 0u);
 	}
+	GF2_PROBE_UN(4);
 }
 
 // ---- one step of the panel path -------------------------------------------------------------
@@ -630,13 +790,44 @@ struct StepLds {
 	u64 Pb[GF2_GMAX][64];     // its reduced pivot rows' window words         [word][pivot BIT]
 	u64 Cm[64];               // combination masks                            [pivot k]
 	int Bk[64];               // pivot k -> pivot bit
+	u64 Tn[16 * 16 * GF2_GMAX];   // nibble tables of Pb: [nibble n][value v][word] = XOR of Pb[word][4n + k] over the bits k of v
 };
+
+// XOR of panel gp's reduced pivot rows selected by multiplier m, all window words at once: 16 nibble lookups of
+// 32 bytes with compile-time bit positions (a loop over the set bits of m costs ~12 VALU instructions per bit
+// in ctz / clear-lowest arithmetic on 64-bit lane values, and these kernels are instruction-bound on few waves).
+__device__ __forceinline__ void nibble_rows(const u64 *Tn, u64 m, u64 *acc)
+{
+#pragma unroll
+	for (int e = 0; e < GF2_GMAX; e++) acc[e] = 0;
+#pragma unroll
+	for (int n = 0; n < 16; n++) {
+		const unsigned half = n < 8 ? (unsigned)m : (unsigned)(m >> 32);
+		const unsigned v = (half >> (4 * (n & 7))) & 15u;
+		const uint4 *q = reinterpret_cast<const uint4 *>(Tn + (n * 16 + v) * GF2_GMAX);
+		const uint4 a = q[0], b = q[1];
+		acc[0] ^= ((u64)a.y << 32) | a.x; acc[1] ^= ((u64)a.w << 32) | a.z;
+		acc[2] ^= ((u64)b.y << 32) | b.x; acc[3] ^= ((u64)b.w << 32) | b.z;
+	}
+}
+// ... one window word only
+__device__ __forceinline__ u64 nibble_word(const u64 *Tn, u64 m, int e)
+{
+	u64 acc = 0;
+#pragma unroll
+	for (int n = 0; n < 16; n++) {
+		const unsigned half = n < 8 ? (unsigned)m : (unsigned)(m >> 32);
+		const unsigned v = (half >> (4 * (n & 7))) & 15u;
+		acc ^= Tn[(n * 16 + v) * GF2_GMAX + e];
+	}
+	return acc;
+}
 
 // Candidate words of the search while panel gp is being narrowed by the same launch.
 struct CandWords {
 	struct Raw { u64 wf, wp; };
 	const u64 *Wb;            // the step's input window buffer
-	const u64 *Pcol;          // LDS: P_gp[bit][word gf]
+	const u64 *Tn;            // LDS: nibble tables of P_gp (StepLds::Tn)
 	const u64 *multset;       // the block's multiplier sets (for the sources' older multipliers)
 	i64 rows;
 	u64 maskp;                // pivot mask of panel gp (0: nothing to apply)
@@ -651,7 +842,7 @@ struct CandWords {
 	}
 	__device__ __forceinline__ u64 word(const Raw &r, i64) const
 	{
-		return r.wf ^ xor_over_bits(Pcol, r.wp & maskp, [](int b) { return b; });
+		return maskp ? r.wf ^ nibble_word(Tn, r.wp & maskp, gf) : r.wf;
 	}
 	// panel gp's multiplier is being recorded by this very launch (take it from the window), older ones are
 	// stored rotated for the bulk update (the TRSM wants plain bit order)
@@ -690,6 +881,11 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	const int lane = t & 63;
 	const bool finder = (int)blockIdx.x < find_wgs;
 	const i64 rb = (i64)blockIdx.x - find_wgs;          // narrow role: row block
+#ifdef GF2_STEP_PROBE
+	const bool probe_on = j0 == gf2_probe_j0 && blockIdx.y == 0;
+	const int probe_step = gp + 1;
+#endif
+	GF2_PROBE_WG(0);
 
 	// Latency is what this kernel costs, so everything it needs goes out in TWO memory round trips and
 	// without control flow around the loads (indices are clamped instead): trip 1 = panel gp's record,
@@ -742,6 +938,12 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 
 	// a row block below the bound holds dead rows only (block 0 still stores the pivot rows)
 	const bool dead_block = !finder && rb != 0 && (rb + 1) * 256 <= bound;
+#ifdef GF2_STEP_PROBE
+	if (probe_on && threadIdx.x == 0 && blockIdx.x < GF2_PROBE_WGS) {       // trip 1 and trip 2 have landed
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		gf2_probe_wg[probe_step][blockIdx.x][1] = wall_clock64();
+	}
+#endif
 	if (recp.p > 0 && !dead_block) {
 		// reduced pivot rows of panel gp restricted to the window, from its source rows (tiny, every workgroup)
 		const bool use = sl < recp.p && e_ >= gp && e_ < gb;
@@ -754,13 +956,26 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 		}
 		__syncthreads();
 		if (use) {
-			u64 c = L.Cm[sl], acc = 0;
-			while (c) { int q = ctz64(c); c &= c - 1; acc ^= L.Sw[e_][q]; }
+			const u64 acc = xor_over_bits(&L.Sw[e_][0], L.Cm[sl], [](int q) { return q; });
 			L.Pb[e_][L.Bk[sl]] = acc;
 			if (!finder && rb == 0) M[tidx(sr, j0 + e_, srows)] = acc;
 		}
 		__syncthreads();
+		{
+			const int n = t >> 4, v = t & 15;               // 256 threads = 16 nibbles x 16 values
+			u64 a[GF2_GMAX] = { 0, 0, 0, 0 };
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const u64 on = ((v >> k) & 1) ? ~0ull : 0ull;
+#pragma unroll
+				for (int e = 0; e < GF2_GMAX; e++) a[e] ^= L.Pb[e][4 * n + k] & on;
+			}
+#pragma unroll
+			for (int e = 0; e < GF2_GMAX; e++) L.Tn[(n * 16 + v) * GF2_GMAX + e] = a[e];
+		}
+		__syncthreads();
 	}
+	GF2_PROBE_WG(2);
 
 	if (!finder) {
 		// ---- narrow panel gp ----
@@ -779,14 +994,9 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 			m = wp & recp.mask;
 			if (m) {
 				u64 acc[GF2_GMAX];
+				nibble_rows(L.Tn, m, acc);                  // (words left of the panel / beyond the block: the tables hold zeros)
 #pragma unroll
-				for (int e = 0; e < GF2_GMAX; e++) acc[e] = 0;
-#pragma unroll
-				for (int e = 0; e < GF2_GMAX; e++)
-					if (e >= gp) acc[e] = xor_over_bits(&L.Pb[e][0], m, [](int b) { return b; });    // words left of the panel are finished (uniform test)
-#pragma unroll
-				for (int e = 0; e < GF2_GMAX; e++)
-					if (e >= gp && e < gb) w[e] ^= acc[e];
+				for (int e = 0; e < GF2_GMAX; e++) w[e] ^= acc[e];
 			}
 			uint4 *dst = reinterpret_cast<uint4 *>(Wb_out + i * GF2_GMAX);
 			dst[0] = make_uint4((unsigned)w[0], (unsigned)(w[0] >> 32), (unsigned)w[1], (unsigned)(w[1] >> 32));
@@ -794,13 +1004,14 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 		}
 		// stored pre-rotated for the bulk update's table layout (field s = what this row reads at step s)
 		mult[i] = rot_fields_rt(upd_T, m, rowq(i));
+		GF2_PROBE_WG(3);
 		return;
 	}
 
 	// ---- search panel gf ----
 	if (u >= units) return;
 	CandWords cw;
-	cw.Wb = Wb_in; cw.Pcol = &L.Pb[gfc][0]; cw.maskp = recp.mask; cw.gf = gfc; cw.gp = gpc;
+	cw.Wb = Wb_in; cw.Tn = L.Tn; cw.maskp = recp.mask; cw.gf = gfc; cw.gp = gpc;
 	cw.multset = multset; cw.rows = rows; cw.upd_T = upd_T; cw.narrowing = gp >= 0;
 	search_panel(cw, raw0, d_n, lo, hi, active, u, lane, rows, j, gf, colmask, first, wide, units, st, died, fu,
 	             pend_rows[t >> 6], panels, aux, pivcol, urow, blk_first_out, sparse_mode);

@@ -1239,4 +1239,20 @@ int gf2bv_device_download(int device, void *h_dst, const void *d_src, int64_t by
 	return GF2BV_OK;
 }
 
+#ifdef GF2_STEP_PROBE
+// Probe build only (tools/probe_step.py): choose the block whose panel steps are recorded, fetch the records.
+int gf2bv_probe_set(int j0)
+{
+	HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gf2_probe_j0), &j0, sizeof(int)));
+	return GF2BV_OK;
+}
+int gf2bv_probe_read(unsigned long long *wg, unsigned long long *un)
+{
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpyFromSymbol(wg, HIP_SYMBOL(gf2_probe_wg), sizeof(gf2_probe_wg)));
+	HIPCHK(hipMemcpyFromSymbol(un, HIP_SYMBOL(gf2_probe_un), sizeof(gf2_probe_un)));
+	return GF2BV_OK;
+}
+#endif
+
 }  // extern "C"
