@@ -1175,13 +1175,17 @@ k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int tile_b
 	aux = sys_at(aux, blockIdx.y * ss.arena_bytes);
 	constexpr int NT = 64 * WPW;
 	constexpr int SPLIT = TW / WPW;
+	static_assert(WPW == 4 && NT == 256, "thread <-> table entry mapping below");
 	__shared__ u64 S[GF2_GMAX * 64 * WPW];     // [panel][slot][word]
-	__shared__ u64 P[GF2_GMAX * 64 * WPW];     // [panel][pivot][word]
+	__shared__ u64 Pbit[GF2_GMAX * 64 * WPW];  // [panel][pivot BIT][word], zero where the panel has no pivot
+	__shared__ u64 Tn[16 * 16 * WPW];          // nibble tables of 64 rows: [nibble n][value v][word] = XOR of rows 4n + k over the bits k of v
+	__shared__ int Bk[GF2_GMAX * 64];          // [panel][pivot k] -> pivot bit
 	const i64 tile = tile_begin + blockIdx.x / SPLIT;
 	const int wofs = (blockIdx.x % SPLIT) * WPW;
 	const i64 w0 = tile * TW + wofs;
 	u64 *Mt = M + tile * srows * TW + wofs;    // row r, word w of this workgroup's slice at Mt[r * TW + w]
-	const int r = threadIdx.x / WPW, w = threadIdx.x % WPW;    // one (row, word) item per thread
+	const int t = threadIdx.x;
+	const int r = t / WPW, w = t % WPW;        // one (row, word) item per thread
 	// words [nw_lo, nw_hi) = the next block's window: k_prio_window forms and stores those on the panel stream
 	const bool live = w0 + w >= wlo && !(w0 + w >= nw_lo && w0 + w < nw_hi);
 	// This step is pure latency (the chip is nearly idle while it runs), so all its parameters are fetched in
@@ -1198,31 +1202,58 @@ k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int tile_b
 		comb[g] = aux[j0 + gc].comb[r];
 #pragma unroll
 		for (int e = 0; e < GF2_GMAX; e++) smul[g][e] = (e < g) ? aux[j0 + gc].src_mult[r][e] : 0ull;
-		if (g >= gb) rec[g].p = 0;
+		if (g >= gb) { rec[g].p = 0; rec[g].mask = 0; }
 	}
 #pragma unroll
 	for (int g = 0; g < GF2_GMAX; g++) {
 		const u64 v = Mt[(i64)(r < rec[g].p ? srow[g] : 0) * TW + w];
 		S[(g * 64 + r) * WPW + w] = (r < rec[g].p && live) ? v : 0ull;
+		Pbit[(g * 64 + r) * WPW + w] = 0;
+		if (w == 0 && ((rec[g].mask >> r) & 1)) Bk[g * 64 + __popcll(rec[g].mask & lanemask_lt(r))] = r;
 	}
 	__syncthreads();
+	// The two products of every panel (P = comb x S, S_h ^= mult x P) select rows by the bits of a 64-bit value.
+	// A loop over the set bits spends ~12 VALU instructions per bit on ctz / clear-lowest arithmetic, so the 64
+	// rows are first folded into 16 nibble tables (thread = one entry, all four words) and every product is
+	// then 16 lookups at compile-time bit positions.
+	auto build_tables = [&](const u64 *rows64) {
+		const int n = t >> 4, v = t & 15;
+		u64 a[WPW] = { 0, 0, 0, 0 };
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const u64 on = ((v >> k) & 1) ? ~0ull : 0ull;
+#pragma unroll
+			for (int e = 0; e < WPW; e++) a[e] ^= rows64[(4 * n + k) * WPW + e] & on;
+		}
+#pragma unroll
+		for (int e = 0; e < WPW; e++) Tn[(n * 16 + v) * WPW + e] = a[e];
+	};
+	auto lookup = [&](u64 m) {
+		u64 acc = 0;
+#pragma unroll
+		for (int n = 0; n < 16; n++) {
+			const unsigned half = n < 8 ? (unsigned)m : (unsigned)(m >> 32);
+			acc ^= Tn[(n * 16 + ((half >> (4 * (n & 7))) & 15u)) * WPW + w];
+		}
+		return acc;
+	};
 #pragma unroll
 	for (int g = 0; g < GF2_GMAX; g++) {
 		if (g >= gb) break;
+		build_tables(&S[g * 64 * WPW]);
+		__syncthreads();
 		if (r < rec[g].p) {
-			const u64 acc = xor_over_bits(S, comb[g], [&](int sl) { return (g * 64 + sl) * WPW + w; });
-			P[(g * 64 + r) * WPW + w] = acc;
+			const u64 acc = lookup(comb[g]);
+			Pbit[(g * 64 + Bk[g * 64 + r]) * WPW + w] = acc;
 			if (live) Mt[(i64)srow[g] * TW + w] = acc;
 		}
+		if (g + 1 >= gb) break;
+		__syncthreads();
+		build_tables(&Pbit[g * 64 * WPW]);
 		__syncthreads();
 #pragma unroll
-		for (int h = g + 1; h < GF2_GMAX; h++) {
-			if (h < gb && r < rec[h].p) {
-				const u64 mk = rec[g].mask;
-				S[(h * 64 + r) * WPW + w] ^= xor_over_bits(P, smul[h][g], [&](int b) {
-					return (g * 64 + __popcll(mk & ((1ull << b) - 1))) * WPW + w; });
-			}
-		}
+		for (int h = g + 1; h < GF2_GMAX; h++)
+			if (h < gb && r < rec[h].p) S[(h * 64 + r) * WPW + w] ^= lookup(smul[h][g]);
 		__syncthreads();
 	}
 	(void)NT;

@@ -66,6 +66,9 @@ for b in blocks:
                      f"end {us(w[nar, 3][w[nar, 3] > 0].min()) if (w[nar, 3] > 0).any() else -1:.1f}..{us(w[nar, 3].max()):.1f}; ")
             last = max(last, w[nar, 3].max())
         print(line)
+        if os.environ.get("PROBE_ENTRIES"):
+            ent = np.sort(us(w[on, 0]))
+            print("         entry times (every 16th workgroup, sorted):", " ".join(f"{x:.0f}" for x in ent[::16]))
         if s < G:
             u = un[s]
             act = u[:, 5] > 0
