@@ -1042,9 +1042,11 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 		Wb_out = sys_at(Wb_out, ao); Uwin = sys_at(Uwin, ao);
 	}
 	constexpr int W = GF2_GMAX;
+	static_assert(W == 4, "thread <-> table entry mapping below");
 	__shared__ u64 S[GF2_GMAX * 64 * W];       // [panel][slot][word]
-	__shared__ u64 P[GF2_GMAX * 64 * W];       // [panel][pivot][word]
-	__shared__ u64 Pbit[GF2_GMAX * 64 * W];    // [panel][pivot BIT][word]
+	__shared__ u64 Pbit[GF2_GMAX * 64 * W];    // [panel][pivot BIT][word], zero where the panel has no pivot
+	__shared__ u64 Tn[16 * 16 * W];            // nibble tables of 64 rows (see k_block_trsm)
+	__shared__ int Bk[GF2_GMAX * 64];          // [panel][pivot k] -> pivot bit
 	const int t = threadIdx.x;
 	const int r = t / W, w = t % W;            // TRSM item: (slot / pivot r, window word w)
 	const bool live = w < gnext;
@@ -1080,52 +1082,48 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 			const u64 v = M[tidx(r < rec[g].p ? srow[g] : 0, wlo + (live ? w : 0), srows)];
 			S[(g * 64 + r) * W + w] = (r < rec[g].p && live) ? v : 0ull;
 			Pbit[(g * 64 + r) * W + w] = 0;
+			if (w == 0 && ((rec[g].mask >> r) & 1)) Bk[g * 64 + __popcll(rec[g].mask & lanemask_lt(r))] = r;
 		}
 		__syncthreads();
+		auto build_tables = [&](const u64 *rows64) {
+			const int n = t >> 4, v = t & 15;
+			u64 a[W] = { 0, 0, 0, 0 };
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const u64 on = ((v >> k) & 1) ? ~0ull : 0ull;
+#pragma unroll
+				for (int e = 0; e < W; e++) a[e] ^= rows64[(4 * n + k) * W + e] & on;
+			}
+#pragma unroll
+			for (int e = 0; e < W; e++) Tn[(n * 16 + v) * W + e] = a[e];
+		};
+		const int unrot = (GF2_IL - rowq(ic)) % GF2_IL;     // multipliers are stored rotated for the table kernel
 #pragma unroll
 		for (int g = 0; g < GF2_GMAX; g++) {
 			if (g >= gb) break;
+			build_tables(&S[g * 64 * W]);
+			__syncthreads();
 			if (r < rec[g].p) {
-				const u64 acc = xor_over_bits(S, comb[g], [&](int sl) { return (g * 64 + sl) * W + w; });
-				P[(g * 64 + r) * W + w] = acc;
+				const u64 acc = nibble_word(Tn, comb[g], w);
+				Pbit[(g * 64 + Bk[g * 64 + r]) * W + w] = acc;
 				if (blockIdx.x == 0 && live) Uwin[(i64)(rec[g].start + r) * GF2_GMAX + w] = acc;
 			}
 			__syncthreads();
-			if ((rec[g].mask >> r) & 1)             // thread (r, w) also files pivot bit r under its bit position
-				Pbit[(g * 64 + r) * W + w] = P[(g * 64 + __popcll(rec[g].mask & lanemask_lt(r))) * W + w];
-			int hneed = 0;
+			build_tables(&Pbit[g * 64 * W]);            // serves the later panels' sources AND this workgroup's rows
+			__syncthreads();
 #pragma unroll
-			for (int h = g + 1; h < GF2_GMAX; h++) {
-				if (h < gb && r < rec[h].p) hneed |= 1 << h;
-			}
-			__syncthreads();                            // Pbit[g] complete
+			for (int h = g + 1; h < GF2_GMAX; h++)
+				if (h < gb && r < rec[h].p) S[(h * 64 + r) * W + w] ^= nibble_word(Tn, smul[h][g], w);
+			if (i < rows && mrow[g]) {
+				u64 acc[W];
+				nibble_rows(Tn, rot_fields_rt(upd_T, mrow[g], unrot), acc);
 #pragma unroll
-			for (int h = g + 1; h < GF2_GMAX; h++) {
-				if ((hneed >> h) & 1) {
-					S[(h * 64 + r) * W + w] ^= xor_over_bits(Pbit, smul[h][g], [&](int b) { return (g * 64 + b) * W + w; });
-				}
+				for (int e = 0; e < W; e++) wv[e] ^= acc[e];
 			}
 			__syncthreads();
 		}
 	}
 	if (i >= rows) return;
-	if (anyp) {
-		const int unrot = (GF2_IL - rowq(i)) % GF2_IL;      // multipliers are stored rotated for the table kernel
-#pragma unroll
-		for (int g = 0; g < GF2_GMAX; g++) {
-			u64 m = mrow[g] ? rot_fields_rt(upd_T, mrow[g], unrot) : 0ull;
-			while (m) {                                 // two pivot rows (2 x 32 bytes) in flight per step
-				const int b0 = ctz64(m); m &= m - 1;
-				const u64 h1 = m ? ~0ull : 0ull; const int b1 = m ? ctz64(m) : b0; m &= m - 1;
-				const u64 *p0 = &Pbit[(g * 64 + b0) * W], *p1 = &Pbit[(g * 64 + b1) * W];
-				u64 v0[W], v1[W];
-#pragma unroll
-				for (int e = 0; e < W; e++) { v0[e] = p0[e]; v1[e] = p1[e]; }
-#pragma unroll
-				for (int e = 0; e < W; e++) wv[e] ^= v0[e] ^ (v1[e] & h1);
-			}
-		}
-	}
 #pragma unroll
 	for (int e = 0; e < W; e++)
 		if (e < gnext) Wb_out[i * GF2_GMAX + e] = wv[e];
