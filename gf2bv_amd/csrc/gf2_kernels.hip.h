@@ -307,7 +307,8 @@ k_win_scatter(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, const u6
 __device__ int gf2_probe_j0 = -1;                                        // block (first panel index) to record
 __device__ unsigned long long gf2_probe_wg[GF2_GMAX + 1][GF2_PROBE_WGS][4];     // [step][workgroup][entry, params in, P built, end]
 __device__ unsigned long long gf2_probe_un[GF2_GMAX + 1][GF2_PROBE_UNITS][6];   // [step][unit][loop start, loop end, arrived, decided, published, chunks]
-__device__ int gf2_probe_step_now;
+__device__ unsigned long long gf2_probe_upd[GF2_PROBE_WGS][6];           // k_update of that block: [workgroup][entry, first tables built, end, spans, table time, -]
+__device__ unsigned long long gf2_probe_wave[4][16];                      // k_update: end time of every wavefront of workgroups 8, 72, 136, 200
 #define GF2_PROBE_WG(k) do { if (probe_on && threadIdx.x == 0 && blockIdx.x < GF2_PROBE_WGS) gf2_probe_wg[probe_step][blockIdx.x][k] = wall_clock64(); } while (0)
 #define GF2_PROBE_UN(k) do { if (gf2_probe_on_u && lane == 0 && u < GF2_PROBE_UNITS) gf2_probe_un[gf2_probe_step_u][u][k] = wall_clock64(); } while (0)
 #define GF2_PROBE_UNV(k, v) do { if (gf2_probe_on_u && lane == 0 && u < GF2_PROBE_UNITS) gf2_probe_un[gf2_probe_step_u][u][k] = (v); } while (0)
@@ -1307,10 +1308,16 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	// two VALU instructions per lookup (shift, v_and_or) instead of three
 	__shared__ __attribute__((aligned(256))) uint4 tab[G * SLOTS * 16];
 	__shared__ int prow[G * 64];                    // [G][64] physical row of pivot bit, -1 if none
+	__shared__ uint4 stage[G * 64 * LPR];           // the tile's segment of every pivot row, [panel][pivot bit][lane] (zero: no pivot)
 	const int lr = threadIdx.x % LPR;
 	const int rr = threadIdx.x / LPR;
 	constexpr int RPP = NT / LPR;
 
+#ifdef GF2_STEP_PROBE
+	const bool uprobe = j0 == gf2_probe_j0 && blockIdx.y == 0 && threadIdx.x == 0 && blockIdx.x < GF2_PROBE_WGS;
+	unsigned long long up_t0 = 0, up_tab = 0, up_spans = 0;
+	if (uprobe) { up_t0 = wall_clock64(); gf2_probe_upd[blockIdx.x][0] = up_t0; }
+#endif
 	int anyp = 0;
 	for (int g = 0; g < gb; g++) anyp |= panels[j0 + g].p;
 	if (!anyp) return;                          // a block without pivots changes nothing
@@ -1339,17 +1346,35 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	if (rbeg >= rows) continue;                 // padding at the end of a tile's line
 	const i64 rend = (rbeg + span < rows) ? rbeg + span : rows;
 	if (!first_span) __syncthreads();           // the previous span's rows are done with the tables
+#ifdef GF2_STEP_PROBE
+	unsigned long long up_a = 0;
+	if (uprobe) { up_a = wall_clock64(); if (up_spans == 1) gf2_probe_upd[blockIdx.x][5] = up_a; }
+#endif
 	// ---- tables ----
-	for (int t = threadIdx.x; t < gb * 64; t += NT) {
-		const int g = t >> 6, b = t & 63;
-		const PanelRec rec = panels[j0 + g];
-		prow[t] = ((rec.mask >> b) & 1) ? aux[j0 + g].slot_row[__popcll(rec.mask & ((1ull << b) - 1))] : -1;
+	if (first_span) {                           // which physical row holds pivot bit b of panel g: the same for every tile
+		for (int t = threadIdx.x; t < gb * 64; t += NT) {
+			const int g = t >> 6, b = t & 63;
+			const PanelRec rec = panels[j0 + g];
+			prow[t] = ((rec.mask >> b) & 1) ? aux[j0 + g].slot_row[__popcll(rec.mask & ((1ull << b) - 1))] : -1;
+		}
+		__syncthreads();
 	}
-	__syncthreads();
 	// words below wlo belong to windows the panel path owns: their table slots stay zero
 	const uint4 keep = make_uint4((w0 + 2 * lr >= wlo) ? ~0u : 0u, (w0 + 2 * lr >= wlo) ? ~0u : 0u,
 	                              (w0 + 2 * lr + 1 >= wlo) ? ~0u : 0u, (w0 + 2 * lr + 1 >= wlo) ? ~0u : 0u);
 	const uint4 *Mq = reinterpret_cast<const uint4 *>(M) + tile * srows * LPR;    // this tile's slab, LPR x uint4 per row
+	// The pivot rows' segments come in with ONE load per thread, all in flight together, and the entries are then
+	// combined from LDS.  (A workgroup whose span crosses into the next tile rebuilds its tables while the other
+	// 255 keep HBM saturated: entries that fetched their <= 3 rows one after the other paid the loaded memory
+	// latency 24 times in a row -- measured +325 us on a 420 us pass for those workgroups, i.e. for the launch.)
+	for (int t = threadIdx.x; t < gb * 64 * LPR; t += NT) {
+		const int pr = prow[t / LPR];
+		uint4 v = Mq[(i64)(pr >= 0 ? pr : 0) * LPR + lr];
+		if (pr < 0) v = make_uint4(0, 0, 0, 0);
+		v.x &= keep.x; v.y &= keep.y; v.z &= keep.z; v.w &= keep.w;
+		stage[t] = v;
+	}
+	__syncthreads();
 	// work item e = (panel g, table t, index idx); stage 1: indices with bits only in the low half or
 	// only in the high half of the field come straight from the (L2-resident) pivot rows;
 	// stage 2: low ^ high.
@@ -1374,10 +1399,8 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 				int bits = idx;
 				while (bits) {
 					const int l = __ffs(bits) - 1; bits &= bits - 1;
-					const int pr = prow[g * 64 + F::shift(t) + l];
-					if (pr >= 0) acc = xor4(acc, Mq[(i64)pr * LPR + lr]);
+					acc = xor4(acc, stage[(g * 64 + F::shift(t) + l) * LPR + lr]);
 				}
-				acc.x &= keep.x; acc.y &= keep.y; acc.z &= keep.z; acc.w &= keep.w;
 				tab[at] = acc;
 			} else {
 				if (!mixed) continue;
@@ -1388,6 +1411,9 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		__syncthreads();
 	}
 
+#ifdef GF2_STEP_PROBE
+	if (uprobe) { const unsigned long long now = wall_clock64(); up_tab += now - up_a; if (up_spans++ == 0) gf2_probe_upd[blockIdx.x][1] = now; }
+#endif
 	// ---- stream the rows ----
 	// Per lane: U rows per half-batch; the global loads (multipliers + data) of half-batch h+1 are issued
 	// before half-batch h is computed and stored, so every wavefront always has HBM requests in flight
@@ -1419,11 +1445,12 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	// after issuing the prefetch, and the software pipeline degenerates to load -> wait -> compute.
 	typedef std::integral_constant<bool, true> FastT;
 	typedef std::integral_constant<bool, false> SafeT;
-	auto load_half = [&](auto tag, Half &H, i64 base) {
+	// rows of a half-batch: base + u * rstride + roff (static split: rstride = RPP, roff = rr; dynamic: 16, lane's row)
+	auto load_half = [&](auto tag, Half &H, i64 base, int rstride, int roff) {
 		constexpr bool FAST = decltype(tag)::value;
 #pragma unroll
 		for (int u = 0; u < U; u++) {
-			const i64 row = base + (i64)u * RPP + rr;
+			const i64 row = base + (i64)u * rstride + roff;
 #ifdef GF2_MB_L2               /* tools/microbench_update.hip: keep the row data L2-resident to time the table work alone */
 			H.qx[u] = (int)((row & 1023) * LPR + lr);
 #else
@@ -1432,7 +1459,7 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		}
 #pragma unroll
 		for (int u = 0; u < U; u++) {
-			const i64 row = base + (i64)u * RPP + rr;
+			const i64 row = base + (i64)u * rstride + roff;
 			u64 any = 0;
 #pragma unroll
 			for (int g = 0; g < G; g++) {
@@ -1449,12 +1476,14 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		// unchanged (FAST) or not at all
 #pragma unroll
 		for (int u = 0; u < U; u++)
-			if (FAST || base + (i64)u * RPP + rr < rend) H.d[u] = Mw[H.qx[u]];
+			if (FAST || base + (i64)u * rstride + roff < rend) H.d[u] = Mw[H.qx[u]];
 	};
 	// this lane's two words against the no-write range (only the tile that holds the next window is affected)
 	const bool nw0 = (int)(w0 + 2 * lr) >= nw_lo && (int)(w0 + 2 * lr) < nw_hi;
 	const bool nw1 = (int)(w0 + 2 * lr + 1) >= nw_lo && (int)(w0 + 2 * lr + 1) < nw_hi;
 	const bool nw_tile = (int)w0 < nw_hi && (int)(w0 + TW) > nw_lo;        // uniform per workgroup
+	const bool nw_lanes = ((nw_lo | nw_hi) & 1) == 0;                       // the range covers whole lanes (always for G = 4)
+	const int qdummy = (int)((srows - 1) * LPR + lr);                       // padding row of the slab (rows < srows - 1)
 	auto compute_half = [&](auto tag, Half &H, i64 base) {
 		constexpr bool FAST = decltype(tag)::value;
 #pragma unroll
@@ -1504,7 +1533,10 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 			}
 #endif
 			}
-			if (FAST || !(nw0 | nw1)) Mw[H.qx[u]] = acc;
+			// FAST: a lane whose two words belong to the next window (whole lanes: the range is lane-aligned there)
+			// stores to the slab's padding row instead -- a select on the index, no control flow around the store
+			if (FAST) Mw[nw0 ? qdummy : H.qx[u]] = acc;
+			else if (!(nw0 | nw1)) Mw[H.qx[u]] = acc;
 			else {                                      // the window's tile: 8-byte stores of the words that may be written
 				u64 *dst = reinterpret_cast<u64 *>(Mw + H.qx[u]);
 				if (!nw0) dst[0] = ((u64)acc.y << 32) | acc.x;
@@ -1515,21 +1547,31 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	constexpr i64 STEP = (i64)RPP * U;
 	Half A, B;
 	i64 base = rbeg;
-	load_half(SafeT(), A, base);
-	if (gb == G && !nw_tile)                            // full blocks, ordinary tiles: the branch-free pipeline
+	load_half(SafeT(), A, base, RPP, rr);
+	if (gb == G && (!nw_tile || nw_lanes))              // full blocks: the branch-free pipeline
 		for (; base + 3 * STEP <= rend; base += 2 * STEP) {
-			load_half(FastT(), B, base + STEP);
+			load_half(FastT(), B, base + STEP, RPP, rr);
 			compute_half(FastT(), A, base);
-			load_half(FastT(), A, base + 2 * STEP);
+			load_half(FastT(), A, base + 2 * STEP, RPP, rr);
 			compute_half(FastT(), B, base + STEP);
 		}
+	// (Handing the rows out dynamically, 16 at a time per wavefront from an LDS counter, makes the four wavefronts of
+	// a SIMD finish together -- with this static split they finish at 515 / 570 / 655 / 750 us of a 750 us pass,
+	// oldest first -- but the pass is not shorter: the SIMD is issue-bound whatever the number of waves left.
+	// Same chip, same run: 262144^2 -1 %, 131072^2 +-0, 65536^2 +7 % (the early finishers make room for the panel
+	// kernels).  Not kept.)
 	for (; base < rend; base += 2 * STEP) {                 // the range's tail, the window's tile, partial blocks
-		load_half(SafeT(), B, base + STEP);             // rows >= rend load nothing (on = false)
+		load_half(SafeT(), B, base + STEP, RPP, rr);    // rows >= rend load nothing (on = false)
 		compute_half(SafeT(), A, base);
-		load_half(SafeT(), A, base + 2 * STEP);
+		load_half(SafeT(), A, base + 2 * STEP, RPP, rr);
 		compute_half(SafeT(), B, base + STEP);
 	}
 	}       // spans
+#ifdef GF2_STEP_PROBE
+	if (j0 == gf2_probe_j0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 8 && blockIdx.x < 256)
+		gf2_probe_wave[blockIdx.x >> 6][threadIdx.x >> 6] = wall_clock64();
+	if (uprobe) { gf2_probe_upd[blockIdx.x][2] = wall_clock64(); gf2_probe_upd[blockIdx.x][3] = up_spans; gf2_probe_upd[blockIdx.x][4] = up_tab; }
+#endif
 }
 
 // ==========================================================================================

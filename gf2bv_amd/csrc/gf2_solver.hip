@@ -1244,6 +1244,16 @@ int gf2bv_device_download(int device, void *h_dst, const void *d_src, int64_t by
 int gf2bv_probe_set(int j0)
 {
 	HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gf2_probe_j0), &j0, sizeof(int)));
+	void *p = nullptr;
+	HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(gf2_probe_upd))); HIPCHK(hipMemset(p, 0, sizeof(gf2_probe_upd)));
+	HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(gf2_probe_wg))); HIPCHK(hipMemset(p, 0, sizeof(gf2_probe_wg)));
+	HIPCHK(hipGetSymbolAddress(&p, HIP_SYMBOL(gf2_probe_un))); HIPCHK(hipMemset(p, 0, sizeof(gf2_probe_un)));
+	return GF2BV_OK;
+}
+int gf2bv_probe_read_update(unsigned long long *upd)
+{
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpyFromSymbol(upd, HIP_SYMBOL(gf2_probe_upd), sizeof(gf2_probe_upd)));
 	return GF2BV_OK;
 }
 int gf2bv_probe_read(unsigned long long *wg, unsigned long long *un)

@@ -19,6 +19,25 @@ void run(const char *name, u64 *M, i64 rows, i64 srows, int ntiles, PanelRec *pa
 	double bytes = 2.0 * (double)(rows - 256) * ntiles * GF2_TW * 8;
 	printf("%-10s G=%d T=%2d NT=%4d nsplit=%3d: %.3f ms  %.2f TB/s per pass  (x%d = %.2f TB/s single-panel equivalent)\n", name, G, T, NT, nsplit, ms,
 	       bytes / ms / 1e9, G, G * bytes / ms / 1e9);
+#ifdef GF2_STEP_PROBE      /* per-workgroup durations of one more launch (-DGF2_STEP_PROBE) */
+	{
+		int zero = 0; CK(hipMemcpyToSymbol(HIP_SYMBOL(gf2_probe_j0), &zero, sizeof(int)));
+		launch(); CK(hipDeviceSynchronize());
+		static unsigned long long h[GF2_PROBE_WGS][6];
+		CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(gf2_probe_upd), sizeof(h)));
+		unsigned long long t0 = ~0ull; for (int k = 0; k < 256; k++) if (h[k][0] < t0) t0 = h[k][0];
+		printf("   WG end (us) by index, every 8th:");
+		for (int k = 0; k < 256; k += (getenv("MB_ALL") ? 1 : 8)) printf(" %.0f", (h[k][2] - t0) / 100.0);
+		printf("\n   second span starts at (us), every 8th:");
+		for (int k = 0; k < 256; k += (getenv("MB_ALL") ? 1 : 8)) printf(" %.0f", h[k][5] ? (h[k][5] - t0) / 100.0 : 0.0);
+		static unsigned long long hw[4][16];
+		CK(hipMemcpyFromSymbol(hw, HIP_SYMBOL(gf2_probe_wave), sizeof(hw)));
+		for (int q = 0; q < 4; q++) { printf("\n   wavefront ends of WG %d:", 8 + 64 * q); for (int w = 0; w < 16; w++) printf(" %.0f", (hw[q][w] - t0) / 100.0); }
+		double mean = 0, mx = 0; for (int k = 0; k < 256; k++) { double e = (h[k][2] - t0) / 100.0; mean += e / 256; if (e > mx) mx = e; }
+		printf("\n   mean end %.0f us, last %.0f us\n", mean, mx);
+		int off = -1; CK(hipMemcpyToSymbol(HIP_SYMBOL(gf2_probe_j0), &off, sizeof(int)));
+	}
+#endif
 }
 
 int main(int argc, char **argv)
@@ -48,13 +67,17 @@ int main(int argc, char **argv)
 #endif
 	for (int ns : {16}) {
 #if GF2_TW == 8
+#ifndef GF2_STEP_PROBE
 		run<1, 16, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
 		run<4, 16, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
 		run<1, 12, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
 		run<2, 12, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
 		run<3, 12, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
+#endif
 		run<4, 12, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
+#ifndef GF2_STEP_PROBE
 		run<1, 8, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
+#endif
 #else
 		run<1, 16, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
 		run<2, 16, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);

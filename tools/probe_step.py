@@ -38,6 +38,9 @@ for b in blocks:
     un = np.zeros((G + 1, UNITS, 6), dtype=np.uint64)
     assert lib.gf2bv_probe_read(wg.ctypes.data_as(ctypes.c_void_p), un.ctypes.data_as(ctypes.c_void_p)) == 0
     wg = wg.astype(np.int64); un = un.astype(np.int64)
+    upd = np.zeros((WGS, 6), dtype=np.uint64)
+    assert lib.gf2bv_probe_read_update(upd.ctypes.data_as(ctypes.c_void_p)) == 0
+    upd = upd.astype(np.int64)
     find_wgs = min(256, (n + 255) // 256 + 3) // 4 if n >= 256 else 1
     units = min(256, max(1, (n + 255) // 256)); find_wgs = (units + 3) // 4
     print(f"N={n} block {b} (rank {sol.rank}, eliminate {sol.stats['ms_eliminate']:.1f} ms); times in us from the step's first stamp")
@@ -86,4 +89,16 @@ for b in blocks:
                 last = max(last, u[k, 4])
             print(line)
         tprev_end = last
+    uo = (upd[:, 2] > 0) & (upd[:, 3] > 0)
+    if uo.any():
+        t0 = upd[uo, 0].min()
+        en = np.sort((upd[uo, 2] - t0) / 100.0)
+        print("   end times (every 16th WG, sorted):", " ".join(f"{x:.0f}" for x in en[::16]), f"last {en[-1]:.0f}")
+        byidx = (upd[:, 2] - t0) / 100.0
+        print("   end times by WG index (every 16th):", " ".join(f"{byidx[k]:.0f}" if uo[k] else "-" for k in range(0, 256, 16)))
+        t0 = upd[uo, 0].min()
+        e = (upd[uo, 0] - t0) / 100.0; tb = (upd[uo, 1] - upd[uo, 0]) / 100.0; en = (upd[uo, 2] - t0) / 100.0
+        print(f" k_update of the block: {uo.sum()} WGs, entry {e.min():.1f}..{e.max():.1f} us, first tables after {tb.min():.1f}..{tb.max():.1f} (mean {tb.mean():.1f}), "
+              f"spans {upd[uo, 3].min()}..{upd[uo, 3].max()}, table time per WG mean {upd[uo, 4].mean() / 100.0:.1f} max {upd[uo, 4].max() / 100.0:.1f}, "
+              f"end {en.min():.1f}..{en.max():.1f} (mean {en.mean():.1f})")
 buf.free()
