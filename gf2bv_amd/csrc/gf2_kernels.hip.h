@@ -787,11 +787,13 @@ __device__ __forceinline__ void search_panel(const Cand &cand, typename Cand::Ra
 // recorded for earlier panels are zeroed by the NEXT step (the bulk update must skip the block's
 // own sources; this step may still be writing them).
 struct StepLds {
-	u64 Sw[GF2_GMAX][64];     // window words of panel gp's source rows      [word][slot]
 	u64 Pb[GF2_GMAX][64];     // its reduced pivot rows' window words         [word][pivot BIT]
 	u64 Cm[64];               // combination masks                            [pivot k]
 	int Bk[64];               // pivot k -> pivot bit
 	u64 Tn[16 * 16 * GF2_GMAX];   // nibble tables of Pb: [nibble n][value v][word] = XOR of Pb[word][4n + k] over the bits k of v
+	// window words of panel gp's source rows [word][slot]: dead once Pb is formed, so they live in the tables' space
+	// (the kernel then fits next to a bulk-update workgroup: 160 KiB - 145 KiB)
+	__device__ __forceinline__ u64 *Sw(int e) { return Tn + e * 64; }
 };
 
 // XOR of panel gp's reduced pivot rows selected by multiplier m, all window words at once: 16 nibble lookups of
@@ -949,7 +951,7 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 		// reduced pivot rows of panel gp restricted to the window, from its source rows (tiny, every workgroup)
 		const bool use = sl < recp.p && e_ >= gp && e_ < gb;
 		const u64 sw = Wb_in[(i64)(use ? sr : 0) * GF2_GMAX + e_];
-		L.Sw[e_][sl] = use ? sw : 0ull;
+		L.Sw(e_)[sl] = use ? sw : 0ull;
 		L.Pb[e_][sl] = 0;
 		if (t < 64) {
 			L.Cm[t] = (t < recp.p) ? cm : 0ull;
@@ -957,7 +959,7 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 		}
 		__syncthreads();
 		if (use) {
-			const u64 acc = xor_over_bits(&L.Sw[e_][0], L.Cm[sl], [](int q) { return q; });
+			const u64 acc = xor_over_bits(L.Sw(e_), L.Cm[sl], [](int q) { return q; });
 			L.Pb[e_][L.Bk[sl]] = acc;
 			if (!finder && rb == 0) M[tidx(sr, j0 + e_, srows)] = acc;
 		}
@@ -1044,8 +1046,11 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 	}
 	constexpr int W = GF2_GMAX;
 	static_assert(W == 4, "thread <-> table entry mapping below");
-	__shared__ u64 S[GF2_GMAX * 64 * W];       // [panel][slot][word]
-	__shared__ u64 Pbit[GF2_GMAX * 64 * W];    // [panel][pivot BIT][word], zero where the panel has no pivot
+	// [panel][slot][word] source rows; once panel g's tables are built its slice is dead and takes the pivot rows
+	// BY BIT position ([panel][pivot bit][word], zero where the panel has no pivot) -- 17 KiB in all, so that a
+	// workgroup fits next to a bulk-update workgroup (160 KiB - 145 KiB of LDS)
+	__shared__ u64 S[GF2_GMAX * 64 * W];
+	u64 *const Pbit = S;
 	__shared__ u64 Tn[16 * 16 * W];            // nibble tables of 64 rows (see k_block_trsm)
 	__shared__ int Bk[GF2_GMAX * 64];          // [panel][pivot k] -> pivot bit
 	const int t = threadIdx.x;
@@ -1082,7 +1087,6 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 		for (int g = 0; g < GF2_GMAX; g++) {
 			const u64 v = M[tidx(r < rec[g].p ? srow[g] : 0, wlo + (live ? w : 0), srows)];
 			S[(g * 64 + r) * W + w] = (r < rec[g].p && live) ? v : 0ull;
-			Pbit[(g * 64 + r) * W + w] = 0;
 			if (w == 0 && ((rec[g].mask >> r) & 1)) Bk[g * 64 + __popcll(rec[g].mask & lanemask_lt(r))] = r;
 		}
 		__syncthreads();
@@ -1104,6 +1108,7 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 			if (g >= gb) break;
 			build_tables(&S[g * 64 * W]);
 			__syncthreads();
+			if (!((rec[g].mask >> r) & 1)) Pbit[(g * 64 + r) * W + w] = 0;      // bit r of the panel has no pivot
 			if (r < rec[g].p) {
 				const u64 acc = nibble_word(Tn, comb[g], w);
 				Pbit[(g * 64 + Bk[g * 64 + r]) * W + w] = acc;
@@ -1285,8 +1290,10 @@ struct UpdateCfg {
 	static constexpr int LDS_BYTES = G * SLOTS * 256 + G * 64 * 4;
 };
 
+// (register budget of a 1024-thread workgroup -- 128 VGPRs -- also when launched with fewer threads: a 768-thread
+// instance then leaves a quarter of every SIMD's register file to the panel kernels)
 template <int G, int T, int NT>
-__global__ void __launch_bounds__(NT)
+__global__ void __launch_bounds__(1024)
 k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
          const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
          const u64 *__restrict__ multset, const int *__restrict__ blk_first,

@@ -215,7 +215,12 @@ hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows, 
 #define UPDATE_IMPL(G, T, NT) { G, T, UpdateCfg<G, T>::LDS_BYTES, NT, launch_update<G, T, NT> }
 #if GF2_TW == 8
 const UpdateImpl kUpdates[] = {
-	UPDATE_IMPL(4, 12, 1024),   // default: 4 panels (256 pivots) per pass, 5/6-bit fields: 48 lookups, 128 KiB LDS
+	// default: 4 panels (256 pivots) per pass, 5/6-bit fields: 48 lookups, 128 KiB of tables; 12 wavefronts with the
+	// register budget of 16, so that a quarter of every SIMD's register file (and 15 KiB of LDS) stays free and the
+	// panel steps of the next block run NEXT TO the bulk update instead of queueing for a CU behind it
+	UPDATE_IMPL(4, 12, 768),
+	UPDATE_IMPL(4, 12, 1024),   // 16 wavefronts: the same pass time in isolation (the SIMDs are issue-bound with 3 waves as with 4)
+	UPDATE_IMPL(4, 12, 512),
 	UPDATE_IMPL(4, 16, 1024),   // 4 panels, nibble fields: 64 lookups, 64 KiB
 	UPDATE_IMPL(3, 12, 1024),   // 3 panels, 36 lookups, 96 KiB
 	UPDATE_IMPL(2, 12, 1024),   // 2 panels, 24 lookups, 64 KiB
@@ -242,10 +247,10 @@ const UpdateImpl *pick_update()
 {
 	const UpdateImpl *chosen = &kUpdates[0];
 	if (const char *e = getenv("GF2BV_UPDATE")) {      // "GxT" or "GxTxTHREADS", e.g. 3x16 or 2x16x512
-		int g = 0, t = 0, nt = 1024;
+		int g = 0, t = 0, nt = 0;
 		if (sscanf(e, "%dx%dx%d", &g, &t, &nt) >= 2)
 			for (const UpdateImpl &c : kUpdates)
-				if (c.G == g && c.T == t && c.threads == nt) { chosen = &c; break; }
+				if (c.G == g && c.T == t && (nt == 0 || c.threads == nt)) { chosen = &c; break; }
 	}
 	return chosen;
 }

@@ -75,6 +75,7 @@ int main(int argc, char **argv)
 		run<3, 12, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
 #endif
 		run<4, 12, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
+		run<4, 12, 768>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
 #ifndef GF2_STEP_PROBE
 		run<1, 8, 1024>(name, M, rows, srows, ntiles, panels, aux, mult, blkf, ns);
 #endif
