@@ -1648,32 +1648,64 @@ k_bs_far(const u64 *__restrict__ M, i64 srows, i64 cw, int qa, int qb, const Pan
 	}
 }
 
-__global__ void __launch_bounds__(1024)
-k_bs_near(const u64 *__restrict__ M, i64 srows, i64 cw, int qa, int qb, const PanelRec *__restrict__ panels,
-          const int *__restrict__ urow, const int *__restrict__ pivcol, int ny, u64 *__restrict__ X,
+// The diagonal blocks of U in compact form: Dg[(q * 64 + r) * 16 + j] = word q + 1 + j of the row of pivot r of panel q
+// (0 beyond the panel's pivots / the coefficient words).  One workgroup per panel, the whole chip at once -- the rows
+// are scattered 64-byte segments in HBM, and k_bs_near, ONE workgroup on a serial chain, spent 14 of its 20 us
+// fetching them.
+__global__ void __launch_bounds__(256)
+k_bs_diag(const u64 *__restrict__ M, i64 srows, int npanels, const PanelRec *__restrict__ panels,
+          const int *__restrict__ urow, u64 *__restrict__ Dg)
+{
+	const int q = blockIdx.x, t = threadIdx.x;
+	const int r = t >> 2, q4 = t & 3;
+	const PanelRec rec = panels[q];
+	const bool on = r < rec.p;
+	const int ur0 = urow[on ? rec.start + r : 0];
+	const int ur = on ? ur0 : 0;                    // (urow[] holds nothing meaningful beyond the rank)
+	u64 v[4];
+#pragma unroll
+	for (int m = 0; m < 4; m++) {
+		const int w = q + 1 + 4 * q4 + m;
+		v[m] = M[tidx(ur, w < npanels ? w : q, srows)];
+		if (!on || w >= npanels) v[m] = 0;
+	}
+	uint4 *dst = reinterpret_cast<uint4 *>(Dg + ((i64)q * 64 + r) * 16 + 4 * q4);
+	dst[0] = make_uint4((unsigned)v[0], (unsigned)(v[0] >> 32), (unsigned)v[1], (unsigned)(v[1] >> 32));
+	dst[1] = make_uint4((unsigned)v[2], (unsigned)(v[2] >> 32), (unsigned)v[3], (unsigned)(v[3] >> 32));
+}
+
+__global__ void __launch_bounds__(256)
+k_bs_near(const u64 *__restrict__ Dg, i64 cw, int qa, int qb, const PanelRec *__restrict__ panels,
+          const int *__restrict__ pivcol, int ny, u64 *__restrict__ X,
           const unsigned char *__restrict__ accv, i64 nacc)
 {
-	__shared__ u64 Xn[GF2_BSG];
+	// 256 threads = 64 pivots x 4 lanes, a lane holding FOUR words of its row per panel.  The 16 panel steps are a
+	// serial chain (read the unknowns solved so far, 64 parities, publish 64 new bits): four wavefronts at the
+	// barrier, the row parity by two DPP quad swaps, one LDS atomic per wavefront (its 16 rows' bits ORed across
+	// the wave).
+	__shared__ u64 Xn[GF2_BSG + 4];
 	const int t = threadIdx.x;
-	const int r = t >> 4, idx = t & 15;           // pivot r of a panel, word q+1+idx of its row
+	const int r = t >> 2, q4 = t & 3;             // pivot r of a panel; words q+1 + 4*q4 .. +3 of its row
 	const int nb = qb - qa;
-	u64 uw[GF2_BSG];
-	int kk[GF2_BSG];
+	u64 uw[GF2_BSG][4];
+	int kk[GF2_BSG], pc[GF2_BSG];
+	PanelRec rec[GF2_BSG];
+#pragma unroll
+	for (int i = 0; i < GF2_BSG; i++) rec[i] = panels[qa + (i < nb ? i : 0)];
 #pragma unroll
 	for (int i = 0; i < GF2_BSG; i++) {
-		uw[i] = 0; kk[i] = -1;
-		if (i < nb) {
-			const PanelRec rec = panels[qa + i];
-			if (r < rec.p) {
-				const int k = rec.start + r;
-				kk[i] = k;
-				const int w = qa + i + 1 + idx;
-				if (w < qb) uw[i] = M[tidx(urow[k], w, srows)];
-			}
-		}
+		const uint4 *src = reinterpret_cast<const uint4 *>(Dg + ((i64)(qa + (i < nb ? i : 0)) * 64 + r) * 16 + 4 * q4);
+		const uint4 a = src[0], b = src[1];
+		const bool on = i < nb && r < rec[i].p;
+		const int k = on ? rec[i].start + r : 0;
+		kk[i] = on ? k : -1;
+		pc[i] = pivcol[k] & 63;
+		const u64 x[4] = { ((u64)a.y << 32) | a.x, ((u64)a.w << 32) | a.z, ((u64)b.y << 32) | b.x, ((u64)b.w << 32) | b.z };
+#pragma unroll
+		for (int m = 0; m < 4; m++) uw[i][m] = (on && qa + i + 1 + 4 * q4 + m < qb) ? x[m] : 0ull;     // words from qb on: k_bs_far
 	}
 	for (int v = 0; v < ny; v++) {                   // the diagonal block sits in registers for every right-hand side
-		if (t < GF2_BSG) Xn[t] = 0;
+		if (t < GF2_BSG + 4) Xn[t] = 0;
 		unsigned ac = 0;                             // bit i: parity so far of pivot (panel i, r)
 #pragma unroll
 		for (int i = 0; i < GF2_BSG; i++)
@@ -1682,13 +1714,17 @@ k_bs_near(const u64 *__restrict__ M, i64 srows, i64 cw, int qa, int qb, const Pa
 #pragma unroll
 		for (int i = GF2_BSG - 1; i >= 0; i--) {
 			if (i >= nb) continue;                       // uniform
-			const int xi = i + 1 + idx;
-			const u64 xv = (xi < nb) ? Xn[xi] : 0ull;
-			const int bit = __popcll(uw[i] & xv) & 1;
-			const u64 bal = __ballot(bit);
-			const int rowpar = __popcll((bal >> ((threadIdx.x & 48))) & 0xFFFFull) & 1;   // my row's 16 lanes
-			if (idx == 0 && kk[i] >= 0 && ((rowpar ^ (ac >> i)) & 1))
-				atomicOr(&Xn[i], 1ull << (pivcol[kk[i]] & 63));
+			int par = 0;
+#pragma unroll
+			for (int m = 0; m < 4; m++) {
+				const int xi = i + 1 + 4 * q4 + m;       // (entries nb .. GF2_BSG + 3 of Xn stay zero)
+				if (xi < GF2_BSG + 4) par ^= __popcll(uw[i][m] & Xn[xi]);
+			}
+			par ^= __builtin_amdgcn_update_dpp(0, par, 0xb1, 0xf, 0xf, false);    // quad_perm [1,0,3,2]
+			par ^= __builtin_amdgcn_update_dpp(0, par, 0x4e, 0xf, 0xf, false);    // quad_perm [2,3,0,1]
+			const bool set = q4 == 0 && kk[i] >= 0 && ((par ^ (int)(ac >> i)) & 1);
+			const u64 bits = wave_or(set ? 1ull << pc[i] : 0ull);
+			if ((t & 63) == 0 && bits) atomicOr(&Xn[i], bits);
 			__syncthreads();
 		}
 		if (t < nb) X[(i64)v * cw + qa + t] = Xn[t];

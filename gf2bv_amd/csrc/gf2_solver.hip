@@ -638,12 +638,16 @@ int enqueue_backward_parity(Solver &S, const std::vector<int> &ycols_host)
 	HIPCHK(hipMemsetAsync(S.out, 0, sizeof(u64) * S.ny * cw, S.sA));
 	unsigned char *accv = reinterpret_cast<unsigned char *>(S.mult);     // forward multipliers are dead by now (2*G*8 bytes per row)
 	const i64 nacc = std::max<i64>(1, S.maxr);
+	// the diagonal blocks of U, gathered by the whole chip into compact form for the serial walk of k_bs_near
+	HIPCHK(pool().alloc((void **)&S.Y, sizeof(u64) * 64 * 16 * std::max(1, S.npanels), S.device));
+	if (S.npanels > 0)
+		k_bs_diag<<<dim3(S.npanels), dim3(256), 0, S.sA>>>(S.M, S.srows, S.npanels, S.panels, S.urow, S.Y);
 	for (int qb = S.npanels; qb > 0; qb -= GF2_BSG) {
 		const int qa = std::max(0, qb - GF2_BSG);
 		const int waves = (qb - qa) * 64;
 		k_bs_far<<<dim3((waves + 3) / 4), dim3(256), 0, S.sA>>>(S.M, S.srows, cw, qa, qb, S.panels, S.urow, S.pivcol, S.ycols, S.ny,
 		                                                        S.out, accv, nacc);
-		k_bs_near<<<dim3(1), dim3(1024), 0, S.sA>>>(S.M, S.srows, cw, qa, qb, S.panels, S.urow, S.pivcol, S.ny, S.out, accv, nacc);
+		k_bs_near<<<dim3(1), dim3(256), 0, S.sA>>>(S.Y, cw, qa, qb, S.panels, S.pivcol, S.ny, S.out, accv, nacc);
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(S.ev2, S.sA));
