@@ -610,8 +610,16 @@ __device__ __forceinline__ void search_panel(const Cand &cand, typename Cand::Ra
 		const int k = S.nslots == 64 ? lane : __popcll(S.have & lanemask_lt(lane));
 		if ((S.have >> lane) & 1) GF2_ST(&me->srow[k], S.srow);
 	}
+	// Unit 0 with a complete column-wise result (every dense panel) publishes ITSELF once the others have arrived:
+	// basis, combinations and source rows are in its registers, and what publishing has to fetch (the rank, the
+	// sources' multipliers) is requested before it starts waiting -- two dependent memory round trips fewer on the
+	// critical path of every step than "last arriver reads unit 0's record and publishes it".
+	const bool self = u == 0 && S.colslots && full == 64 && S.nslots == 64 && !(wide && units > GF2_GROUP);
 	GF2_ST(&me->bc[lane], S.bc);
-	if (lane == 0) { GF2_ST(&me->have, S.have); GF2_ST(&me->first_nonsrc, first_nonsrc); GF2_ST(&me->chunks, chunks); GF2_ST(&me->cnt, S.nslots); }
+	if (lane == 0) {
+		GF2_ST(&me->have, S.have); GF2_ST(&me->first_nonsrc, first_nonsrc); GF2_ST(&me->chunks, chunks); GF2_ST(&me->cnt, S.nslots);
+		GF2_ST(&me->pad, self ? 1 : 0);
+	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every store above has left this wave
 
 	// Rebuild one basis from the source-row lists fu[idx0 .. idx0+n) (records of units or of groups).  The lists
@@ -682,27 +690,45 @@ __device__ __forceinline__ void search_panel(const Cand &cand, typename Cand::Ra
 		if (lane == 0) old = __hip_atomic_fetch_add(&st->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		old = (unsigned)__builtin_amdgcn_readfirstlane((int)old);
 		GF2_PROBE_UN(2);
-		if (old != (unsigned)(units - 1)) return;
+		if (!self && old != (unsigned)(units - 1)) return;
 	}
 
+	u64 mv[GF2_GMAX];                           // a source's multipliers w.r.t. the block's earlier panels
+	int r0, pick = -1, hard, new_first;
+	int srow;                                   // lane s: row of slot s
+	if (self) {
+		r0 = st->rank;
+		srow = S.srow;
+		cand.src_mults(srow, gf, mv);
+		// every unit of this launch arrives, active or not, so this ends; bounded all the same (a hang would take the
+		// device with it): on expiry the solve is flagged and reports an internal error
+		if (old != (unsigned)(units - 1) && !GF2_LD(&st->pad[0])) {
+			const unsigned long long t0 = wall_clock64();          // 100 MHz
+			while (GF2_LD(&st->arrive) != (unsigned)units) {
+				__builtin_amdgcn_s_sleep(1);
+				if (wall_clock64() - t0 > 50000000ull) { if (lane == 0) GF2_ST(&st->pad[0], 1); break; }     // 0.5 s
+			}
+		}
+		pick = 0; hard = chunks > 8; new_first = first_nonsrc;
+		GF2_PROBE_UN(3);
+	} else {
 	// ---- last arriver: publish ----
 	// unit 0 scans the lowest rows: adopting it keeps the alive lower bound exact for free.  Its record is
 	// fetched speculatively in one go (the usual case), not field by field after the decision.
 	const int cnt0 = GF2_LD(&fu[0].cnt), ch0 = GF2_LD(&fu[0].chunks), fn0 = GF2_LD(&fu[0].first_nonsrc);
 	const u64 have0 = GF2_LD(&fu[0].have), bc0 = GF2_LD(&fu[0].bc[lane]);
 	const int srow0 = GF2_LD(&fu[0].srow[lane]);
-	const int r0 = st->rank;
-	int pick = -1;                              // index into fu[] of the record adopted, -1: merge
+	const int self0 = GF2_LD(&fu[0].pad);
+	r0 = st->rank;
+	if (idx0 == 0 && cnt0 == full && self0 == 1) return;    // unit 0 publishes its own result
 	if (full > 0) {
 		if (cnt0 == full) pick = 0;
 		else
 			for (int v = 0; v < nlists; v++)
 				if (GF2_LD(&fu[idx0 + v].cnt) == full) { pick = idx0 + v; break; }
 	}
-	const int hard = (pick < 0) || ((pick == 0 ? ch0 : GF2_LD(&fu[pick].chunks)) > 8);
+	hard = (pick < 0) || ((pick == 0 ? ch0 : GF2_LD(&fu[pick].chunks)) > 8);
 	GF2_PROBE_UN(3);
-	int new_first;
-	int srow;                                   // lane s: row of slot s
 	if (pick >= 0) {
 		S.have = (pick == 0) ? have0 : GF2_LD(&fu[pick].have);
 		S.bc = (pick == 0) ? bc0 : GF2_LD(&fu[pick].bc[lane]);
@@ -717,6 +743,7 @@ __device__ __forceinline__ void search_panel(const Cand &cand, typename Cand::Ra
 		srow = GF2_LD(&spare->srow[lane]);
 		new_first = first;
 	}
+	}
 	const int p = S.nslots;
 	PanelAux *A = aux + j;
 	if ((S.have >> lane) & 1) {
@@ -730,8 +757,7 @@ __device__ __forceinline__ void search_panel(const Cand &cand, typename Cand::Ra
 		died[srow] = j;
 		// multipliers of this source w.r.t. earlier panels of the block: panel gp's is being recorded by this
 		// very launch (take it from the window), older ones are stored rotated (the TRSM wants plain bit order)
-		u64 mv[GF2_GMAX];
-		cand.src_mults(srow, gf, mv);
+		if (!self) cand.src_mults(srow, gf, mv);
 #pragma unroll
 		for (int e = 0; e < GF2_GMAX; e++)
 			if (e < gf) A->src_mult[lane][e] = mv[e];

@@ -721,6 +721,8 @@ int finish_end(Solver &S, gf2bv_result **out)
 	HIPCHK(hipStreamSynchronize(S.sB));
 	tr.mark("finish: sync");
 	const SolveState &hst = S.hst;
+	if (hst.pad[0])      // a panel search gave up waiting for the other units of its launch (must not happen)
+		return fail(GF2BV_ERR_HIP, "internal: panel search timed out waiting for its launch");
 	const std::vector<u64> &hout = S.hout;
 	const std::vector<PanelRec> &hp = S.hp;
 	S.hpiv.resize(hst.rank);
