@@ -308,7 +308,7 @@ __device__ int gf2_probe_j0 = -1;                                        // bloc
 __device__ unsigned long long gf2_probe_wg[GF2_GMAX + 1][GF2_PROBE_WGS][4];     // [step][workgroup][entry, params in, P built, end]
 __device__ unsigned long long gf2_probe_un[GF2_GMAX + 1][GF2_PROBE_UNITS][6];   // [step][unit][loop start, loop end, arrived, decided, published, chunks]
 __device__ unsigned long long gf2_probe_upd[GF2_PROBE_WGS][6];           // k_update of that block: [workgroup][entry, first tables built, end, spans, table time, -]
-__device__ unsigned long long gf2_probe_wave[4][16];                      // k_update: end time of every wavefront of workgroups 8, 72, 136, 200
+__device__ unsigned long long gf2_probe_wave[5][16];                      // k_update: end time of every wavefront of workgroups 8, 72, 136, 200
 #define GF2_PROBE_WG(k) do { if (probe_on && threadIdx.x == 0 && blockIdx.x < GF2_PROBE_WGS) gf2_probe_wg[probe_step][blockIdx.x][k] = wall_clock64(); } while (0)
 #define GF2_PROBE_UN(k) do { if (gf2_probe_on_u && lane == 0 && u < GF2_PROBE_UNITS) gf2_probe_un[gf2_probe_step_u][u][k] = wall_clock64(); } while (0)
 #define GF2_PROBE_UNV(k, v) do { if (gf2_probe_on_u && lane == 0 && u < GF2_PROBE_UNITS) gf2_probe_un[gf2_probe_step_u][u][k] = (v); } while (0)
@@ -1396,6 +1396,9 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	const uint4 keep = make_uint4((w0 + 2 * lr >= wlo) ? ~0u : 0u, (w0 + 2 * lr >= wlo) ? ~0u : 0u,
 	                              (w0 + 2 * lr + 1 >= wlo) ? ~0u : 0u, (w0 + 2 * lr + 1 >= wlo) ? ~0u : 0u);
 	const uint4 *Mq = reinterpret_cast<const uint4 *>(M) + tile * srows * LPR;    // this tile's slab, LPR x uint4 per row
+#ifdef GF2_STEP_PROBE
+	if (uprobe && blockIdx.x == 8 && first_span) gf2_probe_wave[4][0] = wall_clock64();
+#endif
 	// The pivot rows' segments come in with ONE load per thread, all in flight together, and the entries are then
 	// combined from LDS.  (A workgroup whose span crosses into the next tile rebuilds its tables while the other
 	// 255 keep HBM saturated: entries that fetched their <= 3 rows one after the other paid the loaded memory
@@ -1408,40 +1411,58 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		stage[t] = v;
 	}
 	__syncthreads();
-	// work item e = (panel g, table t, index idx); stage 1: indices with bits only in the low half or
-	// only in the high half of the field come straight from the (L2-resident) pivot rows;
-	// stage 2: low ^ high.
-	constexpr int EPP = IL * SLOTS;                 // table entries per panel
+#ifdef GF2_STEP_PROBE
+	if (uprobe && blockIdx.x == 8 && first_span) gf2_probe_wave[4][1] = wall_clock64();
+#endif
+	// A table entry is the XOR of the pivot rows selected by its index.  Pass 0: the PURE entries -- index bits only in
+	// the low half or only in the high half of the field -- straight from the staged rows (<= 3 of them); pass 1: the
+	// mixed ones = low ^ high.  Each pass enumerates exactly its own entries, and what an item is (group, table,
+	// index) depends on the thread alone, not on the panel: decoded once, used for every panel.  (The first version
+	// walked all 2048 entries in both passes and decoded each from scratch: 21 iterations of index arithmetic for
+	// 8 us of the 9-13 us a build took; tools/probe_step.py prints the phases.)
 	for (int pass = 0; pass < 2; pass++) {
-		for (int e = rr; e < gb * EPP; e += RPP) {
-			const int g = e / EPP;
-			const int x = e - g * EPP;                // = IL * (groupoff(m) + idx) + part
-			const int part = x % IL, slot = x / IL;
-			int m = 0;
+		int per_panel = 0;                              // entries of this pass per panel
 #pragma unroll
-			for (int q = 1; q < F::NG; q++) if (slot >= F::groupoff(q)) m = q;
-			const int t = IL * m + part;
-			const int idx = slot - F::groupoff(m);
-			const int kl = F::width(t) >> 1;
-			const int lomask = (1 << kl) - 1;
-			const bool mixed = (idx & lomask) && (idx & ~lomask);
-			const int at = (g * SLOTS + slot) * 16 + part * LPR + lr;
-			if (pass == 0) {
-				if (mixed) continue;
-				uint4 acc = make_uint4(0, 0, 0, 0);
-				int bits = idx;
-				while (bits) {
-					const int l = __ffs(bits) - 1; bits &= bits - 1;
-					acc = xor4(acc, stage[(g * 64 + F::shift(t) + l) * LPR + lr]);
+		for (int m = 0; m < F::NG; m++) {
+			const int w = F::width(IL * m), kl = w >> 1, nlo = (1 << kl) - 1, nhi = (1 << (w - kl)) - 1;
+			per_panel += IL * (pass == 0 ? 1 + nlo + nhi : nlo * nhi);
+		}
+		for (int it = threadIdx.x; it < per_panel * LPR; it += NT) {
+			int e = it / LPR;                           // (lane lr = it % LPR = threadIdx.x % LPR)
+			int off = 0, lo = 0, hi = 0, sh = 0;        // tab index of the entry inside a panel, index halves, field position
+#pragma unroll
+			for (int m = 0; m < F::NG; m++) {
+				const int w = F::width(IL * m), kl = w >> 1, nlo = (1 << kl) - 1, nhi = (1 << (w - kl)) - 1;
+				const int cnt = IL * (pass == 0 ? 1 + nlo + nhi : nlo * nhi);
+				if (e >= 0 && e < cnt) {
+					const int k = e / IL, part = e % IL;
+					if (pass == 0) { lo = k <= nlo ? k : 0; hi = k <= nlo ? 0 : (k - nlo) << kl; }
+					else { lo = 1 + k % nlo; hi = (1 + k / nlo) << kl; }
+					off = (F::groupoff(m) + (lo | hi)) * 16 + part * LPR + lr;
+					sh = F::shift(IL * m + part);
 				}
-				tab[at] = acc;
-			} else {
-				if (!mixed) continue;
-				const int base = at - idx * 16;
-				tab[at] = xor4(tab[base + (idx & lomask) * 16], tab[base + (idx & ~lomask) * 16]);
+				e -= cnt;                               // (negative once found)
+			}
+			const int idx = lo | hi;
+			for (int g = 0; g < gb; g++) {
+				if (pass == 0) {
+					uint4 acc = make_uint4(0, 0, 0, 0);
+					int bits = idx;
+					while (bits) {
+						const int l = __ffs(bits) - 1; bits &= bits - 1;
+						acc = xor4(acc, stage[(g * 64 + sh + l) * LPR + lr]);
+					}
+					tab[g * SLOTS * 16 + off] = acc;
+				} else {
+					const int base = g * SLOTS * 16 + off - idx * 16;
+					tab[base + idx * 16] = xor4(tab[base + lo * 16], tab[base + hi * 16]);
+				}
 			}
 		}
 		__syncthreads();
+#ifdef GF2_STEP_PROBE
+		if (uprobe && blockIdx.x == 8 && first_span) gf2_probe_wave[4][2 + pass] = wall_clock64();
+#endif
 	}
 
 #ifdef GF2_STEP_PROBE

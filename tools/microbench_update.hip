@@ -30,7 +30,7 @@ void run(const char *name, u64 *M, i64 rows, i64 srows, int ntiles, PanelRec *pa
 		for (int k = 0; k < 256; k += (getenv("MB_ALL") ? 1 : 8)) printf(" %.0f", (h[k][2] - t0) / 100.0);
 		printf("\n   second span starts at (us), every 8th:");
 		for (int k = 0; k < 256; k += (getenv("MB_ALL") ? 1 : 8)) printf(" %.0f", h[k][5] ? (h[k][5] - t0) / 100.0 : 0.0);
-		static unsigned long long hw[4][16];
+		static unsigned long long hw[5][16];
 		CK(hipMemcpyFromSymbol(hw, HIP_SYMBOL(gf2_probe_wave), sizeof(hw)));
 		for (int q = 0; q < 4; q++) { printf("\n   wavefront ends of WG %d:", 8 + 64 * q); for (int w = 0; w < 16; w++) printf(" %.0f", (hw[q][w] - t0) / 100.0); }
 		double mean = 0, mx = 0; for (int k = 0; k < 256; k++) { double e = (h[k][2] - t0) / 100.0; mean += e / 256; if (e > mx) mx = e; }

@@ -101,4 +101,9 @@ for b in blocks:
         print(f" k_update of the block: {uo.sum()} WGs, entry {e.min():.1f}..{e.max():.1f} us, first tables after {tb.min():.1f}..{tb.max():.1f} (mean {tb.mean():.1f}), "
               f"spans {upd[uo, 3].min()}..{upd[uo, 3].max()}, table time per WG mean {upd[uo, 4].mean() / 100.0:.1f} max {upd[uo, 4].max() / 100.0:.1f}, "
               f"end {en.min():.1f}..{en.max():.1f} (mean {en.mean():.1f})")
+    wv = np.zeros((5, 16), dtype=np.uint64)
+    assert lib.gf2bv_probe_read_wave(wv.ctypes.data_as(ctypes.c_void_p)) == 0
+    wv = wv.astype(np.int64)
+    print(" k_update table build of workgroup 8 (us since its entry): parameters/prow %.1f, pivot rows staged %.1f, pass 0 %.1f, pass 1 %.1f"
+          % tuple((wv[4, k] - upd[8, 0]) / 100.0 for k in range(4)))
 buf.free()
