@@ -71,11 +71,11 @@ def test_update_configurations_agree(monkeypatch):
     eqs = random_system(rng, rows, cols, .5, 2300, True, 0)
     aug = O.eqs_to_aug(eqs, cols)
     want = O.solve_words(aug, rows, cols, 1)
-    for cfg in ("4x12", "4x16", "3x12", "2x12", "2x16", "1x12", "1x16", "1x8"):
+    for cfg in ("4x12", "4x12x1024", "4x12x512", "4x16", "3x12", "2x12", "2x16", "1x12", "1x16", "1x8"):
         monkeypatch.setenv("GF2BV_UPDATE", cfg)
         got = hip.solve_words(aug, rows, cols, 1)
         assert_same(got, want, 1)
-        g, t = (int(v) for v in cfg.split("x"))
+        g, t = (int(v) for v in cfg.split("x")[:2])
         assert (got.stats["panels_per_sweep"], got.stats["tables_per_sweep"]) == (g, g * t)
 
 
