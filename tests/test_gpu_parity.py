@@ -9,7 +9,7 @@ import pytest
 from gf2bv_amd import LinearSystem, _internal, hip, m4ri_solve
 from oracle import gf2_oracle as O
 from tests import harness as H
-from tests.systems import random_system
+from tests.systems import random_system, structured_system
 
 pytestmark = pytest.mark.gpu
 
@@ -77,6 +77,20 @@ def test_update_configurations_agree(monkeypatch):
         assert_same(got, want, 1)
         g, t = (int(v) for v in cfg.split("x")[:2])
         assert (got.stats["panels_per_sweep"], got.stats["tables_per_sweep"]) == (g, g * t)
+
+
+@pytest.mark.parametrize("kind", ["zero_cols", "dup_cols", "dup_head", "dead_head"])
+def test_dense_systems_that_leave_the_fast_search_paths(kind):
+    """Dense candidates send the first chunk of a panel through the column-wise elimination and nearly full bases
+    through the targeted completion; these systems make those paths come up short (missing pivots that never turn
+    up, a first chunk of rank 5, dead and duplicate rows at the head of the scan) so that the fall-backs, the packed
+    incomplete lists and the merges run -- against the oracle, both modes, several sizes (one and several units)."""
+    rng = random.Random(sum(map(ord, kind)))
+    for rows, cols in ((70, 64), (200, 130), (700, 640), (2600, 2500), (5000, 1100)):
+        eqs = structured_system(rng, rows, cols, kind)
+        aug = O.eqs_to_aug(eqs, cols)
+        for mode in (0, 1):
+            assert_same(hip.solve_words(aug, rows, cols, mode), O.solve_words(aug, rows, cols, mode), mode)
 
 
 def test_digits_path_equals_words_path():
