@@ -1267,6 +1267,12 @@ int gf2bv_probe_read_update(unsigned long long *upd)
 	HIPCHK(hipMemcpyFromSymbol(upd, HIP_SYMBOL(gf2_probe_upd), sizeof(gf2_probe_upd)));
 	return GF2BV_OK;
 }
+int gf2bv_probe_read_gj(unsigned long long *w)
+{
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpyFromSymbol(w, HIP_SYMBOL(gf2_probe_gj), sizeof(gf2_probe_gj)));
+	return GF2BV_OK;
+}
 int gf2bv_probe_read_wave(unsigned long long *w)
 {
 	HIPCHK(hipDeviceSynchronize());

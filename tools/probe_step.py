@@ -106,4 +106,9 @@ for b in blocks:
     wv = wv.astype(np.int64)
     print(" k_update table build of workgroup 8 (us since its entry): parameters/prow %.1f, pivot rows staged %.1f, pass 0 %.1f, pass 1 %.1f"
           % tuple((wv[4, k] - upd[8, 0]) / 100.0 for k in range(4)))
+    gj = np.zeros(4, dtype=np.uint64)
+    assert lib.gf2bv_probe_read_gj(gj.ctypes.data_as(ctypes.c_void_p)) == 0
+    gj = gj.astype(np.int64)
+    print(" column-wise first chunk of unit 0 (last panel of the run): transpose in %.2f us, 64 pivots %.2f, transpose back + hand-over %.2f"
+          % ((gj[1] - gj[0]) / 100.0, (gj[2] - gj[1]) / 100.0, (gj[3] - gj[2]) / 100.0))
 buf.free()
