@@ -408,9 +408,19 @@ __device__ __forceinline__ u64 transpose_stage(u64 x, int lane)
 {
 	constexpr u64 mk = K == 32 ? 0x00000000ffffffffull : K == 16 ? 0x0000ffff0000ffffull : K == 8 ? 0x00ff00ff00ff00ffull
 	                 : K == 4 ? 0x0f0f0f0f0f0f0f0full : K == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
-	const unsigned plo = (unsigned)__builtin_amdgcn_ds_bpermute((lane ^ K) << 2, (int)(unsigned)x);
-	const unsigned phi = (unsigned)__builtin_amdgcn_ds_bpermute((lane ^ K) << 2, (int)(unsigned)(x >> 32));
-	const u64 pv = ((u64)phi << 32) | plo;
+	// the partner lane's value: inside a row of 16 lanes by DPP (quad permutes, a rotation by 8, or a shift left for
+	// the lower and a shift right for the upper banks), across rows through the LDS crossbar
+	auto partner = [&](unsigned v) -> unsigned {
+		if (K == 1) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xb1, 0xf, 0xf, false);        // quad_perm [1,0,3,2]
+		if (K == 2) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4e, 0xf, 0xf, false);        // quad_perm [2,3,0,1]
+		if (K == 8) return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);       // row_ror:8
+		if (K == 4) {
+			const int a = __builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xf, 0x5, false);                    // row_shl:4 into banks 0, 2
+			return (unsigned)__builtin_amdgcn_update_dpp(a, (int)v, 0x114, 0xf, 0xa, false);                 // row_shr:4 into banks 1, 3
+		}
+		return (unsigned)__builtin_amdgcn_ds_bpermute((lane ^ K) << 2, (int)v);
+	};
+	const u64 pv = ((u64)partner((unsigned)(x >> 32)) << 32) | partner((unsigned)x);
 	return (lane & K) ? ((x & ~mk) | ((pv >> K) & mk)) : ((x & mk) | ((pv << K) & ~mk));
 }
 __device__ __forceinline__ u64 wave_transpose64(u64 x, int lane)
