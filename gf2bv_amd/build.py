@@ -45,7 +45,7 @@ def build(force: bool = False, verbose: bool = False) -> None:
         subprocess.check_call(cmd)
     ext_src = [os.path.join(CSRC, "_internal.cpp"), hip_src[2]]
     if force or _stale(EXT, ext_src + [HIP_LIB]):
-        cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"],
+        cmd = ["g++", "-O2", "-std=c++17", "-pthread", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"],
                ext_src[0], "-L" + HERE, "-lgf2bv_hip", "-Wl,-rpath,$ORIGIN", "-o", EXT]
         if verbose:
             print(" ".join(cmd))
