@@ -8,9 +8,9 @@ There is no CPU fallback: importing works anywhere, solving needs the GPU.
 """
 from ._internal import AffineSpace, m4ri_solve, mul_bit_quad, to_bits, tuple_where, xor_tuple
 from .bitvec import BitVec
-from .linsys import DimensionTooLargeError, LinearSystem, Zeros
+from .linsys import DimensionTooLargeError, LinearSystem, QuadraticSystem, Zeros
 
 __all__ = [
-    "AffineSpace", "BitVec", "DimensionTooLargeError", "LinearSystem", "Zeros",
+    "AffineSpace", "BitVec", "DimensionTooLargeError", "LinearSystem", "QuadraticSystem", "Zeros",
     "m4ri_solve", "mul_bit_quad", "to_bits", "tuple_where", "xor_tuple",
 ]

@@ -9,7 +9,7 @@ from __future__ import annotations
 
 from typing import Iterable, Optional, Sequence, Union
 
-from ._internal import AffineSpace, m4ri_solve, m4ri_solve_many
+from ._internal import AffineSpace, m4ri_solve, m4ri_solve_many, mul_bit_quad
 from .bitvec import BitVec
 
 Zeros = Sequence[Union[BitVec, int]]
@@ -125,6 +125,99 @@ class LinearSystem:
     def evaluate(self, bv: BitVec, sol: tuple) -> int:
         raw, shift = 0, 0
         for value, width in zip(sol, self._sizes):
+            raw |= value << shift
+            shift += width
+        return bv.evaluate(raw)
+
+
+class QuadraticSystem(LinearSystem):
+    """Quadratic equations over GF(2) by linearisation: on top of the n unknowns of ``sizes`` every product
+    x_i x_j (j < i) is an unknown of its own, n(n-1)/2 of them after the linear ones, and the linearised system
+    goes through the same solve path (e.g. 128 unknowns -> 8256 columns, the NLFSR example).  Solutions whose
+    "product" unknowns do not equal the products of their linear part are filtered out by ``convert_sol``.
+
+    Own restatement of gf2bv/__init__.py:290-408 (same surface: ``gens``, ``mul_bit``, ``bit_assert``,
+    ``convert_sol``, ``solve_one`` = first of ``solve_all``, ``evaluate``, pickling).  One convention of the
+    reference is kept on purpose: ``mul_bit`` combines the constant / linear parts of its operands as
+    ``a & b`` (x_i^2 = x_i), i.e. the constant x linear cross terms are not formed -- callers multiply
+    bits without constant terms (gf2bv/__init__.py:334-338)."""
+
+    def __init__(self, sizes: Iterable[int]):
+        sizes = list(sizes)
+        n = sum(sizes)
+        pairs = n * (n - 1) // 2
+        super().__init__(sizes + [pairs])
+        self._quad_sizes = sizes
+        self._lin_size = n
+        self._quad_size = pairs
+        self._const_lin_mask = (1 << (n + 1)) - 1          # constant bit + the n linear unknowns
+
+    def gens(self):
+        return super().gens()[:-1]                          # the block of product unknowns is internal
+
+    def __reduce__(self):
+        return (self.__class__, (self._quad_sizes,))
+
+    # product of two single-bit expressions, as an equation int over the linearised unknowns
+    def _mul_bit(self, a: int, b: int) -> int:
+        low = (a & self._const_lin_mask) & b
+        # pair (i, j), j < i, sits at bit 1 + n + i(i-1)/2 + j; it is present iff a_i b_j + a_j b_i = 1
+        return mul_bit_quad(self._lin_size, a >> 1, b >> 1, low, self._basis)
+
+    def mul_bit(self, a: BitVec, b: BitVec) -> BitVec:
+        if len(a) != 1 or len(b) != 1:
+            raise ValueError("The inputs should be single bits")
+        return BitVec((self._mul_bit(a._bits[0], b._bits[0]),))
+
+    # "bit a equals v" plus everything that follows from it after multiplying by each unknown
+    def _bit_assert(self, a: int, v: int) -> list:
+        assert v in (0, 1), "Invalid bit"
+        assert a not in (0, 1), "a should not be a constant"
+        assert a >> (self._lin_size + 1) == 0, "Not a linear term"
+        zeros = [a ^ v]
+        for i in range(1, self._lin_size + 1):
+            x = self._basis[i]
+            if x == a:
+                continue
+            zeros.append(self._mul_bit(a, x) ^ (x if v else 0))     # a * x = v * x
+        return zeros
+
+    def bit_assert(self, a: BitVec, v: int) -> Zeros:
+        if len(a) != 1:
+            raise ValueError("The input should be a single bit")
+        return self._bit_assert(a._bits[0], v)
+
+    def _products_match(self, lin: int, quad: int) -> bool:
+        n = self._lin_size
+        for i in range(n):
+            if (lin >> i) & 1:
+                # products with x_i = 1: pairs (i, j) for j < i must repeat the low i bits of lin
+                want = lin & ((1 << i) - 1)
+            else:
+                want = 0
+            if quad & ((1 << i) - 1) != want:
+                return False
+            quad >>= i
+        assert quad == 0, "Invalid quadratic part"
+        return True
+
+    def convert_sol(self, s: int) -> Optional[tuple]:
+        lin = s & ((1 << self._lin_size) - 1)
+        quad = s >> self._lin_size
+        assert quad >> self._quad_size == 0, "Invalid solution"
+        if not self._products_match(lin, quad):
+            return None
+        return self._convert_sol(lin)[:-1]
+
+    def solve_one(self, zeros: Zeros):
+        # the particular solution of the linearised system need not be consistent: take the first one that is
+        for sol in self.solve_all(zeros):
+            return sol
+        return None
+
+    def evaluate(self, bv: BitVec, sol: tuple) -> int:
+        raw, shift = 0, 0
+        for value, width in zip(sol, self._quad_sizes):
             raw |= value << shift
             shift += width
         return bv.evaluate(raw)

@@ -119,6 +119,62 @@ def main():
                       "expect": "solve_one(zeros) == tuple(random.Random(3142).getstate()[1][:-1])",
                       "source": "examples/mt.py:19-54"}
 
+    # QuadraticSystem (gf2bv/__init__.py:290-408): two variables of 3 + 2 bits -> 5 linear + 10 product unknowns.
+    # Expected solutions: brute force over the 32 assignments of the ORIGINAL quadratic equations (no solver involved).
+    q = gf2bv.QuadraticSystem([3, 2])
+    x, y = q.gens()
+    planted = (0b101, 0b10)
+    def val(bv):
+        return q.evaluate(bv, planted)
+    polys = [
+        lambda X, Y: (X[0] & Y[1]) ^ X[2],
+        lambda X, Y: ((X[0] ^ X[1]) & (Y[0] ^ X[2])) ^ Y[1],
+        lambda X, Y: (X[1] & X[2]) ^ (Y[0] & Y[1]) ^ X[0],
+        lambda X, Y: X[1] ^ Y[0],
+    ]
+    def bits(v, n):
+        return [(v >> i) & 1 for i in range(n)]
+    consts = [p_(bits(planted[0], 3), bits(planted[1], 2)) for p_ in polys]
+    zeros = [q.mul_bit(x[0], y[1]) ^ x[2] ^ consts[0],
+             q.mul_bit(x[0] ^ x[1], y[0] ^ x[2]) ^ y[1] ^ consts[1],
+             q.mul_bit(x[1], x[2]) ^ q.mul_bit(y[0], y[1]) ^ x[0] ^ consts[2]]
+    zeros += list(q.bit_assert(x[1] ^ y[0], consts[3]))
+    eqs = padded(q, zeros)
+    sols = sorted([xv, yv] for xv in range(8) for yv in range(4)
+                  if [p_(bits(xv, 3), bits(yv, 2)) for p_ in polys] == consts)
+    out["quadratic"] = {"sizes": [3, 2], "cols": q._cols, "eqs": [hex(e) for e in eqs], "sha256": fingerprint(eqs, q._cols),
+                        "planted": list(planted), "consts": consts,
+                        "expect": {"solutions": sols},
+                        "source": "gf2bv/__init__.py:290-408 (mul_bit, bit_assert); solutions by brute force over the 32 assignments"}
+
+    # examples/nlfsr.py: the linearised equations of the filtered LFSR (first 3000 outputs; fingerprint only)
+    from gf2bv.crypto.lfsr import FibonacciLFSR, GaloisLFSR
+    n_bits, taps, select = 128, 0xD670201BAC7515352A273372B2A95B23, (13, 24, 35, 46, 57)
+    def filt(x0, x1, x2, x3, x4):
+        return (x0 & x1) ^ (x0 & x1 & x3 & x4) ^ x0 ^ x1 ^ x2
+    nl = {}
+    for name, kind, seed in (("galois", GaloisLFSR, 1), ("fibonacci", FibonacciLFSR, 2)):
+        secret = random.Random(seed).getrandbits(n_bits)
+        lfsr = kind(n_bits, taps, secret)
+        stream = []
+        for _ in range(3000):
+            lfsr()
+            stream.append(filt(*[(lfsr.state >> i) & 1 for i in select]))
+        qs = gf2bv.QuadraticSystem([n_bits])
+        (xv,) = qs.gens()
+        sym = kind(n_bits, taps, xv)
+        zs = []
+        for bit in stream:
+            sym()
+            if bit:
+                x0, x1, x2, _, _ = [sym.state[i] for i in select]
+                zs.append(qs.mul_bit(x0, x1) ^ x0 ^ qs.mul_bit(x1, x2) ^ x1 ^ x2 ^ 1)
+        e = qs.get_eqs(zs)
+        nl[name] = {"seed": seed, "outputs": 3000, "equations": len(e), "cols": qs._cols, "sha256": fingerprint(e, qs._cols)}
+    out["nlfsr"] = {"variants": nl, "taps": hex(taps), "select": list(select),
+                    "expect": "solve_all(zeros of 2**14 + 1000 outputs) == [(Random(seed).getrandbits(128),)]",
+                    "source": "examples/nlfsr.py:9-64 with the secret fixed to Random(seed).getrandbits(128)"}
+
     with open(os.path.join(HERE, "golden.json"), "w") as f:
         json.dump(out, f, indent=1)
     shutil.rmtree(tmp, ignore_errors=True)

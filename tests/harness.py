@@ -7,8 +7,8 @@ import json
 import os
 import random
 
-from gf2bv_amd import LinearSystem
-from gf2bv_amd.crypto import MT19937, Xoshiro256starstar
+from gf2bv_amd import LinearSystem, QuadraticSystem
+from gf2bv_amd.crypto import MT19937, FibonacciLFSR, GaloisLFSR, Xoshiro256starstar
 
 GOLDEN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden.json")))
 MT_VARIANTS = ((32, None), (17, None), (9, None), (1, None), (1337, 19968 // 1337 + 10), (137, 19968 // 137 + 60))
@@ -67,3 +67,45 @@ def simple_system(inp=None):
         return lin, list(sym), (0, 0, 0)
     z = magic(*inp)
     return lin, [s ^ v for s, v in zip(sym, z)], z
+
+
+# ---- QuadraticSystem (caller of the same path; gf2bv/__init__.py:290-408, examples/nlfsr.py) ----------------------
+def quadratic_small_system(consts):
+    """The 3 + 2-bit quadratic system of golden.json["quadratic"]: zeros for the given right-hand sides."""
+    q = QuadraticSystem([3, 2])
+    x, y = q.gens()
+    zeros = [q.mul_bit(x[0], y[1]) ^ x[2] ^ consts[0],
+             q.mul_bit(x[0] ^ x[1], y[0] ^ x[2]) ^ y[1] ^ consts[1],
+             q.mul_bit(x[1], x[2]) ^ q.mul_bit(y[0], y[1]) ^ x[0] ^ consts[2]]
+    zeros += list(q.bit_assert(x[1] ^ y[0], consts[3]))
+    return q, zeros
+
+
+NLFSR_BITS, NLFSR_TAPS, NLFSR_SELECT = 128, 0xD670201BAC7515352A273372B2A95B23, (13, 24, 35, 46, 57)
+NLFSR_KINDS = {"galois": (GaloisLFSR, 1), "fibonacci": (FibonacciLFSR, 2)}
+
+
+def nlfsr_filter(x0, x1, x2, x3, x4):
+    return (x0 & x1) ^ (x0 & x1 & x3 & x4) ^ x0 ^ x1 ^ x2
+
+
+def nlfsr_system(name: str, outputs: int):
+    """examples/nlfsr.py with the secret fixed to Random(seed).getrandbits(128): one quadratic (annihilator) equation
+    per output bit 1, linearised.  Returns (QuadraticSystem, zeros, secret)."""
+    kind, seed = NLFSR_KINDS[name]
+    secret = random.Random(seed).getrandbits(NLFSR_BITS)
+    lfsr = kind(NLFSR_BITS, NLFSR_TAPS, secret)
+    stream = []
+    for _ in range(outputs):
+        lfsr()
+        stream.append(nlfsr_filter(*[(lfsr.state >> i) & 1 for i in NLFSR_SELECT]))
+    q = QuadraticSystem([NLFSR_BITS])
+    (x,) = q.gens()
+    sym = kind(NLFSR_BITS, NLFSR_TAPS, x)
+    zeros = []
+    for bit in stream:
+        sym()
+        if bit:
+            x0, x1, x2, _, _ = [sym.state[i] for i in NLFSR_SELECT]
+            zeros.append(q.mul_bit(x0, x1) ^ x0 ^ q.mul_bit(x1, x2) ^ x1 ^ x2 ^ 1)
+    return q, zeros, secret

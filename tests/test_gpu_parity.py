@@ -147,6 +147,27 @@ def test_golden_fixtures_through_linear_system():
     assert space.dimension == 0 and space.basis == ()
 
 
+def test_quadratic_golden_on_the_gpu():
+    """golden.json["quadratic"] through QuadraticSystem.solve_all / solve_one: the brute-force solution set."""
+    e = H.GOLDEN["quadratic"]
+    q, zeros = H.quadratic_small_system(e["consts"])
+    sols = sorted(list(s) for s in q.solve_all(zeros))
+    assert sols == e["expect"]["solutions"]
+    assert list(q.solve_one(zeros)) in e["expect"]["solutions"]
+    raw = q.solve_raw_space(zeros)
+    ref = O.m4ri_solve(H.padded_eqs(q, zeros), q._cols, 1)
+    assert (raw.origin, raw.basis) == (ref.origin, ref.basis)
+
+
+@pytest.mark.parametrize("name", sorted(H.NLFSR_KINDS))
+def test_nlfsr_state_recovery(name):
+    """examples/nlfsr.py:36-64: 2**14 + 1000 outputs of the filtered 128-bit LFSR -> ~8700 linearised equations in
+    8256 unknowns -> the secret state, by solve_all and by solve_one."""
+    q, zeros, secret = H.nlfsr_system(name, 2 ** 14 + 1000)
+    assert list(q.solve_all(zeros)) == [(secret,)]
+    assert q.solve_one(zeros) == (secret,)
+
+
 @pytest.mark.parametrize("bs,samples", H.MT_VARIANTS)
 def test_mt19937_state_recovery(bs, samples):
     """examples/mt.py: all six variants, sol == state of random.Random(3142)."""

@@ -75,3 +75,69 @@ def test_mt19937_kat(bs, samples):
     py = H.MT19937(sol).to_python_random()
     assert all(py.getrandbits(bs) == o for o in out[:50])
     assert random.Random(3142).getrandbits(bs) == out[0]
+
+
+def test_quadratic_golden():
+    """QuadraticSystem (gf2bv/__init__.py:290-408): this repo's restatement builds the reference's equation list bit for
+    bit; the oracle's solution space, filtered by convert_sol, is the brute-force solution set of the quadratic system."""
+    e = G["quadratic"]
+    q, zeros = H.quadratic_small_system(e["consts"])
+    eqs = H.padded_eqs(q, zeros)
+    assert [hex(v) for v in eqs] == e["eqs"] and H.fingerprint(eqs, q._cols) == e["sha256"]
+    assert q._cols == e["cols"] == 5 + 10 and len(q.gens()) == 2
+    sp = O.m4ri_solve(eqs, q._cols, 1)
+    sols = sorted(list(s) for s in (q.convert_sol(raw) for raw in sp) if s is not None)
+    assert sols == e["expect"]["solutions"] and e["planted"] in sols
+    x, y = q.gens()
+    for sol in sols:                    # evaluate() works on the linear part (as in the reference): the asserted linear bit
+        assert q.evaluate(x[1] ^ y[0], tuple(sol)) == e["consts"][3]
+
+
+def test_quadratic_system_semantics():
+    q = H.QuadraticSystem([3, 2])
+    x, y = q.gens()
+    n = 5
+    rng = random.Random(9)
+
+    def value(eq, assign):              # equation int under an assignment of the 5 bits, products filled in
+        quad, pos = 0, 0
+        for i in range(n):
+            for j in range(i):
+                quad |= (((assign >> i) & 1) & ((assign >> j) & 1)) << pos
+                pos += 1
+        return bin(eq & ((((quad << n) | assign) << 1) | 1)).count("1") & 1
+
+    for _ in range(100):                # products of linear forms without constant terms
+        a, b = rng.getrandbits(n) << 1, rng.getrandbits(n) << 1
+        eq = q._mul_bit(a, b)
+        for assign in range(32):
+            assert value(eq, assign) == (bin((a >> 1) & assign).count("1") & bin((b >> 1) & assign).count("1") & 1)
+    with pytest.raises(ValueError):
+        q.mul_bit(x, y[0])
+    with pytest.raises(ValueError):
+        q.bit_assert(x, 1)
+    zs = q.bit_assert(x[0] ^ y[1], 1)
+    assert len(zs) == n + 1 and zs[0] == (x[0] ^ y[1] ^ 1)._bits[0]
+    # convert_sol: consistent product block -> the variables; inconsistent -> None
+    lin = 0b10110
+    quad, pos = 0, 0
+    for i in range(n):
+        for j in range(i):
+            quad |= (((lin >> i) & 1) & ((lin >> j) & 1)) << pos
+            pos += 1
+    assert q.convert_sol(lin | (quad << n)) == (0b110, 0b10)
+    assert q.convert_sol(lin | ((quad ^ 1) << n)) is None
+    import pickle
+    q2 = pickle.loads(pickle.dumps(q))
+    assert isinstance(q2, H.QuadraticSystem) and q2._quad_sizes == [3, 2] and q2._cols == 15
+
+
+@pytest.mark.parametrize("name", sorted(H.NLFSR_KINDS))
+def test_nlfsr_equations_golden(name):
+    """examples/nlfsr.py: the linearised annihilator equations of the first 3000 outputs, as the reference's Python
+    layer builds them (fingerprint)."""
+    v = G["nlfsr"]["variants"][name]
+    q, zeros, _ = H.nlfsr_system(name, v["outputs"])
+    eqs = q.get_eqs(zeros)
+    assert (len(eqs), q._cols) == (v["equations"], v["cols"])
+    assert H.fingerprint(eqs, q._cols) == v["sha256"]
