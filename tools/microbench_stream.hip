@@ -48,9 +48,10 @@ template <typename F> float timeit(F f, int reps = 5)
 	float ms; CK(hipEventElapsedTime(&ms, e0, e1)); return ms / reps;
 }
 
-int main()
+int main(int argc, char **argv)
 {
-	const size_t bytes = (size_t)2 << 30;          // 2 GiB working set (>> 256 MiB infinity cache)
+	// default 2 GiB working set (>> 256 MiB infinity cache); argv[1] = MiB (e.g. 64: resident in the infinity cache)
+	const size_t bytes = argc > 1 ? (size_t)atol(argv[1]) << 20 : (size_t)2 << 30;
 	const size_t n = bytes / 16;
 	uint4 *a, *b; unsigned *o;
 	CK(hipMalloc(&a, bytes)); CK(hipMalloc(&b, bytes)); CK(hipMalloc(&o, 64));
