@@ -1,20 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: GF(2) row-XORs/s + solve wall-time, dense N x N solve_one.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n 65536]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload single|batch] [--n 65536]
 
-One "step" = one complete solve_one of a synthetic dense N x N GF(2) system that is already
-resident in HBM (forward elimination + consistency check + back-substitution + export), through
-the C ABI (gf2bv_solve_device).  Default workload = BASELINE.json configs[1]: 65536 x 65536,
-full rank (seed committed below).  With --gpus N (launched by torch.distributed.run, one rank per
-GPU) every rank solves its own independent systems -- the path shards by system, no data-path
-collective -- and the solutions are gathered once at the end over RCCL ("scaling": "weak").
+Two workloads, both through the C ABI, inputs resident in HBM before the timed region:
 
-Rank 0 prints ONE JSON line (see the contract in the task statement), carrying
-  roofline     : the sweep kernel (dominant): algorithmic bytes (16 B per active word per sweep)
-                 / HIP-event time of the sweep launches, against 8 TB/s HBM
-  cpu_baseline : the CPU oracle (M4RM-style "port", OpenMP) timed on this host on a bounded
-                 sample of the same generator (rank 0, N=1 only)
+  single (default at N = 1; BASELINE.json configs[1]): one "step" = one complete solve_one of a synthetic dense
+      65536 x 65536 full-rank system (tile-major copy + forward elimination + consistency check + back-substitution +
+      export) by gf2bv_solve_device.  The default N = 1 run adds, as extra fields that are never `value`:
+      `target_262144` (the north-star size, 2 steps after 1 warm-up), `batch_throughput` (one GPU's share of configs[3])
+      and `cpu_baseline`.
+  batch  (default at N > 1; BASELINE.json configs[3]): 512 independent 32768 x 32768 systems, sharded in contiguous
+      blocks over the ranks (gf2bv_amd.batch.shard_bounds), every rank solving its block with
+      gf2bv_solve_batch_device (lock-step gangs) -- no collective on the data path -- then ONE all_gather of the
+      fixed-size records [status, rank, origin] (RCCL over xGMI).  One "step" = the whole 512-system job; the total is
+      fixed, so "scaling" is "strong".
+
+Launched for N > 1 as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU).
+Rank 0 prints ONE JSON line carrying
+  roofline     : the bulk-update kernel (dominant): algorithmic bytes (16 B per active word per pass) / HIP-event time
+                 of its launches, against 8 TB/s HBM
+  cpu_baseline : the CPU oracle (M4RM-style "port", OpenMP) timed on this host on a bounded sample (rank 0, N = 1 only)
 torch is plumbing here: device memory, the RCCL gather, barriers.
 """
 from __future__ import annotations
@@ -32,11 +38,12 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402  (first, so its HIP runtime is the one loaded)
 import torch.distributed as dist  # noqa: E402
 
-from gf2bv_amd import hip  # noqa: E402
+from gf2bv_amd import batch, hip  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # synthetic-generator seeds whose N x N matrix has full rank (found with tools/find_full_rank_seed.py)
 FULL_RANK_SEEDS = {65536: 1234, 32768: 1234}
+BATCH_SEED0 = 5000             # system i of the batch workload uses generator seed BATCH_SEED0 + i
 
 
 def parse():
@@ -44,15 +51,21 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=65536, help="system size N (rows = cols)")
+    ap.add_argument("--workload", choices=["auto", "single", "batch"], default="auto",
+                    help="auto = single at N = 1 (configs[1]), batch at N > 1 (configs[3])")
+    ap.add_argument("--n", type=int, default=65536, help="single: system size N (rows = cols)")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-n", type=int, default=65536, help="size of the bounded CPU-baseline sample")
-    ap.add_argument("--batch-systems", type=int, default=16,
-                    help="also time a gang batch of this many independent --batch-n systems (0 = skip); extra field, not `value`")
+    ap.add_argument("--cpu-n", type=int, default=None, help="size of the bounded CPU-baseline sample (default: 65536 single / 32768 batch)")
+    ap.add_argument("--batch-total", type=int, default=512, help="batch: systems in the whole job (sharded over the ranks)")
     ap.add_argument("--batch-n", type=int, default=32768)
+    ap.add_argument("--batch-systems", type=int, default=64,
+                    help="single: also time a gang batch of this many --batch-n systems = one GPU's share of configs[3] "
+                         "(0 = skip); extra field, not `value`")
+    ap.add_argument("--target-n", type=int, default=262144,
+                    help="single: also run the north-star size (1 warm-up + 2 steps) as `target_262144` (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true",
-                    help="do not bracket sweep launches with HIP events (roofline becomes null)")
+                    help="do not bracket bulk-update launches with HIP events (roofline becomes null)")
     return ap.parse_args()
 
 
@@ -97,25 +110,15 @@ def cpu_baseline(n: int, seed: int) -> dict:
     }
 
 
-def batch_throughput(n: int, nsys: int, device: int) -> dict:
-    """BASELINE configs[3] per-GPU share in miniature: nsys independent n x n systems resident in HBM, solved by
-    gf2bv_solve_batch_device (lock-step gangs); every solution checked by the residual kernel."""
-    stride = hip.padded_stride(n)
-    buf = hip.DeviceBuffer(nsys * n * stride * 8, device)
-    for i in range(nsys):
-        hip.synth_device(buf.ptr + i * n * stride * 8, n, n, stride, 5000 + i, device=device)
-    best, sols = None, None
-    for _ in range(2):                                   # first pass warms the allocator
-        t0 = time.perf_counter()
-        sols = hip.solve_batch_device(buf.ptr, nsys, n * stride, n, n, stride, hip.MODE_SINGLE, device)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    bad = sum(hip.residual_device(buf.ptr + i * n * stride * 8, n, n, stride, s.origin, device=device)
-              for i, s in enumerate(sols))
-    xors = float(sum(s.stats["row_xors"] for s in sols))
+def gpu_equals_oracle(cb: dict, m: int, seed: int, device: int) -> bool:
+    """parity gate, second half: the CPU sample solved on the GPU must give the oracle's answer word for word"""
+    st2 = hip.padded_stride(m)
+    buf = hip.DeviceBuffer(m * st2 * 8, device)
+    hip.synth_device(buf.ptr, m, m, st2, seed, device=device)
+    g = hip.solve_device(buf.ptr, m, m, st2, hip.MODE_SINGLE, device=device)
     buf.free()
-    return {"n": n, "systems": nsys, "ms_per_system": best / nsys * 1e3, "row_xors_per_s": xors / best,
-            "residual_rows": int(bad), "all_solved": all(s.solved for s in sols)}
+    o_status, o_origin = cb.pop("_status"), cb.pop("_origin")
+    return bool(g.rank == cb["rank"] and g.status == o_status and np.array_equal(g.origin, o_origin))
 
 
 def pmc_traffic(n: int, g: int, t: int):
@@ -125,9 +128,295 @@ def pmc_traffic(n: int, g: int, t: int):
     if not os.path.exists(path):
         return None
     for rec in json.load(open(path)):
-        if rec["n"] == n and rec["G"] == g and rec["T"] == t:
+        if rec["n"] == n and rec["G"] == g and rec["T"] == t and rec.get("current", True):
             return rec["hbm_bytes_per_pass"]
     return None
+
+
+def roofline_block(stats_list, sweep_ms_total: float, n: int, device: int, ceil: dict | None, note: str | None = None):
+    """`stats_list`: the gf2bv_stats of the solves whose bulk-update launches took `sweep_ms_total` (HIP events)."""
+    if sweep_ms_total <= 0:
+        return None
+    s0 = stats_list[0]
+    alg_bytes = 16.0 * float(sum(s["sweep_words"] for s in stats_list))
+    launches = sum(s["n_sweeps"] for s in stats_list)
+    achieved = alg_bytes / (sweep_ms_total * 1e-3) / 1e9
+    g = s0["panels_per_sweep"]
+    t = s0["tables_per_sweep"] // g
+    out = {
+        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, g, t),
+        "kernel": f"k_update<G={g},T={t}> (bulk update, {g} panels = {64 * g} pivots per pass)",
+        "alg_bytes_total": alg_bytes, "kernel_ms_total": sweep_ms_total,
+        # one pass applies G panels: HBM rate a one-panel-per-pass sweep would need for the same wall time
+        "single_panel_equivalent_GBs": achieved * g,
+    }
+    if ceil:
+        out.update({"measured_rmw_stream_GBs": ceil["rmw_gbs"], "measured_read_stream_GBs": ceil["read_gbs"],
+                    "frac_of_measured_rmw": achieved / ceil["rmw_gbs"]})
+    if note:
+        out["note"] = note
+    return out, launches
+
+
+def timed_single(mat: torch.Tensor, n: int, stride: int, steps: int, warmup: int, device: int, dev, world: int,
+                 kernel_events: bool):
+    """W untimed + K timed solve_one steps of the resident system; returns (elapsed seconds over ranks, stats, sols)."""
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    cw = (n + 63) // 64
+    sols = torch.zeros(steps, cw, dtype=torch.int64, device=dev)
+    stats = []
+
+    def step():
+        return hip.solve_device(mat.data_ptr(), n, n, stride, hip.MODE_SINGLE, device=device, stream=stream,
+                                time_kernels=kernel_events)
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        s = step()
+        stats.append(s)
+        sols[k].copy_(torch.from_numpy(s.origin.view(np.int64)))
+    if world > 1:
+        gathered = [torch.empty_like(sols) for _ in range(world)]
+        dist.all_gather(gathered, sols)          # the single end-of-job gather (RCCL over xGMI)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, stats, sols
+
+
+def batch_throughput(n: int, nsys: int, device: int, dev) -> dict:
+    """BASELINE configs[3], one GPU's share (64 of the 512 systems at 8 GPUs): nsys independent n x n systems resident in
+    HBM, solved by gf2bv_solve_batch_device (lock-step gangs) through gf2bv_amd.batch -- the function the N > 1 run
+    uses on every rank; every solution checked by the residual kernel."""
+    mats = batch.synth_shard(n, [BATCH_SEED0 + i for i in range(nsys)], device)
+    stride = hip.padded_stride(n)
+    best, sols = None, None
+    for _ in range(2):                                   # first pass warms the allocator
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        _, sols = batch.solve_shard(n, mats, device)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    bad = sum(hip.residual_device(mats[i].data_ptr(), n, n, stride, s.origin, device=device) for i, s in enumerate(sols))
+    xors = float(sum(s.stats["row_xors"] for s in sols))
+    del mats
+    return {"n": n, "systems": nsys, "ms_per_system": best / nsys * 1e3, "systems_per_s": nsys / best,
+            "row_xors_per_s": xors / best, "residual_rows": int(bad), "all_solved": all(s.solved for s in sols),
+            "gang_systems": int(sols[0].stats.get("gang_systems", 0))}
+
+
+def run_single(args, world, rank, local_rank, dev):
+    n = args.n
+    seed = args.seed if args.seed is not None else FULL_RANK_SEEDS.get(n, 1234)
+    stride = hip.padded_stride(n)
+    # the system lives in HBM before the timed region; the solver works on its own tile-major copy
+    # (the row-major -> tile-major pass is part of every timed step), so one pristine matrix suffices
+    mat = torch.empty(n * stride, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    hip.synth_device(mat.data_ptr(), n, n, stride, seed + rank, device=local_rank, stream=stream)
+    torch.cuda.synchronize(dev)
+    elapsed, stats, _ = timed_single(mat, n, stride, args.steps, args.warmup, local_rank, dev, world,
+                                     not args.no_kernel_events)
+
+    # correctness gate on this rank: A x = b on the untouched input, by the independent residual kernel
+    bad = hip.residual_device(mat.data_ptr(), n, n, stride, stats[-1].origin, device=local_rank, stream=stream)
+    ok = torch.tensor([1 if (bad == 0 and all(s.solved for s in stats)) else 0], device=dev)
+    agg = torch.tensor([float(sum(s.stats["row_xors"] for s in stats))], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(agg)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    del mat
+    if rank != 0:
+        return None
+    s0 = stats[-1].stats
+    ceil = hip.stream_ceiling(2 << 30, local_rank)
+    rl = roofline_block([s.stats for s in stats], float(sum(s.stats["ms_sweep"] for s in stats)), n, local_rank, ceil)
+    roofline = None
+    if rl:
+        roofline, launches = rl
+        roofline["passes"] = s0["n_sweeps"]
+        roofline["alg_bytes_per_pass"] = roofline["alg_bytes_total"] / max(launches, 1)
+        roofline["avg_pass_ms"] = roofline["kernel_ms_total"] / max(launches, 1)
+    out = {
+        "metric": "GF(2) row-XORs/s (solve_one, dense NxN)", "value": float(agg.item()) / elapsed,
+        "unit": "row-XORs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {
+            "workload": f"synthetic dense {n}x{n} GF(2) solve_one, planted RHS, seed {seed}"
+                        + (" (full rank)" if n in FULL_RANK_SEEDS and args.seed is None else ""),
+            "systems_per_step_per_gpu": 1, "parallelism": f"independent systems x{world}",
+            "tables_per_sweep": s0["tables_per_sweep"], "table_bits": s0["table_bits"],
+            "tile_words": s0["tile_words"], "rank": int(stats[-1].rank),
+        },
+        "solve_wall_ms": {"eliminate": float(np.mean([s.stats["ms_eliminate"] for s in stats])),
+                          "backsub": float(np.mean([s.stats["ms_backsub"] for s in stats])),
+                          "export": float(np.mean([s.stats["ms_export"] for s in stats])),
+                          "total_host": float(np.mean([s.stats["ms_total"] for s in stats]))},
+        "parity_gate": {"residual_rows": int(bad), "all_ranks_ok": bool(ok.item())},
+        # table-count independent work rate: (alive rows x 64-column panels) eliminated per second, whole job
+        "row_panels_per_s": world * n * ((n + 63) // 64) / 2 / (elapsed / args.steps),
+        "roofline": roofline,
+    }
+    if world == 1 and args.target_n > 0 and n == 65536:
+        out[f"target_{args.target_n}"] = target_leg(args.target_n, local_rank, dev, ceil)
+    if world == 1 and args.batch_systems > 0:
+        out["batch_throughput"] = batch_throughput(args.batch_n, args.batch_systems, local_rank, dev)
+    if world == 1 and not args.no_cpu_baseline:
+        m = args.cpu_n or 65536
+        cb = cpu_baseline(m, seed)
+        out["parity_gate"]["gpu_equals_cpu_oracle_on_sample"] = gpu_equals_oracle(cb, m, seed, local_rank)
+        out["cpu_baseline"] = cb
+    return out
+
+
+def target_leg(n: int, device: int, dev, ceil: dict) -> dict:
+    """The north-star size (BASELINE.json: >= 70 % of the HBM roofline at 262144^2): 1 warm-up + 2 timed solve_one steps
+    of the resident system, the same code path as the headline steps; extra field, never `value`."""
+    stride = hip.padded_stride(n)
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    need = 2.6 * n * stride * 8
+    if free_b < need:
+        return {"skipped": f"needs {need / 2**30:.1f} GiB of free HBM, {free_b / 2**30:.1f} available"}
+    mat = torch.empty(n * stride, dtype=torch.int64, device=dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    seed = 1234
+    hip.synth_device(mat.data_ptr(), n, n, stride, seed, device=device, stream=stream)
+    torch.cuda.synchronize(dev)
+    steps = 2
+    elapsed, stats, _ = timed_single(mat, n, stride, steps, 1, device, dev, 1, True)
+    bad = hip.residual_device(mat.data_ptr(), n, n, stride, stats[-1].origin, device=device, stream=stream)
+    del mat
+    s0 = stats[-1].stats
+    roofline, launches = roofline_block([s.stats for s in stats], float(sum(s.stats["ms_sweep"] for s in stats)), n, device, ceil)
+    roofline["passes"] = s0["n_sweeps"]
+    roofline["alg_bytes_per_pass"] = roofline["alg_bytes_total"] / max(launches, 1)
+    roofline["avg_pass_ms"] = roofline["kernel_ms_total"] / max(launches, 1)
+    return {"n": n, "seed": seed, "steps": steps, "warmup": 1, "ms_per_step": elapsed / steps * 1e3,
+            "row_xors_per_s": float(sum(s.stats["row_xors"] for s in stats)) / elapsed,
+            "rank": int(stats[-1].rank), "residual_rows": int(bad), "all_solved": all(s.solved for s in stats),
+            "solve_wall_ms": {"eliminate": float(np.mean([s.stats["ms_eliminate"] for s in stats])),
+                              "backsub": float(np.mean([s.stats["ms_backsub"] for s in stats]))},
+            "roofline": roofline}
+
+
+def run_batch(args, world, rank, local_rank, dev):
+    """BASELINE configs[3]: args.batch_total independent n x n systems, contiguous blocks per rank, one gather."""
+    n, total = args.batch_n, args.batch_total
+    lo, hi = batch.shard_bounds(total, world, rank)
+    seeds = [BATCH_SEED0 + i for i in range(lo, hi)]
+    stride = hip.padded_stride(n)
+    mats = batch.synth_shard(n, seeds, local_rank)             # resident in HBM before the timed region
+    torch.cuda.synchronize(dev)
+    kernel_events = not args.no_kernel_events
+
+    def step():
+        recs, sols = batch.solve_shard(n, mats, local_rank, time_kernels=kernel_events)
+        allrec = batch.gather_records(recs, total)              # the single end-of-job collective (no-op at N = 1)
+        return allrec, sols
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    allrec, sols, all_sols = None, None, []
+    for _ in range(args.steps):
+        allrec, sols = step()
+        all_sols.extend(sols)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # parity gate: every local system's A x = b on the untouched input (independent kernel); the gathered table must
+    # hold this rank's records at its block and report every system of the job solved
+    bad = sum(hip.residual_device(mats[i].data_ptr(), n, n, stride, s.origin, device=local_rank)
+              for i, s in enumerate(sols))
+    rec_ok = bool(allrec.shape[0] == total and int((allrec[:, 0] != 0).sum().item()) == 0)
+    mine = np.stack([batch.make_record(s.status, s.rank, s.origin) for s in sols]) if sols else None
+    if mine is not None:
+        rec_ok = rec_ok and bool(np.array_equal(allrec[lo:hi].cpu().numpy(), mine))
+    ok = torch.tensor([1 if (bad == 0 and rec_ok and all(s.solved for s in sols)) else 0], device=dev)
+    agg = torch.tensor([float(sum(s.stats["row_xors"] for s in all_sols)),
+                        float(sum(16.0 * s.stats["sweep_words"] for s in all_sols)),
+                        # a gang's launches serve all its systems and every member reports the gang's time
+                        float(sum(s.stats["ms_sweep"] / max(s.stats.get("gang_systems", 1), 1) for s in all_sols)),
+                        float(sum(s.stats["n_sweeps"] / max(s.stats.get("gang_systems", 1), 1) for s in all_sols))],
+                       dtype=torch.float64, device=dev)
+    per_rank = torch.tensor([float(hi - lo) * args.steps / elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(agg)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    del mats
+    if rank != 0:
+        return None
+    row_xors, alg_bytes, sweep_ms, launches = (float(x) for x in agg.tolist())
+    s0 = sols[0].stats
+    ceil = hip.stream_ceiling(2 << 30, local_rank)
+    roofline = None
+    if sweep_ms > 0:
+        achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
+        g = s0["panels_per_sweep"]
+        roofline = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": f"k_update<G={g},T={s0['tables_per_sweep'] // g}> (bulk update of a gang: {s0.get('gang_systems', 0)} "
+                      f"systems x {64 * g} pivots per launch)",
+            "launches": launches, "alg_bytes_per_launch": alg_bytes / max(launches, 1),
+            "avg_launch_ms": sweep_ms / max(launches, 1),
+            "measured_rmw_stream_GBs": ceil["rmw_gbs"], "measured_read_stream_GBs": ceil["read_gbs"],
+            "frac_of_measured_rmw": achieved / ceil["rmw_gbs"],
+            "note": "summed over all ranks; two gangs are in flight per GPU (a gang's back-substitution and export overlap "
+                    "the next gang's elimination), so a launch's duration includes the share of the chip the other gang took",
+        }
+    out = {
+        "metric": "GF(2) row-XORs/s (batch of independent dense NxN solve_one, sharded)", "value": row_xors / elapsed,
+        "unit": "row-XORs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {
+            "workload": f"batch of {total} independent synthetic dense {n}x{n} GF(2) solve_one systems (seeds {BATCH_SEED0}..), "
+                        f"contiguous blocks of {total}/{world} per GPU, one all_gather of [status, rank, origin] records at the end",
+            "systems_total": total, "systems_per_gpu": (total + world - 1) // world, "n": n,
+            "parallelism": f"independent systems, shard x{world}, gangs of {s0.get('gang_systems', 0)}",
+            "tables_per_sweep": s0["tables_per_sweep"], "table_bits": s0["table_bits"], "tile_words": s0["tile_words"],
+            "collective": ("all_gather over nccl (RCCL)" if world > 1 else "none (single rank)"),
+        },
+        "systems_per_s": total * args.steps / elapsed,
+        "ms_per_system_per_gpu": elapsed / args.steps / ((total + world - 1) // world) * 1e3,
+        "rank0_systems_per_s": float(per_rank.item()),
+        "parity_gate": {"residual_rows_rank0": int(bad), "all_ranks_ok": bool(ok.item()),
+                        "gathered_records": int(allrec.shape[0])},
+        "row_panels_per_s": total * args.steps * n * ((n + 63) // 64) / 2 / elapsed,
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        m = args.cpu_n or n
+        cb = cpu_baseline(m, BATCH_SEED0)
+        out["parity_gate"]["gpu_equals_cpu_oracle_on_sample"] = gpu_equals_oracle(cb, m, BATCH_SEED0, local_rank)
+        out["cpu_baseline"] = cb
+    return out
 
 
 def main():
@@ -143,116 +432,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
-
-    n = args.n
-    seed = args.seed if args.seed is not None else FULL_RANK_SEEDS.get(n, 1234)
-    stride = hip.padded_stride(n)
-    cw = (n + 63) // 64
-    # the system lives in HBM before the timed region; the solver works on its own tile-major copy
-    # (the row-major -> tile-major pass is part of every timed step), so one pristine matrix suffices
-    mat = torch.empty(n * stride, dtype=torch.int64, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    hip.synth_device(mat.data_ptr(), n, n, stride, seed + rank, device=local_rank, stream=stream)
-    torch.cuda.synchronize(dev)
-
-    sols = torch.zeros(args.steps, cw, dtype=torch.int64, device=dev)
-    stats = []
-
-    def step(i: int):
-        return hip.solve_device(mat.data_ptr(), n, n, stride, hip.MODE_SINGLE, device=local_rank,
-                                stream=stream, time_kernels=not args.no_kernel_events)
-
-    for i in range(args.warmup):
-        step(i)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        s = step(args.warmup + k)
-        stats.append(s)
-        sols[k].copy_(torch.from_numpy(s.origin.view(np.int64)))
-    if world > 1:
-        gathered = [torch.empty_like(sols) for _ in range(world)]
-        dist.all_gather(gathered, sols)          # the single end-of-job gather (RCCL over xGMI)
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # correctness gate on this rank: A x = b on the untouched input, by the independent residual kernel
-    bad = hip.residual_device(mat.data_ptr(), n, n, stride, stats[-1].origin, device=local_rank, stream=stream)
-    ok = torch.tensor([1 if (bad == 0 and all(s.solved for s in stats)) else 0], device=dev)
-    row_xors_local = float(sum(s.stats["row_xors"] for s in stats))
-    agg = torch.tensor([row_xors_local], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(agg)
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    workload = args.workload if args.workload != "auto" else ("single" if world == 1 else "batch")
+    out = (run_single if workload == "single" else run_batch)(args, world, rank, local_rank, dev)
     if rank == 0:
-        s0 = stats[-1].stats
-        sweep_ms = float(np.mean([s.stats["ms_sweep"] for s in stats]))
-        n_sweeps = s0["n_sweeps"]
-        alg_bytes = 16.0 * s0["sweep_words"]
-        roofline = None
-        if sweep_ms > 0:
-            achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
-            g = s0["panels_per_sweep"]
-            ceil = hip.stream_ceiling(2 << 30, local_rank)
-            roofline = {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, g, s0["tables_per_sweep"] // g),
-                "kernel": f"k_update<G={g},T={s0['tables_per_sweep'] // g}> (bulk update, {g} panels = {64 * g} pivots per pass)",
-                "passes": n_sweeps,
-                "alg_bytes_per_pass": alg_bytes / max(n_sweeps, 1),
-                "avg_pass_ms": sweep_ms / max(n_sweeps, 1),
-                # same-run practical ceilings of this device (plain streaming kernels, 2 GiB)
-                "measured_rmw_stream_GBs": ceil["rmw_gbs"], "measured_read_stream_GBs": ceil["read_gbs"],
-                "frac_of_measured_rmw": achieved / ceil["rmw_gbs"],
-                # one pass applies G panels: HBM rate a one-panel-per-pass sweep would need for the same wall time
-                "single_panel_equivalent_GBs": achieved * g,
-            }
-        out = {
-            "metric": "GF(2) row-XORs/s (solve_one, dense NxN)", "value": float(agg.item()) / elapsed,
-            "unit": "row-XORs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {
-                "workload": f"synthetic dense {n}x{n} GF(2) solve_one, planted RHS, seed {seed}"
-                            + (" (full rank)" if n in FULL_RANK_SEEDS and args.seed is None else ""),
-                "systems_per_step_per_gpu": 1, "parallelism": f"independent systems x{world}",
-                "tables_per_sweep": s0["tables_per_sweep"], "table_bits": s0["table_bits"],
-                "tile_words": s0["tile_words"], "rank": int(stats[-1].rank),
-            },
-            "solve_wall_ms": {"eliminate": float(np.mean([s.stats["ms_eliminate"] for s in stats])),
-                              "backsub": float(np.mean([s.stats["ms_backsub"] for s in stats])),
-                              "export": float(np.mean([s.stats["ms_export"] for s in stats])),
-                              "total_host": float(np.mean([s.stats["ms_total"] for s in stats]))},
-            "parity_gate": {"residual_rows": int(bad), "all_ranks_ok": bool(ok.item())},
-            # table-count independent work rate: (alive rows x 64-column panels) eliminated per second, whole job
-            "row_panels_per_s": world * n * ((n + 63) // 64) / 2 / (elapsed / args.steps),
-            "roofline": roofline,
-        }
-        if world == 1 and args.batch_systems > 0:
-            out["batch_throughput"] = batch_throughput(args.batch_n, args.batch_systems, local_rank)
-        if world == 1 and not args.no_cpu_baseline:
-            cb = cpu_baseline(args.cpu_n, seed)
-            # parity gate, second half: the same sample on the GPU must give the oracle's answer word for word
-            m = args.cpu_n
-            st2 = hip.padded_stride(m)
-            buf = hip.DeviceBuffer(m * st2 * 8, local_rank)
-            hip.synth_device(buf.ptr, m, m, st2, seed, device=local_rank)
-            g = hip.solve_device(buf.ptr, m, m, st2, hip.MODE_SINGLE, device=local_rank)
-            buf.free()
-            o_status, o_origin = cb.pop("_status"), cb.pop("_origin")
-            same = g.rank == cb["rank"] and g.status == o_status and np.array_equal(g.origin, o_origin)
-            out["parity_gate"]["gpu_equals_cpu_oracle_on_sample"] = bool(same)
-            out["cpu_baseline"] = cb
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

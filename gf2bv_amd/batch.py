@@ -53,8 +53,8 @@ def gather_records(local: torch.Tensor, nsys: int, group=None) -> torch.Tensor:
     return out
 
 
-def solve_synthetic_shard(n: int, seeds: list, device_index: int, mats: torch.Tensor | None = None) -> torch.Tensor:
-    """Solve this rank's block of synthetic n x n systems on its GPU; returns [len(seeds), R] records (on GPU)."""
+def synth_shard(n: int, seeds: list, device_index: int, mats: torch.Tensor | None = None) -> torch.Tensor:
+    """This rank's block of synthetic n x n systems, generated in HBM on torch's current stream (asynchronous)."""
     from . import hip
     stride = hip.padded_stride(n)
     dev = torch.device("cuda", device_index)
@@ -63,8 +63,27 @@ def solve_synthetic_shard(n: int, seeds: list, device_index: int, mats: torch.Te
     stream = torch.cuda.current_stream(dev).cuda_stream
     for i, seed in enumerate(seeds):
         hip.synth_device(mats[i].data_ptr(), n, n, stride, seed, device=device_index, stream=stream)
-    sols = hip.solve_batch_device(mats.data_ptr(), len(seeds), n * stride, n, n, stride, hip.MODE_SINGLE,
-                                  device=device_index) if seeds else []
+    return mats
+
+
+def solve_shard(n: int, mats: torch.Tensor, device_index: int, time_kernels: bool = False):
+    """Solve this rank's block (mats: [nsys, n * stride] int64, resident in HBM) on its GPU as lock-step gangs.
+
+    Returns (records [nsys, R] int64 on the GPU, list of hip.Solution).  The gangs are ordered after torch's
+    current stream -- the stream that produced `mats` (gf2bv_solve_batch_device's ordering contract)."""
+    from . import hip
+    stride = hip.padded_stride(n)
+    dev = torch.device("cuda", device_index)
+    nsys = int(mats.shape[0])
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    sols = hip.solve_batch_device(mats.data_ptr(), nsys, n * stride, n, n, stride, hip.MODE_SINGLE,
+                                  device=device_index, stream=stream, time_kernels=time_kernels) if nsys else []
     recs = np.stack([make_record(s.status, s.rank, s.origin) for s in sols]) if sols else \
         np.zeros((0, record_words(n)), dtype=np.int64)
-    return torch.from_numpy(recs).to(dev)
+    return torch.from_numpy(recs).to(dev), sols
+
+
+def solve_synthetic_shard(n: int, seeds: list, device_index: int, mats: torch.Tensor | None = None) -> torch.Tensor:
+    """Generate and solve this rank's block of synthetic n x n systems; returns [len(seeds), R] records (on GPU)."""
+    mats = synth_shard(n, seeds, device_index, mats)
+    return solve_shard(n, mats, device_index)[0]

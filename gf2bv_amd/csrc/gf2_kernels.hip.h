@@ -107,7 +107,12 @@ struct SolveState {
 	unsigned arrive;     // search units that have finished (last arriver publishes)
 	int wide;            // search: 1 = the previous panel was hard (sparse / rank deficient): scan with all units
 	unsigned garr[GF2_MAXGROUPS];    // hard panels: arrivals per group of GF2_GROUP units (two-level merge)
-	int pad[3];
+	// who publishes a panel that unit 0 completed on its own: 1 = unit 0 has announced that it will (and may be waiting
+	// for the others), 2 = the last arriver has seen that and left it to unit 0, 0 = unit 0 has given the job up (the
+	// last arriver publishes), 3 = published (unit 0 may be through before the last arriver gets to look)
+	unsigned claim;
+	int self_giveups;    // statistics: panels whose unit 0 stopped waiting and left publishing to the last arriver
+	int pad[1];
 };
 
 // Scratch of one search unit (wavefront).
@@ -588,7 +593,7 @@ __device__ __forceinline__ void search_panel(const Cand &cand, typename Cand::Ra
                                              int units, SolveState *__restrict__ st, int *__restrict__ died,
                                              FindUnit *__restrict__ fu, int *pend, PanelRec *__restrict__ panels,
                                              PanelAux *__restrict__ aux, int *__restrict__ pivcol, int *__restrict__ urow,
-                                             int *__restrict__ blk_first_out, int sparse_mode)
+                                             int *__restrict__ blk_first_out, int sparse_mode, int self_wait)
 {
 	const i64 rclamp = rows - 1;
 	i64 i_n = lo + lane, i_c;
@@ -646,6 +651,7 @@ __device__ __forceinline__ void search_panel(const Cand &cand, typename Cand::Ra
 	if (lane == 0) {
 		GF2_ST(&me->have, S.have); GF2_ST(&me->first_nonsrc, first_nonsrc); GF2_ST(&me->chunks, chunks); GF2_ST(&me->cnt, S.nslots);
 		GF2_ST(&me->pad, self ? 1 : 0);
+		if (self) GF2_ST(&st->claim, 1u);
 	}
 	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every store above has left this wave
 
@@ -727,13 +733,30 @@ __device__ __forceinline__ void search_panel(const Cand &cand, typename Cand::Ra
 		r0 = st->rank;
 		srow = S.srow;
 		cand.src_mults(srow, gf, mv);
-		// every unit of this launch arrives, active or not, so this ends; bounded all the same (a hang would take the
-		// device with it): on expiry the solve is flagged and reports an internal error
-		if (old != (unsigned)(units - 1) && !GF2_LD(&st->pad[0])) {
-			const unsigned long long t0 = wall_clock64();          // 100 MHz
-			while (GF2_LD(&st->arrive) != (unsigned)units) {
+		// Publication must not happen before every unit of this launch has arrived (see `active` in k_panel_step).  Unit 0
+		// waits for them -- but only briefly: HIP does not promise that the other workgroups of a launch are resident while
+		// this one spins (a chip shared with other gangs, processes or a profiler), so after `self_wait` ticks (100 MHz) it
+		// gives the job up and the LAST ARRIVER publishes from unit 0's stored record, the path every other panel takes.
+		// st->claim settles who does it: 1 -> 2 by the last arriver ("all here, yours"), 1 -> 0 by unit 0 ("yours").
+		if (old != (unsigned)(units - 1)) {
+			const unsigned long long t0 = wall_clock64();
+			bool mine = false;
+			for (;;) {
+				if (GF2_LD(&st->arrive) == (unsigned)units || GF2_LD(&st->claim) == 2u) { mine = true; break; }
+				if (wall_clock64() - t0 >= (unsigned long long)self_wait) break;
 				__builtin_amdgcn_s_sleep(1);
-				if (wall_clock64() - t0 > 50000000ull) { if (lane == 0) GF2_ST(&st->pad[0], 1); break; }     // 0.5 s
+			}
+			if (!mine) {
+				unsigned won = 0;
+				if (lane == 0) {
+					unsigned expect = 1u;
+					won = __hip_atomic_compare_exchange_strong(&st->claim, &expect, 0u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+					                                           __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+					if (won) __hip_atomic_fetch_add(&st->self_giveups, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				won = (unsigned)__builtin_amdgcn_readfirstlane((int)won);
+				if (won) return;                                   // the last arriver publishes
+				// the last arriver got there first (claim == 2): every unit has arrived, go on
 			}
 		}
 		pick = 0; hard = chunks > 8; new_first = first_nonsrc;
@@ -747,7 +770,17 @@ __device__ __forceinline__ void search_panel(const Cand &cand, typename Cand::Ra
 	const int srow0 = GF2_LD(&fu[0].srow[lane]);
 	const int self0 = GF2_LD(&fu[0].pad);
 	r0 = st->rank;
-	if (idx0 == 0 && cnt0 == full && self0 == 1) return;    // unit 0 publishes its own result
+	if (idx0 == 0 && cnt0 == full && self0 == 1) {          // unit 0 means to publish its own result ...
+		unsigned left = 0;
+		if (lane == 0) {
+			unsigned expect = 1u;
+			// ... and still does (it sees claim == 2 or the full count) -- or already has (3: the full count was all it
+			// waited for); only 0 means that it has stopped waiting and this unit publishes from its record
+			left = (__hip_atomic_compare_exchange_strong(&st->claim, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+			                                             __HIP_MEMORY_SCOPE_AGENT) || expect != 0u) ? 1u : 0u;
+		}
+		if (__builtin_amdgcn_readfirstlane((int)left)) return;
+	}
 	if (full > 0) {
 		if (cnt0 == full) pick = 0;
 		else
@@ -812,6 +845,7 @@ __device__ __forceinline__ void search_panel(const Cand &cand, typename Cand::Ra
 		st->first = new_first;
 		st->wide = hard;
 		if (blk_first_out) *blk_first_out = new_first;     // last panel of a block: row bound for its bulk update
+		GF2_ST(&st->claim, 3u);
 		GF2_ST(&st->arrive, 0u);
 	}
 	GF2_PROBE_UN(4);
@@ -920,7 +954,7 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
              int *__restrict__ died, FindUnit *__restrict__ fu, int units, int find_wgs,
              PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol,
              int *__restrict__ urow, u64 *__restrict__ multset, int *__restrict__ blk_first_out, int upd_T,
-             int sparse_mode, SysStride ss)
+             int sparse_mode, int self_wait, SysStride ss)
 {
 	__builtin_amdgcn_s_setprio(3);          // panel path = critical path: win issue arbitration against bulk-update waves
 	{
@@ -1070,7 +1104,7 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	cw.Wb = Wb_in; cw.Tn = L.Tn; cw.maskp = recp.mask; cw.gf = gfc; cw.gp = gpc;
 	cw.multset = multset; cw.rows = rows; cw.upd_T = upd_T; cw.narrowing = gp >= 0;
 	search_panel(cw, raw0, d_n, lo, hi, active, u, lane, rows, j, gf, colmask, first, wide, units, st, died, fu,
-	             pend_rows[t >> 6], panels, aux, pivcol, urow, blk_first_out, sparse_mode);
+	             pend_rows[t >> 6], panels, aux, pivcol, urow, blk_first_out, sparse_mode, self_wait);
 }
 
 // The next block's window, on the panel stream: every row >= blk_first gets block b's update applied to

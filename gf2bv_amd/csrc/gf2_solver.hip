@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <new>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -34,6 +35,15 @@ int fail(int code, const char *what, hipError_t e = hipSuccess)
 	else snprintf(buf, sizeof buf, "%s", what);
 	g_err = buf;
 	return code;
+}
+
+// Nothing may propagate through the C ABI: allocation failures of the host-side containers become GF2BV_ERR_NOMEM.
+template <class F>
+int guarded(F &&body)
+{
+	try { return body(); }
+	catch (const std::bad_alloc &) { return fail(GF2BV_ERR_NOMEM, "out of host memory"); }
+	catch (const std::exception &e) { return fail(GF2BV_ERR_HIP, e.what()); }
 }
 
 #define HIPCHK(call)                                                     \
@@ -261,14 +271,18 @@ hipError_t launch_ysweep(dim3 grid, hipStream_t s, u64 *Y, i64 ys, i64 rows, con
                          const u64 *mult, int ntiles, int rpb)
 {
 	constexpr int lds = SweepCfg<YK, YTW>::LDS_BYTES;
-	static bool attr_set[16] = {};
+	static std::mutex attr_mu;
+	static std::map<int, bool> attr_set;          // device -> the > 64 KiB dynamic-LDS attribute has been raised there
 	int dev = 0;
 	(void)hipGetDevice(&dev);
-	if (dev < 16 && !attr_set[dev]) {
-		hipError_t e = hipFuncSetAttribute((const void *)k_sweep<YK, YTW, YNT>,
-		                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-		if (e != hipSuccess) return e;
-		attr_set[dev] = true;
+	{
+		std::lock_guard<std::mutex> lk(attr_mu);
+		if (!attr_set[dev]) {
+			hipError_t e = hipFuncSetAttribute((const void *)k_sweep<YK, YTW, YNT>,
+			                                   hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+			if (e != hipSuccess) return e;
+			attr_set[dev] = true;
+		}
 	}
 	k_sweep<YK, YTW, YNT><<<grid, dim3(YNT), lds, s>>>(Y, ys, rows, rec, 1, mult, 0, ntiles, rpb);
 	return hipGetLastError();
@@ -290,6 +304,7 @@ struct Solver {
 	// gang: nsys same-shape systems eliminated in lock-step by the same launches (blockIdx.y = system);
 	// system s lives at M + s * m_stride words / arena + s * arena_stride bytes, its input at src + s * src_sys_words
 	int nsys = 1;
+	int gang_nsys = 1;            // (a view: the size of the gang it belongs to)
 	i64 m_stride = 0, src_sys_words = 0;
 	size_t arena_stride = 0;
 	bool view = false;            // a non-owning window on one system of a gang (back-substitution, export)
@@ -313,6 +328,8 @@ struct Solver {
 	bool ext_events = true;       // hand-off and timing events ride on kernel start / completion signals (hipExtLaunchKernel)
 	                              // instead of marker packets: ~1 % at every size; GF2BV_EXT_EVENTS=0 restores hipEventRecord
 	int sparse_mode = 2;          // search skips absent columns: 0 never, 1 always, 2 per chunk by density (GF2BV_SPARSE)
+	int self_wait = 5000;         // ticks (100 MHz) unit 0 of a panel search waits for the other units before it leaves
+	                              // publishing to the last arriver: 50 us (GF2BV_SELF_WAIT_US; 0 = never wait)
 	u64 *Y = nullptr;
 	int *ycols = nullptr;
 	u64 *out = nullptr;
@@ -383,6 +400,31 @@ struct gf2bv_result {
 
 namespace {
 
+// Pool resources of an entry point that must go back on every return path (error paths included).
+struct Scratch {
+	std::vector<void *> bufs;
+	std::vector<hipEvent_t> timing_events;
+	hipStream_t sync_first = nullptr;          // synchronised before anything is released (work may still be in flight)
+	~Scratch()
+	{
+		if (sync_first) (void)hipStreamSynchronize(sync_first);
+		for (void *p : bufs) pool().release(p);
+		for (hipEvent_t e : timing_events) pool().release_event(e, true);
+	}
+	hipError_t alloc(void **out, size_t bytes, int device)
+	{
+		hipError_t e = pool().alloc(out, bytes, device);
+		if (e == hipSuccess) bufs.push_back(*out);
+		return e;
+	}
+	hipError_t event(hipEvent_t *ev)
+	{
+		hipError_t e = pool().event(ev, true);
+		if (e == hipSuccess) timing_events.push_back(*ev);
+		return e;
+	}
+};
+
 int check_device(int device)
 {
 	int n = 0;
@@ -417,6 +459,7 @@ int solver_alloc(Solver &S)
 	if (const char *e = getenv("GF2BV_DEBUG_SYNC")) S.dbg_sync = atoi(e);
 	if (const char *e = getenv("GF2BV_EXT_EVENTS")) S.ext_events = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_SPARSE")) { int v = atoi(e); if (v >= 0 && v <= 2) S.sparse_mode = v; }
+	if (const char *e = getenv("GF2BV_SELF_WAIT_US")) { int v = atoi(e); if (v >= 0 && v <= 1000000) S.self_wait = v * 100; }
 	if (getenv("GF2BV_SERIAL")) { S.sB = S.sA; S.own_sB = false; }     // ablation: no look-ahead overlap
 	else {
 		// the bulk path yields to the (latency-critical) panel path wherever both have work queued: lowest priority
@@ -543,7 +586,7 @@ int enqueue_forward(Solver &S)
 			                      S.M, S.rows, S.srows, j0, gp, gf, gb, colmask,
 			                      (const u64 *)half[s ? (s - 1) & 1 : 0], half[s & 1], S.st, S.died, S.fu, S.units, find_wgs,
 			                      S.panels, S.aux, S.pivcol, S.urow, mset,
-			                      gf == gb - 1 ? S.blk_first + b : (int *)nullptr, S.impl->T, S.sparse_mode, S.ss());
+			                      gf == gb - 1 ? S.blk_first + b : (int *)nullptr, S.impl->T, S.sparse_mode, S.self_wait, S.ss());
 		}
 		if (b == S.nblocks - 1)
 			k_win_scatter<<<dim3((unsigned)((S.rows * gb + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, gb, half[gb & 1], S.died, S.ss());
@@ -721,8 +764,6 @@ int finish_end(Solver &S, gf2bv_result **out)
 	HIPCHK(hipStreamSynchronize(S.sB));
 	tr.mark("finish: sync");
 	const SolveState &hst = S.hst;
-	if (hst.pad[0])      // a panel search gave up waiting for the other units of its launch (must not happen)
-		return fail(GF2BV_ERR_HIP, "internal: panel search timed out waiting for its launch");
 	const std::vector<u64> &hout = S.hout;
 	const std::vector<PanelRec> &hp = S.hp;
 	S.hpiv.resize(hst.rank);
@@ -757,6 +798,8 @@ int finish_end(Solver &S, gf2bv_result **out)
 	st.tables_per_sweep = S.impl->G * S.impl->T;
 	st.table_bits = (64 + S.impl->T - 1) / S.impl->T;
 	st.tile_words = TW;
+	st.gang_systems = S.view ? S.gang_nsys : S.nsys;
+	st.search_handovers = hst.self_giveups;
 	{
 		const int G = S.impl->G;
 		for (int b = 0; b < S.nblocks; b++) {
@@ -798,6 +841,7 @@ int make_view(const Solver &S, int s, Solver &V)
 {
 	V = S;
 	V.view = true;
+	V.gang_nsys = S.nsys;
 	V.nsys = 1; V.m_stride = 0; V.arena_stride = 0; V.src_sys_words = 0;
 	V.own_sA = V.own_sB = false;
 	V.src = nullptr; V.tmp_src = nullptr;
@@ -839,6 +883,15 @@ int solve_gang(Solver &S, gf2bv_result **out)
 	for (int s = 0; s < S.nsys; s++) {
 		rc = finish_end(V[s], &out[s]);
 		if (rc) return rc;
+	}
+	if (S.time_kernels) {        // one set of bulk-update launches served the whole gang: every member reports the gang's time
+		float total = 0;
+		for (size_t i = 0; i + 1 < S.kev.size(); i += 2) {
+			float ms = 0;
+			(void)hipEventElapsedTime(&ms, S.kev[i], S.kev[i + 1]);
+			total += ms;
+		}
+		for (int s = 0; s < S.nsys; s++) out[s]->stats.ms_sweep = total;
 	}
 	return GF2BV_OK;
 }
@@ -892,6 +945,7 @@ const char *gf2bv_last_error(void) { return g_err.c_str(); }
 int gf2bv_solve_device(void *d_aug, int64_t rows, int64_t cols, int64_t stride_words, int mode,
                        int device, void *stream, int time_kernels, gf2bv_result **out)
 {
+	return guarded([&]() -> int {
 	if (!out || !d_aug) return fail(GF2BV_ERR_ARG, "null pointer");
 	*out = nullptr;
 	int rc = check_shape(rows, cols, mode);
@@ -910,11 +964,13 @@ int gf2bv_solve_device(void *d_aug, int64_t rows, int64_t cols, int64_t stride_w
 	rc = solver_enqueue(S);
 	if (rc) return rc;
 	return solver_finish(S, out);
+	});
 }
 
 int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words, int64_t rows, int64_t cols,
-                             int64_t stride_words, int mode, int device, gf2bv_result **out)
+                             int64_t stride_words, int mode, int device, void *stream, int time_kernels, gf2bv_result **out)
 {
+	return guarded([&]() -> int {
 	if (!out || !d_aug || nsys < 0) return fail(GF2BV_ERR_ARG, "null pointer");
 	for (i64 s = 0; s < nsys; s++) out[s] = nullptr;
 	int rc = check_shape(rows, cols, mode);
@@ -933,6 +989,15 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 	const i64 ngangs = gang ? (nsys + gang - 1) / gang : 0;
 	int NS = (int)std::min<i64>(ngangs, 2);
 	if (const char *e = getenv("GF2BV_BATCH_THREADS")) { int v = atoi(e); if (v >= 1) NS = (int)std::min<i64>(ngangs, v); }
+	// Ordering contract: the matrices are whatever `stream` (the caller's stream, NULL = the null stream) has
+	// produced when this call is made.  The gangs run on the library's own non-blocking streams, which are not
+	// ordered against any other stream by themselves: each waits for an event recorded on `stream` here.
+	struct Ready {
+		hipEvent_t ev = nullptr;
+		~Ready() { pool().release_event(ev, false); }
+	} ready;
+	HIPCHK(pool().event(&ready.ev, false));
+	HIPCHK(hipEventRecord(ready.ev, (hipStream_t)stream));
 	std::vector<int> rcs(NS, GF2BV_OK);
 	std::vector<std::string> errs(NS);
 	std::vector<std::thread> workers;
@@ -941,7 +1006,9 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 			if (hipSetDevice(device) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipSetDevice"; return; }
 			hipStream_t st = nullptr;
 			if (pool().stream(&st, device, false) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipStreamCreate"; return; }
+			if (hipStreamWaitEvent(st, ready.ev, 0) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipStreamWaitEvent"; }
 			for (i64 q = t; q < ngangs && rcs[t] == GF2BV_OK; q += NS) {
+				try {
 				const i64 s0 = q * gang;
 				Solver S;
 				S.t_begin = std::chrono::steady_clock::now();
@@ -951,8 +1018,10 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 				S.src = (const u64 *)d_aug + s0 * sys_stride_words;
 				S.src_sys_words = sys_stride_words;
 				S.rows = rows; S.cols = cols; S.stride = stride_words; S.mode = mode;
+				S.time_kernels = time_kernels != 0;
 				int rc = solve_gang(S, &out[s0]);
 				if (rc != GF2BV_OK) { rcs[t] = rc; errs[t] = g_err; }
+				} catch (const std::bad_alloc &) { rcs[t] = GF2BV_ERR_NOMEM; errs[t] = "out of host memory"; }
 				(void)hipStreamSynchronize(st);
 			}
 			pool().release_stream(st, device, false);
@@ -962,11 +1031,13 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 	for (int t = 0; t < NS; t++)
 		if (rcs[t] != GF2BV_OK) return fail(rcs[t], errs[t].c_str());
 	return GF2BV_OK;
+	});
 }
 
 int gf2bv_solve_words(const uint64_t *aug, int64_t rows, int64_t cols, int64_t stride_words, int mode,
                       int device, gf2bv_result **out)
 {
+	return guarded([&]() -> int {
 	if (!out || (!aug && rows > 0)) return fail(GF2BV_ERR_ARG, "null pointer");
 	*out = nullptr;
 	int rc = check_shape(rows, cols, mode);
@@ -984,8 +1055,10 @@ int gf2bv_solve_words(const uint64_t *aug, int64_t rows, int64_t cols, int64_t s
 	S.stride = wt;
 	HIPCHK(pool().alloc((void **)&S.tmp_src, sizeof(u64) * std::max<i64>(1, rows) * S.stride, device));
 	S.src = S.tmp_src;
+	Scratch scratch;                  // (declared after S: released first, after synchronising the solve's stream)
+	scratch.sync_first = S.sA;
 	hipEvent_t p0, p1;
-	HIPCHK(pool().event(&p0, true)); HIPCHK(pool().event(&p1, true));
+	HIPCHK(scratch.event(&p0)); HIPCHK(scratch.event(&p1));
 	HIPCHK(hipEventRecord(p0, S.sA));
 	if (rows > 0)
 		HIPCHK(hipMemcpy2DAsync(S.tmp_src, S.stride * 8, aug, stride_words * 8, wt * 8, rows, hipMemcpyHostToDevice, S.sA));
@@ -998,13 +1071,14 @@ int gf2bv_solve_words(const uint64_t *aug, int64_t rows, int64_t cols, int64_t s
 		(void)hipEventElapsedTime(&S.ms_pack, p0, p1);
 		rc = solver_finish(S, out);
 	}
-	pool().release_event(p0, true); pool().release_event(p1, true);
 	return rc;
+	});
 }
 
 int gf2bv_solve_batch_digits(const uint32_t *digits, const int64_t *digit_off, int bits_per_digit, int64_t nsys,
                              int64_t rows, int64_t cols, int mode, int device, gf2bv_result **out)
 {
+	return guarded([&]() -> int {
 	if (!out || !digit_off || nsys < 0) return fail(GF2BV_ERR_ARG, "null pointer");
 	for (i64 s = 0; s < nsys; s++) out[s] = nullptr;
 	int rc = check_shape(rows, cols, mode);
@@ -1051,11 +1125,13 @@ int gf2bv_solve_batch_digits(const uint32_t *digits, const int64_t *digit_off, i
 		if (rc) return rc;
 	}
 	return GF2BV_OK;
+	});
 }
 
 int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bits_per_digit, int64_t rows,
                        int64_t cols, int mode, int device, gf2bv_result **out)
 {
+	return guarded([&]() -> int {
 	if (!out || !digit_off) return fail(GF2BV_ERR_ARG, "null pointer");
 	*out = nullptr;
 	int rc = check_shape(rows, cols, mode);
@@ -1074,12 +1150,14 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 	S.stride = ntiles * TW;
 	HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * ntiles * TW * slab_rows(rows), device));     // packed straight into tiles
 	const i64 ndig = digit_off[rows];
+	Scratch scratch;                  // digits, offsets and the pack events go back to the pool on every path
+	scratch.sync_first = S.sA;
 	uint32_t *d_dig = nullptr;
 	i64 *d_off = nullptr;
-	HIPCHK(pool().alloc((void **)&d_dig, sizeof(uint32_t) * std::max<i64>(1, ndig), device));
-	HIPCHK(pool().alloc((void **)&d_off, sizeof(i64) * (rows + 1), device));
+	HIPCHK(scratch.alloc((void **)&d_dig, sizeof(uint32_t) * std::max<i64>(1, ndig), device));
+	HIPCHK(scratch.alloc((void **)&d_off, sizeof(i64) * (rows + 1), device));
 	hipEvent_t p0, p1;
-	HIPCHK(pool().event(&p0, true)); HIPCHK(pool().event(&p1, true));
+	HIPCHK(scratch.event(&p0)); HIPCHK(scratch.event(&p1));
 	HIPCHK(hipEventRecord(p0, S.sA));
 	if (ndig) HIPCHK(hipMemcpyAsync(d_dig, digits, sizeof(uint32_t) * ndig, hipMemcpyHostToDevice, S.sA));
 	HIPCHK(hipMemcpyAsync(d_off, digit_off, sizeof(i64) * (rows + 1), hipMemcpyHostToDevice, S.sA));
@@ -1098,10 +1176,8 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 		(void)hipEventElapsedTime(&S.ms_pack, p0, p1);
 		rc = solver_finish(S, out);
 	}
-	(void)hipStreamSynchronize(S.sA);
-	pool().release(d_dig); pool().release(d_off);
-	pool().release_event(p0, true); pool().release_event(p1, true);
 	return rc;
+	});
 }
 
 // ---- result accessors ----------------------------------------------------------------------------

@@ -41,10 +41,11 @@ class Stats(ctypes.Structure):
         ("rank", ctypes.c_int64), ("dimension", ctypes.c_int64),
         ("status", ctypes.c_int32), ("n_panels", ctypes.c_int32), ("n_sweeps", ctypes.c_int32),
         ("panels_per_sweep", ctypes.c_int32), ("tables_per_sweep", ctypes.c_int32), ("table_bits", ctypes.c_int32),
-        ("tile_words", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("tile_words", ctypes.c_int32), ("gang_systems", ctypes.c_int32),
         ("sweep_words", ctypes.c_double), ("row_xors", ctypes.c_double),
         ("ms_pack", ctypes.c_float), ("ms_eliminate", ctypes.c_float), ("ms_sweep", ctypes.c_float),
         ("ms_backsub", ctypes.c_float), ("ms_export", ctypes.c_float), ("ms_total", ctypes.c_float),
+        ("search_handovers", ctypes.c_int32), ("reserved1", ctypes.c_int32),
     ]
 
     def as_dict(self) -> dict:
@@ -70,7 +71,7 @@ def lib():
         L.gf2bv_solve_digits.argtypes = [vp, vp, i32, i64, i64, i32, i32, pp]
         L.gf2bv_solve_words.argtypes = [vp, i64, i64, i64, i32, i32, pp]
         L.gf2bv_solve_device.argtypes = [vp, i64, i64, i64, i32, i32, vp, i32, pp]
-        L.gf2bv_solve_batch_device.argtypes = [vp, i64, i64, i64, i64, i64, i32, i32, pp]
+        L.gf2bv_solve_batch_device.argtypes = [vp, i64, i64, i64, i64, i64, i32, i32, vp, i32, pp]
         L.gf2bv_solve_batch_digits.argtypes = [vp, vp, i32, i64, i64, i64, i32, i32, pp]
         for name, res in (("gf2bv_result_status", i32), ("gf2bv_result_rank", i64),
                           ("gf2bv_result_dimension", i64), ("gf2bv_result_words", i64)):
@@ -179,9 +180,12 @@ def solve_device(d_ptr: int, rows: int, cols: int, stride: int, mode: int = MODE
 
 
 def solve_batch_device(d_ptr: int, nsys: int, sys_stride: int, rows: int, cols: int, stride: int,
-                       mode: int = MODE_SINGLE, device: int = 0) -> list:
+                       mode: int = MODE_SINGLE, device: int = 0, stream: int = 0, time_kernels: bool = False) -> list:
+    """nsys equal-shape systems resident in device memory, solved as lock-step gangs.  `stream` = the stream that
+    produced the matrices (0 = the null stream): the gangs are ordered after it."""
     hs = (ctypes.c_void_p * max(nsys, 1))()
-    rc = lib().gf2bv_solve_batch_device(d_ptr, nsys, sys_stride, rows, cols, stride, mode, device, hs)
+    rc = lib().gf2bv_solve_batch_device(d_ptr, nsys, sys_stride, rows, cols, stride, mode, device, stream or None,
+                                        1 if time_kernels else 0, hs)
     return _take_all(hs, nsys, rc, mode)
 
 

@@ -53,7 +53,7 @@ typedef struct gf2bv_stats {
 	int32_t tables_per_sweep;  /* G*T: grease tables applied per row per pass                  */
 	int32_t table_bits;        /* k: index bits of the widest table                            */
 	int32_t tile_words;        /* 64-bit words of one row segment handled by a lane group      */
-	int32_t reserved0;
+	int32_t gang_systems;      /* systems that shared this solve's kernel launches (1: a solve of its own)    */
 	double  sweep_words;       /* sum over sweeps of rows_swept x active_words  (unit of work) */
 	double  row_xors;          /* sum over sweeps of rows_swept x T                            */
 	float   ms_pack;           /* digits/words -> device matrix (H2D + pack kernel)            */
@@ -62,6 +62,9 @@ typedef struct gf2bv_stats {
 	float   ms_backsub;        /* consistency check + back-substitution + kernel basis         */
 	float   ms_export;         /* D2H of origin / basis                                        */
 	float   ms_total;          /* host wall clock of the whole call                            */
+	int32_t search_handovers;  /* panels whose first search unit stopped waiting for the rest of its launch and
+	                              left publishing to the last arriver (co-residency is not assumed)           */
+	int32_t reserved1;
 } gf2bv_stats;
 
 /* ---- library / device ------------------------------------------------------------------ */
@@ -86,7 +89,9 @@ int gf2bv_solve_words(const uint64_t *aug, int64_t rows, int64_t cols, int64_t s
 
 /* Same, matrix resident in DEVICE memory (row-major augmented words, left untouched: the solver
  * first copies it into its own tile-major working layout, one extra pass over the matrix).
- * d_aug must be 16-byte aligned and stride_words even.  `stream` is a hipStream_t or NULL.
+ * d_aug must be 16-byte aligned and stride_words even.  `stream` is a HIP stream handle or NULL: the solve is
+ * enqueued on it (so it is ordered after whatever produced the matrix there) and the call returns when
+ * the result is on the host.
  * `time_kernels` != 0 brackets every bulk-update launch with HIP events (fills ms_sweep). */
 int gf2bv_solve_device(void *d_aug, int64_t rows, int64_t cols, int64_t stride_words,
                        int mode, int device, void *stream, int time_kernels, gf2bv_result **out);
@@ -96,11 +101,16 @@ int gf2bv_solve_device(void *d_aug, int64_t rows, int64_t cols, int64_t stride_w
  * The systems run in lock-step "gangs": one set of kernel launches eliminates a whole gang
  * (grid dimension y = system), so the latency-bound panel path is paid once per gang and the bulk
  * updates of all its systems fill the chip; results are identical to nsys separate calls.  In the
- * stats of a gang member ms_eliminate is the gang's elimination time and ms_sweep is 0.
- * Independent systems are the unit that bench.py shards across GPUs. */
+ * stats of a gang member ms_eliminate is the gang's elimination time, and ms_sweep (with
+ * `time_kernels` != 0) the time inside the GANG's bulk-update launches (one launch serves all its
+ * systems), not a per-system share.
+ * Ordering: the gangs run on the library's own streams; they start after everything that was
+ * enqueued on `stream` (a HIP stream handle, NULL = the null stream) when the call is made -- the stream
+ * that produced the matrices -- and the call returns when all systems are solved.
+ * Independent systems are the unit that bench.py shards across GPUs (BASELINE configs[3]). */
 int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words,
                              int64_t rows, int64_t cols, int64_t stride_words,
-                             int mode, int device, gf2bv_result **out);
+                             int mode, int device, void *stream, int time_kernels, gf2bv_result **out);
 
 /* Batch of `nsys` independent equal-shape systems given as digit arrays (see gf2bv_solve_digits):
  * row r of system s is entry s*rows + r of digit_off (nsys*rows + 1 entries).  One upload, lock-step
@@ -133,6 +143,7 @@ void gf2bv_space_combine(const uint64_t *origin, const uint64_t *basis, int64_t 
 /* ---- synthetic systems + independent residual check (bench / tests) ----------------------- */
 /* word w of row r = mix64(mix64(seed) ^ ((r<<20)|w)); planted solution = pseudo-row 0xFFFFF;
  * RHS = <row, planted>.  Writes rows x stride_words words at d_aug. */
+/* (asynchronous: the generator kernel is enqueued on `stream` and the call returns) */
 int gf2bv_synth_device(void *d_aug, int64_t rows, int64_t cols, int64_t stride_words,
                        uint64_t seed, int device, void *stream);
 /* counts rows i with <A_i, x> != b_i on an (untouched) device matrix; x in host memory */

@@ -7,6 +7,10 @@ if ROOT not in sys.path:
 
 # Build the HIP library, the CPython shim and the CPU oracle BEFORE test modules are collected
 # (they import gf2bv_amd at module level; the built artefacts are git-ignored).
+# torch FIRST: it brings its own copy of the HIP runtime, and a process must end up with ONE -- libgf2bv_hip.so then
+# binds to the copy that is already loaded (as in bench.py); loaded the other way round, torch.cuda sees no device.
+import torch  # noqa: E402,F401
+
 import __graft_entry__  # noqa: E402
 
 __graft_entry__.build()

@@ -1,0 +1,96 @@
+"""BASELINE configs[3] on the GPU: the batch workload's real shard functions (gf2bv_amd.batch.synth_shard /
+solve_shard / gather_records -- what `bench.py --gpus N` runs on every rank), one GPU's share of the 512-system job,
+the end-of-job gather over RCCL (backend "nccl", world size 1 on a one-GPU box) and bench.py's batch mode itself."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+
+from gf2bv_amd import batch, hip
+from oracle import gf2_oracle as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert hip.device_count() >= 1 and torch.cuda.is_available(), "gpu tests need an MI355X"
+
+
+def _check_records(n, seeds, recs, sols, mats, oracle_diff=()):
+    stride = hip.padded_stride(n)
+    assert recs.shape == (len(seeds), batch.record_words(n)) and recs.is_cuda
+    host = recs.cpu().numpy()
+    for i, (seed, s) in enumerate(zip(seeds, sols)):
+        assert s.solved and s.rank >= n - 8
+        assert hip.residual_device(mats[i].data_ptr(), n, n, stride, s.origin) == 0       # A x = b, independent kernel
+        assert np.array_equal(host[i], batch.make_record(s.status, s.rank, s.origin))
+    for i in oracle_diff:                                                                   # word for word vs the oracle
+        want = O.solve_words(O.gen_synthetic(n, n, seeds[i]), n, n, 0, algo=1)
+        assert sols[i].status == want["status"] and sols[i].rank == want["rank"]
+        assert np.array_equal(sols[i].pivots, want["pivcols"]) and np.array_equal(sols[i].origin, want["origin"])
+
+
+@pytest.mark.timeout(900)
+def test_c4_one_gpu_share_64_systems_of_32768():
+    """One GPU's block of configs[3] at 8 GPUs: 64 x 32768^2 (8.7 GiB resident), through the shard functions."""
+    n, world, rank, total = 32768, 8, 3, 512
+    lo, hi = batch.shard_bounds(total, world, rank)
+    assert hi - lo == 64
+    seeds = [5000 + i for i in range(lo, hi)]
+    mats = batch.synth_shard(n, seeds, 0)
+    recs, sols = batch.solve_shard(n, mats, 0, time_kernels=True)
+    _check_records(n, seeds, recs, sols, mats, oracle_diff=(0, 37))
+    assert all(s.stats["gang_systems"] >= 2 for s in sols)                                  # ran as gangs
+    assert all(s.stats["ms_sweep"] > 0 for s in sols)
+    # no stream synchronisation between generation and solve: a second pass over re-generated inputs must agree
+    mats2 = batch.synth_shard(n, seeds[:16], 0, mats[:16])
+    recs2, _ = batch.solve_shard(n, mats2, 0)
+    assert torch.equal(recs2, recs[:16])
+
+
+def test_gather_records_over_nccl_world_size_1():
+    """The end-of-job collective with the backend the multi-GPU run uses (RCCL), on this box's one GPU."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        n, total = 2048, 5
+        lo, hi = batch.shard_bounds(total, 1, 0)
+        seeds = [900 + i for i in range(lo, hi)]
+        mats = batch.synth_shard(n, seeds, 0)
+        recs, sols = batch.solve_shard(n, mats, 0)
+        allrec = batch.gather_records(recs, total)
+        torch.cuda.synchronize()
+        assert allrec.is_cuda and torch.equal(allrec, recs)
+        _check_records(n, seeds, allrec, sols, mats, oracle_diff=(0, 4))
+        # an uneven split as rank 0 of a larger job would see it: padding rows never leak into the table
+        part = batch.gather_records(recs[:3], 3)
+        assert torch.equal(part, recs[:3])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_bench_batch_mode_end_to_end():
+    """bench.py --workload batch (what --gpus N > 1 runs on every rank), launched through torch.distributed.run."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "batch", "--steps", "2",
+           "--warmup", "1", "--batch-total", "12", "--batch-n", "4096", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=550, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["n_gpus"] == 1 and line["config"]["systems_total"] == 12
+    assert line["parity_gate"]["all_ranks_ok"] and line["parity_gate"]["residual_rows_rank0"] == 0
+    assert line["parity_gate"]["gathered_records"] == 12
+    assert line["value"] > 0 and line["roofline"]["achieved"] > 0

@@ -328,6 +328,60 @@ def test_concurrent_gangs_saturating_the_chip(monkeypatch):
     buf.free()
 
 
+def test_search_handover_without_co_residency(monkeypatch):
+    """GF2BV_SELF_WAIT_US=0: the first search unit of a dense panel never waits for the rest of its launch -- the
+    situation on a chip where its workgroups are not co-resident -- and the last arriver publishes from its record.
+    Same results, and the hand-over path is seen to have run."""
+    monkeypatch.setenv("GF2BV_SELF_WAIT_US", "0")
+    rng = random.Random(77)
+    handovers = 0
+    for rows, cols, cap in ((3000, 2500, None), (5000, 4097, 4000), (9000, 8200, None)):
+        eqs = random_system(rng, rows, cols, .5, cap, True, 0)
+        aug = O.eqs_to_aug(eqs, cols)
+        for mode in (0, 1):
+            got = hip.solve_words(aug, rows, cols, mode)
+            assert_same(got, O.solve_words(aug, rows, cols, mode), mode)
+            handovers += got.stats["search_handovers"]
+    assert handovers > 0
+    n, stride = 16384, hip.padded_stride(16384)
+    buf = hip.DeviceBuffer(n * stride * 8)
+    hip.synth_device(buf.ptr, n, n, stride, 99)
+    s = hip.solve_device(buf.ptr, n, n, stride, 0)
+    assert s.solved and hip.residual_device(buf.ptr, n, n, stride, s.origin) == 0 and s.stats["search_handovers"] > 0
+    buf.free()
+
+
+def test_concurrent_gangs_next_to_a_saturating_stream(monkeypatch):
+    """Gangs from two host threads while a third keeps every CU busy with the streaming kernel of the ceiling
+    measurement: panel-search workgroups are dispatched late or not together; the solves must stay correct
+    (they used to rely on the co-residency of a launch's workgroups and could report an internal time-out)."""
+    import threading
+    monkeypatch.setenv("GF2BV_GANG", "6")
+    n, nsys = 8192, 18
+    stride = hip.padded_stride(n)
+    buf = hip.DeviceBuffer(nsys * n * stride * 8)
+    for i in range(nsys):
+        hip.synth_device(buf.ptr + i * n * stride * 8, n, n, stride, 8100 + i)
+    stop = threading.Event()
+
+    def hog():
+        while not stop.is_set():
+            hip.stream_ceiling(1 << 30)
+
+    t = threading.Thread(target=hog)
+    t.start()
+    try:
+        for rep in range(2):
+            sols = hip.solve_batch_device(buf.ptr, nsys, n * stride, n, n, stride, 0)
+            for i, s in enumerate(sols):
+                assert s.solved and s.rank >= n - 8
+                assert hip.residual_device(buf.ptr + i * n * stride * 8, n, n, stride, s.origin) == 0
+    finally:
+        stop.set()
+        t.join()
+    buf.free()
+
+
 def test_back_substitution_paths_agree(monkeypatch):
     """solve_one's blocked parity back-substitution vs the general multi-RHS sweep path (solve_all's)."""
     rng = random.Random(31)
