@@ -55,6 +55,8 @@ struct AffineSpaceObject {
 	int64_t dim, words;
 	uint64_t *origin;   // words
 	uint64_t *basis;    // dim x words
+	int device;         // the device whose solve produced the space (its large walks are materialised there);
+	                    // -1: built from host integers by the test hook _space_from_ints -- walked on the host
 };
 
 struct SpaceIterObject {
@@ -64,7 +66,17 @@ struct SpaceIterObject {
 	uint64_t idx;       // Gray index
 	uint8_t *state;     // Slow: dim+1 counter bits
 	int done;
+	// Large spaces: the elements are materialised on the device a chunk at a time (gf2bv_space_enumerate) and the
+	// iterator only slices ints out of the chunk -- no per-item XOR on the host.  Small ones (a chunk would be under
+	// 64 KiB) are stepped on the host as in the reference: a kernel launch costs more than their whole walk.
+	gf2bv_space *dev;   // nullptr: host stepping
+	const uint64_t *chunk;   // the space handle's pinned buffer, filled by the last gf2bv_space_enumerate
+	int64_t chunk_cap, chunk_fill, chunk_pos;
+	uint64_t next_first;     // index of the first element of the next chunk
+	int wrapped;             // next_first has run past 2^64 - 1 (dimension 64 only)
 };
+
+constexpr int64_t kChunkBytes = 8 << 20, kDeviceMinBytes = 64 << 10;
 
 PyTypeObject *AffineSpace_Type, *SpaceIterGray_Type, *SpaceIterSlow_Type;
 
@@ -118,16 +130,66 @@ PyObject *space_iter(AffineSpaceObject *self)
 	it->done = 0;
 	it->state = nullptr;
 	size_t nw = (size_t)(self->words ? self->words : 1);
+	it->dev = nullptr; it->chunk = nullptr; it->chunk_cap = it->chunk_fill = it->chunk_pos = 0; it->next_first = 0; it->wrapped = 0;
 	it->cur = (uint64_t *)malloc(nw * sizeof(uint64_t));
-	memcpy(it->cur, self->origin, (size_t)self->words * sizeof(uint64_t));
 	if (!gray) it->state = (uint8_t *)calloc((size_t)self->dim + 1, 1);
+	if (!it->cur || (!gray && !it->state)) { Py_DECREF(it); return PyErr_NoMemory(); }
+	memcpy(it->cur, self->origin, (size_t)self->words * sizeof(uint64_t));
+	// device enumeration when a chunk is worth a launch: min(2^dim, chunk capacity) elements of `words` words
+	const int64_t row_bytes = (int64_t)nw * 8;
+	int64_t cap = std::max<int64_t>(1, kChunkBytes / row_bytes);
+	if (self->dim < 40) cap = std::min<int64_t>(cap, (int64_t)1 << self->dim);
+	if (self->device >= 0 && self->words > 0 && cap * row_bytes >= kDeviceMinBytes) {
+		if (gf2bv_space_open(self->origin, self->basis, self->dim, self->words, self->device, &it->dev) != GF2BV_OK) {
+			PyErr_SetString(PyExc_RuntimeError, gf2bv_last_error());
+			Py_DECREF(it);
+			return nullptr;
+		}
+		it->chunk_cap = cap;
+	}
 	return (PyObject *)it;
+}
+
+// total number of elements still to be produced from index `first` on, capped at `cap` (2^dim may not fit 64 bits)
+int64_t remaining_from(int64_t dim, uint64_t first, int wrapped, int64_t cap)
+{
+	if (wrapped) return 0;
+	if (dim >= 64) {                                   // 2^64 (or more) elements: only the wrap ends the walk
+		const uint64_t left = ~first;                  // elements first .. 2^64 - 1 = left + 1
+		return (left >= (uint64_t)cap) ? cap : (int64_t)left + 1;
+	}
+	const uint64_t total = (uint64_t)1 << dim;
+	if (first >= total) return 0;
+	return (int64_t)std::min<uint64_t>(total - first, (uint64_t)cap);
+}
+
+// next element from the device-filled chunk; refills when it runs dry.  Returns nullptr with no error set at the end.
+PyObject *iter_next_chunked(SpaceIterObject *self, int gray)
+{
+	AffineSpaceObject *sp = self->space;
+	if (self->chunk_pos >= self->chunk_fill) {
+		// (binary walk with dimension > 64: the first 2^64 elements only involve basis[0..63]; nobody gets further)
+		const int64_t n = remaining_from(sp->dim, self->next_first, self->wrapped, self->chunk_cap);
+		if (n <= 0) return nullptr;
+		int rc;
+		Py_BEGIN_ALLOW_THREADS
+		rc = gf2bv_space_enumerate(self->dev, self->next_first, n, gray, nullptr);
+		Py_END_ALLOW_THREADS
+		if (rc != GF2BV_OK) { PyErr_SetString(PyExc_RuntimeError, gf2bv_last_error()); return nullptr; }
+		self->chunk = gf2bv_space_buffer(self->dev);
+		const uint64_t before = self->next_first;
+		self->next_first += (uint64_t)n;
+		if (self->next_first < before || (sp->dim >= 64 && self->next_first == 0)) self->wrapped = 1;
+		self->chunk_fill = n; self->chunk_pos = 0;
+	}
+	return words_to_pylong(self->chunk + self->chunk_pos++ * sp->words, sp->words);
 }
 
 void iter_dealloc(SpaceIterObject *self)
 {
 	PyTypeObject *tp = Py_TYPE(self);
 	Py_XDECREF(self->space);
+	if (self->dev) gf2bv_space_close(self->dev);
 	free(self->cur);
 	free(self->state);
 	tp->tp_free((PyObject *)self);
@@ -138,6 +200,7 @@ void iter_dealloc(SpaceIterObject *self)
 // row whose index is the bit in which gray(idx) and gray(idx+1) differ.
 PyObject *iter_next_gray(SpaceIterObject *self)
 {
+	if (self->dev) return iter_next_chunked(self, 1);
 	if (self->done) return nullptr;
 	AffineSpaceObject *sp = self->space;
 	PyObject *ret = words_to_pylong(self->cur, sp->words);
@@ -157,6 +220,7 @@ PyObject *iter_next_gray(SpaceIterObject *self)
 // Binary counter walk for dimension > 64, _internal.c:63-91 (basis[0] is the LSB).
 PyObject *iter_next_slow(SpaceIterObject *self)
 {
+	if (self->dev) return iter_next_chunked(self, 0);
 	AffineSpaceObject *sp = self->space;
 	const int64_t n = sp->dim;
 	if (self->state[n]) return nullptr;
@@ -222,8 +286,14 @@ PyObject *result_to_py(gf2bv_result *res, long mode)
 		if (sp) {
 			sp->dim = gf2bv_result_dimension(res);
 			sp->words = words;
+			sp->device = 0;
 			sp->origin = (uint64_t *)calloc((size_t)(words ? words : 1), sizeof(uint64_t));
 			sp->basis = (uint64_t *)calloc((size_t)((sp->dim * words) > 0 ? sp->dim * words : 1), sizeof(uint64_t));
+			if (!sp->origin || !sp->basis) {
+				Py_DECREF(sp);                   // (space_dealloc frees whichever half exists)
+				gf2bv_result_free(res);
+				return PyErr_NoMemory();
+			}
 			gf2bv_result_origin(res, sp->origin);
 			gf2bv_result_basis(res, sp->basis);
 			ret = (PyObject *)sp;
@@ -550,8 +620,10 @@ PyObject *py_space_from_ints(PyObject *, PyObject *const *args, Py_ssize_t nargs
 	if (!sp) return nullptr;
 	sp->dim = dim;
 	sp->words = words;
+	sp->device = -1;                 // host-built: walked on the host (no GPU needed for the host-logic tests)
 	sp->origin = (uint64_t *)calloc((size_t)words, sizeof(uint64_t));
 	sp->basis = (uint64_t *)calloc((size_t)((dim * words) > 0 ? dim * words : 1), sizeof(uint64_t));
+	if (!sp->origin || !sp->basis) { Py_DECREF(sp); return PyErr_NoMemory(); }
 	for (int64_t k = -1; k < dim; k++) {
 		PyObject *v = k < 0 ? args[1] : PyTuple_GET_ITEM(args[2], k);
 		if (!PyLong_Check(v)) { Py_DECREF(sp); PyErr_SetString(PyExc_TypeError, "integers expected"); return nullptr; }

@@ -1719,6 +1719,7 @@ k_check_rhs(const u64 *__restrict__ M, i64 rows, i64 srows, i64 cols,
 // U is read exactly once overall.
 #define GF2_BSG 16
 #define GF2_BSV 8            // right-hand sides one parity back-substitution handles together (U is read once for all)
+#define GF2_BS_MAXRHS 64     // more right-hand sides than this take the table sweeps over Y instead of ceil(n / GF2_BSV) parity passes
 
 // Right-hand side t of the back-substitution is column ycols[t] of U (the RHS column `cols`, or a free
 // column when a kernel basis is wanted); X holds ny solution vectors of cw words, accv ny x nacc bytes.
@@ -1846,12 +1847,13 @@ k_bs_near(const u64 *__restrict__ Dg, i64 cw, int qa, int qb, const PanelRec *__
 __global__ void __launch_bounds__(256)
 k_extract_y(const u64 *__restrict__ M, i64 srows, const SolveState *__restrict__ st,
             const int *__restrict__ urow, const int *__restrict__ pivcol,
-            const int *__restrict__ ycols, int ny, u64 *__restrict__ Y, i64 ys)
+            const int *__restrict__ ycols, int ny, u64 *__restrict__ Y, i64 ys, i64 k0)
 {
+	// (k0: first pivot of this launch -- a launch dimension holds fewer than 2^32 work-items)
 	const int lane = threadIdx.x & 63;
 	const i64 wave = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 	const int nyw = (ny + 63) >> 6;
-	const i64 k = wave / nyw;
+	const i64 k = k0 + wave / nyw;
 	const int tw = (int)(wave % nyw);
 	if (k >= st->rank) return;
 	const int t = tw * 64 + lane;
@@ -1981,11 +1983,11 @@ k_sweep(u64 *__restrict__ M, i64 stride, i64 rows_total, const PanelRec *__restr
 // kernel vector (t < ny-1).  out is ny x cw words, zero-initialised.
 __global__ void __launch_bounds__(256)
 k_scatter_solution(const u64 *__restrict__ Y, i64 ys, const SolveState *__restrict__ st,
-                   const int *__restrict__ pivcol, int ny, u64 *__restrict__ out, i64 cw)
+                   const int *__restrict__ pivcol, int ny, u64 *__restrict__ out, i64 cw, i64 k0)
 {
 	const int nyw = (ny + 63) >> 6;
 	const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	const i64 k = g / nyw;
+	const i64 k = k0 + g / nyw;
 	const int tw = (int)(g % nyw);
 	if (k >= st->rank) return;
 	u64 y = Y[k * ys + tw];
@@ -1994,6 +1996,31 @@ k_scatter_solution(const u64 *__restrict__ Y, i64 ys, const SolveState *__restri
 		int b = ctz64(y); y &= y - 1;
 		i64 t = (i64)tw * 64 + b;
 		if (t < ny) atomicOr(&out[t * cw + (c >> 6)], 1ull << (c & 63));
+	}
+}
+
+// ------------------------------------------------------------------------------------------
+// AffineSpace enumeration (replaces the per-item loops of _internal.c:101-122 / :63-91): element first + v of the
+// space, v < count, one 64-bit word per thread: out[v][w] = origin[w] ^ XOR of basis[i][w] over the set bits i of
+// code(first + v); gray: code(g) = g ^ (g >> 1) (the reflected Gray walk of AffineSpaceIterator), otherwise
+// code(g) = g (AffineSpaceIteratorSlow / get).  The basis (dimension x words, a few hundred KiB at most) stays in L2.
+__global__ void __launch_bounds__(256)
+k_space_enumerate(const u64 *__restrict__ origin, const u64 *__restrict__ basis, int dim, i64 words, u64 first,
+                  i64 count, int gray, u64 *__restrict__ out)
+{
+	const i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+	if (w >= words) return;
+	const u64 o = origin[w];
+	for (i64 v = blockIdx.y; v < count; v += gridDim.y) {
+		const u64 g = first + (u64)v;
+		u64 code = gray ? (g ^ (g >> 1)) : g;
+		if (dim < 64) code &= (1ull << dim) - 1;
+		u64 acc = o;
+		while (code) {
+			const int i = ctz64(code); code &= code - 1;
+			acc ^= basis[(i64)i * words + w];
+		}
+		out[v * words + w] = acc;
 	}
 }
 

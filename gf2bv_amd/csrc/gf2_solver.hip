@@ -647,10 +647,13 @@ int enqueue_backward(Solver &S, const std::vector<int> &ycols_host)
 	u64 *bmult = S.mult;              // forward multipliers are dead by now
 	const int rpb = 2048;
 	if (S.maxr > 0) {
-		i64 waves = S.maxr * nyw;
-		if (waves >= (1ll << 26)) return fail(GF2BV_ERR_ARG, "kernel basis too large: rank x free columns exceeds one launch (2^32 work-items)");
-		k_extract_y<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, S.sA>>>(S.M, S.srows, S.st, S.urow, S.pivcol,
-		                                                                      S.ycols, S.ny, S.Y, S.ys);
+		// (a launch dimension holds fewer than 2^32 work-items: pivots go in chunks of 2^24 wavefronts)
+		const i64 kchunk = std::max<i64>(1, (1ll << 24) / nyw);
+		for (i64 k0 = 0; k0 < S.maxr; k0 += kchunk) {
+			const i64 waves = std::min(kchunk, S.maxr - k0) * nyw;
+			k_extract_y<<<dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, S.sA>>>(S.M, S.srows, S.st, S.urow, S.pivcol,
+			                                                                      S.ycols, S.ny, S.Y, S.ys, k0);
+		}
 		const int ytiles = (int)(S.ys / YTW);
 		for (int q = S.npanels - 1; q >= 1; q--) {
 			const i64 bound = std::min<i64>((i64)64 * q, S.maxr);      // pivots before panel q
@@ -659,9 +662,11 @@ int enqueue_backward(Solver &S, const std::vector<int> &ycols_host)
 			const i64 nrb = (bound + rpb - 1) / rpb;
 			HIPCHK(launch_ysweep(dim3((unsigned)(ytiles * nrb)), S.sA, S.Y, S.ys, S.maxr, S.panels + q, bmult, ytiles, rpb));
 		}
-		i64 thr = S.maxr * nyw;
-		k_scatter_solution<<<dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, S.sA>>>(S.Y, S.ys, S.st, S.pivcol, S.ny,
-		                                                                              S.out, std::max<i64>(1, S.cw));
+		for (i64 k0 = 0; k0 < S.maxr; k0 += kchunk << 6) {
+			const i64 thr = std::min(kchunk << 6, S.maxr - k0) * nyw;
+			k_scatter_solution<<<dim3((unsigned)((thr + 255) / 256)), dim3(256), 0, S.sA>>>(S.Y, S.ys, S.st, S.pivcol, S.ny,
+			                                                                              S.out, std::max<i64>(1, S.cw), k0);
+		}
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(S.ev2, S.sA));
@@ -685,12 +690,16 @@ int enqueue_backward_parity(Solver &S, const std::vector<int> &ycols_host)
 	HIPCHK(pool().alloc((void **)&S.Y, sizeof(u64) * 64 * 16 * std::max(1, S.npanels), S.device));
 	if (S.npanels > 0)
 		k_bs_diag<<<dim3(S.npanels), dim3(256), 0, S.sA>>>(S.M, S.srows, S.npanels, S.panels, S.urow, S.Y);
-	for (int qb = S.npanels; qb > 0; qb -= GF2_BSG) {
-		const int qa = std::max(0, qb - GF2_BSG);
-		const int waves = (qb - qa) * 64;
-		k_bs_far<<<dim3((waves + 3) / 4), dim3(256), 0, S.sA>>>(S.M, S.srows, cw, qa, qb, S.panels, S.urow, S.pivcol, S.ycols, S.ny,
-		                                                        S.out, accv, nacc);
-		k_bs_near<<<dim3(1), dim3(256), 0, S.sA>>>(S.Y, cw, qa, qb, S.panels, S.pivcol, S.ny, S.out, accv, nacc);
+	// right-hand sides in groups of GF2_BSV (U is streamed once per group; the groups are independent)
+	for (int v0 = 0; v0 < S.ny; v0 += GF2_BSV) {
+		const int nv = std::min(GF2_BSV, S.ny - v0);
+		for (int qb = S.npanels; qb > 0; qb -= GF2_BSG) {
+			const int qa = std::max(0, qb - GF2_BSG);
+			const int waves = (qb - qa) * 64;
+			k_bs_far<<<dim3((waves + 3) / 4), dim3(256), 0, S.sA>>>(S.M, S.srows, cw, qa, qb, S.panels, S.urow, S.pivcol, S.ycols + v0, nv,
+			                                                        S.out + (i64)v0 * cw, accv, nacc);
+			k_bs_near<<<dim3(1), dim3(256), 0, S.sA>>>(S.Y, cw, qa, qb, S.panels, S.pivcol, nv, S.out + (i64)v0 * cw, accv, nacc);
+		}
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(S.ev2, S.sA));
@@ -741,8 +750,10 @@ int finish_begin(Solver &S)
 		std::vector<int> yc;
 		if (!S.hst.inconsistent) yc = S.free_order;
 		yc.push_back((int)S.cols);
-		// few right-hand sides (the usual kernel dimensions): the parity path; otherwise the sweeps over Y
-		int rc = ((int)yc.size() <= GF2_BSV && !getenv("GF2BV_YSWEEP")) ? enqueue_backward_parity(S, yc) : enqueue_backward(S, yc);
+		// up to GF2_BS_MAXRHS right-hand sides (kernel dimensions of the reference's use: solve_all caps at 16): the parity
+		// path, GF2_BSV of them per pass over U; larger bases: the table sweeps over the bit matrix Y (one pass over Y per
+		// panel whatever the dimension)
+		int rc = ((int)yc.size() <= GF2_BS_MAXRHS && !getenv("GF2BV_YSWEEP")) ? enqueue_backward_parity(S, yc) : enqueue_backward(S, yc);
 		if (rc) return rc;
 	}
 	HIPCHK(hipMemcpyAsync(&S.hst, S.st, sizeof S.hst, hipMemcpyDeviceToHost, S.sA));
@@ -1218,6 +1229,79 @@ void gf2bv_space_combine(const uint64_t *origin, const uint64_t *basis, int64_t 
 	for (i64 i = 0; i < dimension && (i >> 6) < selector_words; i++)
 		if ((selector[i >> 6] >> (i & 63)) & 1)
 			for (i64 w = 0; w < words; w++) o[w] ^= basis[i * words + w];
+}
+
+// ---- AffineSpace on the device: bulk enumeration ------------------------------------------------
+struct gf2bv_space {
+	int device = 0;
+	int64_t dim = 0, words = 0;
+	u64 *d_origin = nullptr, *d_basis = nullptr;
+	u64 *d_out = nullptr;
+	u64 *h_out = nullptr;         // pinned staging: the device-to-host copy runs at link speed, and callers that pass no
+	size_t out_words = 0;         // output pointer read the elements straight from it (gf2bv_space_buffer)
+	hipStream_t st = nullptr;
+};
+
+int gf2bv_space_open(const uint64_t *origin, const uint64_t *basis, int64_t dimension, int64_t words, int device,
+                     gf2bv_space **out)
+{
+	return guarded([&]() -> int {
+	if (!out || !origin || dimension < 0 || words <= 0 || (dimension > 0 && !basis)) return fail(GF2BV_ERR_ARG, "bad space");
+	*out = nullptr;
+	int rc = check_device(device);
+	if (rc) return rc;
+	gf2bv_space *sp = new gf2bv_space();
+	sp->device = device; sp->dim = dimension; sp->words = words;
+	auto bail = [&](hipError_t e, const char *what) { gf2bv_space_close(sp); return fail(GF2BV_ERR_HIP, what, e); };
+	hipError_t e = pool().stream(&sp->st, device, false);
+	if (e != hipSuccess) return bail(e, "hipStreamCreate");
+	if ((e = pool().alloc((void **)&sp->d_origin, sizeof(u64) * words, device)) != hipSuccess) return bail(e, "hipMalloc");
+	if ((e = pool().alloc((void **)&sp->d_basis, sizeof(u64) * std::max<i64>(1, dimension * words), device)) != hipSuccess) return bail(e, "hipMalloc");
+	if ((e = hipMemcpyAsync(sp->d_origin, origin, sizeof(u64) * words, hipMemcpyHostToDevice, sp->st)) != hipSuccess) return bail(e, "hipMemcpy");
+	if (dimension > 0 && (e = hipMemcpyAsync(sp->d_basis, basis, sizeof(u64) * dimension * words, hipMemcpyHostToDevice, sp->st)) != hipSuccess)
+		return bail(e, "hipMemcpy");
+	if ((e = hipStreamSynchronize(sp->st)) != hipSuccess) return bail(e, "hipStreamSynchronize");      // the caller's buffers may go away
+	*out = sp;
+	return GF2BV_OK;
+	});
+}
+
+int gf2bv_space_enumerate(gf2bv_space *sp, uint64_t first, int64_t count, int gray, uint64_t *out_words)
+{
+	return guarded([&]() -> int {
+	if (!sp || count < 0) return fail(GF2BV_ERR_ARG, "null pointer");
+	if (count == 0) return GF2BV_OK;
+	HIPCHK(hipSetDevice(sp->device));
+	const size_t need = (size_t)count * sp->words;
+	if (need > sp->out_words) {
+		pool().release(sp->d_out); sp->d_out = nullptr; sp->out_words = 0;
+		if (sp->h_out) { (void)hipHostFree(sp->h_out); sp->h_out = nullptr; }
+		HIPCHK(pool().alloc((void **)&sp->d_out, sizeof(u64) * need, sp->device));
+		HIPCHK(hipHostMalloc((void **)&sp->h_out, sizeof(u64) * need, hipHostMallocDefault));
+		sp->out_words = need;
+	}
+	const dim3 grid((unsigned)((sp->words + 255) / 256), (unsigned)std::min<i64>(count, 65535));
+	k_space_enumerate<<<grid, dim3(256), 0, sp->st>>>(sp->d_origin, sp->d_basis, (int)std::min<i64>(sp->dim, 64), sp->words,
+	                                                  (u64)first, (i64)count, gray, sp->d_out);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpyAsync(sp->h_out, sp->d_out, sizeof(u64) * need, hipMemcpyDeviceToHost, sp->st));
+	HIPCHK(hipStreamSynchronize(sp->st));
+	if (out_words) memcpy(out_words, sp->h_out, sizeof(u64) * need);
+	return GF2BV_OK;
+	});
+}
+
+const uint64_t *gf2bv_space_buffer(const gf2bv_space *sp) { return sp ? reinterpret_cast<const uint64_t *>(sp->h_out) : nullptr; }
+
+void gf2bv_space_close(gf2bv_space *sp)
+{
+	if (!sp) return;
+	(void)hipSetDevice(sp->device);
+	if (sp->st) (void)hipStreamSynchronize(sp->st);
+	pool().release(sp->d_origin); pool().release(sp->d_basis); pool().release(sp->d_out);
+	if (sp->h_out) (void)hipHostFree(sp->h_out);
+	if (sp->st) pool().release_stream(sp->st, sp->device, false);
+	delete sp;
 }
 
 // ---- synthetic + residual + buffers --------------------------------------------------------------

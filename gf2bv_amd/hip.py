@@ -29,7 +29,8 @@ EXPORTS = [
     "gf2bv_solve_batch_digits",
     "gf2bv_result_status", "gf2bv_result_rank", "gf2bv_result_dimension", "gf2bv_result_words",
     "gf2bv_result_origin", "gf2bv_result_basis", "gf2bv_result_pivots", "gf2bv_result_stats",
-    "gf2bv_result_free", "gf2bv_space_combine", "gf2bv_synth_device", "gf2bv_residual_device",
+    "gf2bv_result_free", "gf2bv_space_combine", "gf2bv_space_open", "gf2bv_space_enumerate", "gf2bv_space_buffer", "gf2bv_space_close",
+    "gf2bv_synth_device", "gf2bv_residual_device",
     "gf2bv_stream_ceiling_device",
     "gf2bv_device_alloc", "gf2bv_device_free", "gf2bv_device_upload", "gf2bv_device_download",
 ]
@@ -84,6 +85,10 @@ def lib():
         L.gf2bv_result_free.restype = None
         L.gf2bv_space_combine.argtypes = [vp, vp, i64, i64, vp, i64, vp]
         L.gf2bv_space_combine.restype = None
+        L.gf2bv_space_open.argtypes = [vp, vp, i64, i64, i32, pp]
+        L.gf2bv_space_enumerate.argtypes = [vp, ctypes.c_uint64, i64, i32, vp]
+        L.gf2bv_space_close.argtypes = [vp]
+        L.gf2bv_space_close.restype = None
         L.gf2bv_synth_device.argtypes = [vp, i64, i64, i64, ctypes.c_uint64, i32, vp]
         L.gf2bv_residual_device.argtypes = [vp, i64, i64, i64, vp, i32, vp, ctypes.POINTER(i64)]
         L.gf2bv_stream_ceiling_device.argtypes = [i32, i64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
@@ -223,6 +228,22 @@ def solve_batch_words(augs, rows: int, cols: int, mode: int = MODE_SINGLE, devic
         return solve_batch_device(buf.ptr, nsys, rows * stride, rows, cols, stride, mode, device)
     finally:
         buf.free()
+
+
+def space_enumerate(origin: np.ndarray, basis: np.ndarray, first: int, count: int, gray: bool = True,
+                    device: int = 0) -> np.ndarray:
+    """Elements first .. first+count-1 of the affine space origin + span(basis), materialised on the device
+    ([count, words] uint64): Gray order (AffineSpaceIterator) or binary order (AffineSpaceIteratorSlow / get)."""
+    origin = np.ascontiguousarray(origin, dtype=np.uint64)
+    basis = np.ascontiguousarray(basis, dtype=np.uint64).reshape(-1, len(origin))
+    h = ctypes.c_void_p()
+    _check(lib().gf2bv_space_open(origin.ctypes.data, basis.ctypes.data, basis.shape[0], len(origin), device, ctypes.byref(h)))
+    try:
+        out = np.zeros((count, len(origin)), dtype=np.uint64)
+        _check(lib().gf2bv_space_enumerate(h, first, count, 1 if gray else 0, out.ctypes.data))
+        return out
+    finally:
+        lib().gf2bv_space_close(h)
 
 
 def synth_device(d_ptr: int, rows: int, cols: int, stride: int, seed: int, device: int = 0, stream: int = 0):

@@ -140,6 +140,21 @@ void gf2bv_space_combine(const uint64_t *origin, const uint64_t *basis, int64_t 
                          int64_t words, const uint64_t *selector, int64_t selector_words,
                          uint64_t *out);
 
+/* ---- AffineSpace on the device: bulk enumeration (gf2bv/_internal.c:101-122 Gray walk, :63-91 binary walk) ---- */
+/* The reference yields one element per call: one row XOR and one int export each.  Here a whole range of elements is
+ * materialised by one kernel: element g of the walk = origin ^ XOR of basis[i] over the set bits i of code(g), with
+ * code(g) = g ^ (g >> 1) for gray != 0 (AffineSpaceIterator, dimension <= 64) and code(g) = g otherwise
+ * (AffineSpaceIteratorSlow, AffineSpace.get).  gf2bv_space_open uploads origin (words) and basis (dimension x words)
+ * once; gf2bv_space_enumerate writes elements first .. first+count-1 (count x words uint64) to out_words (host
+ * memory) -- or, with out_words == NULL, leaves them in the handle's own pinned buffer, valid until the next
+ * enumerate / close (gf2bv_space_buffer): the iterators of the CPython binding slice their ints straight out of it. */
+typedef struct gf2bv_space gf2bv_space;
+int  gf2bv_space_open(const uint64_t *origin, const uint64_t *basis, int64_t dimension, int64_t words, int device,
+                      gf2bv_space **out);
+int  gf2bv_space_enumerate(gf2bv_space *space, uint64_t first, int64_t count, int gray, uint64_t *out_words);
+const uint64_t *gf2bv_space_buffer(const gf2bv_space *space);
+void gf2bv_space_close(gf2bv_space *space);
+
 /* ---- synthetic systems + independent residual check (bench / tests) ----------------------- */
 /* word w of row r = mix64(mix64(seed) ^ ((r<<20)|w)); planted solution = pseudo-row 0xFFFFF;
  * RHS = <row, planted>.  Writes rows x stride_words words at d_aug. */
