@@ -1226,7 +1226,8 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 // k_prio_window) written into the matrix.  One thread per (pivot, word).
 __global__ void __launch_bounds__(256)
 k_unwind(u64 *__restrict__ M, i64 srows, int G, int npanels, int nblocks, const SolveState *__restrict__ st,
-         const int *__restrict__ pivcol, const int *__restrict__ urow, const u64 *__restrict__ Uwin, SysStride ss)
+         const int *__restrict__ pivcol, const int *__restrict__ urow, const u64 *__restrict__ Uwin, int world, int wrank,
+         SysStride ss)
 {
 	{
 		const i64 ao = blockIdx.y * ss.arena_bytes;
@@ -1241,7 +1242,27 @@ k_unwind(u64 *__restrict__ M, i64 srows, int G, int npanels, int nblocks, const 
 	if (b + 1 >= nblocks) return;                       // the last block has no next window
 	const int wlo = (b + 1) * G;
 	const int gnext = (npanels - wlo < G) ? npanels - wlo : G;
+	// (column-slab solve: the window of block b + 1 was carried forward -- and Uwin filled -- by the rank that owns its tile)
+	if (world > 1 && ((wlo + e) >> GF2_TW_LOG) % world != wrank) return;
 	if (e < gnext) M[tidx(urow[k], wlo + e, srows)] = Uwin[k * GF2_GMAX + e];
+}
+
+// Column-slab solve (one system over several GPUs): a rank that did not factorise block b receives its records and
+// reconstructs what the panel path would have left behind there -- the dead marks of the block's source rows and
+// their entries in the pivot lists.  One workgroup, 64 threads per panel.
+__global__ void __launch_bounds__(256)
+k_import_marks(int j0, int gb, const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
+               int *__restrict__ died, int *__restrict__ pivcol, int *__restrict__ urow)
+{
+	const int g = threadIdx.x >> 6, lane = threadIdx.x & 63;
+	if (g >= gb) return;
+	const PanelRec rec = panels[j0 + g];
+	if ((rec.mask >> lane) & 1) pivcol[rec.start + __popcll(rec.mask & lanemask_lt(lane))] = 64 * (j0 + g) + lane;
+	if (lane < rec.p) {
+		const int sr = aux[j0 + g].slot_row[lane];
+		urow[rec.start + lane] = sr;
+		died[sr] = j0 + g;
+	}
 }
 
 // ==========================================================================================
@@ -1257,7 +1278,7 @@ k_unwind(u64 *__restrict__ M, i64 srows, int G, int npanels, int nblocks, const 
 // shares this short, latency-bound step.
 template <int TW, int WPW>
 __global__ void __launch_bounds__(64 * WPW)
-k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int tile_begin,
+k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int tile_begin, int tile_step,
              const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux, int nw_lo, int nw_hi, SysStride ss)
 {
 	__builtin_amdgcn_s_setprio(2);
@@ -1271,7 +1292,7 @@ k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int tile_b
 	__shared__ u64 Pbit[GF2_GMAX * 64 * WPW];  // [panel][pivot BIT][word], zero where the panel has no pivot
 	__shared__ u64 Tn[16 * 16 * WPW];          // nibble tables of 64 rows: [nibble n][value v][word] = XOR of rows 4n + k over the bits k of v
 	__shared__ int Bk[GF2_GMAX * 64];          // [panel][pivot k] -> pivot bit
-	const i64 tile = tile_begin + blockIdx.x / SPLIT;
+	const i64 tile = tile_begin + (i64)(blockIdx.x / SPLIT) * tile_step;     // (tile_step > 1: the tiles of one rank of a column-slab solve)
 	const int wofs = (blockIdx.x % SPLIT) * WPW;
 	const i64 w0 = tile * TW + wofs;
 	u64 *Mt = M + tile * srows * TW + wofs;    // row r, word w of this workgroup's slice at Mt[r * TW + w]
@@ -1384,7 +1405,7 @@ __global__ void __launch_bounds__(1024)
 k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
          const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
          const u64 *__restrict__ multset, const int *__restrict__ blk_first,
-         int tile_begin, int ntiles, int nsplit, int nw_lo, int nw_hi, SysStride ss)
+         int tile_begin, int ntiles, int tile_step, int nw_lo, int nw_hi, SysStride ss)
 {
 	// Words [nw_lo, nw_hi) -- the next block's window -- are never WRITTEN here: the panel stream owns them
 	// (k_prio_window has carried them into Wb, and the next block's panel steps store its pivot rows there
@@ -1428,13 +1449,12 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	chunk = (chunk + ALIGN - 1) / ALIGN * ALIGN;
 	i64 pos = (i64)blockIdx.x * chunk;
 	const i64 pend = (pos + chunk < total) ? pos + chunk : total;
-	(void)nsplit;
 	for (bool first_span = true; pos < pend; first_span = false) {
 	const int ct = (int)(pos / R);
 	const i64 r0 = pos - (i64)ct * R;
 	const i64 span = (R - r0 < pend - pos) ? R - r0 : pend - pos;
 	pos += span;
-	const i64 tile = tile_begin + ct;
+	const i64 tile = tile_begin + (i64)ct * tile_step;     // (tile_step > 1: the tiles one rank of a column-slab solve owns)
 	const i64 w0 = tile * TW;
 	const i64 rbeg = rlo + r0;
 	if (rbeg >= rows) continue;                 // padding at the end of a tile's line

@@ -211,14 +211,14 @@ struct UpdateImpl {
 template <int G, int T, int NT>
 hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows, int j0, int gb, int wlo,
                          const PanelRec *panels, const PanelAux *aux, const u64 *multset, const int *blk_first,
-                         int tile_begin, int ntiles, int nsplit, int nw_lo, int nw_hi, SysStride ss, hipEvent_t begun,
+                         int tile_begin, int ntiles, int tile_step, int nw_lo, int nw_hi, SysStride ss, hipEvent_t begun,
                          hipEvent_t done)
 {
 	// the tables are static shared memory (see k_update): no dynamic LDS, no attribute to raise
 	// `begun` / `done` (optional): timing and hand-off events ride on this kernel's own start / completion signals
 	// instead of marker packets around it
 	hipExtLaunchKernelGGL((k_update<G, T, NT>), grid, dim3(NT), 0, s, begun, done, 0, M, rows, srows, j0, gb, wlo, panels, aux,
-	                      multset, blk_first, tile_begin, ntiles, nsplit, nw_lo, nw_hi, ss);
+	                      multset, blk_first, tile_begin, ntiles, tile_step, nw_lo, nw_hi, ss);
 	return hipGetLastError();
 }
 
@@ -305,6 +305,11 @@ struct Solver {
 	// system s lives at M + s * m_stride words / arena + s * arena_stride bytes, its input at src + s * src_sys_words
 	int nsys = 1;
 	int gang_nsys = 1;            // (a view: the size of the gang it belongs to)
+	// column-slab solve of ONE system over `world` GPUs: this rank owns the column tiles t with t % world == wrank
+	// (cyclic, so that the shrinking trailing matrix stays balanced) and runs the bulk path on those only; the panel
+	// path of a block runs on the owner of its window's tile (see gf2bv_slab_* below)
+	int world = 1, wrank = 0;
+	bool ext_M = false;           // the working matrix belongs to the caller (slab solves: a tensor the ranks exchange tiles of)
 	i64 m_stride = 0, src_sys_words = 0;
 	size_t arena_stride = 0;
 	bool view = false;            // a non-owning window on one system of a gang (back-substitution, export)
@@ -372,7 +377,7 @@ struct Solver {
 		if (sB) (void)hipStreamSynchronize(sB);
 		if (arena || M) (void)hipStreamSynchronize(sA);
 		Pool &P = pool();
-		for (void *p : { arena, (void *)Y, (void *)ycols, (void *)out, (void *)M, (void *)tmp_src }) P.release(p);
+		for (void *p : { arena, (void *)Y, (void *)ycols, (void *)out, (void *)(ext_M ? nullptr : M), (void *)tmp_src }) P.release(p);
 		arena = nullptr; Y = nullptr; ycols = nullptr; out = nullptr; M = nullptr; tmp_src = nullptr;
 		st = nullptr; panels = nullptr; aux = nullptr; fu = nullptr; died = nullptr; pivcol = nullptr;
 		urow = nullptr; blk_first = nullptr; mult = nullptr; Wb = nullptr;
@@ -519,7 +524,7 @@ int pick_update_wgs(i64 est_rows, int ntiles, int nsys)
 int launch_trsm(Solver &S, hipStream_t st, int j0, int gb, int wlo, int tile_begin, int ntiles, int nw_lo, int nw_hi)
 {
 	constexpr int WPW = 4;
-	k_block_trsm<TW, WPW><<<dim3(ntiles * (TW / WPW), S.nsys), dim3(64 * WPW), 0, st>>>(S.M, S.srows, j0, gb, wlo, tile_begin,
+	k_block_trsm<TW, WPW><<<dim3(ntiles * (TW / WPW), S.nsys), dim3(64 * WPW), 0, st>>>(S.M, S.srows, j0, gb, wlo, tile_begin, S.world,
 	                                                                                   S.panels, S.aux, nw_lo, nw_hi, S.ss());
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
@@ -540,7 +545,7 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 	hipEvent_t begun = nullptr, done = nullptr;
 	if (S.ext_events) { begun = ka; done = S.time_kernels ? kb : S.evPrio[b]; }
 	HIPCHK(S.impl->update(dim3((unsigned)wgs, S.nsys), st, S.M, S.rows, S.srows, j0, gb, wlo, S.panels, S.aux, mset,
-	                      S.blk_first + b, tile_begin, ntiles, 0, nw_lo, nw_hi, S.ss(), begun, done));
+	                      S.blk_first + b, tile_begin, ntiles, S.world, nw_lo, nw_hi, S.ss(), begun, done));
 	if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, st));
 	if (S.ext_events) *handoff = done;
 	else { HIPCHK(hipEventRecord(S.evPrio[b], st)); *handoff = S.evPrio[b]; }
@@ -555,81 +560,134 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 //     factorised, never writing the next window's words.  So A runs a whole block ahead of B and
 //     the two overlap: per-block time is max(panel path, bulk path), and B never idles when it is
 //     the longer one.
-int enqueue_forward(Solver &S)
+// ---- one block of the forward elimination, in the three pieces the two streams interleave ----
+struct BlockGeom { int j0, gb, wlo, tb, nt_all, gnext; u64 *mset; };
+BlockGeom block_geom(const Solver &S, int b)
 {
 	const int G = S.impl->G;
-	const int tiles_total = (int)S.ntiles;
+	BlockGeom g;
+	g.j0 = b * G;
+	g.gb = std::min(G, S.npanels - g.j0);
+	g.wlo = g.j0 + g.gb;
+	g.mset = S.mult + (i64)(b & 1) * G * S.rows;
+	// trailing tiles; the next block's window [wlo, wlo + gnext) sits in the first one or two of them
+	g.tb = g.wlo / TW;
+	g.nt_all = (g.wlo < S.wt) ? (int)S.ntiles - g.tb : 0;
+	g.gnext = (b + 1 < S.nblocks) ? std::min(G, S.npanels - g.wlo) : 0;
+	return g;
+}
+
+// stream A: factorise block b on its compact window -- step s narrows panel s-1 (window half (s-1)&1 -> half s&1)
+// while searching panel s; gb+1 launches; evA[b] = "block b factorised"
+int enqueue_block_panel(Solver &S, int b)
+{
+	const BlockGeom g = block_geom(S, b);
 	const unsigned row_blocks = (unsigned)((S.rows + 255) / 256);
+	u64 *const half[2] = { S.Wb, S.Wb + (i64)GF2_GMAX * S.rows };
+	for (int s = 0; s <= g.gb; s++) {
+		const int gp = s - 1, gf = (s < g.gb) ? s : -1;
+		const i64 c0 = (i64)(g.j0 + std::max(gf, 0)) * 64;
+		const u64 colmask = (S.cols - c0 >= 64) ? ~0ull : ((1ull << (S.cols - c0)) - 1);
+		const int find_wgs = gf >= 0 ? (S.units + 3) / 4 : 0;
+		const unsigned wgs = (unsigned)find_wgs + (gp >= 0 ? row_blocks : 0u);
+		// the block's last step carries the hand-off event as its own completion signal (no marker packet)
+		const bool ext = S.ext_events && s == g.gb && b != S.nblocks - 1;
+		hipExtLaunchKernelGGL(k_panel_step, dim3(wgs, S.nsys), dim3(256), 0, S.sA, nullptr, ext ? S.evA[b] : nullptr, 0,
+		                      S.M, S.rows, S.srows, g.j0, gp, gf, g.gb, colmask,
+		                      (const u64 *)half[s ? (s - 1) & 1 : 0], half[s & 1], S.st, S.died, S.fu, S.units, find_wgs,
+		                      S.panels, S.aux, S.pivcol, S.urow, g.mset,
+		                      gf == g.gb - 1 ? S.blk_first + b : (int *)nullptr, S.impl->T, S.sparse_mode, S.self_wait, S.ss());
+	}
+	if (b == S.nblocks - 1)
+		k_win_scatter<<<dim3((unsigned)((S.rows * g.gb + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, half[g.gb & 1], S.died, S.ss());
+	HIPCHK(hipGetLastError());
+	if (!(S.ext_events && b != S.nblocks - 1)) HIPCHK(hipEventRecord(S.evA[b], S.sA));
+	if (S.dbg_sync & 1) HIPCHK(hipDeviceSynchronize());
+	return GF2BV_OK;
+}
+
+// stream B: TRSM + bulk update of block b on every trailing tile this rank owns (never WRITING the next window);
+// waitPrio[b] = "bulk of block b complete"
+int enqueue_block_bulk(Solver &S, int b)
+{
+	const BlockGeom g = block_geom(S, b);
+	HIPCHK(hipStreamWaitEvent(S.sB, S.evA[b], 0));
+	// column-slab solve: the tiles t >= tb with t % world == wrank
+	int t0 = g.tb, nt = g.nt_all;
+	if (S.world > 1 && nt > 0) {
+		t0 = g.tb + ((S.wrank - g.tb % S.world) + S.world) % S.world;
+		nt = (t0 < (int)S.ntiles) ? ((int)S.ntiles - t0 + S.world - 1) / S.world : 0;
+	}
+	if (nt > 0) {
+		int rc = launch_trsm(S, S.sB, g.j0, g.gb, g.wlo, t0, nt, g.wlo, g.wlo + g.gnext);
+		if (rc) return rc;
+		rc = launch_update_timed(S, S.sB, b, g.j0, g.gb, g.wlo, g.mset, t0, nt, g.wlo, g.wlo + g.gnext, &S.waitPrio[b]);
+		if (rc) return rc;
+	} else {
+		HIPCHK(hipEventRecord(S.evPrio[b], S.sB));      // "bulk of block b complete" (nothing to do)
+		S.waitPrio[b] = S.evPrio[b];
+	}
+	if (S.dbg_sync & 2) HIPCHK(hipDeviceSynchronize());
+	return GF2BV_OK;
+}
+
+// stream A: the next block's window (needs the bulk update of block b-1, nothing newer)
+int enqueue_block_prio(Solver &S, int b)
+{
+	if (b + 1 >= S.nblocks) return GF2BV_OK;
+	const BlockGeom g = block_geom(S, b);
+	const unsigned row_blocks = (unsigned)((S.rows + 255) / 256);
+	if (b > 0) HIPCHK(hipStreamWaitEvent(S.sA, S.waitPrio[b - 1], 0));
+	k_prio_window<<<dim3(row_blocks, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, g.wlo, std::max(g.gnext, 1),
+	                                                             S.panels, S.aux, g.mset, S.blk_first + b, S.Wb, S.Uwin,
+	                                                             S.impl->T, S.ss());
+	HIPCHK(hipGetLastError());
+	return GF2BV_OK;
+}
+
+int enqueue_forward_begin(Solver &S, bool gather_first_window)
+{
 	HIPCHK(hipEventRecord(S.ev0, S.sA));
 	HIPCHK(hipStreamWaitEvent(S.sB, S.ev0, 0));     // sB starts after the setup memsets on sA
-	if (S.npanels > 0) {
-		const int g0 = std::min(G, S.npanels);
+	if (S.npanels > 0 && gather_first_window) {
+		const int g0 = std::min(S.impl->G, S.npanels);
 		k_win_gather<<<dim3((unsigned)((S.rows * g0 + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, 0, g0, S.Wb, S.ss());
 	}
-	for (int b = 0; b < S.nblocks; b++) {
-		const int j0 = b * G;
-		const int gb = std::min(G, S.npanels - j0);
-		const int wlo = j0 + gb;
-		u64 *mset = S.mult + (i64)(b & 1) * G * S.rows;
-		// ---- stream A: factorise the block ----
-		// step s: narrow panel s-1 (window half (s-1)&1 -> half s&1) while searching panel s; gb+1 launches
-		u64 *const half[2] = { S.Wb, S.Wb + (i64)GF2_GMAX * S.rows };
-		for (int s = 0; s <= gb; s++) {
-			const int gp = s - 1, gf = (s < gb) ? s : -1;
-			const i64 c0 = (i64)(j0 + std::max(gf, 0)) * 64;
-			const u64 colmask = (S.cols - c0 >= 64) ? ~0ull : ((1ull << (S.cols - c0)) - 1);
-			const int find_wgs = gf >= 0 ? (S.units + 3) / 4 : 0;
-			const unsigned wgs = (unsigned)find_wgs + (gp >= 0 ? row_blocks : 0u);
-			// the block's last step carries the hand-off event as its own completion signal (no marker packet)
-			const bool ext = S.ext_events && s == gb && b != S.nblocks - 1;
-			hipExtLaunchKernelGGL(k_panel_step, dim3(wgs, S.nsys), dim3(256), 0, S.sA, nullptr, ext ? S.evA[b] : nullptr, 0,
-			                      S.M, S.rows, S.srows, j0, gp, gf, gb, colmask,
-			                      (const u64 *)half[s ? (s - 1) & 1 : 0], half[s & 1], S.st, S.died, S.fu, S.units, find_wgs,
-			                      S.panels, S.aux, S.pivcol, S.urow, mset,
-			                      gf == gb - 1 ? S.blk_first + b : (int *)nullptr, S.impl->T, S.sparse_mode, S.self_wait, S.ss());
-		}
-		if (b == S.nblocks - 1)
-			k_win_scatter<<<dim3((unsigned)((S.rows * gb + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, gb, half[gb & 1], S.died, S.ss());
-		HIPCHK(hipGetLastError());
-		if (!(S.ext_events && b != S.nblocks - 1)) HIPCHK(hipEventRecord(S.evA[b], S.sA));
-		if (S.dbg_sync & 1) HIPCHK(hipDeviceSynchronize());
-		// trailing tiles; the next block's window [wlo, wlo + gnext) sits in the first one or two of them
-		const int tb = wlo / TW;
-		const int nt_all = (wlo < S.wt) ? tiles_total - tb : 0;
-		const int gnext = (b + 1 < S.nblocks) ? std::min(G, S.npanels - wlo) : 0;
-		// ---- stream B: TRSM + bulk update of block b on every trailing tile (never WRITING the next window) ----
-		HIPCHK(hipStreamWaitEvent(S.sB, S.evA[b], 0));
-		if (nt_all > 0) {
-			int rc = launch_trsm(S, S.sB, j0, gb, wlo, tb, nt_all, wlo, wlo + gnext);
-			if (rc) return rc;
-			rc = launch_update_timed(S, S.sB, b, j0, gb, wlo, mset, tb, nt_all, wlo, wlo + gnext, &S.waitPrio[b]);
-			if (rc) return rc;
-		} else {
-			HIPCHK(hipEventRecord(S.evPrio[b], S.sB));      // "bulk of block b complete" (nothing to do)
-			S.waitPrio[b] = S.evPrio[b];
-		}
-		if (S.dbg_sync & 2) HIPCHK(hipDeviceSynchronize());
-		// ---- stream A: the next block's window (needs the bulk update of block b-1, nothing newer) ----
-		if (b + 1 < S.nblocks) {
-			if (b > 0) HIPCHK(hipStreamWaitEvent(S.sA, S.waitPrio[b - 1], 0));
-			k_prio_window<<<dim3(row_blocks, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, j0, gb, wlo, std::max(gnext, 1),
-			                                                             S.panels, S.aux, mset, S.blk_first + b, S.Wb, S.Uwin,
-			                                                             S.impl->T, S.ss());
-		}
-	}
-	// join: the panel stream waits for the last bulk update, then checks consistency
+	return GF2BV_OK;
+}
+
+// join: the panel stream waits for the last bulk update; pivot rows get their parked window words
+int enqueue_forward_join(Solver &S)
+{
 	HIPCHK(hipEventRecord(S.ev3, S.sB));
 	HIPCHK(hipStreamWaitEvent(S.sA, S.ev3, 0));
 	if (S.nblocks > 1 && S.maxr > 0)
 		k_unwind<<<dim3((unsigned)((S.maxr * GF2_GMAX + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(
-			S.M, S.srows, G, S.npanels, S.nblocks, S.st, S.pivcol, S.urow, S.Uwin, S.ss());
-	{
-		int g = (int)std::min<i64>(1024, (S.rows + 255) / 256);
-		k_check_rhs<<<dim3(g, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, S.cols, S.died, S.st, S.ss());
-	}
+			S.M, S.srows, S.impl->G, S.npanels, S.nblocks, S.st, S.pivcol, S.urow, S.Uwin, S.world, S.wrank, S.ss());
+	HIPCHK(hipGetLastError());
+	return GF2BV_OK;
+}
+
+int enqueue_check_rhs(Solver &S)
+{
+	int g = (int)std::min<i64>(1024, (S.rows + 255) / 256);
+	k_check_rhs<<<dim3(g, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, S.cols, S.died, S.st, S.ss());
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(S.ev1, S.sA));
 	return GF2BV_OK;
+}
+
+int enqueue_forward(Solver &S)
+{
+	int rc = enqueue_forward_begin(S, true);
+	if (rc) return rc;
+	for (int b = 0; b < S.nblocks; b++) {
+		if ((rc = enqueue_block_panel(S, b))) return rc;
+		if ((rc = enqueue_block_bulk(S, b))) return rc;
+		if ((rc = enqueue_block_prio(S, b))) return rc;
+	}
+	if ((rc = enqueue_forward_join(S))) return rc;
+	return enqueue_check_rhs(S);
 }
 
 // back-substitution on Y = selected columns of U (RHS [+ free columns]); then scatter.
@@ -1229,6 +1287,172 @@ void gf2bv_space_combine(const uint64_t *origin, const uint64_t *basis, int64_t 
 	for (i64 i = 0; i < dimension && (i >> 6) < selector_words; i++)
 		if ((selector[i >> 6] >> (i & 63)) & 1)
 			for (i64 w = 0; w < words; w++) o[w] ^= basis[i * words + w];
+}
+
+// ---- column-slab solve: ONE system over several GPUs ---------------------------------
+// Rank r of `world` owns the column tiles t with t % world == r (cyclic: the trailing matrix shrinks from the left).
+// Per block of G panels:
+//   * the rank that owns the tile of the block's window runs the panel path there (gf2bv_slab_factor) -- exactly
+//     the single-GPU kernels on its compact window, the window of the NEXT block it owns being carried forward by
+//     k_prio_window as before -- and exports the block's records: SolveState, alive bound, PanelRec / PanelAux of its
+//     panels and the per-row multipliers (G x rows x 8 bytes): the payload of ONE broadcast over xGMI;
+//   * every rank imports the payload (gf2bv_slab_apply) and runs k_block_trsm + k_update on the tiles it owns.
+// After the last block each rank moves its pivot rows' parked window words into its tiles (gf2bv_slab_finish_local);
+// the ranks' tiles are then gathered on one rank (the caller's collective: the working matrix is the caller's
+// buffer), which has every record and finishes like a single-GPU solve (gf2bv_slab_solve: consistency check,
+// back-substitution, export).  The communication is the caller's (torch.distributed: RCCL on GPUs, gloo in the CPU-side
+// tests): this library stays free of it, like the rest of the C ABI.
+struct gf2bv_slab {
+	Solver S;
+	size_t payload_bytes = 0;
+	size_t o_blk = 0, o_pan = 0, o_aux = 0, o_mult = 0;
+	int next_prio = 0;         // k_prio_window(b) has been enqueued for all b < next_prio (on this rank, where it owns the next window)
+};
+
+namespace {
+int slab_owner_of_block(const Solver &S, int b) { return ((b * S.impl->G) / TW) % S.world; }
+}
+
+int gf2bv_slab_open(void *d_aug, int64_t rows, int64_t cols, int64_t stride_words, void *d_work, int64_t work_words,
+                    int world, int rank, int device, gf2bv_slab **out)
+{
+	return guarded([&]() -> int {
+	if (!out || !d_aug || !d_work || world < 1 || rank < 0 || rank >= world) return fail(GF2BV_ERR_ARG, "bad slab arguments");
+	*out = nullptr;
+	int rc = check_shape(rows, cols, GF2BV_MODE_SINGLE);
+	if (rc) return rc;
+	if (stride_words % 2 != 0 || stride_words < (cols + 1 + 63) / 64 || ((uintptr_t)d_aug & 15) || ((uintptr_t)d_work & 15))
+		return fail(GF2BV_ERR_ARG, "device matrix needs 16-byte alignment and an even stride_words covering cols+1 bits");
+	if (work_words < gf2bv_slab_work_words(rows, cols)) return fail(GF2BV_ERR_ARG, "working matrix too small (gf2bv_slab_work_words)");
+	rc = check_device(device);
+	if (rc) return rc;
+	gf2bv_slab *h = new gf2bv_slab();
+	Solver &S = h->S;
+	S.t_begin = std::chrono::steady_clock::now();
+	S.device = device;
+	hipError_t e = pool().stream(&S.sA, device, false);
+	if (e != hipSuccess) { delete h; return fail(GF2BV_ERR_HIP, "hipStreamCreate", e); }
+	S.own_sA = true;
+	S.src = (const u64 *)d_aug;
+	S.rows = rows; S.cols = cols; S.stride = stride_words; S.mode = GF2BV_MODE_SINGLE;
+	S.world = world; S.wrank = rank;
+	S.M = (u64 *)d_work; S.ext_M = true;
+	rc = solver_alloc(S);                           // (converts the whole input: tiles of other ranks are simply never touched again)
+	if (rc == GF2BV_OK) rc = enqueue_forward_begin(S, slab_owner_of_block(S, 0) == rank);
+	if (rc != GF2BV_OK) { delete h; return rc; }
+	const i64 R = std::max<i64>(1, S.rows);
+	const int G = S.impl->G;
+	size_t off = 0;
+	auto carve = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
+	(void)carve(sizeof(SolveState)); h->o_blk = carve(sizeof(int)); h->o_pan = carve(sizeof(PanelRec) * G);
+	h->o_aux = carve(sizeof(PanelAux) * G); h->o_mult = carve(sizeof(u64) * G * R);
+	h->payload_bytes = off;
+	*out = h;
+	return GF2BV_OK;
+	});
+}
+
+int64_t gf2bv_slab_work_words(int64_t rows, int64_t cols)
+{
+	const i64 wt = (cols + 1 + 63) / 64, ntiles = (wt + TW - 1) / TW;
+	return ntiles * TW * slab_rows(rows);
+}
+int64_t gf2bv_slab_tiles(int64_t cols) { return ((cols + 1 + 63) / 64 + TW - 1) / TW; }
+int64_t gf2bv_slab_blocks(const gf2bv_slab *h) { return h ? h->S.nblocks : -1; }
+int gf2bv_slab_owner(const gf2bv_slab *h, int block) { return h ? slab_owner_of_block(h->S, block) : -1; }
+int64_t gf2bv_slab_payload_bytes(const gf2bv_slab *h) { return h ? (int64_t)h->payload_bytes : -1; }
+
+// Owner of block b: (carry its window forward,) factorise it, export the records into d_payload; returns when they are there.
+int gf2bv_slab_factor(gf2bv_slab *h, int b, void *d_payload)
+{
+	return guarded([&]() -> int {
+	if (!h || !d_payload || b < 0 || b >= h->S.nblocks) return fail(GF2BV_ERR_ARG, "bad block");
+	Solver &S = h->S;
+	if (slab_owner_of_block(S, b) != S.wrank) return fail(GF2BV_ERR_ARG, "this rank does not own the block's window");
+	HIPCHK(hipSetDevice(S.device));
+	int rc;
+	// the window of block b: carried forward from block b-1's records (imported by gf2bv_slab_apply(b-1)) -- needs this
+	// rank's bulk update of block b-2, nothing newer: the look-ahead of the single-GPU solve, per owner
+	if (b > 0 && (rc = enqueue_block_prio(S, b - 1))) return rc;
+	if ((rc = enqueue_block_panel(S, b))) return rc;
+	const BlockGeom g = block_geom(S, b);
+	char *P = (char *)d_payload;
+	const int G = S.impl->G;
+	HIPCHK(hipMemcpyAsync(P, S.st, sizeof(SolveState), hipMemcpyDeviceToDevice, S.sA));
+	HIPCHK(hipMemcpyAsync(P + h->o_blk, S.blk_first + b, sizeof(int), hipMemcpyDeviceToDevice, S.sA));
+	HIPCHK(hipMemcpyAsync(P + h->o_pan, S.panels + g.j0, sizeof(PanelRec) * g.gb, hipMemcpyDeviceToDevice, S.sA));
+	HIPCHK(hipMemcpyAsync(P + h->o_aux, S.aux + g.j0, sizeof(PanelAux) * g.gb, hipMemcpyDeviceToDevice, S.sA));
+	HIPCHK(hipMemcpyAsync(P + h->o_mult, g.mset, sizeof(u64) * G * S.rows, hipMemcpyDeviceToDevice, S.sA));
+	HIPCHK(hipStreamSynchronize(S.sA));
+	return GF2BV_OK;
+	});
+}
+
+// Every rank: take block b's records (the other ranks import them from the broadcast payload), then TRSM + bulk update of
+// the tiles this rank owns.  Asynchronous.
+int gf2bv_slab_apply(gf2bv_slab *h, int b, const void *d_payload)
+{
+	return guarded([&]() -> int {
+	if (!h || !d_payload || b < 0 || b >= h->S.nblocks) return fail(GF2BV_ERR_ARG, "bad block");
+	Solver &S = h->S;
+	HIPCHK(hipSetDevice(S.device));
+	const BlockGeom g = block_geom(S, b);
+	if (slab_owner_of_block(S, b) != S.wrank) {
+		const char *P = (const char *)d_payload;
+		const int G = S.impl->G;
+		// the multiplier set (b & 1) was last read by this rank's bulk update of block b-2
+		if (b >= 2) HIPCHK(hipStreamWaitEvent(S.sA, S.waitPrio[b - 2], 0));
+		HIPCHK(hipMemcpyAsync(S.st, P, sizeof(SolveState), hipMemcpyDeviceToDevice, S.sA));
+		HIPCHK(hipMemcpyAsync(S.blk_first + b, P + h->o_blk, sizeof(int), hipMemcpyDeviceToDevice, S.sA));
+		HIPCHK(hipMemcpyAsync(S.panels + g.j0, P + h->o_pan, sizeof(PanelRec) * g.gb, hipMemcpyDeviceToDevice, S.sA));
+		HIPCHK(hipMemcpyAsync(S.aux + g.j0, P + h->o_aux, sizeof(PanelAux) * g.gb, hipMemcpyDeviceToDevice, S.sA));
+		HIPCHK(hipMemcpyAsync(g.mset, P + h->o_mult, sizeof(u64) * G * S.rows, hipMemcpyDeviceToDevice, S.sA));
+		k_import_marks<<<dim3(1), dim3(256), 0, S.sA>>>(g.j0, g.gb, S.panels, S.aux, S.died, S.pivcol, S.urow);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipEventRecord(S.evA[b], S.sA));
+		// the payload buffer may be reused by the caller once this returns
+		HIPCHK(hipStreamSynchronize(S.sA));
+	}
+	return enqueue_block_bulk(S, b);
+	});
+}
+
+// After the last block: this rank's tiles are final (pivot rows' parked window words moved in); synchronous.
+int gf2bv_slab_finish_local(gf2bv_slab *h)
+{
+	return guarded([&]() -> int {
+	if (!h) return fail(GF2BV_ERR_ARG, "null pointer");
+	Solver &S = h->S;
+	HIPCHK(hipSetDevice(S.device));
+	int rc = enqueue_forward_join(S);
+	if (rc) return rc;
+	HIPCHK(hipStreamSynchronize(S.sA));
+	HIPCHK(hipStreamSynchronize(S.sB));
+	return GF2BV_OK;
+	});
+}
+
+// On the rank that holds ALL tiles (after the caller's gather): consistency check, back-substitution, export -- the tail
+// of a single-GPU solve_one.
+int gf2bv_slab_solve(gf2bv_slab *h, gf2bv_result **out)
+{
+	return guarded([&]() -> int {
+	if (!h || !out) return fail(GF2BV_ERR_ARG, "null pointer");
+	*out = nullptr;
+	Solver &S = h->S;
+	HIPCHK(hipSetDevice(S.device));
+	int rc = enqueue_check_rhs(S);
+	if (rc == GF2BV_OK) rc = enqueue_backward_single(S);
+	if (rc) return rc;
+	return solver_finish(S, out);
+	});
+}
+
+void gf2bv_slab_close(gf2bv_slab *h)
+{
+	if (!h) return;
+	(void)hipSetDevice(h->S.device);
+	delete h;
 }
 
 // ---- AffineSpace on the device: bulk enumeration ------------------------------------------------

@@ -30,6 +30,9 @@ EXPORTS = [
     "gf2bv_result_status", "gf2bv_result_rank", "gf2bv_result_dimension", "gf2bv_result_words",
     "gf2bv_result_origin", "gf2bv_result_basis", "gf2bv_result_pivots", "gf2bv_result_stats",
     "gf2bv_result_free", "gf2bv_space_combine", "gf2bv_space_open", "gf2bv_space_enumerate", "gf2bv_space_buffer", "gf2bv_space_close",
+    "gf2bv_slab_work_words", "gf2bv_slab_tiles", "gf2bv_slab_open", "gf2bv_slab_blocks", "gf2bv_slab_owner",
+    "gf2bv_slab_payload_bytes", "gf2bv_slab_factor", "gf2bv_slab_apply", "gf2bv_slab_finish_local", "gf2bv_slab_solve",
+    "gf2bv_slab_close",
     "gf2bv_synth_device", "gf2bv_residual_device",
     "gf2bv_stream_ceiling_device",
     "gf2bv_device_alloc", "gf2bv_device_free", "gf2bv_device_upload", "gf2bv_device_download",
@@ -89,6 +92,22 @@ def lib():
         L.gf2bv_space_enumerate.argtypes = [vp, ctypes.c_uint64, i64, i32, vp]
         L.gf2bv_space_close.argtypes = [vp]
         L.gf2bv_space_close.restype = None
+        L.gf2bv_slab_work_words.argtypes = [i64, i64]
+        L.gf2bv_slab_work_words.restype = i64
+        L.gf2bv_slab_tiles.argtypes = [i64]
+        L.gf2bv_slab_tiles.restype = i64
+        L.gf2bv_slab_open.argtypes = [vp, i64, i64, i64, vp, i64, i32, i32, i32, pp]
+        L.gf2bv_slab_blocks.argtypes = [vp]
+        L.gf2bv_slab_blocks.restype = i64
+        L.gf2bv_slab_owner.argtypes = [vp, i32]
+        L.gf2bv_slab_payload_bytes.argtypes = [vp]
+        L.gf2bv_slab_payload_bytes.restype = i64
+        L.gf2bv_slab_factor.argtypes = [vp, i32, vp]
+        L.gf2bv_slab_apply.argtypes = [vp, i32, vp]
+        L.gf2bv_slab_finish_local.argtypes = [vp]
+        L.gf2bv_slab_solve.argtypes = [vp, pp]
+        L.gf2bv_slab_close.argtypes = [vp]
+        L.gf2bv_slab_close.restype = None
         L.gf2bv_synth_device.argtypes = [vp, i64, i64, i64, ctypes.c_uint64, i32, vp]
         L.gf2bv_residual_device.argtypes = [vp, i64, i64, i64, vp, i32, vp, ctypes.POINTER(i64)]
         L.gf2bv_stream_ceiling_device.argtypes = [i32, i64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]

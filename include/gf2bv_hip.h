@@ -140,6 +140,34 @@ void gf2bv_space_combine(const uint64_t *origin, const uint64_t *basis, int64_t 
                          int64_t words, const uint64_t *selector, int64_t selector_words,
                          uint64_t *out);
 
+/* ---- column-slab solve: ONE system over the GPUs of a node (replaces the single _mzd_pluq call of
+ * gf2bv/_internal.c:431-433 for systems one GPU should not solve alone) --------------------------------------------
+ * One process per GPU.  Rank r of `world` owns the column tiles t with t % world == r (gf2bv_slab_tiles(cols) tiles
+ * of 8 words).  The caller owns the working matrix (d_work: gf2bv_slab_work_words(rows, cols) uint64, tile-major: tile
+ * t is the contiguous slab d_work[t * slab_words .. (t+1) * slab_words), slab_words = work_words / tiles) and ALL the
+ * communication:
+ *     for b in range(gf2bv_slab_blocks(h)):
+ *         if gf2bv_slab_owner(h, b) == rank: gf2bv_slab_factor(h, b, payload)    # panel path of the block, records out
+ *         broadcast(payload, src = gf2bv_slab_owner(h, b))                       # ONE collective per block (RCCL over xGMI)
+ *         gf2bv_slab_apply(h, b, payload)                                        # TRSM + bulk update of the own tiles
+ *     gf2bv_slab_finish_local(h); gather every rank's tiles of d_work on rank 0; gf2bv_slab_solve(h, &result) there
+ * payload: gf2bv_slab_payload_bytes(h) bytes of device memory (block records + rows x 32 bytes of multipliers).
+ * Results are bit-identical to gf2bv_solve_device on the same matrix (the elimination is the same; only who applies
+ * it to which columns differs).  d_aug: the full row-major system on every rank (left untouched). */
+typedef struct gf2bv_slab gf2bv_slab;
+int64_t gf2bv_slab_work_words(int64_t rows, int64_t cols);
+int64_t gf2bv_slab_tiles(int64_t cols);
+int     gf2bv_slab_open(void *d_aug, int64_t rows, int64_t cols, int64_t stride_words, void *d_work, int64_t work_words,
+                        int world, int rank, int device, gf2bv_slab **out);
+int64_t gf2bv_slab_blocks(const gf2bv_slab *h);
+int     gf2bv_slab_owner(const gf2bv_slab *h, int block);
+int64_t gf2bv_slab_payload_bytes(const gf2bv_slab *h);
+int     gf2bv_slab_factor(gf2bv_slab *h, int block, void *d_payload);
+int     gf2bv_slab_apply(gf2bv_slab *h, int block, const void *d_payload);
+int     gf2bv_slab_finish_local(gf2bv_slab *h);
+int     gf2bv_slab_solve(gf2bv_slab *h, gf2bv_result **out);
+void    gf2bv_slab_close(gf2bv_slab *h);
+
 /* ---- AffineSpace on the device: bulk enumeration (gf2bv/_internal.c:101-122 Gray walk, :63-91 binary walk) ---- */
 /* The reference yields one element per call: one row XOR and one int export each.  Here a whole range of elements is
  * materialised by one kernel: element g of the walk = origin ^ XOR of basis[i] over the set bits i of code(g), with

@@ -11,7 +11,7 @@ template <int G, int T, int NT>
 void run(const char *name, u64 *M, i64 rows, i64 srows, int ntiles, PanelRec *panels, PanelAux *aux, u64 *mult, int *blkf, int nsplit)
 {
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-	auto launch = [&] { k_update<G, T, NT><<<dim3(256), dim3(NT), 0>>>(M, rows, srows, 0, G, 0, panels, aux, mult, blkf, 0, ntiles, nsplit, 0, 0, SysStride{0, 0}); };
+	auto launch = [&] { k_update<G, T, NT><<<dim3(256), dim3(NT), 0>>>(M, rows, srows, 0, G, 0, panels, aux, mult, blkf, 0, ntiles, 1, 0, 0, SysStride{0, 0}); };
 	launch(); CK(hipDeviceSynchronize());
 	const int reps = getenv("MB_REPS") ? atoi(getenv("MB_REPS")) : 5;      // MB_REPS=400: sustained load (clocks settle)
 	CK(hipEventRecord(e0)); for (int r = 0; r < reps; r++) launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
