@@ -51,8 +51,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", choices=["auto", "single", "batch"], default="auto",
-                    help="auto = single at N = 1 (configs[1]), batch at N > 1 (configs[3])")
+    ap.add_argument("--workload", choices=["auto", "single", "batch", "sharded"], default="auto",
+                    help="auto = single at N = 1 (configs[1]), batch at N > 1 (configs[3]); sharded = ONE --n system with its "
+                         "columns over the ranks (SURVEY 8f-1, strong scaling)")
     ap.add_argument("--n", type=int, default=65536, help="single: system size N (rows = cols)")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -419,6 +420,57 @@ def run_batch(args, world, rank, local_rank, dev):
     return out
 
 
+def run_sharded(args, world, rank, local_rank, dev):
+    """ONE dense N x N system, column tiles cyclic over the ranks (gf2bv_amd.slab): per block one broadcast of the
+    block's records from the owner of its window, bulk update of the own tiles on every rank, tiles collected on rank 0."""
+    from gf2bv_amd import slab
+    n = args.n
+    seed = args.seed if args.seed is not None else FULL_RANK_SEEDS.get(n, 1234)
+    stride = hip.padded_stride(n)
+    mat = torch.empty(n * stride, dtype=torch.int64, device=dev)       # the same system on every rank
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    hip.synth_device(mat.data_ptr(), n, n, stride, seed, device=local_rank, stream=stream)
+    torch.cuda.synchronize(dev)
+    if world == 1 and not dist.is_initialized():                       # the schedule talks to a process group
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29544")
+        dist.init_process_group("gloo", rank=0, world_size=1)
+    sols = []
+    for _ in range(args.warmup):
+        slab.solve_one_sharded(mat, n, n, stride, local_rank)
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sols.append(slab.solve_one_sharded(mat, n, n, stride, local_rank))
+    torch.cuda.synchronize(dev)
+    dist.barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return None
+    bad = hip.residual_device(mat.data_ptr(), n, n, stride, sols[-1].origin, device=local_rank, stream=stream)
+    s0 = sols[-1].stats
+    return {
+        "metric": "GF(2) row-XORs/s (ONE dense NxN solve_one, columns sharded over the GPUs)",
+        "value": float(sum(s.stats["row_xors"] for s in sols)) / elapsed, "unit": "row-XORs/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+        "config": {"workload": f"ONE synthetic dense {n}x{n} GF(2) solve_one, seed {seed}, column tiles cyclic over {world} GPUs, "
+                               f"one broadcast of {n * 32 / 2**20:.1f} MiB of multipliers + block records per block of 256 pivots, "
+                               f"tiles collected on rank 0 for the back-substitution",
+                   "parallelism": f"column slabs x{world}", "tables_per_sweep": s0["tables_per_sweep"],
+                   "tile_words": s0["tile_words"], "rank": int(sols[-1].rank)},
+        "parity_gate": {"residual_rows": int(bad), "all_solved": all(s.solved for s in sols)},
+        "roofline": None,
+    }
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -433,10 +485,10 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=dev)
     workload = args.workload if args.workload != "auto" else ("single" if world == 1 else "batch")
-    out = (run_single if workload == "single" else run_batch)(args, world, rank, local_rank, dev)
+    out = {"single": run_single, "batch": run_batch, "sharded": run_sharded}[workload](args, world, rank, local_rank, dev)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

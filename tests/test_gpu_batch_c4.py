@@ -94,3 +94,13 @@ def test_bench_batch_mode_end_to_end():
     assert line["parity_gate"]["all_ranks_ok"] and line["parity_gate"]["residual_rows_rank0"] == 0
     assert line["parity_gate"]["gathered_records"] == 12
     assert line["value"] > 0 and line["roofline"]["achieved"] > 0
+
+
+@pytest.mark.timeout(600)
+def test_bench_sharded_mode_single_rank():
+    """bench.py --workload sharded (ONE system, column slabs over the ranks) at world size 1: the schedule end to end."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "sharded", "--n", "8192", "--steps", "2", "--warmup", "1"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=550, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["parity_gate"]["residual_rows"] == 0 and line["parity_gate"]["all_solved"]
