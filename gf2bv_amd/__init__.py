@@ -9,8 +9,10 @@ There is no CPU fallback: importing works anywhere, solving needs the GPU.
 from ._internal import AffineSpace, m4ri_solve, mul_bit_quad, to_bits, tuple_where, xor_tuple
 from .bitvec import BitVec
 from .linsys import DimensionTooLargeError, LinearSystem, QuadraticSystem, Zeros
+from .packed import PackedBitVec, PackedLinearSystem
 
 __all__ = [
-    "AffineSpace", "BitVec", "DimensionTooLargeError", "LinearSystem", "QuadraticSystem", "Zeros",
+    "AffineSpace", "BitVec", "DimensionTooLargeError", "LinearSystem", "PackedBitVec", "PackedLinearSystem",
+    "QuadraticSystem", "Zeros",
     "m4ri_solve", "mul_bit_quad", "to_bits", "tuple_where", "xor_tuple",
 ]

@@ -415,6 +415,49 @@ PyObject *py_m4ri_solve(PyObject *, PyObject *const *args, Py_ssize_t nargs)
 	return result_to_py(res, mode);
 }
 
+// m4ri_solve_packed(buffer, rows, words, cols, mode) -> None | int | AffineSpace.
+// New entry: the equations arrive ALREADY PACKED -- `rows` x `words` little-endian 64-bit words in the
+// bit order of the equation ints (bit 0 = affine term, bit k = coefficient of variable k-1), e.g. the numpy array a
+// PackedLinearSystem builds -- instead of as a list of Python ints.  No PyLong is created or read: the buffer goes
+// to gf2bv_solve_digits as 32-bit "digits" and the device pack kernel (k_pack_digits) does what
+// gf2bv/_internal.c:403-426 does bit by bit.  Same checks, same result types as m4ri_solve.
+PyObject *py_m4ri_solve_packed(PyObject *, PyObject *const *args, Py_ssize_t nargs)
+{
+	if (nargs != 5) { PyErr_SetString(PyExc_TypeError, "m4ri_solve_packed requires 5 arguments"); return nullptr; }
+	const Py_ssize_t rows = PyLong_AsSsize_t(args[1]), words = PyLong_AsSsize_t(args[2]);
+	if ((rows == -1 || words == -1) && PyErr_Occurred()) return nullptr;
+	Py_ssize_t cols;
+	long mode;
+	if (!parse_cols_mode(args[3], args[4], &cols, &mode)) return nullptr;
+	if (rows < cols) {
+		PyErr_SetString(PyExc_ValueError,
+		                "Number of rows must be greater than or equal to number of columns, try pad with zeros.");
+		return nullptr;
+	}
+	Py_buffer view;
+	if (PyObject_GetBuffer(args[0], &view, PyBUF_C_CONTIGUOUS) != 0) return nullptr;
+	if (words <= 0 || view.len != rows * words * 8 || words * 64 < cols + 1) {
+		PyBuffer_Release(&view);
+		PyErr_SetString(PyExc_ValueError, "buffer must hold rows x words 64-bit words covering cols + 1 bits");
+		return nullptr;
+	}
+	std::vector<int64_t> off;
+	try { off.resize((size_t)rows + 1); } catch (const std::bad_alloc &) { PyBuffer_Release(&view); return PyErr_NoMemory(); }
+	for (Py_ssize_t r = 0; r <= rows; r++) off[(size_t)r] = (int64_t)r * words * 2;
+	gf2bv_result *res = nullptr;
+	int rc;
+	Py_BEGIN_ALLOW_THREADS
+	rc = gf2bv_solve_digits(static_cast<const uint32_t *>(view.buf), off.data(), 32, rows, cols, (int)mode, 0, &res);
+	Py_END_ALLOW_THREADS
+	PyBuffer_Release(&view);
+	if (rc != GF2BV_OK) {
+		PyErr_Format(rc == GF2BV_ERR_ARG ? PyExc_ValueError : PyExc_RuntimeError,
+		             "gf2bv_amd: HIP solve failed (%d): %s", rc, gf2bv_last_error());
+		return nullptr;
+	}
+	return result_to_py(res, mode);
+}
+
 // m4ri_solve_many(list_of_equation_lists, cols, mode) -> list of (None | int | AffineSpace).
 // New entry (no counterpart in the reference): independent systems of one shape -- one per output
 // bit / per instance in the recovery examples -- are solved as lock-step gangs by one call; every
@@ -640,6 +683,8 @@ PyObject *py_device_count(PyObject *, PyObject *) { return PyLong_FromLong(gf2bv
 PyMethodDef module_methods[] = {
 	{"m4ri_solve", FAST(py_m4ri_solve), METH_FASTCALL,
 	 "m4ri_solve(equations, cols, mode)\n--\n\nSolve the linear system on the MI355X; None when inconsistent."},
+	{"m4ri_solve_packed", FAST(py_m4ri_solve_packed), METH_FASTCALL,
+	 "m4ri_solve_packed(buffer, rows, words, cols, mode)\n--\n\nm4ri_solve on equations already packed as rows x words 64-bit words (equation-int bit order)."},
 	{"m4ri_solve_many", FAST(py_m4ri_solve_many), METH_FASTCALL,
 	 "m4ri_solve_many(systems, cols, mode)\n--\n\nSolve a list of same-shape systems in one batched call; list of m4ri_solve results."},
 	{"to_bits", FAST(py_to_bits), METH_FASTCALL, "to_bits(n, a)\n--\n\nLow n bits of a, LSB first."},
