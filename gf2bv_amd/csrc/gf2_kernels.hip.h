@@ -954,8 +954,11 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
              int *__restrict__ died, FindUnit *__restrict__ fu, int units, int find_wgs,
              PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol,
              int *__restrict__ urow, u64 *__restrict__ multset, int *__restrict__ blk_first_out, int upd_T,
-             int sparse_mode, int self_wait, SysStride ss)
+             int sparse_mode, int self_wait, int rpt, SysStride ss)
 {
+	// rpt: row blocks of 256 per narrow workgroup.  Every narrow workgroup rebuilds panel gp's pivot rows and their
+	// nibble tables (~3 us) before it can touch a row, so with one block each the prologue WAS the narrow step -- and
+	// rows/256 workgroups had to find a slot next to the bulk update's.  A workgroup now walks rpt blocks.
 	__builtin_amdgcn_s_setprio(3);          // panel path = critical path: win issue arbitration against bulk-update waves
 	{
 		const i64 ao = blockIdx.y * ss.arena_bytes;
@@ -991,12 +994,15 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	const int first = st->first, wide = st->wide;       // (search role)
 	if (gp < 0) { recp.p = 0; recp.mask = 0; bound = 0; }
 
-	// narrow role: this thread's row
-	const i64 i = rb * 256 + t;
-	const i64 ic = (!finder && i < rows) ? i : 0;
-	const int my_died = died[ic];
-	const uint4 *src = reinterpret_cast<const uint4 *>(Wb_in + ic * GF2_GMAX);
-	const uint4 my_lo = src[0], my_hi = src[1];
+	// narrow role: this thread's first row (the others are fetched one block ahead inside the loop)
+	const i64 i0 = rb * rpt * 256 + t;
+	const i64 ic = (!finder && i0 < rows) ? i0 : 0;
+	int my_died = died[ic];
+	uint4 my_lo, my_hi;
+	{
+		const uint4 *src = reinterpret_cast<const uint4 *>(Wb_in + ic * GF2_GMAX);
+		my_lo = src[0]; my_hi = src[1];
+	}
 
 	// search role: this unit's slice and its first chunk
 	const int u = (int)blockIdx.x * 4 + (t >> 6);
@@ -1026,8 +1032,8 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	raw0.wf = Wb_in[i_c * GF2_GMAX + gfc];
 	raw0.wp = Wb_in[i_c * GF2_GMAX + gpc];
 
-	// a row block below the bound holds dead rows only (block 0 still stores the pivot rows)
-	const bool dead_block = !finder && rb != 0 && (rb + 1) * 256 <= bound;
+	// a workgroup whose rows all lie below the bound holds dead rows only (workgroup 0 still stores the pivot rows)
+	const bool dead_block = !finder && rb != 0 && (rb + 1) * rpt * 256 <= bound;
 #ifdef GF2_STEP_PROBE
 	if (probe_on && threadIdx.x == 0 && blockIdx.x < GF2_PROBE_WGS) {       // trip 1 and trip 2 have landed
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1073,27 +1079,41 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 		u64 *mult = multset + (i64)gp * rows;
 		if (rb == 0 && t < p)                           // the multipliers panel gp's sources recorded for earlier panels
 			for (int e = 0; e < gp; e++) multset[(i64)e * rows + sr] = 0;
-		if (i >= rows) return;
-		u64 m = 0;
-		if (!dead_block && my_died > j0 + gp) {         // alive when panel gp was eliminated
-			u64 w[GF2_GMAX] = { ((u64)my_lo.y << 32) | my_lo.x, ((u64)my_lo.w << 32) | my_lo.z,
-			                    ((u64)my_hi.y << 32) | my_hi.x, ((u64)my_hi.w << 32) | my_hi.z };
-			u64 wp = 0;
+		for (int r = 0; r < rpt; r++) {
+			const i64 i = i0 + (i64)r * 256;
+			if (i - t >= rows) break;                   // (uniform: the whole block lies beyond the last row)
+			// the next block's row is requested before this one is worked on
+			const i64 in = i + 256;
+			const i64 inc = (r + 1 < rpt && in < rows) ? in : 0;
+			const int nx_died = died[inc];
+			const uint4 *nsrc = reinterpret_cast<const uint4 *>(Wb_in + inc * GF2_GMAX);
+			const uint4 nx_lo = nsrc[0], nx_hi = nsrc[1];
+			if (i < rows) {
+				u64 m = 0;
+				// (blocks below the bound hold dead rows only -- except the very first, which holds the pivot rows' sources)
+				const bool dead_rows = !(rb == 0 && r == 0) && i - t + 256 <= bound;
+				if (!dead_block && !dead_rows && my_died > j0 + gp) {         // alive when panel gp was eliminated
+					u64 w[GF2_GMAX] = { ((u64)my_lo.y << 32) | my_lo.x, ((u64)my_lo.w << 32) | my_lo.z,
+					                    ((u64)my_hi.y << 32) | my_hi.x, ((u64)my_hi.w << 32) | my_hi.z };
+					u64 wp = 0;
 #pragma unroll
-			for (int e = 0; e < GF2_GMAX; e++) if (e == gp) wp = w[e];
-			m = wp & recp.mask;
-			if (m) {
-				u64 acc[GF2_GMAX];
-				nibble_rows(L.Tn, m, acc);                  // (words left of the panel / beyond the block: the tables hold zeros)
+					for (int e = 0; e < GF2_GMAX; e++) if (e == gp) wp = w[e];
+					m = wp & recp.mask;
+					if (m) {
+						u64 acc[GF2_GMAX];
+						nibble_rows(L.Tn, m, acc);              // (words left of the panel / beyond the block: the tables hold zeros)
 #pragma unroll
-				for (int e = 0; e < GF2_GMAX; e++) w[e] ^= acc[e];
+						for (int e = 0; e < GF2_GMAX; e++) w[e] ^= acc[e];
+					}
+					uint4 *dst = reinterpret_cast<uint4 *>(Wb_out + i * GF2_GMAX);
+					dst[0] = make_uint4((unsigned)w[0], (unsigned)(w[0] >> 32), (unsigned)w[1], (unsigned)(w[1] >> 32));
+					dst[1] = make_uint4((unsigned)w[2], (unsigned)(w[2] >> 32), (unsigned)w[3], (unsigned)(w[3] >> 32));
+				}
+				// stored pre-rotated for the bulk update's table layout (field s = what this row reads at step s)
+				mult[i] = rot_fields_rt(upd_T, m, rowq(i));
 			}
-			uint4 *dst = reinterpret_cast<uint4 *>(Wb_out + i * GF2_GMAX);
-			dst[0] = make_uint4((unsigned)w[0], (unsigned)(w[0] >> 32), (unsigned)w[1], (unsigned)(w[1] >> 32));
-			dst[1] = make_uint4((unsigned)w[2], (unsigned)(w[2] >> 32), (unsigned)w[3], (unsigned)(w[3] >> 32));
+			my_died = nx_died; my_lo = nx_lo; my_hi = nx_hi;
 		}
-		// stored pre-rotated for the bulk update's table layout (field s = what this row reads at step s)
-		mult[i] = rot_fields_rt(upd_T, m, rowq(i));
 		GF2_PROBE_WG(3);
 		return;
 	}

@@ -333,6 +333,7 @@ struct Solver {
 	bool ext_events = true;       // hand-off and timing events ride on kernel start / completion signals (hipExtLaunchKernel)
 	                              // instead of marker packets: ~1 % at every size; GF2BV_EXT_EVENTS=0 restores hipEventRecord
 	int sparse_mode = 2;          // search skips absent columns: 0 never, 1 always, 2 per chunk by density (GF2BV_SPARSE)
+	int narrow_rpt = 1;           // row blocks of 256 per narrow workgroup of a panel step (set in solver_alloc; GF2BV_NARROW_RPT)
 	int self_wait = 5000;         // ticks (100 MHz) unit 0 of a panel search waits for the other units before it leaves
 	                              // publishing to the last arriver: 50 us (GF2BV_SELF_WAIT_US; 0 = never wait)
 	u64 *Y = nullptr;
@@ -464,6 +465,12 @@ int solver_alloc(Solver &S)
 	if (const char *e = getenv("GF2BV_DEBUG_SYNC")) S.dbg_sync = atoi(e);
 	if (const char *e = getenv("GF2BV_EXT_EVENTS")) S.ext_events = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_SPARSE")) { int v = atoi(e); if (v >= 0 && v <= 2) S.sparse_mode = v; }
+	// narrow workgroups: as many rows each as keeps ~256 of them (all systems of a gang together) busy, at most 8 blocks
+	{
+		const i64 blocks = (S.rows + 255) / 256 * std::max(1, S.nsys);
+		S.narrow_rpt = (int)std::min<i64>(8, std::max<i64>(1, blocks / 256));
+		if (const char *e = getenv("GF2BV_NARROW_RPT")) { int v = atoi(e); if (v >= 1 && v <= 64) S.narrow_rpt = v; }
+	}
 	if (const char *e = getenv("GF2BV_SELF_WAIT_US")) { int v = atoi(e); if (v >= 0 && v <= 1000000) S.self_wait = v * 100; }
 	if (getenv("GF2BV_SERIAL")) { S.sB = S.sA; S.own_sB = false; }     // ablation: no look-ahead overlap
 	else {
@@ -589,14 +596,14 @@ int enqueue_block_panel(Solver &S, int b)
 		const i64 c0 = (i64)(g.j0 + std::max(gf, 0)) * 64;
 		const u64 colmask = (S.cols - c0 >= 64) ? ~0ull : ((1ull << (S.cols - c0)) - 1);
 		const int find_wgs = gf >= 0 ? (S.units + 3) / 4 : 0;
-		const unsigned wgs = (unsigned)find_wgs + (gp >= 0 ? row_blocks : 0u);
+		const unsigned wgs = (unsigned)find_wgs + (gp >= 0 ? (row_blocks + S.narrow_rpt - 1) / S.narrow_rpt : 0u);
 		// the block's last step carries the hand-off event as its own completion signal (no marker packet)
 		const bool ext = S.ext_events && s == g.gb && b != S.nblocks - 1;
 		hipExtLaunchKernelGGL(k_panel_step, dim3(wgs, S.nsys), dim3(256), 0, S.sA, nullptr, ext ? S.evA[b] : nullptr, 0,
 		                      S.M, S.rows, S.srows, g.j0, gp, gf, g.gb, colmask,
 		                      (const u64 *)half[s ? (s - 1) & 1 : 0], half[s & 1], S.st, S.died, S.fu, S.units, find_wgs,
 		                      S.panels, S.aux, S.pivcol, S.urow, g.mset,
-		                      gf == g.gb - 1 ? S.blk_first + b : (int *)nullptr, S.impl->T, S.sparse_mode, S.self_wait, S.ss());
+		                      gf == g.gb - 1 ? S.blk_first + b : (int *)nullptr, S.impl->T, S.sparse_mode, S.self_wait, S.narrow_rpt, S.ss());
 	}
 	if (b == S.nblocks - 1)
 		k_win_scatter<<<dim3((unsigned)((S.rows * g.gb + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, half[g.gb & 1], S.died, S.ss());

@@ -51,6 +51,28 @@ class LinearSystem:
                 flat.append(z)
         return [e for e in flat if e]          # literal zeros carry no information
 
+    # -- Sage export (reference :167-212) --------------------------------------------------------------------
+    def get_sage_mat_slow(self, zeros: Zeros, *, tqdm=lambda x, desc: x):
+        """(A, b) over GF(2) with A x = b, as Sage objects -- needs Sage at call time (reference :167-192)."""
+        from sage.all import GF, matrix, vector          # noqa: PLC0415  (optional dependency, as in the reference)
+        eqs = self.get_eqs(zeros)
+        F2 = GF(2)
+        b = vector(F2, [e & 1 for e in eqs])
+        A = matrix(F2, len(eqs), self._cols)
+        for i, e in enumerate(tqdm(eqs, desc="Converting equations")):
+            e >>= 1
+            while e:
+                low = e & -e
+                A[i, low.bit_length() - 1] = 1
+                e ^= low
+        return A, b
+
+    def get_sage_mat(self, zeros: Zeros):
+        """The reference's fast variant (reference :194-212) renders the matrix as a PNG through libgd for Sage's
+        unpickler (_internal.c:678-765); that helper is outside this package's scope (DESIGN.md
+        section 8), so this is the per-row variant above: same result, slower."""
+        return self.get_sage_mat_slow(zeros)
+
     # -- boundary call (reference :229-240) ------------------------------------------------------------
     def _solve_internal(self, zeros: Zeros, mode: int):
         eqs = self.get_eqs(zeros)
@@ -173,6 +195,11 @@ class QuadraticSystem(LinearSystem):
     def _bit_assert(self, a: int, v: int) -> list:
         assert v in (0, 1), "Invalid bit"
         assert a not in (0, 1), "a should not be a constant"
+        # DEVIATION from the reference, on purpose and documented: gf2bv/__init__.py:349 asserts
+        # `a >> self._lin_size == 0`, which rejects every expression that contains the LAST linear unknown (bit
+        # lin_size of an equation int: bit 0 is the constant, unknown g is bit g + 1) although it is a linear term;
+        # the bound that matches the representation is lin_size + 1.  Every input the reference accepts gives the
+        # same zeros here; inputs it rejects by that off-by-one are accepted.
         assert a >> (self._lin_size + 1) == 0, "Not a linear term"
         zeros = [a ^ v]
         for i in range(1, self._lin_size + 1):
