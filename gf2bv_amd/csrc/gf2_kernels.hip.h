@@ -36,12 +36,15 @@ typedef long long i64;
 
 #define GF2_GMAX 4                // max panels per block
 #ifndef GF2_TW
-#define GF2_TW 8                  // 64-bit words per column tile: 8 (64-byte row segments) or 16 (128-byte)
+#define GF2_TW 2                  // 64-bit words per column tile: 2 (16-byte row segments: the byte-field bulk update
+                                  // k_update16, one lane per row segment -- the product since round 2), or 8 / 16
+                                  // (64- / 128-byte segments: the 5/6-bit-field k_update of round 1, -DGF2_TW=8 for A/B runs)
 #endif
-#define GF2_TW_LOG (GF2_TW == 16 ? 4 : 3)
+#define GF2_TW_LOG (GF2_TW == 16 ? 4 : GF2_TW == 8 ? 3 : 1)
 #define GF2_LPR (GF2_TW / 2)      // lanes per row segment, 16 bytes each
-#define GF2_IL (16 / GF2_LPR)     // table entries interleaved in one 256-byte LDS slot: 4 (TW=8) or 2 (TW=16)
-static_assert(GF2_TW == 8 || GF2_TW == 16, "tile width");
+#define GF2_IL (16 / GF2_LPR)     // table entries interleaved in one 256-byte LDS slot: 4 (TW=8), 2 (TW=16), 16 (TW=2)
+static_assert(GF2_TW == 2 || GF2_TW == 8 || GF2_TW == 16, "tile width");
+#define GF2_OWN_LOG 3             // column-slab solves: the unit of ownership is 8 words (one or four tiles)
 #define GF2_FEW_UNITS 8           // search units used while panels are easy (dense systems)
 #ifndef GF2_BATCH
 #define GF2_BATCH 4
@@ -185,6 +188,10 @@ struct Fields {
 // rot_fields for a table count chosen at run time (the panel path is not templated on the update config)
 __device__ __forceinline__ u64 rot_fields_rt(int T, u64 m, int q)
 {
+#if GF2_TW == 2
+	(void)T; (void)q;
+	return m;                     // (not used by the 16-byte-tile layout: see mult_stored / mult_plain)
+#else
 	switch (T) {
 	case 8: return Fields<8>::rot_fields(m, q);
 	case 12: return Fields<12>::rot_fields(m, q);
@@ -194,6 +201,28 @@ __device__ __forceinline__ u64 rot_fields_rt(int T, u64 m, int q)
 #endif
 	default: return Fields<16>::rot_fields(m, q);
 	}
+#endif
+}
+
+// ---- where a row's multipliers live, and in which form -----------------------------------------------------------
+// TW = 8 / 16: one array per panel, multset[g * R + row], fields rotated by rowq(row) for the table layout of k_update.
+// TW = 2 (k_update16): 32 bytes per row, multset[row * 4 + (g ^ rq_hi)], bytes rotated by rq_lo (rq = row & 15): two
+// 16-byte loads per row, and a lookup address is one v_perm_b32 (see k_update16).  R = rows (padded to 64 for TW = 2:
+// the bulk update reads whole wavefronts of rows; the padding stays zero).
+__host__ __device__ __forceinline__ i64 mult_rows(i64 rows) { return GF2_TW == 2 ? ((rows + 63) & ~(i64)63) : rows; }
+__host__ __device__ __forceinline__ i64 midx(int g, i64 row, i64 rows)
+{
+	return GF2_TW == 2 ? row * 4 + (g ^ (int)((row >> 3) & 1)) : (i64)g * rows + row;
+}
+__device__ __forceinline__ u64 mult_stored(int T, u64 m, i64 row)           // plain bit order -> stored form
+{
+	if (GF2_TW == 2) { const int sh = 8 * (int)(row & 7); return sh ? ((m >> sh) | (m << (64 - sh))) : m; }
+	return rot_fields_rt(T, m, rowq(row));
+}
+__device__ __forceinline__ u64 mult_plain(int T, u64 v, i64 row)            // stored form -> plain bit order
+{
+	if (GF2_TW == 2) { const int sh = 8 * (int)(row & 7); return sh ? ((v << sh) | (v >> (64 - sh))) : v; }
+	return rot_fields_rt(T, v, (GF2_IL - rowq(row)) % GF2_IL);
 }
 
 // Gang execution: several systems of one shape are eliminated in lock-step by the same launches;
@@ -207,6 +236,20 @@ __device__ __forceinline__ P *sys_at(P *p, i64 bytes)
 {
 	typedef typename std::remove_cv<P>::type Q;
 	return reinterpret_cast<P *>(reinterpret_cast<char *>(const_cast<Q *>(p)) + bytes);
+}
+
+// Column-slab solves (one system over `world` GPUs): rank r owns the units u (2^ulog items each: tiles, or 4-word
+// groups) with u % world == r.  The ct-th owned item at or after `first` (world <= 1: simply first + ct).
+__host__ __device__ __forceinline__ i64 owned_item(i64 ct, i64 first, int ulog, int world, int wrank)
+{
+	if (world <= 1) return first + ct;
+	const i64 usz = (i64)1 << ulog;
+	const i64 u_first = first >> ulog;
+	const i64 u0 = u_first + (((wrank - u_first % world) % world) + world) % world;      // first owned unit >= u_first
+	const i64 head = (u0 == u_first) ? usz - (first & (usz - 1)) : 0;                     // its items from `first` on
+	if (ct < head) return first + ct;
+	const i64 c2 = ct - head;
+	return ((u0 + ((head ? 1 : 0) + c2 / usz) * world) << ulog) + c2 % usz;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -941,10 +984,10 @@ struct CandWords {
 		u64 mv[GF2_GMAX];
 #pragma unroll
 		for (int e = 0; e < GF2_GMAX; e++)      // all loads first
-			mv[e] = (e >= gfl) ? 0ull : (narrowing && e == gp) ? Wb[(i64)srow * GF2_GMAX + gp] : multset[(i64)e * rows + srow];
+			mv[e] = (e >= gfl) ? 0ull : (narrowing && e == gp) ? Wb[(i64)srow * GF2_GMAX + gp] : multset[midx(e, srow, rows)];
 #pragma unroll
 		for (int e = 0; e < GF2_GMAX; e++)
-			out[e] = (e >= gfl) ? 0ull : (narrowing && e == gp) ? (mv[e] & maskp) : rot_fields_rt(upd_T, mv[e], (GF2_IL - rowq(srow)) % GF2_IL);
+			out[e] = (e >= gfl) ? 0ull : (narrowing && e == gp) ? (mv[e] & maskp) : mult_plain(upd_T, mv[e], srow);
 	}
 };
 
@@ -1076,9 +1119,8 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	if (!finder) {
 		// ---- narrow panel gp ----
 		const int p = recp.p;
-		u64 *mult = multset + (i64)gp * rows;
 		if (rb == 0 && t < p)                           // the multipliers panel gp's sources recorded for earlier panels
-			for (int e = 0; e < gp; e++) multset[(i64)e * rows + sr] = 0;
+			for (int e = 0; e < gp; e++) multset[midx(e, sr, rows)] = 0;
 		for (int r = 0; r < rpt; r++) {
 			const i64 i = i0 + (i64)r * 256;
 			if (i - t >= rows) break;                   // (uniform: the whole block lies beyond the last row)
@@ -1110,7 +1152,7 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 					dst[1] = make_uint4((unsigned)w[2], (unsigned)(w[2] >> 32), (unsigned)w[3], (unsigned)(w[3] >> 32));
 				}
 				// stored pre-rotated for the bulk update's table layout (field s = what this row reads at step s)
-				mult[i] = rot_fields_rt(upd_T, m, rowq(i));
+				multset[midx(gp, i, rows)] = mult_stored(upd_T, m, i);
 			}
 			my_died = nx_died; my_lo = nx_lo; my_hi = nx_hi;
 		}
@@ -1178,7 +1220,7 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 		comb[g] = aux[j0 + gc].comb[r];
 #pragma unroll
 		for (int e = 0; e < GF2_GMAX; e++) smul[g][e] = (e < g) ? aux[j0 + gc].src_mult[r][e] : 0ull;
-		mrow[g] = multset[(i64)gc * rows + ic];
+		mrow[g] = multset[midx(gc, ic, rows)];
 		if (g >= gb) { rec[g].p = 0; rec[g].mask = 0; mrow[g] = 0; }
 	}
 	u64 wv[W];
@@ -1209,7 +1251,6 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 #pragma unroll
 			for (int e = 0; e < W; e++) Tn[(n * 16 + v) * W + e] = a[e];
 		};
-		const int unrot = (GF2_IL - rowq(ic)) % GF2_IL;     // multipliers are stored rotated for the table kernel
 #pragma unroll
 		for (int g = 0; g < GF2_GMAX; g++) {
 			if (g >= gb) break;
@@ -1229,7 +1270,7 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 				if (h < gb && r < rec[h].p) S[(h * 64 + r) * W + w] ^= nibble_word(Tn, smul[h][g], w);
 			if (i < rows && mrow[g]) {
 				u64 acc[W];
-				nibble_rows(Tn, rot_fields_rt(upd_T, mrow[g], unrot), acc);
+				nibble_rows(Tn, mult_plain(upd_T, mrow[g], ic), acc);       // (stored rotated for the table kernel)
 #pragma unroll
 				for (int e = 0; e < W; e++) wv[e] ^= acc[e];
 			}
@@ -1263,7 +1304,7 @@ k_unwind(u64 *__restrict__ M, i64 srows, int G, int npanels, int nblocks, const 
 	const int wlo = (b + 1) * G;
 	const int gnext = (npanels - wlo < G) ? npanels - wlo : G;
 	// (column-slab solve: the window of block b + 1 was carried forward -- and Uwin filled -- by the rank that owns its tile)
-	if (world > 1 && ((wlo + e) >> GF2_TW_LOG) % world != wrank) return;
+	if (world > 1 && ((wlo + e) >> GF2_OWN_LOG) % world != wrank) return;
 	if (e < gnext) M[tidx(urow[k], wlo + e, srows)] = Uwin[k * GF2_GMAX + e];
 }
 
@@ -1294,11 +1335,11 @@ k_import_marks(int j0, int gb, const PanelRec *__restrict__ panels, const PanelA
 //   P_g[k] = XOR_{s in comb_g[k]} S_g[s]          (pivot rows of panel g)
 //   S_h[s] ^= XOR_{b in src_mult_h[s][g]} P_g[b]  (sources of later panels h > g were alive then)
 // and stores P_g[k] in place (physical row slot_row_g[k]), words >= wlo only.
-// One workgroup handles WPW words of one tile (16/WPW workgroups per tile) so the whole chip
-// shares this short, latency-bound step.
+// One workgroup handles a GROUP of WPW = 4 consecutive words (half a 64-byte tile, two 16-byte tiles) so the whole chip
+// shares this short, latency-bound step; groups [group_begin, ...) that this rank owns (owned_item).
 template <int TW, int WPW>
 __global__ void __launch_bounds__(64 * WPW)
-k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int tile_begin, int tile_step,
+k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int group_begin, int world, int wrank,
              const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux, int nw_lo, int nw_hi, SysStride ss)
 {
 	__builtin_amdgcn_s_setprio(2);
@@ -1306,18 +1347,15 @@ k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int tile_b
 	panels = sys_at(panels, blockIdx.y * ss.arena_bytes);
 	aux = sys_at(aux, blockIdx.y * ss.arena_bytes);
 	constexpr int NT = 64 * WPW;
-	constexpr int SPLIT = TW / WPW;
 	static_assert(WPW == 4 && NT == 256, "thread <-> table entry mapping below");
 	__shared__ u64 S[GF2_GMAX * 64 * WPW];     // [panel][slot][word]
 	__shared__ u64 Pbit[GF2_GMAX * 64 * WPW];  // [panel][pivot BIT][word], zero where the panel has no pivot
 	__shared__ u64 Tn[16 * 16 * WPW];          // nibble tables of 64 rows: [nibble n][value v][word] = XOR of rows 4n + k over the bits k of v
 	__shared__ int Bk[GF2_GMAX * 64];          // [panel][pivot k] -> pivot bit
-	const i64 tile = tile_begin + (i64)(blockIdx.x / SPLIT) * tile_step;     // (tile_step > 1: the tiles of one rank of a column-slab solve)
-	const int wofs = (blockIdx.x % SPLIT) * WPW;
-	const i64 w0 = tile * TW + wofs;
-	u64 *Mt = M + tile * srows * TW + wofs;    // row r, word w of this workgroup's slice at Mt[r * TW + w]
+	const i64 w0 = owned_item(blockIdx.x, group_begin, GF2_OWN_LOG - 2, world, wrank) * WPW;
 	const int t = threadIdx.x;
 	const int r = t / WPW, w = t % WPW;        // one (row, word) item per thread
+	auto at = [&](i64 row) -> u64 & { return M[tidx(row, w0 + w, srows)]; };
 	// words [nw_lo, nw_hi) = the next block's window: k_prio_window forms and stores those on the panel stream
 	const bool live = w0 + w >= wlo && !(w0 + w >= nw_lo && w0 + w < nw_hi);
 	// This step is pure latency (the chip is nearly idle while it runs), so all its parameters are fetched in
@@ -1338,7 +1376,7 @@ k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int tile_b
 	}
 #pragma unroll
 	for (int g = 0; g < GF2_GMAX; g++) {
-		const u64 v = Mt[(i64)(r < rec[g].p ? srow[g] : 0) * TW + w];
+		const u64 v = at(r < rec[g].p ? srow[g] : 0);
 		S[(g * 64 + r) * WPW + w] = (r < rec[g].p && live) ? v : 0ull;
 		Pbit[(g * 64 + r) * WPW + w] = 0;
 		if (w == 0 && ((rec[g].mask >> r) & 1)) Bk[g * 64 + __popcll(rec[g].mask & lanemask_lt(r))] = r;
@@ -1377,7 +1415,7 @@ k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int tile_b
 		if (r < rec[g].p) {
 			const u64 acc = lookup(comb[g]);
 			Pbit[(g * 64 + Bk[g * 64 + r]) * WPW + w] = acc;
-			if (live) Mt[(i64)srow[g] * TW + w] = acc;
+			if (live) at(srow[g]) = acc;
 		}
 		if (g + 1 >= gb) break;
 		__syncthreads();
@@ -1409,6 +1447,7 @@ k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int tile_b
 // bank exactly once (SQ_LDS_BANK_CONFLICT ~ 0).  The multipliers arrive already rotated (field s holds
 // what the row needs at step s), so no per-lookup select is needed.
 //
+#if GF2_TW != 2
 // Rows whose multipliers are all 0 (dead rows, the block's own sources, sparse rows) are not written back.
 template <int G, int T>
 struct UpdateCfg {
@@ -1425,7 +1464,7 @@ __global__ void __launch_bounds__(1024)
 k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
          const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
          const u64 *__restrict__ multset, const int *__restrict__ blk_first,
-         int tile_begin, int ntiles, int tile_step, int nw_lo, int nw_hi, SysStride ss)
+         int tile_begin, int ntiles, int world, int wrank, int nw_lo, int nw_hi, SysStride ss)
 {
 	// Words [nw_lo, nw_hi) -- the next block's window -- are never WRITTEN here: the panel stream owns them
 	// (k_prio_window has carried them into Wb, and the next block's panel steps store its pivot rows there
@@ -1474,7 +1513,7 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	const i64 r0 = pos - (i64)ct * R;
 	const i64 span = (R - r0 < pend - pos) ? R - r0 : pend - pos;
 	pos += span;
-	const i64 tile = tile_begin + (i64)ct * tile_step;     // (tile_step > 1: the tiles one rank of a column-slab solve owns)
+	const i64 tile = owned_item(ct, tile_begin, GF2_OWN_LOG - GF2_TW_LOG, world, wrank);     // (column-slab solve: the tiles this rank owns)
 	const i64 w0 = tile * TW;
 	const i64 rbeg = rlo + r0;
 	if (rbeg >= rows) continue;                 // padding at the end of a tile's line
@@ -1728,6 +1767,255 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	if (uprobe) { gf2_probe_upd[blockIdx.x][2] = wall_clock64(); gf2_probe_upd[blockIdx.x][3] = up_spans; gf2_probe_upd[blockIdx.x][4] = up_tab; }
 #endif
 }
+
+#else   // GF2_TW == 2
+// ------------------------------------------------------------------------------------------
+// Bulk update, second form: 16-BYTE column tiles and BYTE bit-fields.
+//
+// The LDS holds G x T x 2^k x E bytes of tables (G panels, T = 64/k fields of k bits, entries of E bytes =
+// the tile width); the lookups a row segment costs are G x T whatever E is.  k_update above spends its
+// 128 KiB on E = 64: T = 12 fields of 5-6 bits, 48 lookups of 64 B per 64-byte segment -- 24 bytes of LDS
+// reads per byte of HBM traffic, and the LDS + VALU issue is what binds it.  Here E = 16:
+// a tile is TWO words wide, a lane owns a whole row segment, k = 8: 32 tables of 256 entries = 128 KiB, 32
+// lookups of 16 B per 16-byte segment -- 16 bytes of LDS per HBM byte -- and the address of a lookup is ONE
+// v_perm_b32 (field byte -> bits 8..15, lane constant -> bits 0..7, 64-KiB page -> bit 16).
+//
+// LDS layout: two groups (pages) of 16 tables = panels {0,1} and {2,3}; slot `idx` of a group = 256 B =
+// [entry idx of table 0 | ... | table 15] = all 64 banks; table 8 * (panel & 1) + byte.  ds_read_b128 is
+// serviced 16 lanes at a time whose rows (consecutive lanes = consecutive rows) have 16 different values of
+// rq = row & 15; at step s = 8 * s_hi + s_lo of a group a row reads table 8 * (s_hi ^ rq_hi) + ((s_lo + rq_lo) & 7)
+// (rq_lo = rq & 7, rq_hi = rq >> 3): a bijection of rq for every s, so every read touches each bank once.
+// The panel path stores the multipliers so that this needs no per-lookup work: mult4[row][j] (32 B per row,
+// two 16-byte loads) = rotr64(multiplier of panel j ^ rq_hi, 8 * rq_lo) -- midx / mult_stored above (mult_slot /
+// mult_rot: the same for host code).
+//
+// Measured (tools/microbench_update16.hip, MI355X): the table work (0.32-0.35 ms per GiB pass) hides completely under
+// the stream; the stream carries 32 bytes of multipliers per 16 bytes of row data (L2 hits, ~0.045 ms per GiB of them):
+// 4.1 TB/s per pass in isolation against 3.99 for k_update<4,12,768> -- and, being bound by the memory side and not by
+// LDS + VALU issue, it does not slow down when the next block's panel steps share its CUs (the 64-byte-tile kernel
+// loses 7-12 % of its isolated rate inside a solve).
+__host__ __device__ __forceinline__ int mult_slot(int g, i64 row) { return g ^ (int)((row >> 3) & 1); }
+__host__ __device__ __forceinline__ u64 mult_rot(u64 m, i64 row)
+{
+	const int sh = 8 * (int)(row & 7);
+	return sh ? ((m >> sh) | (m << (64 - sh))) : m;
+}
+__host__ __device__ __forceinline__ u64 mult_unrot(u64 m, i64 row)
+{
+	const int sh = 8 * (int)(row & 7);
+	return sh ? ((m << sh) | (m >> (64 - sh))) : m;
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const u32x4 *lds_u4_ptr;
+
+// HALF: the tile's first word belongs to the next block's window (the panel stream owns it): only the second
+// word is stored (one tile of one block per solve at most, its own small launch).
+// LB: the thread count the register budget is taken from (__launch_bounds__).  768 threads at the budget of 1024
+// (128 VGPRs) leave a quarter of every SIMD's register file -- and 27 KiB of LDS -- to the panel kernels of the next
+// block, which then run NEXT TO this kernel instead of queueing for a CU behind it.
+template <int NT, bool HALF, int DEPTH, bool PIPE, int LB>
+__global__ void __launch_bounds__(LB)
+k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
+           const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
+           const u64 *__restrict__ mult4, const int *__restrict__ blk_first,
+           int tile_begin, int ntiles, int world, int wrank, SysStride ss)
+{
+	{
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		M += blockIdx.y * ss.m_words;
+		panels = sys_at(panels, ao); aux = sys_at(aux, ao); mult4 = sys_at(mult4, ao); blk_first = sys_at(blk_first, ao);
+	}
+	constexpr int NW = NT / 64;
+	__shared__ __attribute__((aligned(256))) uint4 tab[2 * 256 * 16];      // 128 KiB, must sit at LDS address 0 (checked below)
+	__shared__ uint4 stage[GF2_GMAX * 64];          // the tile's segment of every pivot row, [panel][pivot bit] (zero: no pivot)
+	__shared__ int prow[GF2_GMAX * 64];             // physical row of pivot bit, -1 if none
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	if ((unsigned)(size_t)tab != 0u) __builtin_trap();      // lookup addresses are absolute (folds away when the compiler placed it at 0)
+
+	int anyp = 0;
+	for (int g = 0; g < gb; g++) anyp |= panels[j0 + g].p;
+	if (!anyp) return;
+	// Work = (tile, row) pairs, tile-major, rows from the alive bound (rounded down to a wavefront's 64) to the
+	// padded end; every workgroup takes one contiguous span (see k_update) in steps of NW x 64 rows.
+	const i64 rlo = (i64)(*blk_first) & ~(i64)63;
+	const i64 R64 = (rows + 63) & ~(i64)63;          // the slab and the multiplier array are padded to this
+	constexpr int ALIGN = NW * 64;
+	const i64 R = (R64 - rlo + ALIGN - 1) / ALIGN * ALIGN;
+	const i64 total = (i64)ntiles * R;
+	i64 chunk = (total + gridDim.x - 1) / gridDim.x;
+	chunk = (chunk + ALIGN - 1) / ALIGN * ALIGN;
+	i64 pos = (i64)blockIdx.x * chunk;
+	const i64 pend = (pos + chunk < total) ? pos + chunk : total;
+
+	// lane constants: byte s % 3 of KC[s / 3] = 16 * (table read at step s), byte 3 = 1 (the page bit of group 1)
+	unsigned KC[6];
+	{
+		const int rq_lo = lane & 7, rq_hi = (lane >> 3) & 1;
+#pragma unroll
+		for (int v = 0; v < 6; v++) {
+			unsigned k = 1u << 24;
+#pragma unroll
+			for (int b = 0; b < 3; b++) {
+				const int s = 3 * v + b;
+				if (s < 16) k |= (unsigned)(16 * (8 * ((s >> 3) ^ rq_hi) + (((s & 7) + rq_lo) & 7))) << (8 * b);
+			}
+			asm volatile("" : "+v"(k));             // keep them in registers as built
+			KC[v] = k;
+		}
+	}
+
+	for (bool first_span = true; pos < pend; first_span = false) {
+		const int ct = (int)(pos / R);
+		const i64 r0 = pos - (i64)ct * R;
+		const i64 span = (R - r0 < pend - pos) ? R - r0 : pend - pos;
+		pos += span;
+		const i64 tile = owned_item(ct, tile_begin, GF2_OWN_LOG - 1, world, wrank);     // (column-slab solve: the tiles this rank owns)
+		const i64 rbeg = rlo + r0;
+		if (rbeg >= R64) continue;
+		const i64 rend = (rbeg + span < R64) ? rbeg + span : R64;
+		if (!first_span) __syncthreads();           // the previous span's rows are done with the tables
+		// ---- tables ----
+		if (first_span) {
+			for (int t = threadIdx.x; t < GF2_GMAX * 64; t += NT) {
+				const int g = t >> 6, b = t & 63;
+				int pr = -1;
+				if (g < gb) {
+					const PanelRec rec = panels[j0 + g];
+					if ((rec.mask >> b) & 1) pr = aux[j0 + g].slot_row[__popcll(rec.mask & ((1ull << b) - 1))];
+				}
+				prow[t] = pr;
+			}
+			__syncthreads();
+		}
+		const uint4 *Mq = reinterpret_cast<const uint4 *>(M) + tile * srows;       // this tile's slab, one uint4 per row
+		if (threadIdx.x < GF2_GMAX * 64) {
+			const int pr = prow[threadIdx.x];
+			uint4 v = Mq[pr >= 0 ? pr : 0];
+			// words left of wlo belong to windows the panel path owns: their table bits stay zero
+			const bool k0 = pr >= 0 && 2 * tile >= wlo, k1 = pr >= 0 && 2 * tile + 1 >= wlo;
+			if (!k0) { v.x = 0; v.y = 0; }
+			if (!k1) { v.z = 0; v.w = 0; }
+			stage[threadIdx.x] = v;
+		}
+		__syncthreads();
+		// pass 0: the entries whose index has bits in one nibble only, straight from the staged rows (<= 4 of them)
+		for (int it = threadIdx.x; it < 2 * 31 * 16; it += NT) {
+			const int sub = it & 15, e = (it >> 4) % 31, grp = (it >> 4) / 31;
+			const int idx = e <= 15 ? e : (e - 15) << 4;
+			const uint4 *st = stage + (2 * grp + (sub >> 3)) * 64 + 8 * (sub & 7);
+			uint4 acc = make_uint4(0, 0, 0, 0);
+			int bits = idx;
+			while (bits) {
+				const int l = __ffs(bits) - 1; bits &= bits - 1;
+				acc = xor4(acc, st[l]);
+			}
+			tab[grp * 4096 + idx * 16 + sub] = acc;
+		}
+		__syncthreads();
+		// pass 1: the mixed ones = low-nibble entry ^ high-nibble entry
+		for (int it = threadIdx.x; it < 2 * 225 * 16; it += NT) {
+			const int sub = it & 15, k = (it >> 4) % 225, grp = (it >> 4) / 225;
+			const int lo = 1 + k % 15, hi = (1 + k / 15) << 4;
+			uint4 *tb = tab + grp * 4096 + sub;
+			tb[(lo | hi) * 16] = xor4(tb[lo * 16], tb[hi * 16]);
+		}
+		__syncthreads();
+
+		// ---- stream the rows ----
+		// A wavefront takes 64 consecutive rows (1 KiB of the slab, 2 KiB of multipliers) per batch; the loads of
+		// batch i+1 are in flight while batch i does its 32 lookups.  No control flow around vector-memory
+		// instructions (the compiler then waits with vmcnt(N > 0), see k_update): a wave knows its batch count up
+		// front and its last prefetch re-reads its last batch.
+		uint4 *Mw = reinterpret_cast<uint4 *>(M) + tile * srows;
+		const uint4 *mq = reinterpret_cast<const uint4 *>(mult4);
+		const i64 nsteps = (rend - rbeg + ALIGN - 1) / ALIGN;
+		// batches of this wave: rows rbeg + (i * NW + wv) * 64 + lane, i < nb
+		i64 nb = nsteps;
+		if (rbeg + ((nsteps - 1) * NW + wv) * 64 >= rend) nb--;
+		struct Bt { uint4 d, m0, m1; i64 row; };
+		auto load = [&](Bt &H, i64 i) {
+			const i64 ic = i < nb ? i : nb - 1;         // (a prefetch past the end re-reads the last batch: no control flow around loads)
+			const i64 row = rbeg + (ic * NW + wv) * 64 + lane;
+			H.row = row;
+			H.m0 = mq[row * 2]; H.m1 = mq[row * 2 + 1];
+#ifdef GF2_MB_L2               /* tools/microbench_update16.hip: keep the row data L2-resident to time the table work alone */
+			H.d = Mw[row & 4095];
+#else
+			H.d = Mw[row];
+#endif
+		};
+		// round r = 0..3 of a batch: the 8 lookups of (group r >> 1, half r & 1)
+		auto issue = [&](u32x4 *v, const Bt &H, int r) {
+			const unsigned mw[8] = { H.m0.x, H.m0.y, H.m0.z, H.m0.w, H.m1.x, H.m1.y, H.m1.z, H.m1.w };
+			const int grp = r >> 1, hf = r & 1;
+#pragma unroll
+			for (int k = 0; k < 8; k++) {
+				const int s = 8 * hf + k;
+				// {byte 0: lane constant of step s, byte 1: the field, byte 2: page, byte 3: 0} in one v_perm_b32
+				// (selector codes 0-3 = bytes of the second source, 4-7 = bytes of the first, 12 = 0x00)
+				const unsigned sel = (unsigned)(s % 3) | ((4u + (unsigned)(k & 3)) << 8) | ((grp ? 3u : 12u) << 16) | (12u << 24);
+				const unsigned at = __builtin_amdgcn_perm(mw[2 * (2 * grp + hf) + (k >> 2)], KC[s / 3], sel);
+				v[k] = *(lds_u4_ptr)(size_t)at;
+			}
+		};
+		auto fold = [&](uint4 &acc, const u32x4 *v) {
+#pragma unroll
+			for (int h = 0; h < 4; h++) {
+				acc.x = __builtin_amdgcn_bitop3_b32(acc.x, v[2 * h].x, v[2 * h + 1].x, 0x96);
+				acc.y = __builtin_amdgcn_bitop3_b32(acc.y, v[2 * h].y, v[2 * h + 1].y, 0x96);
+				acc.z = __builtin_amdgcn_bitop3_b32(acc.z, v[2 * h].z, v[2 * h + 1].z, 0x96);
+				acc.w = __builtin_amdgcn_bitop3_b32(acc.w, v[2 * h].w, v[2 * h + 1].w, 0x96);
+			}
+		};
+		auto store = [&](const Bt &H, const uint4 &acc) {
+#ifdef GF2_MB_L2
+			const i64 q = H.row & 4095;
+#else
+			const i64 q = H.row;
+#endif
+			if (HALF) reinterpret_cast<u64 *>(Mw + q)[1] = ((u64)acc.w << 32) | acc.z;
+			else Mw[q] = acc;
+		};
+		if (nb > 0) {
+			// DEPTH batches in flight per wave (loads DEPTH-1 batches ahead); PIPE: the lookups of round r+1 -- also
+			// across the batch boundary -- are issued before the XORs of round r, so the LDS always has this wave's
+			// next 8 reads queued
+			Bt H[DEPTH];
+#pragma unroll
+			for (int d = 0; d < DEPTH - 1; d++) load(H[d], d);
+			u32x4 va[8], vb[8];
+#ifndef GF2_MB_NOLOOKUP
+			if (PIPE) issue(va, H[0], 0);
+#endif
+			for (i64 i = 0; i < nb; i += DEPTH) {
+#pragma unroll
+				for (int d = 0; d < DEPTH; d++) {
+					if (i + d >= nb) break;              // wave-uniform
+					load(H[(d + DEPTH - 1) % DEPTH], i + d + DEPTH - 1);
+					Bt &C = H[d];
+					uint4 acc = C.d;
+#ifdef GF2_MB_NOLOOKUP         /* tools/microbench_update16.hip: time the HBM stream (multiplier loads included) without the table work */
+					acc.x ^= C.m0.x ^ C.m0.y ^ C.m0.z ^ C.m0.w; acc.y ^= C.m1.x ^ C.m1.y ^ C.m1.z ^ C.m1.w;
+#else
+					if (PIPE) {
+						issue(vb, C, 1); fold(acc, va);
+						issue(va, C, 2); fold(acc, vb);
+						issue(vb, C, 3); fold(acc, va);
+						issue(va, H[(d + 1) % DEPTH], 0); fold(acc, vb);      // (past the end: a harmless extra round)
+					} else {
+#pragma unroll
+						for (int r = 0; r < 4; r++) { issue(va, C, r); fold(acc, va); }
+					}
+#endif
+					store(C, acc);
+				}
+			}
+		}
+	}       // spans
+}
+
+#endif  // GF2_TW
 
 // ==========================================================================================
 // BACK-SUBSTITUTION

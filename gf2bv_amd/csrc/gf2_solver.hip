@@ -67,6 +67,8 @@ struct Trace {
 };
 // rows of one tile slab: slab bytes = 256 (mod 8192), so neighbouring tiles are skewed across channels
 inline i64 slab_rows(i64 rows) { return round_up(std::max<i64>(rows, 1), 64) + 2; }
+// column tiles of a row of wt words: whole ownership units of 8 words (one 64-byte tile / four 16-byte tiles)
+inline i64 tiles_for(i64 wt) { return round_up(std::max<i64>(wt, 1), (i64)1 << GF2_OWN_LOG) / GF2_TW; }
 
 
 // ---- resource pool -----------------------------------------------------------------------------
@@ -205,25 +207,59 @@ Pool &pool()
 struct UpdateImpl {
 	int G, T, lds_bytes, threads;
 	hipError_t (*update)(dim3, hipStream_t, u64 *, i64, i64, int, int, int, const PanelRec *, const PanelAux *,
-	                     const u64 *, const int *, int, int, int, int, int, SysStride, hipEvent_t, hipEvent_t);
+	                     const u64 *, const int *, int, int, int, int, int, int, SysStride, hipEvent_t, hipEvent_t);
 };
 
+#if GF2_TW != 2
 template <int G, int T, int NT>
 hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows, int j0, int gb, int wlo,
                          const PanelRec *panels, const PanelAux *aux, const u64 *multset, const int *blk_first,
-                         int tile_begin, int ntiles, int tile_step, int nw_lo, int nw_hi, SysStride ss, hipEvent_t begun,
+                         int tile_begin, int ntiles, int world, int wrank, int nw_lo, int nw_hi, SysStride ss, hipEvent_t begun,
                          hipEvent_t done)
 {
 	// the tables are static shared memory (see k_update): no dynamic LDS, no attribute to raise
 	// `begun` / `done` (optional): timing and hand-off events ride on this kernel's own start / completion signals
 	// instead of marker packets around it
 	hipExtLaunchKernelGGL((k_update<G, T, NT>), grid, dim3(NT), 0, s, begun, done, 0, M, rows, srows, j0, gb, wlo, panels, aux,
-	                      multset, blk_first, tile_begin, ntiles, tile_step, nw_lo, nw_hi, ss);
+	                      multset, blk_first, tile_begin, ntiles, world, wrank, nw_lo, nw_hi, ss);
 	return hipGetLastError();
 }
-
 #define UPDATE_IMPL(G, T, NT) { G, T, UpdateCfg<G, T>::LDS_BYTES, NT, launch_update<G, T, NT> }
-#if GF2_TW == 8
+#else
+// 16-byte tiles: G = 4 panels, T = 8 byte fields per panel.  nw_lo < 0 selects the HALF instance (only the tile's second
+// word is stored: its first one belongs to the next block's window); the window's whole tiles are simply not launched.
+template <int NT, int DEPTH, bool PIPE, int LB>
+hipError_t launch_update16(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows, int j0, int gb, int wlo,
+                           const PanelRec *panels, const PanelAux *aux, const u64 *multset, const int *blk_first,
+                           int tile_begin, int ntiles, int world, int wrank, int nw_lo, int nw_hi, SysStride ss, hipEvent_t begun,
+                           hipEvent_t done)
+{
+	(void)nw_hi;
+	if (nw_lo < 0)
+		hipExtLaunchKernelGGL((k_update16<NT, true, DEPTH, PIPE, LB>), grid, dim3(NT), 0, s, begun, done, 0, M, rows, srows, j0, gb, wlo,
+		                      panels, aux, multset, blk_first, tile_begin, ntiles, world, wrank, ss);
+	else
+		hipExtLaunchKernelGGL((k_update16<NT, false, DEPTH, PIPE, LB>), grid, dim3(NT), 0, s, begun, done, 0, M, rows, srows, j0, gb, wlo,
+		                      panels, aux, multset, blk_first, tile_begin, ntiles, world, wrank, ss);
+	return hipGetLastError();
+}
+#define UPDATE16_IMPL(NT, D, P, LB) { 4, 8, 2 * 256 * 256 + GF2_GMAX * 64 * 20, NT, launch_update16<NT, D, P, LB> }
+#endif
+
+#if GF2_TW == 2
+const UpdateImpl kUpdates[] = {
+	// default: 8 wavefronts (two per SIMD, 157 VGPRs: three batches of 64 rows in flight per wavefront, the lookups of
+	// round r+1 issued before the XORs of round r); the kernel is bound by the memory side, so more wavefronts buy
+	// nothing (65536^2 / 131072^2 wall: 37.8 / 212.9 ms; 12 wavefronts 38.4 / 212.5; 16: 40.7 / 221) and half of every
+	// SIMD's registers plus 27 KiB of LDS stay free for the panel kernels of the next block
+	UPDATE16_IMPL(512, 3, true, 512),
+	UPDATE16_IMPL(768, 2, true, 768),
+	UPDATE16_IMPL(768, 2, true, 1024),
+	UPDATE16_IMPL(1024, 2, false, 1024),
+	UPDATE16_IMPL(768, 3, true, 768),
+	UPDATE16_IMPL(640, 2, true, 640),
+};
+#elif GF2_TW == 8
 const UpdateImpl kUpdates[] = {
 	// default: 4 panels (256 pivots) per pass, 5/6-bit fields: 48 lookups, 128 KiB of tables; 12 wavefronts with the
 	// register budget of 16, so that a quarter of every SIMD's register file (and 15 KiB of LDS) stays free and the
@@ -261,6 +297,10 @@ const UpdateImpl *pick_update()
 		if (sscanf(e, "%dx%dx%d", &g, &t, &nt) >= 2)
 			for (const UpdateImpl &c : kUpdates)
 				if (c.G == g && c.T == t && (nt == 0 || c.threads == nt)) { chosen = &c; break; }
+		if (GF2_TW == 2) {                               // "NT" alone picks among the 16-byte-tile instances, in table order
+			int idx = atoi(e);
+			if (idx >= 0 && idx < (int)(sizeof kUpdates / sizeof kUpdates[0]) && !strchr(e, 'x')) chosen = &kUpdates[idx];
+		}
 	}
 	return chosen;
 }
@@ -449,7 +489,7 @@ int solver_alloc(Solver &S)
 	S.npanels = (int)((S.cols + 63) / 64);
 	S.maxr = std::min(S.rows, S.cols);
 	S.impl = pick_update();
-	S.ntiles = (S.wt + TW - 1) / TW;
+	S.ntiles = tiles_for(S.wt);
 	S.srows = slab_rows(S.rows);
 	S.m_stride = S.ntiles * TW * S.srows;
 	if (!S.M) HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * S.m_stride * S.nsys, S.device));
@@ -486,7 +526,7 @@ int solver_alloc(Solver &S)
 		const size_t o_st = carve(sizeof(SolveState)), o_pan = carve(sizeof(PanelRec) * NP), o_aux = carve(sizeof(PanelAux) * NP),
 		             o_fu = carve(sizeof(FindUnit) * (S.units + 1 + GF2_MAXGROUPS)), o_alive = carve(sizeof(int) * (size_t)R),
 		             o_piv = carve(sizeof(int) * (S.maxr + 64)), o_urow = carve(sizeof(int) * (S.maxr + 64)),
-		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * 2 * G * R),
+		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * 2 * G * mult_rows(R)),
 		             o_wb = carve(sizeof(u64) * 2 * GF2_GMAX * R), o_uw = carve(sizeof(u64) * GF2_GMAX * (S.maxr + 64));
 		S.arena_stride = off;
 		HIPCHK(pool().alloc(&S.arena, off * S.nsys, S.device));
@@ -524,22 +564,38 @@ int pick_update_wgs(i64 est_rows, int ntiles, int nsys)
 	i64 want = 256;
 	if (const char *e = getenv("GF2BV_WGS")) { int v = atoi(e); if (v > 0) want = v; }
 	want = std::max<i64>(1, want / std::max(1, nsys));
-	const i64 cap = std::max<i64>(1, (i64)ntiles * est_rows / 4096);
+	const i64 cap = std::max<i64>(1, (i64)ntiles * TW / 8 * est_rows / 4096);
 	return (int)std::min(want, cap);
 }
 
-int launch_trsm(Solver &S, hipStream_t st, int j0, int gb, int wlo, int tile_begin, int ntiles, int nw_lo, int nw_hi)
+// items (tiles, 4-word groups) in [first, end) that this rank owns -- units of 2^ulog items, see owned_item()
+i64 owned_count(i64 first, i64 end, int ulog, int world, int wrank)
+{
+	if (end <= first) return 0;
+	if (world <= 1) return end - first;
+	i64 n = 0;
+	for (i64 u = first >> ulog; u <= (end - 1) >> ulog; u++)
+		if (u % world == wrank) n += std::min<i64>(end, (u + 1) << ulog) - std::max<i64>(first, u << ulog);
+	return n;
+}
+
+// TRSM of block b on the 4-word groups [wlo / 4, end of the row) this rank owns
+int launch_trsm(Solver &S, hipStream_t st, int j0, int gb, int wlo, int nw_lo, int nw_hi)
 {
 	constexpr int WPW = 4;
-	k_block_trsm<TW, WPW><<<dim3(ntiles * (TW / WPW), S.nsys), dim3(64 * WPW), 0, st>>>(S.M, S.srows, j0, gb, wlo, tile_begin, S.world,
-	                                                                                   S.panels, S.aux, nw_lo, nw_hi, S.ss());
+	const i64 g0 = wlo / WPW, g1 = S.ntiles * TW / WPW;
+	const i64 ng = owned_count(g0, g1, GF2_OWN_LOG - 2, S.world, S.wrank);
+	if (ng <= 0) return GF2BV_OK;
+	k_block_trsm<TW, WPW><<<dim3((unsigned)ng, S.nsys), dim3(64 * WPW), 0, st>>>(S.M, S.srows, j0, gb, wlo, (int)g0, S.world, S.wrank,
+	                                                                           S.panels, S.aux, nw_lo, nw_hi, S.ss());
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
 
-// Bulk update of block b; *handoff receives the event that means "bulk of block b complete".
+// One bulk-update launch of block b on the `ntiles` owned tiles from tile_begin on; `last`: it carries the hand-off
+// ("bulk of block b complete") and *handoff receives that event.
 int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wlo, u64 *mset, int tile_begin, int ntiles,
-                        int nw_lo, int nw_hi, hipEvent_t *handoff)
+                        int nw_lo, int nw_hi, bool last, hipEvent_t *handoff)
 {
 	hipEvent_t ka = nullptr, kb = nullptr;
 	if (S.time_kernels) {
@@ -550,10 +606,11 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 	const i64 est_rows = std::max<i64>(256, S.rows - (i64)j0 * 64);      // alive rows of a dense system (the kernel uses the true bound)
 	const int wgs = pick_update_wgs(est_rows, ntiles, S.nsys);
 	hipEvent_t begun = nullptr, done = nullptr;
-	if (S.ext_events) { begun = ka; done = S.time_kernels ? kb : S.evPrio[b]; }
+	if (S.ext_events) { begun = ka; done = S.time_kernels ? kb : (last ? S.evPrio[b] : nullptr); }
 	HIPCHK(S.impl->update(dim3((unsigned)wgs, S.nsys), st, S.M, S.rows, S.srows, j0, gb, wlo, S.panels, S.aux, mset,
-	                      S.blk_first + b, tile_begin, ntiles, S.world, nw_lo, nw_hi, S.ss(), begun, done));
+	                      S.blk_first + b, tile_begin, ntiles, S.world, S.wrank, nw_lo, nw_hi, S.ss(), begun, done));
 	if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, st));
+	if (!last) return GF2BV_OK;
 	if (S.ext_events) *handoff = done;
 	else { HIPCHK(hipEventRecord(S.evPrio[b], st)); *handoff = S.evPrio[b]; }
 	return GF2BV_OK;
@@ -576,7 +633,7 @@ BlockGeom block_geom(const Solver &S, int b)
 	g.j0 = b * G;
 	g.gb = std::min(G, S.npanels - g.j0);
 	g.wlo = g.j0 + g.gb;
-	g.mset = S.mult + (i64)(b & 1) * G * S.rows;
+	g.mset = S.mult + (i64)(b & 1) * G * mult_rows(S.rows);
 	// trailing tiles; the next block's window [wlo, wlo + gnext) sits in the first one or two of them
 	g.tb = g.wlo / TW;
 	g.nt_all = (g.wlo < S.wt) ? (int)S.ntiles - g.tb : 0;
@@ -619,19 +676,39 @@ int enqueue_block_bulk(Solver &S, int b)
 {
 	const BlockGeom g = block_geom(S, b);
 	HIPCHK(hipStreamWaitEvent(S.sB, S.evA[b], 0));
-	// column-slab solve: the tiles t >= tb with t % world == wrank
-	int t0 = g.tb, nt = g.nt_all;
-	if (S.world > 1 && nt > 0) {
-		t0 = g.tb + ((S.wrank - g.tb % S.world) + S.world) % S.world;
-		nt = (t0 < (int)S.ntiles) ? ((int)S.ntiles - t0 + S.world - 1) / S.world : 0;
+	bool launched = false;
+	if (g.nt_all > 0) {
+		int rc = launch_trsm(S, S.sB, g.j0, g.gb, g.wlo, g.wlo, g.wlo + g.gnext);
+		if (rc) return rc;
+#if GF2_TW == 2
+		// 16-byte tiles: the next block's window is whole tiles that are simply left out; when it ends in the middle of a
+		// tile (an odd number of window words: the block before a short last one) that tile takes the HALF instance first
+		// (the LAST block has no next window: its trailing words start at wlo, possibly in the middle of a tile whose first
+		// word is the block's own -- the table entries are zero there, see `keep` in k_update16 -- and nobody else writes it)
+		const int wend = g.wlo + g.gnext;
+		const int tfull = g.gnext > 0 ? (wend + 1) / 2 : g.wlo / 2;      // first tile with no window word
+		const i64 nfull = owned_count(tfull, S.ntiles, GF2_OWN_LOG - 1, S.world, S.wrank);
+		if ((wend & 1) && g.gnext > 0 && owned_count(wend / 2, wend / 2 + 1, GF2_OWN_LOG - 1, S.world, S.wrank) > 0) {
+			rc = launch_update_timed(S, S.sB, b, g.j0, g.gb, g.wlo, g.mset, wend / 2, 1, -1, 0, nfull <= 0, &S.waitPrio[b]);
+			if (rc) return rc;
+			launched = nfull <= 0;
+		}
+		if (nfull > 0) {
+			rc = launch_update_timed(S, S.sB, b, g.j0, g.gb, g.wlo, g.mset, tfull, (int)nfull, 0, 0, true, &S.waitPrio[b]);
+			if (rc) return rc;
+			launched = true;
+		}
+#else
+		const i64 nt = owned_count(g.tb, S.ntiles, GF2_OWN_LOG - GF2_TW_LOG, S.world, S.wrank);
+		if (nt > 0) {
+			rc = launch_update_timed(S, S.sB, b, g.j0, g.gb, g.wlo, g.mset, g.tb, (int)nt, g.wlo, g.wlo + g.gnext, true, &S.waitPrio[b]);
+			if (rc) return rc;
+			launched = true;
+		}
+#endif
 	}
-	if (nt > 0) {
-		int rc = launch_trsm(S, S.sB, g.j0, g.gb, g.wlo, t0, nt, g.wlo, g.wlo + g.gnext);
-		if (rc) return rc;
-		rc = launch_update_timed(S, S.sB, b, g.j0, g.gb, g.wlo, g.mset, t0, nt, g.wlo, g.wlo + g.gnext, &S.waitPrio[b]);
-		if (rc) return rc;
-	} else {
-		HIPCHK(hipEventRecord(S.evPrio[b], S.sB));      // "bulk of block b complete" (nothing to do)
+	if (!launched) {
+		HIPCHK(hipEventRecord(S.evPrio[b], S.sB));      // "bulk of block b complete" (no update launch of this rank carries it)
 		S.waitPrio[b] = S.evPrio[b];
 	}
 	if (S.dbg_sync & 2) HIPCHK(hipDeviceSynchronize());
@@ -872,7 +949,7 @@ int finish_end(Solver &S, gf2bv_result **out)
 	st.n_panels = S.npanels;
 	st.panels_per_sweep = S.impl->G;
 	st.tables_per_sweep = S.impl->G * S.impl->T;
-	st.table_bits = (64 + S.impl->T - 1) / S.impl->T;
+	st.table_bits = (64 + S.impl->T - 1) / S.impl->T;          // (16-byte tiles: 8 byte fields per panel)
 	st.tile_words = TW;
 	st.gang_systems = S.view ? S.gang_nsys : S.nsys;
 	st.search_handovers = hst.self_giveups;
@@ -1163,7 +1240,7 @@ int gf2bv_solve_batch_digits(const uint32_t *digits, const int64_t *digit_off, i
 	rc = check_device(device);
 	if (rc) return rc;
 	if (nsys == 0) return GF2BV_OK;
-	const i64 wt = (cols + 1 + 63) / 64, ntiles = (wt + TW - 1) / TW, srows = slab_rows(rows);
+	const i64 wt = (cols + 1 + 63) / 64, ntiles = tiles_for(wt), srows = slab_rows(rows);
 	const i64 m_stride = ntiles * TW * srows;
 	const i64 nrows_all = nsys * rows, ndig = digit_off[nrows_all];
 	// all digits and offsets go up once; every gang packs its own systems straight into tile-major slabs
@@ -1222,7 +1299,7 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 	S.own_sA = true;
 	S.rows = rows; S.cols = cols; S.mode = mode;
 	const i64 wt = (cols + 1 + 63) / 64;
-	const i64 ntiles = (wt + TW - 1) / TW;
+	const i64 ntiles = tiles_for(wt);
 	S.stride = ntiles * TW;
 	HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * ntiles * TW * slab_rows(rows), device));     // packed straight into tiles
 	const i64 ndig = digit_off[rows];
@@ -1317,7 +1394,7 @@ struct gf2bv_slab {
 };
 
 namespace {
-int slab_owner_of_block(const Solver &S, int b) { return ((b * S.impl->G) / TW) % S.world; }
+int slab_owner_of_block(const Solver &S, int b) { return ((b * S.impl->G) >> GF2_OWN_LOG) % S.world; }
 }
 
 int gf2bv_slab_open(void *d_aug, int64_t rows, int64_t cols, int64_t stride_words, void *d_work, int64_t work_words,
@@ -1352,7 +1429,7 @@ int gf2bv_slab_open(void *d_aug, int64_t rows, int64_t cols, int64_t stride_word
 	size_t off = 0;
 	auto carve = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
 	(void)carve(sizeof(SolveState)); h->o_blk = carve(sizeof(int)); h->o_pan = carve(sizeof(PanelRec) * G);
-	h->o_aux = carve(sizeof(PanelAux) * G); h->o_mult = carve(sizeof(u64) * G * R);
+	h->o_aux = carve(sizeof(PanelAux) * G); h->o_mult = carve(sizeof(u64) * G * mult_rows(R));
 	h->payload_bytes = off;
 	*out = h;
 	return GF2BV_OK;
@@ -1361,10 +1438,10 @@ int gf2bv_slab_open(void *d_aug, int64_t rows, int64_t cols, int64_t stride_word
 
 int64_t gf2bv_slab_work_words(int64_t rows, int64_t cols)
 {
-	const i64 wt = (cols + 1 + 63) / 64, ntiles = (wt + TW - 1) / TW;
+	const i64 wt = (cols + 1 + 63) / 64, ntiles = tiles_for(wt);
 	return ntiles * TW * slab_rows(rows);
 }
-int64_t gf2bv_slab_tiles(int64_t cols) { return ((cols + 1 + 63) / 64 + TW - 1) / TW; }
+int64_t gf2bv_slab_tiles(int64_t cols) { return tiles_for((cols + 1 + 63) / 64) * TW >> GF2_OWN_LOG; }      // ownership units of 8 words
 int64_t gf2bv_slab_blocks(const gf2bv_slab *h) { return h ? h->S.nblocks : -1; }
 int gf2bv_slab_owner(const gf2bv_slab *h, int block) { return h ? slab_owner_of_block(h->S, block) : -1; }
 int64_t gf2bv_slab_payload_bytes(const gf2bv_slab *h) { return h ? (int64_t)h->payload_bytes : -1; }
@@ -1389,7 +1466,7 @@ int gf2bv_slab_factor(gf2bv_slab *h, int b, void *d_payload)
 	HIPCHK(hipMemcpyAsync(P + h->o_blk, S.blk_first + b, sizeof(int), hipMemcpyDeviceToDevice, S.sA));
 	HIPCHK(hipMemcpyAsync(P + h->o_pan, S.panels + g.j0, sizeof(PanelRec) * g.gb, hipMemcpyDeviceToDevice, S.sA));
 	HIPCHK(hipMemcpyAsync(P + h->o_aux, S.aux + g.j0, sizeof(PanelAux) * g.gb, hipMemcpyDeviceToDevice, S.sA));
-	HIPCHK(hipMemcpyAsync(P + h->o_mult, g.mset, sizeof(u64) * G * S.rows, hipMemcpyDeviceToDevice, S.sA));
+	HIPCHK(hipMemcpyAsync(P + h->o_mult, g.mset, sizeof(u64) * G * mult_rows(S.rows), hipMemcpyDeviceToDevice, S.sA));
 	HIPCHK(hipStreamSynchronize(S.sA));
 	return GF2BV_OK;
 	});
@@ -1413,7 +1490,7 @@ int gf2bv_slab_apply(gf2bv_slab *h, int b, const void *d_payload)
 		HIPCHK(hipMemcpyAsync(S.blk_first + b, P + h->o_blk, sizeof(int), hipMemcpyDeviceToDevice, S.sA));
 		HIPCHK(hipMemcpyAsync(S.panels + g.j0, P + h->o_pan, sizeof(PanelRec) * g.gb, hipMemcpyDeviceToDevice, S.sA));
 		HIPCHK(hipMemcpyAsync(S.aux + g.j0, P + h->o_aux, sizeof(PanelAux) * g.gb, hipMemcpyDeviceToDevice, S.sA));
-		HIPCHK(hipMemcpyAsync(g.mset, P + h->o_mult, sizeof(u64) * G * S.rows, hipMemcpyDeviceToDevice, S.sA));
+		HIPCHK(hipMemcpyAsync(g.mset, P + h->o_mult, sizeof(u64) * G * mult_rows(S.rows), hipMemcpyDeviceToDevice, S.sA));
 		k_import_marks<<<dim3(1), dim3(256), 0, S.sA>>>(g.j0, g.gb, S.panels, S.aux, S.died, S.pivcol, S.urow);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(S.evA[b], S.sA));

@@ -65,12 +65,21 @@ def test_all_zero_and_identity_systems():
 
 
 def test_update_configurations_agree(monkeypatch):
-    """Every (panels-per-pass G, tables-per-panel T) instantiation of the bulk-update kernel gives the same bits."""
+    """Every instantiation of the bulk-update kernel gives the same bits: (panels per pass G, tables per panel T,
+    threads) for the 64-byte-tile kernel, (threads, batches in flight, LDS pipelining) for the 16-byte-tile one."""
     rng = random.Random(77)
     rows, cols = 2600, 2500
     eqs = random_system(rng, rows, cols, .5, 2300, True, 0)
     aug = O.eqs_to_aug(eqs, cols)
     want = O.solve_words(aug, rows, cols, 1)
+    base = hip.solve_words(aug, rows, cols, 1)
+    if base.stats["tile_words"] == 2:                      # k_update16: instances by index (GF2BV_UPDATE=0..5)
+        for cfg in ("0", "1", "2", "3", "4", "5"):
+            monkeypatch.setenv("GF2BV_UPDATE", cfg)
+            got = hip.solve_words(aug, rows, cols, 1)
+            assert_same(got, want, 1)
+            assert (got.stats["panels_per_sweep"], got.stats["tables_per_sweep"], got.stats["table_bits"]) == (4, 32, 8)
+        return
     for cfg in ("4x12", "4x12x1024", "4x12x512", "4x16", "3x12", "2x12", "2x16", "1x12", "1x16", "1x8"):
         monkeypatch.setenv("GF2BV_UPDATE", cfg)
         got = hip.solve_words(aug, rows, cols, 1)

@@ -1,6 +1,7 @@
 // Isolated timing of the bulk-update kernel (k_update) with synthetic multipliers / pivot rows:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DGF2_MB_NOLOOKUP | -DGF2_MB_L2] tools/microbench_update.hip -o /tmp/mbu && /tmp/mbu
 // full build: real kernel;  NOLOOKUP: HBM stream only;  L2: table work only (row data stays in L2).
+#define GF2_TW 8        /* the 64-byte-tile kernel of round 1 (the product builds with GF2_TW = 2 since round 2) */
 #include "../gf2bv_amd/csrc/gf2_kernels.hip.h"
 #include <cstdio>
 #include <cstdlib>

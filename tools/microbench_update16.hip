@@ -1,9 +1,9 @@
-// Isolated timing + correctness check of the 16-byte-tile bulk update (k_update16) with synthetic multipliers / pivot rows:
+// Isolated timing + correctness check of the 16-byte-tile bulk update (k_update16, the GF2_TW = 2 build) with synthetic multipliers / pivot rows:
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 [-DGF2_MB_NOLOOKUP | -DGF2_MB_L2] tools/microbench_update16.hip -o /tmp/mbu16 && /tmp/mbu16 [rows] [ntiles] [wgs]
 // full build: real kernel (checked against a host recomputation on a sample of rows);  NOLOOKUP: HBM stream only;
 // L2: table work only (row data stays in L2).
+#define GF2_TW 2
 #include "../gf2bv_amd/csrc/gf2_kernels.hip.h"
-#include "update16_experiment.hip.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -17,7 +17,7 @@ template <int NT, int DEPTH, bool PIPE>
 void run(const char *name, u64 *M, i64 rows, i64 srows, int ntiles, PanelRec *panels, PanelAux *aux, u64 *mult4, int *blkf, int wgs)
 {
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-	auto launch = [&] { k_update16<NT, false, DEPTH, PIPE><<<dim3(wgs), dim3(NT), 0>>>(M, rows, srows, 0, GF2_GMAX, 0, panels, aux, mult4, blkf, 0, ntiles, SysStride{0, 0}); };
+	auto launch = [&] { k_update16<NT, false, DEPTH, PIPE, NT><<<dim3(wgs), dim3(NT), 0>>>(M, rows, srows, 0, GF2_GMAX, 0, panels, aux, mult4, blkf, 0, ntiles, 1, 0, SysStride{0, 0}); };
 	launch(); CK(hipDeviceSynchronize());
 	const int reps = getenv("MB_REPS") ? atoi(getenv("MB_REPS")) : 5;      // MB_REPS=400: sustained load (clocks settle)
 	CK(hipEventRecord(e0)); for (int r = 0; r < reps; r++) launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
@@ -44,12 +44,7 @@ int main(int argc, char **argv)
 	for (int g = 0; g < 4; g++) for (int r = 0; r < 256; r++) plain[(size_t)g * rows + r] = 0;     // pivot rows: not updated
 	for (i64 r = 0; r < rows; r++)
 		for (int g = 0; g < 4; g++) {
-			const int sl = mult_slot(g, r);
-#ifdef GF2_MULT_SPLIT
-			hm[((size_t)(sl >> 1) * R64 + r) * 2 + (sl & 1)] = mult_rot(plain[(size_t)g * rows + r], r);
-#else
-			hm[(size_t)r * 4 + sl] = mult_rot(plain[(size_t)g * rows + r], r);
-#endif
+			hm[(size_t)r * 4 + mult_slot(g, r)] = mult_rot(plain[(size_t)g * rows + r], r);
 		}
 	CK(hipMemcpy(mult4, hm.data(), hm.size() * 8, hipMemcpyHostToDevice));
 	std::vector<PanelRec> hp(GF2_GMAX); std::vector<PanelAux> ha(GF2_GMAX);
@@ -70,7 +65,7 @@ int main(int argc, char **argv)
 		std::vector<u64> h0((size_t)ctiles * csr * 2), h1(h0.size());
 		for (auto &v : h0) v = rnd();
 		CK(hipMemcpy(M, h0.data(), h0.size() * 8, hipMemcpyHostToDevice));
-		k_update16<768, false, 3, true><<<dim3(7), dim3(768), 0>>>(M, crow, csr, 0, GF2_GMAX, 0, panels, aux, mult4, blkf, 0, ctiles, SysStride{0, 0});
+		k_update16<768, false, 3, true, 768><<<dim3(7), dim3(768), 0>>>(M, crow, csr, 0, GF2_GMAX, 0, panels, aux, mult4, blkf, 0, ctiles, 1, 0, SysStride{0, 0});
 		CK(hipDeviceSynchronize());
 		CK(hipMemcpy(h1.data(), M, h1.size() * 8, hipMemcpyDeviceToHost));
 		i64 bad = 0, checked = 0;
