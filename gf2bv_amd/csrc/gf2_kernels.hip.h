@@ -115,7 +115,14 @@ struct SolveState {
 	// last arriver publishes), 3 = published (unit 0 may be through before the last arriver gets to look)
 	unsigned claim;
 	int self_giveups;    // statistics: panels whose unit 0 stopped waiting and left publishing to the last arriver
-	int pad[1];
+	// Dense blocks: k_block_fast finds the pivots of ALL panels of a block from a few hundred candidate rows in one
+	// launch.  fast_off: NOT worth trying on the next block (cleared by a success, or by a general block whose last
+	// panel was easy and full; set by a failed attempt; 0 at the start); fast_done: block index + 1 of the block it
+	// last completed -- the general panel steps of that block then have nothing to search and their narrow halves are
+	// done in one pass.
+	int fast_off, fast_done;
+	int fast_blocks;     // statistics: blocks factorised by k_block_fast
+	int pad[2];
 };
 
 // Scratch of one search unit (wavefront).
@@ -887,7 +894,10 @@ __device__ __forceinline__ void search_panel(const Cand &cand, typename Cand::Ra
 		st->rank = r0 + p;
 		st->first = new_first;
 		st->wide = hard;
-		if (blk_first_out) *blk_first_out = new_first;     // last panel of a block: row bound for its bulk update
+		if (blk_first_out) {                               // last panel of a block: row bound for its bulk update; and an
+			*blk_first_out = new_first;                    // easy, full last panel says the next block may be dense again
+			st->fast_off = (!hard && p == 64) ? 0 : 1;
+		}
 		GF2_ST(&st->claim, 3u);
 		GF2_ST(&st->arrive, 0u);
 	}
@@ -991,13 +1001,244 @@ struct CandWords {
 	}
 };
 
+// ---- dense blocks: all panels of a block from a few hundred candidate rows, in ONE launch ---------------------------
+// A random dense panel is complete after ~66 rows, so the G searches of a block need ~270 rows in all -- but the
+// general path spends a launch per panel (each waiting for the narrow step of ALL rows before it, G + 1 launches and
+// ~20 us each next to a running bulk update) because a sparse or rank-deficient panel may need pivots from anywhere.
+// k_block_fast (one workgroup per system) takes the first GF2_FAST_CH x 64 alive-bound rows as candidates, keeps their
+// window words in LDS and runs the whole block on them: per panel the column-wise elimination of one chunk on
+// wavefront 0 (gj_columns) + the targeted completion from the next chunk (find_absorb), the pivot rows' remaining window
+// words from the sources (comb x source words, as the narrow prologue forms them), their nibble tables, and the narrow
+// step of the CANDIDATES only.  A candidate's eliminated word g is left in place: it is the row's multiplier.  Nothing
+// the general path relies on is touched before all panels are complete (PanelAux and the scratch Pfast are written
+// early, both are overwritten by whoever publishes); on any surprise -- a chunk that is not dense, more than
+// GF2_FEW_MISSING columns short, a completion that does not complete, too few rows, a short last block -- it sets
+// fast_off and returns, and the general steps (always enqueued behind it) factorise the block as if it had never run.
+// On success they find fast_done set: the searches return at once and ONE of them narrows all rows for all panels
+// (narrow_all_panels: the multipliers are all that the rest of the solve needs from a narrow step).
+#define GF2_FAST_CH 5
+#define GF2_FAST_NC (64 * GF2_FAST_CH)
+
+__device__ __forceinline__ void build_nibble_tables(StepLds &L, int t)
+{
+	const int n = t >> 4, v = t & 15;               // 256 threads = 16 nibbles x 16 values
+	u64 a[GF2_GMAX] = { 0, 0, 0, 0 };
+#pragma unroll
+	for (int k = 0; k < 4; k++) {
+		const u64 on = ((v >> k) & 1) ? ~0ull : 0ull;
+#pragma unroll
+		for (int e = 0; e < GF2_GMAX; e++) a[e] ^= L.Pb[e][4 * n + k] & on;
+	}
+#pragma unroll
+	for (int e = 0; e < GF2_GMAX; e++) L.Tn[(n * 16 + v) * GF2_GMAX + e] = a[e];
+}
+
+// The narrow steps of all GF2_GMAX panels of a block that k_block_fast factorised (every panel full: 64 pivots, mask
+// all ones), for the rows of this workgroup: the multipliers.  The pivot rows' window words are in the matrix.
+__device__ __forceinline__ void narrow_all_panels(StepLds &L, const u64 *__restrict__ M, i64 rows, i64 srows, int j0,
+                                                  const u64 *__restrict__ Wb_in, const int *__restrict__ died,
+                                                  const PanelAux *__restrict__ aux, u64 *__restrict__ multset, int upd_T,
+                                                  i64 rb, int rpt)
+{
+	__shared__ u64 Pall[GF2_GMAX - 1][GF2_GMAX][64];        // [panel][word][pivot bit]
+	const int t = threadIdx.x, e_ = t >> 6, sl = t & 63;
+#pragma unroll
+	for (int g = 0; g < GF2_GMAX - 1; g++)
+		Pall[g][e_][sl] = (e_ > g) ? M[tidx(aux[j0 + g].slot_row[sl], j0 + e_, srows)] : 0ull;
+	for (int r = 0; r < rpt; r++) {
+		const i64 i = (rb * rpt + r) * 256 + t;
+		if (i - t >= rows) break;                           // (uniform)
+		const i64 ic = i < rows ? i : rows - 1;
+		const bool alive = i < rows && died[ic] == GF2_NEVER;
+		const uint4 *src = reinterpret_cast<const uint4 *>(Wb_in + ic * GF2_GMAX);
+		const uint4 lo = src[0], hi = src[1];
+		u64 w[GF2_GMAX] = { ((u64)lo.y << 32) | lo.x, ((u64)lo.w << 32) | lo.z, ((u64)hi.y << 32) | hi.x, ((u64)hi.w << 32) | hi.z };
+		u64 m[GF2_GMAX];
+#pragma unroll
+		for (int g = 0; g < GF2_GMAX; g++) {
+			m[g] = alive ? w[g] : 0ull;
+			if (g == GF2_GMAX - 1) break;
+			__syncthreads();                                // the previous tables are done with
+			L.Pb[e_][sl] = Pall[g][e_][sl];
+			__syncthreads();
+			build_nibble_tables(L, t);
+			__syncthreads();
+			if (m[g]) {
+				u64 acc[GF2_GMAX];
+				nibble_rows(L.Tn, m[g], acc);
+#pragma unroll
+				for (int e = 0; e < GF2_GMAX; e++) if (e > g) w[e] ^= acc[e];
+			}
+		}
+		if (i < rows) {
+#pragma unroll
+			for (int g = 0; g < GF2_GMAX; g++) multset[midx(g, i, rows)] = mult_stored(upd_T, m[g], i);
+		}
+	}
+}
+
+__global__ void __launch_bounds__(256)
+k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int full_cols, int blk,
+             const u64 *__restrict__ Wb_in, SolveState *__restrict__ st, int *__restrict__ died,
+             PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol, int *__restrict__ urow,
+             int *__restrict__ blk_first_out, u64 *__restrict__ Pfast, SysStride ss)
+{
+	__builtin_amdgcn_s_setprio(3);
+	{
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		M += blockIdx.y * ss.m_words;
+		Wb_in = sys_at(Wb_in, ao); st = sys_at(st, ao); died = sys_at(died, ao); panels = sys_at(panels, ao);
+		aux = sys_at(aux, ao); pivcol = sys_at(pivcol, ao); urow = sys_at(urow, ao); blk_first_out = sys_at(blk_first_out, ao);
+		Pfast = sys_at(Pfast, ao);
+	}
+	__shared__ StepLds L;
+	__shared__ u64 cw[GF2_FAST_NC * GF2_GMAX];          // candidates' window words; word g becomes the multiplier once panel g is through
+	__shared__ unsigned char used[GF2_FAST_NC];         // dead on entry, or a source of an earlier panel
+	__shared__ int srcs[GF2_GMAX][64];                  // [panel][pivot column] -> candidate that is its source
+	__shared__ u64 combs[GF2_GMAX][64];
+	__shared__ int ok;
+	__shared__ int crow[GF2_FAST_NC];                   // candidate -> row: the first GF2_FAST_NC ALIVE rows from the bound on
+	__shared__ int wcnt[4];
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	const int first = st->first, r0 = st->rank;
+	if (st->fast_off || gb != GF2_GMAX || !full_cols || rows - first < GF2_FAST_NC) {      // (uniform)
+		if (t == 0) st->fast_off = 1;
+		return;
+	}
+	// the alive rows are not contiguous (the leftovers of the previous blocks' candidate sets sit between their
+	// sources): compact them, 256 rows per round, at most 8 rounds
+	int have_c = 0;
+	for (int round = 0; round < 8 && have_c < GF2_FAST_NC; round++) {
+		const i64 i = (i64)first + round * 256 + t;
+		const bool alive = i < rows && died[i < rows ? i : rows - 1] == GF2_NEVER;
+		const u64 bal = __ballot(alive);
+		if (lane == 0) wcnt[wv] = __popcll(bal);
+		__syncthreads();
+		int before = have_c, total = 0;
+#pragma unroll
+		for (int q = 0; q < 4; q++) { if (q < wv) before += wcnt[q]; total += wcnt[q]; }
+		const int pos = before + __popcll(bal & lanemask_lt(lane));
+		if (alive && pos < GF2_FAST_NC) crow[pos] = (int)i;
+		have_c += total;
+		__syncthreads();
+	}
+	if (have_c < GF2_FAST_NC) {                             // (uniform)
+		if (t == 0) st->fast_off = 1;
+		return;
+	}
+	for (int c = t; c < GF2_FAST_NC; c += 256) {
+		const uint4 *src = reinterpret_cast<const uint4 *>(Wb_in + (i64)crow[c] * GF2_GMAX);
+		const uint4 lo = src[0], hi = src[1];
+		cw[c * 4 + 0] = ((u64)lo.y << 32) | lo.x; cw[c * 4 + 1] = ((u64)lo.w << 32) | lo.z;
+		cw[c * 4 + 2] = ((u64)hi.y << 32) | hi.x; cw[c * 4 + 3] = ((u64)hi.w << 32) | hi.z;
+		used[c] = 0;
+	}
+	if (t == 0) ok = 1;
+	__syncthreads();
+	const int e_ = t >> 6, sl = t & 63;
+#pragma unroll 1
+	for (int g = 0; g < GF2_GMAX; g++) {
+		if (wv == 0) {
+			const int c = 64 * g + lane;
+			const u64 w = used[c] ? 0ull : cw[c * 4 + g];
+			bool good = __popcll(__ballot(__popcll(w) > 12)) >= 48;
+			FindState S;
+			S.bw = 0; S.bc = 0; S.have = 0; S.nslots = 0; S.colslots = false; S.srow = 0;
+			if (good) {
+				const u64 took = gj_columns(S, w, c, lane);
+				if ((took >> lane) & 1) used[c] = 1;
+				good = S.nslots >= 64 - GF2_FEW_MISSING;
+				if (good && S.nslots < 64) {
+					const int c2 = c + 64;
+					const u64 w2 = used[c2] ? 0ull : cw[c2 * 4 + g];
+					const u64 took2 = find_absorb(S, w2, c2, ~0ull, lane, (int *)nullptr, 0);
+					if ((took2 >> lane) & 1) used[c2] = 1;
+					good = S.nslots == 64;
+				}
+			}
+			if (!good) { if (lane == 0) ok = 0; }
+			else { combs[g][lane] = S.bc; srcs[g][lane] = S.srow; L.Cm[lane] = S.bc; }
+		}
+		__syncthreads();
+		if (!ok) {                                          // (uniform) leave everything to the general steps
+			if (t == 0) st->fast_off = 1;
+			return;
+		}
+		// the pivot rows' window words right of the panel: comb x source words (the sources' words sit in the tables' space)
+		const bool use = e_ >= g;
+		L.Sw(e_)[sl] = use ? cw[srcs[g][sl] * 4 + e_] : 0ull;
+		__syncthreads();
+		const u64 acc = use ? xor_over_bits(L.Sw(e_), L.Cm[sl], [](int q) { return q; }) : 0ull;
+		__syncthreads();
+		L.Pb[e_][sl] = (e_ > g) ? acc : 0ull;               // (word g of pivot b is the single bit b: nothing to look up there)
+		Pfast[(g * GF2_GMAX + e_) * 64 + sl] = acc;
+		if (t < 64) {
+			PanelAux *A = aux + j0 + g;
+			A->slot_row[t] = crow[srcs[g][t]];
+			A->comb[t] = combs[g][t];
+#pragma unroll
+			for (int e = 0; e < GF2_GMAX; e++) A->src_mult[t][e] = (e < g) ? cw[srcs[g][t] * 4 + e] : 0ull;
+		}
+		__syncthreads();
+		if (g + 1 < GF2_GMAX) {
+			build_nibble_tables(L, t);
+			__syncthreads();
+			for (int c = t; c < GF2_FAST_NC; c += 256) {
+				const u64 m = used[c] ? 0ull : cw[c * 4 + g];
+				if (m) {
+					u64 a4[GF2_GMAX];
+					nibble_rows(L.Tn, m, a4);
+#pragma unroll
+					for (int e = 0; e < GF2_GMAX; e++) if (e > g) cw[c * 4 + e] ^= a4[e];
+				}
+			}
+			__syncthreads();
+		}
+	}
+	// ---- every panel is complete: publish the block ----
+	int nf = GF2_FAST_NC - 1;                               // first candidate that is still alive
+	if (wv == 0) {
+		for (int ch = GF2_FAST_CH - 1; ch >= 0; ch--) {
+			const u64 free_ = __ballot(!used[64 * ch + lane]);
+			if (free_) nf = 64 * ch + ctz64(free_);
+		}
+	}
+#pragma unroll
+	for (int g = 0; g < GF2_GMAX; g++)
+		if (e_ >= g) M[tidx(crow[srcs[g][sl]], j0 + e_, srows)] = Pfast[(g * GF2_GMAX + e_) * 64 + sl];
+	if (t < 64) {
+#pragma unroll
+		for (int g = 0; g < GF2_GMAX; g++) {
+			const int row = crow[srcs[g][t]];
+			died[row] = j0 + g;
+			urow[r0 + 64 * g + t] = row;
+			pivcol[r0 + 64 * g + t] = 64 * (j0 + g) + t;
+		}
+	}
+	if (t == 0) {
+		const int new_first = crow[nf];                    // (at least GF2_FAST_NC - 64 * GF2_GMAX candidates are left over)
+#pragma unroll
+		for (int g = 0; g < GF2_GMAX; g++) {
+			panels[j0 + g].start = r0 + 64 * g; panels[j0 + g].p = 64; panels[j0 + g].mask = ~0ull;
+			aux[j0 + g].first_after = (g == GF2_GMAX - 1) ? new_first : first;
+		}
+		st->rank = r0 + 64 * GF2_GMAX;
+		st->first = new_first;
+		st->wide = 0;
+		*blk_first_out = new_first;
+		st->fast_off = 0;
+		st->fast_done = blk + 1;
+		st->fast_blocks++;
+	}
+}
+
 __global__ void __launch_bounds__(256)
 k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, int gb, u64 colmask,
              const u64 *__restrict__ Wb_in, u64 *__restrict__ Wb_out, SolveState *__restrict__ st,
              int *__restrict__ died, FindUnit *__restrict__ fu, int units, int find_wgs,
              PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol,
              int *__restrict__ urow, u64 *__restrict__ multset, int *__restrict__ blk_first_out, int upd_T,
-             int sparse_mode, int self_wait, int rpt, SysStride ss)
+             int sparse_mode, int self_wait, int rpt, int blk, SysStride ss)
 {
 	// rpt: row blocks of 256 per narrow workgroup.  Every narrow workgroup rebuilds panel gp's pivot rows and their
 	// nibble tables (~3 us) before it can touch a row, so with one block each the prologue WAS the narrow step -- and
@@ -1017,6 +1258,12 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	const int lane = t & 63;
 	const bool finder = (int)blockIdx.x < find_wgs;
 	const i64 rb = (i64)blockIdx.x - find_wgs;          // narrow role: row block
+	// k_block_fast has factorised this block: nothing to search, and the narrow halves of ALL its panels are done by
+	// the narrow workgroups of the step that would have narrowed panel 0 (the other steps of the block are empty launches)
+	if (st->fast_done == blk + 1) {
+		if (!finder && gp == 0) narrow_all_panels(L, M, rows, srows, j0, Wb_in, died, aux, multset, upd_T, rb, rpt);
+		return;
+	}
 #ifdef GF2_STEP_PROBE
 	const bool probe_on = j0 == gf2_probe_j0 && blockIdx.y == 0;
 	const int probe_step = gp + 1;

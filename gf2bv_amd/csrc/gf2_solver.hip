@@ -369,6 +369,8 @@ struct Solver {
 	u64 *mult = nullptr;          // 2 sets x G x rows (ping-pong between consecutive blocks)
 	u64 *Wb = nullptr;            // 2 x rows x GMAX window words (the panel steps ping-pong between the halves)
 	u64 *Uwin = nullptr;          // rank x GMAX: pivot rows' words of the following window (k_prio_window -> k_unwind)
+	u64 *Pfast = nullptr;         // scratch of k_block_fast: the pivot rows' window words of a block, [panel][word][column]
+	bool fast_blocks = true;      // try the one-launch block search on dense blocks (GF2BV_FAST=0 disables)
 	int units = 0;
 	bool ext_events = true;       // hand-off and timing events ride on kernel start / completion signals (hipExtLaunchKernel)
 	                              // instead of marker packets: ~1 % at every size; GF2BV_EXT_EVENTS=0 restores hipEventRecord
@@ -504,6 +506,7 @@ int solver_alloc(Solver &S)
 	if (const char *e = getenv("GF2BV_UNITS")) { int v = atoi(e); if (v >= 1 && v <= 256) S.units = std::min(S.units, v); }
 	if (const char *e = getenv("GF2BV_DEBUG_SYNC")) S.dbg_sync = atoi(e);
 	if (const char *e = getenv("GF2BV_EXT_EVENTS")) S.ext_events = atoi(e) != 0;
+	if (const char *e = getenv("GF2BV_FAST")) S.fast_blocks = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_SPARSE")) { int v = atoi(e); if (v >= 0 && v <= 2) S.sparse_mode = v; }
 	// narrow workgroups: as many rows each as keeps ~256 of them (all systems of a gang together) busy, at most 8 blocks
 	{
@@ -527,14 +530,15 @@ int solver_alloc(Solver &S)
 		             o_fu = carve(sizeof(FindUnit) * (S.units + 1 + GF2_MAXGROUPS)), o_alive = carve(sizeof(int) * (size_t)R),
 		             o_piv = carve(sizeof(int) * (S.maxr + 64)), o_urow = carve(sizeof(int) * (S.maxr + 64)),
 		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * 2 * G * mult_rows(R)),
-		             o_wb = carve(sizeof(u64) * 2 * GF2_GMAX * R), o_uw = carve(sizeof(u64) * GF2_GMAX * (S.maxr + 64));
+		             o_wb = carve(sizeof(u64) * 2 * GF2_GMAX * R), o_uw = carve(sizeof(u64) * GF2_GMAX * (S.maxr + 64)),
+		             o_pf = carve(sizeof(u64) * GF2_GMAX * GF2_GMAX * 64);
 		S.arena_stride = off;
 		HIPCHK(pool().alloc(&S.arena, off * S.nsys, S.device));
 		char *base = (char *)S.arena;
 		S.st = (SolveState *)(base + o_st); S.panels = (PanelRec *)(base + o_pan); S.aux = (PanelAux *)(base + o_aux);
 		S.fu = (FindUnit *)(base + o_fu); S.died = (int *)(base + o_alive); S.pivcol = (int *)(base + o_piv);
 		S.urow = (int *)(base + o_urow); S.blk_first = (int *)(base + o_blk); S.mult = (u64 *)(base + o_mult);
-		S.Wb = (u64 *)(base + o_wb); S.Uwin = (u64 *)(base + o_uw);
+		S.Wb = (u64 *)(base + o_wb); S.Uwin = (u64 *)(base + o_uw); S.Pfast = (u64 *)(base + o_pf);
 		// zero everything that is read before it is written: state, panel records, unit scratch, block bounds, multipliers
 		for (int s = 0; s < S.nsys; s++) {
 			char *b = base + (size_t)s * off;
@@ -648,6 +652,11 @@ int enqueue_block_panel(Solver &S, int b)
 	const BlockGeom g = block_geom(S, b);
 	const unsigned row_blocks = (unsigned)((S.rows + 255) / 256);
 	u64 *const half[2] = { S.Wb, S.Wb + (i64)GF2_GMAX * S.rows };
+	// dense blocks: all G panels from a few hundred candidate rows in one launch; the general steps behind it find the
+	// block done (or, when it gave up, untouched)
+	if (S.fast_blocks && g.gb == GF2_GMAX && (i64)(g.j0 + g.gb) * 64 <= S.cols && S.rows >= GF2_FAST_NC)
+		k_block_fast<<<dim3(1, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, 1, b, (const u64 *)half[0], S.st, S.died,
+		                                                      S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, S.Pfast, S.ss());
 	for (int s = 0; s <= g.gb; s++) {
 		const int gp = s - 1, gf = (s < g.gb) ? s : -1;
 		const i64 c0 = (i64)(g.j0 + std::max(gf, 0)) * 64;
@@ -660,7 +669,7 @@ int enqueue_block_panel(Solver &S, int b)
 		                      S.M, S.rows, S.srows, g.j0, gp, gf, g.gb, colmask,
 		                      (const u64 *)half[s ? (s - 1) & 1 : 0], half[s & 1], S.st, S.died, S.fu, S.units, find_wgs,
 		                      S.panels, S.aux, S.pivcol, S.urow, g.mset,
-		                      gf == g.gb - 1 ? S.blk_first + b : (int *)nullptr, S.impl->T, S.sparse_mode, S.self_wait, S.narrow_rpt, S.ss());
+		                      gf == g.gb - 1 ? S.blk_first + b : (int *)nullptr, S.impl->T, S.sparse_mode, S.self_wait, S.narrow_rpt, b, S.ss());
 	}
 	if (b == S.nblocks - 1)
 		k_win_scatter<<<dim3((unsigned)((S.rows * g.gb + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, half[g.gb & 1], S.died, S.ss());
@@ -953,6 +962,7 @@ int finish_end(Solver &S, gf2bv_result **out)
 	st.tile_words = TW;
 	st.gang_systems = S.view ? S.gang_nsys : S.nsys;
 	st.search_handovers = hst.self_giveups;
+	st.fast_blocks = hst.fast_blocks;
 	{
 		const int G = S.impl->G;
 		for (int b = 0; b < S.nblocks; b++) {
@@ -1003,7 +1013,7 @@ int make_view(const Solver &S, int s, Solver &V)
 	auto mv = [ao](auto *&p) { p = reinterpret_cast<decltype(+p)>(reinterpret_cast<char *>(p) + ao); };
 	V.M = S.M + S.m_stride * s;
 	V.arena = (char *)S.arena + ao;
-	mv(V.st); mv(V.panels); mv(V.aux); mv(V.fu); mv(V.died); mv(V.pivcol); mv(V.urow); mv(V.blk_first); mv(V.mult); mv(V.Wb); mv(V.Uwin);
+	mv(V.st); mv(V.panels); mv(V.aux); mv(V.fu); mv(V.died); mv(V.pivcol); mv(V.urow); mv(V.blk_first); mv(V.mult); mv(V.Wb); mv(V.Uwin); mv(V.Pfast);
 	V.Y = nullptr; V.ycols = nullptr; V.out = nullptr;
 	V.ev2 = nullptr;
 	HIPCHK(pool().event(&V.ev2, true));

@@ -49,7 +49,7 @@ class Stats(ctypes.Structure):
         ("sweep_words", ctypes.c_double), ("row_xors", ctypes.c_double),
         ("ms_pack", ctypes.c_float), ("ms_eliminate", ctypes.c_float), ("ms_sweep", ctypes.c_float),
         ("ms_backsub", ctypes.c_float), ("ms_export", ctypes.c_float), ("ms_total", ctypes.c_float),
-        ("search_handovers", ctypes.c_int32), ("reserved1", ctypes.c_int32),
+        ("search_handovers", ctypes.c_int32), ("fast_blocks", ctypes.c_int32),
     ]
 
     def as_dict(self) -> dict:

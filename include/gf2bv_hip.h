@@ -64,7 +64,7 @@ typedef struct gf2bv_stats {
 	float   ms_total;          /* host wall clock of the whole call                            */
 	int32_t search_handovers;  /* panels whose first search unit stopped waiting for the rest of its launch and
 	                              left publishing to the last arriver (co-residency is not assumed)           */
-	int32_t reserved1;
+	int32_t fast_blocks;       /* blocks of 4 panels factorised by the one-launch dense block search (k_block_fast)     */
 } gf2bv_stats;
 
 /* ---- library / device ------------------------------------------------------------------ */

@@ -342,6 +342,7 @@ def test_search_handover_without_co_residency(monkeypatch):
     situation on a chip where its workgroups are not co-resident -- and the last arriver publishes from its record.
     Same results, and the hand-over path is seen to have run."""
     monkeypatch.setenv("GF2BV_SELF_WAIT_US", "0")
+    monkeypatch.setenv("GF2BV_FAST", "0")           # (the one-launch block search would bypass the per-panel searches on these dense systems)
     rng = random.Random(77)
     handovers = 0
     for rows, cols, cap in ((3000, 2500, None), (5000, 4097, 4000), (9000, 8200, None)):
@@ -389,6 +390,34 @@ def test_concurrent_gangs_next_to_a_saturating_stream(monkeypatch):
         stop.set()
         t.join()
     buf.free()
+
+
+def test_one_launch_block_search_and_its_fallbacks(monkeypatch):
+    """k_block_fast: dense blocks are factorised from a few hundred candidate rows in one launch (fast_blocks > 0, same
+    bits as the per-panel searches: GF2BV_FAST=0), and whatever it cannot handle -- a rank cap in the middle of the
+    matrix, sparse rows, duplicate columns, fewer alive rows than candidates -- falls back block by block."""
+    rng = random.Random(321)
+    cases = [(3000, 2900, None, .5), (5000, 4097, 2600, .5), (2600, 2500, None, .02), (1400, 1300, 1290, .5)]
+    for rows, cols, cap, dens in cases:
+        eqs = random_system(rng, rows, cols, dens, cap, True, 0)
+        aug = O.eqs_to_aug(eqs, cols)
+        for mode in (0, 1):
+            want = O.solve_words(aug, rows, cols, mode)
+            monkeypatch.setenv("GF2BV_FAST", "1")
+            fast = hip.solve_words(aug, rows, cols, mode)
+            monkeypatch.setenv("GF2BV_FAST", "0")
+            slow = hip.solve_words(aug, rows, cols, mode)
+            assert_same(fast, want, mode)
+            assert_same(slow, want, mode)
+            assert slow.stats["fast_blocks"] == 0
+            if dens == .5 and cap is None:
+                assert fast.stats["fast_blocks"] >= (cols // 256) - 2
+            # (a sparse system fills in as it is eliminated: its later blocks may well go through the fast search)
+    for kind in ("zero_cols", "dup_cols"):
+        eqs = structured_system(rng, 2600, 2500, kind)
+        aug = O.eqs_to_aug(eqs, 2500)
+        monkeypatch.setenv("GF2BV_FAST", "1")
+        assert_same(hip.solve_words(aug, 2600, 2500, 1), O.solve_words(aug, 2600, 2500, 1), 1)
 
 
 def test_back_substitution_paths_agree(monkeypatch):

@@ -13,5 +13,5 @@ for r in range(reps):
     sol = hip.solve_device(buf.ptr, n, n, stride, 0, time_kernels=tk)
     dt = time.time() - t
     s = sol.stats
-    print(f"N={n} rank={sol.rank} wall={dt*1e3:.1f}ms elim={s['ms_eliminate']:.1f} sweep={s['ms_sweep']:.1f} back={s['ms_backsub']:.1f} total={s['ms_total']:.1f}", flush=True)
+    print(f"N={n} rank={sol.rank} wall={dt*1e3:.1f}ms elim={s['ms_eliminate']:.1f} sweep={s['ms_sweep']:.1f} back={s['ms_backsub']:.1f} total={s['ms_total']:.1f} fast_blocks={s['fast_blocks']} handovers={s['search_handovers']}", flush=True)
 buf.free()
