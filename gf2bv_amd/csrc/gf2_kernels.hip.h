@@ -122,7 +122,12 @@ struct SolveState {
 	// done in one pass.
 	int fast_off, fast_done;
 	int fast_blocks;     // statistics: blocks factorised by k_block_fast
-	int pad[2];
+	// Optimistic enqueue (see enqueue_forward): once the first block has gone through k_block_fast, the host enqueues
+	// the following blocks WITHOUT the general panel steps behind the fast search.  If the search then gives up on a
+	// block, nothing can factorise it: poison = its index + 1, and every later panel-path kernel returns at once
+	// (the bulk kernels of unpublished blocks find no pivots and do nothing) until the host resumes from that block.
+	int poison;
+	int pad[1];
 };
 
 // Scratch of one search unit (wavefront).
@@ -336,11 +341,12 @@ k_win_gather(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, u64
 // Alive rows get their window back (only needed for the final block: the RHS bit may live in it).
 __global__ void __launch_bounds__(256)
 k_win_scatter(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, const u64 *__restrict__ Wb,
-              const int *__restrict__ died, SysStride ss)
+              const int *__restrict__ died, const SolveState *__restrict__ st, SysStride ss)
 {
 	M += blockIdx.y * ss.m_words;
 	Wb = sys_at(Wb, blockIdx.y * ss.arena_bytes);
 	died = sys_at(died, blockIdx.y * ss.arena_bytes);
+	if (sys_at(st, blockIdx.y * ss.arena_bytes)->poison) return;
 	const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
 	const i64 i = t / gb;
 	const int g = (int)(t % gb);
@@ -1078,7 +1084,7 @@ __device__ __forceinline__ void narrow_all_panels(StepLds &L, const u64 *__restr
 }
 
 __global__ void __launch_bounds__(256)
-k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int full_cols, int blk,
+k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_only, int blk,
              const u64 *__restrict__ Wb_in, SolveState *__restrict__ st, int *__restrict__ died,
              PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol, int *__restrict__ urow,
              int *__restrict__ blk_first_out, u64 *__restrict__ Pfast, SysStride ss)
@@ -1101,8 +1107,11 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int full_
 	__shared__ int wcnt[4];
 	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
 	const int first = st->first, r0 = st->rank;
-	if (st->fast_off || gb != GF2_GMAX || !full_cols || rows - first < GF2_FAST_NC) {      // (uniform)
-		if (t == 0) st->fast_off = 1;
+	if (st->poison) return;
+	// fast_only: no general steps are enqueued behind this launch -- giving up poisons the rest of the enqueued work
+	auto give_up = [&]() { if (t == 0) { st->fast_off = 1; if (fast_only) st->poison = blk + 1; } };
+	if (st->fast_off || gb != GF2_GMAX || rows - first < GF2_FAST_NC) {      // (uniform)
+		give_up();
 		return;
 	}
 	// the alive rows are not contiguous (the leftovers of the previous blocks' candidate sets sit between their
@@ -1123,7 +1132,7 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int full_
 		__syncthreads();
 	}
 	if (have_c < GF2_FAST_NC) {                             // (uniform)
-		if (t == 0) st->fast_off = 1;
+		give_up();
 		return;
 	}
 	for (int c = t; c < GF2_FAST_NC; c += 256) {
@@ -1161,7 +1170,7 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int full_
 		}
 		__syncthreads();
 		if (!ok) {                                          // (uniform) leave everything to the general steps
-			if (t == 0) st->fast_off = 1;
+			give_up();
 			return;
 		}
 		// the pivot rows' window words right of the panel: comb x source words (the sources' words sit in the tables' space)
@@ -1232,6 +1241,24 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int full_
 	}
 }
 
+// The narrow halves of a block that k_block_fast has factorised, as a launch of its own (optimistic enqueue: no
+// general steps exist for the block).
+__global__ void __launch_bounds__(256)
+k_narrow_all(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int blk, const u64 *__restrict__ Wb_in,
+             const SolveState *__restrict__ st, const int *__restrict__ died, const PanelAux *__restrict__ aux,
+             u64 *__restrict__ multset, int upd_T, int rpt, SysStride ss)
+{
+	__builtin_amdgcn_s_setprio(3);
+	{
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		M += blockIdx.y * ss.m_words;
+		Wb_in = sys_at(Wb_in, ao); st = sys_at(st, ao); died = sys_at(died, ao); aux = sys_at(aux, ao); multset = sys_at(multset, ao);
+	}
+	if (st->poison || st->fast_done != blk + 1) return;
+	__shared__ StepLds L;
+	narrow_all_panels(L, M, rows, srows, j0, Wb_in, died, aux, multset, upd_T, (i64)blockIdx.x, rpt);
+}
+
 __global__ void __launch_bounds__(256)
 k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, int gb, u64 colmask,
              const u64 *__restrict__ Wb_in, u64 *__restrict__ Wb_out, SolveState *__restrict__ st,
@@ -1258,6 +1285,7 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 	const int lane = t & 63;
 	const bool finder = (int)blockIdx.x < find_wgs;
 	const i64 rb = (i64)blockIdx.x - find_wgs;          // narrow role: row block
+	if (st->poison) return;
 	// k_block_fast has factorised this block: nothing to search, and the narrow halves of ALL its panels are done by
 	// the narrow workgroups of the step that would have narrowed panel 0 (the other steps of the block are empty launches)
 	if (st->fast_done == blk + 1) {
@@ -1431,9 +1459,10 @@ __global__ void __launch_bounds__(256)
 k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo, int gnext,
               const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
               const u64 *__restrict__ multset, const int *__restrict__ blk_first, u64 *__restrict__ Wb_out,
-              u64 *__restrict__ Uwin, int upd_T, SysStride ss)
+              u64 *__restrict__ Uwin, int upd_T, const SolveState *__restrict__ st, SysStride ss)
 {
 	__builtin_amdgcn_s_setprio(3);
+	if (sys_at(st, blockIdx.y * ss.arena_bytes)->poison) return;     // (the window buffer must stay what the resumed block needs)
 	{
 		const i64 ao = blockIdx.y * ss.arena_bytes;
 		M += blockIdx.y * ss.m_words;

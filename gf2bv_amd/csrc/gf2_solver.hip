@@ -371,6 +371,7 @@ struct Solver {
 	u64 *Uwin = nullptr;          // rank x GMAX: pivot rows' words of the following window (k_prio_window -> k_unwind)
 	u64 *Pfast = nullptr;         // scratch of k_block_fast: the pivot rows' window words of a block, [panel][word][column]
 	bool fast_blocks = true;      // try the one-launch block search on dense blocks (GF2BV_FAST=0 disables)
+	bool optimistic = true;       // ... and drop the general panel steps behind it once block 0 has taken it (GF2BV_OPTIMISTIC=0)
 	int units = 0;
 	bool ext_events = true;       // hand-off and timing events ride on kernel start / completion signals (hipExtLaunchKernel)
 	                              // instead of marker packets: ~1 % at every size; GF2BV_EXT_EVENTS=0 restores hipEventRecord
@@ -507,6 +508,7 @@ int solver_alloc(Solver &S)
 	if (const char *e = getenv("GF2BV_DEBUG_SYNC")) S.dbg_sync = atoi(e);
 	if (const char *e = getenv("GF2BV_EXT_EVENTS")) S.ext_events = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_FAST")) S.fast_blocks = atoi(e) != 0;
+	if (const char *e = getenv("GF2BV_OPTIMISTIC")) S.optimistic = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_SPARSE")) { int v = atoi(e); if (v >= 0 && v <= 2) S.sparse_mode = v; }
 	// narrow workgroups: as many rows each as keeps ~256 of them (all systems of a gang together) busy, at most 8 blocks
 	{
@@ -647,15 +649,31 @@ BlockGeom block_geom(const Solver &S, int b)
 
 // stream A: factorise block b on its compact window -- step s narrows panel s-1 (window half (s-1)&1 -> half s&1)
 // while searching panel s; gb+1 launches; evA[b] = "block b factorised"
-int enqueue_block_panel(Solver &S, int b)
+// fast_only: the block gets the one-launch search and the one-pass narrow step only (see enqueue_forward)
+bool fast_block_possible(const Solver &S, const BlockGeom &g)
+{
+	return S.fast_blocks && g.gb == GF2_GMAX && (i64)(g.j0 + g.gb) * 64 <= S.cols && S.rows >= GF2_FAST_NC;
+}
+
+int enqueue_block_panel(Solver &S, int b, bool fast_only = false)
 {
 	const BlockGeom g = block_geom(S, b);
 	const unsigned row_blocks = (unsigned)((S.rows + 255) / 256);
 	u64 *const half[2] = { S.Wb, S.Wb + (i64)GF2_GMAX * S.rows };
+	if (fast_only) {
+		k_block_fast<<<dim3(1, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, 1, b, (const u64 *)half[0], S.st, S.died,
+		                                                      S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, S.Pfast, S.ss());
+		hipExtLaunchKernelGGL(k_narrow_all, dim3((row_blocks + S.narrow_rpt - 1) / S.narrow_rpt, S.nsys), dim3(256), 0, S.sA, nullptr,
+		                      S.ext_events ? S.evA[b] : nullptr, 0, (const u64 *)S.M, S.rows, S.srows, g.j0, b, (const u64 *)half[0],
+		                      (const SolveState *)S.st, (const int *)S.died, (const PanelAux *)S.aux, g.mset, S.impl->T, S.narrow_rpt, S.ss());
+		HIPCHK(hipGetLastError());
+		if (!S.ext_events) HIPCHK(hipEventRecord(S.evA[b], S.sA));
+		return GF2BV_OK;
+	}
 	// dense blocks: all G panels from a few hundred candidate rows in one launch; the general steps behind it find the
 	// block done (or, when it gave up, untouched)
-	if (S.fast_blocks && g.gb == GF2_GMAX && (i64)(g.j0 + g.gb) * 64 <= S.cols && S.rows >= GF2_FAST_NC)
-		k_block_fast<<<dim3(1, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, 1, b, (const u64 *)half[0], S.st, S.died,
+	if (fast_block_possible(S, g))
+		k_block_fast<<<dim3(1, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, 0, b, (const u64 *)half[0], S.st, S.died,
 		                                                      S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, S.Pfast, S.ss());
 	for (int s = 0; s <= g.gb; s++) {
 		const int gp = s - 1, gf = (s < g.gb) ? s : -1;
@@ -672,7 +690,7 @@ int enqueue_block_panel(Solver &S, int b)
 		                      gf == g.gb - 1 ? S.blk_first + b : (int *)nullptr, S.impl->T, S.sparse_mode, S.self_wait, S.narrow_rpt, b, S.ss());
 	}
 	if (b == S.nblocks - 1)
-		k_win_scatter<<<dim3((unsigned)((S.rows * g.gb + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, half[g.gb & 1], S.died, S.ss());
+		k_win_scatter<<<dim3((unsigned)((S.rows * g.gb + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, half[g.gb & 1], S.died, S.st, S.ss());
 	HIPCHK(hipGetLastError());
 	if (!(S.ext_events && b != S.nblocks - 1)) HIPCHK(hipEventRecord(S.evA[b], S.sA));
 	if (S.dbg_sync & 1) HIPCHK(hipDeviceSynchronize());
@@ -733,7 +751,7 @@ int enqueue_block_prio(Solver &S, int b)
 	if (b > 0) HIPCHK(hipStreamWaitEvent(S.sA, S.waitPrio[b - 1], 0));
 	k_prio_window<<<dim3(row_blocks, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, g.wlo, std::max(g.gnext, 1),
 	                                                             S.panels, S.aux, g.mset, S.blk_first + b, S.Wb, S.Uwin,
-	                                                             S.impl->T, S.ss());
+	                                                             S.impl->T, S.st, S.ss());
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
@@ -774,12 +792,49 @@ int enqueue_forward(Solver &S)
 {
 	int rc = enqueue_forward_begin(S, true);
 	if (rc) return rc;
-	for (int b = 0; b < S.nblocks; b++) {
-		if ((rc = enqueue_block_panel(S, b))) return rc;
+	// Optimistic enqueue for dense systems.  k_block_fast decides ON THE DEVICE whether a block goes the fast way, so the
+	// general panel steps have to be enqueued behind it all the same, and on a fast block they are G + 1 empty launches
+	// of ~4.5 us each on the critical path.  One look at the device settles it for the usual case: block 0 is enqueued
+	// both ways and the host waits for its panel path (a ~50 us stall, once per solve); if the fast search took it, the
+	// blocks that can take it at all (full blocks with enough rows left) get k_block_fast + k_narrow_all only.  Should the
+	// search give up on one of them after all, it poisons the panel path from there on (SolveState::poison) and the
+	// host resumes from that block with both paths -- the matrix and the window buffer are exactly as that block needs.
+	bool optimistic = false;
+	int b = 0;
+	SolveState hst{};
+	if (S.fast_blocks && S.optimistic && S.nsys == 1 && S.world == 1 && S.nblocks >= 8 && fast_block_possible(S, block_geom(S, 0))) {
+		if ((rc = enqueue_block_panel(S, 0))) return rc;
+		if ((rc = enqueue_block_bulk(S, 0))) return rc;
+		if ((rc = enqueue_block_prio(S, 0))) return rc;
+		HIPCHK(hipMemcpyAsync(&hst, S.st, sizeof hst, hipMemcpyDeviceToHost, S.sA));
+		HIPCHK(hipStreamSynchronize(S.sA));
+		optimistic = hst.fast_done == 1;
+		b = 1;
+	}
+	auto fast_only_ok = [&](int blk) {
+		// rows left when the block starts: at most 64 leftover candidates sit below the bound besides the pivots found
+		return fast_block_possible(S, block_geom(S, blk)) && S.rows - (i64)blk * 64 * S.impl->G >= GF2_FAST_NC + 128;
+	};
+	for (; b < S.nblocks; b++) {
+		if ((rc = enqueue_block_panel(S, b, optimistic && fast_only_ok(b)))) return rc;
 		if ((rc = enqueue_block_bulk(S, b))) return rc;
 		if ((rc = enqueue_block_prio(S, b))) return rc;
 	}
 	if ((rc = enqueue_forward_join(S))) return rc;
+	if (optimistic) {
+		HIPCHK(hipMemcpyAsync(&hst, S.st, sizeof hst, hipMemcpyDeviceToHost, S.sA));
+		HIPCHK(hipStreamSynchronize(S.sA));
+		if (hst.poison) {                               // a block the fast search could not take: resume there, both paths
+			const int pb = hst.poison - 1;
+			HIPCHK(hipMemsetAsync(&S.st->poison, 0, sizeof(int), S.sA));
+			for (b = pb; b < S.nblocks; b++) {
+				if ((rc = enqueue_block_panel(S, b))) return rc;
+				if ((rc = enqueue_block_bulk(S, b))) return rc;
+				if ((rc = enqueue_block_prio(S, b))) return rc;
+			}
+			if ((rc = enqueue_forward_join(S))) return rc;
+		}
+	}
 	return enqueue_check_rhs(S);
 }
 
