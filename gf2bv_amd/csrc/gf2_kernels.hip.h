@@ -1016,7 +1016,7 @@ struct CandWords {
 // wavefront 0 (gj_columns) + the targeted completion from the next chunk (find_absorb), the pivot rows' remaining window
 // words from the sources (comb x source words, as the narrow prologue forms them), their nibble tables, and the narrow
 // step of the CANDIDATES only.  A candidate's eliminated word g is left in place: it is the row's multiplier.  Nothing
-// the general path relies on is touched before all panels are complete (PanelAux and the scratch Pfast are written
+// the general path relies on is touched before all panels are complete (PanelAux is written
 // early, both are overwritten by whoever publishes); on any surprise -- a chunk that is not dense, more than
 // GF2_FEW_MISSING columns short, a completion that does not complete, too few rows, a short last block -- it sets
 // fast_off and returns, and the general steps (always enqueued behind it) factorise the block as if it had never run.
@@ -1095,7 +1095,7 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_
 		M += blockIdx.y * ss.m_words;
 		Wb_in = sys_at(Wb_in, ao); st = sys_at(st, ao); died = sys_at(died, ao); panels = sys_at(panels, ao);
 		aux = sys_at(aux, ao); pivcol = sys_at(pivcol, ao); urow = sys_at(urow, ao); blk_first_out = sys_at(blk_first_out, ao);
-		Pfast = sys_at(Pfast, ao);
+		(void)Pfast;                                        // (scratch of an earlier version: the pivot rows' words stay in registers)
 	}
 	__shared__ StepLds L;
 	__shared__ u64 cw[GF2_FAST_NC * GF2_GMAX];          // candidates' window words; word g becomes the multiplier once panel g is through
@@ -1115,19 +1115,39 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_
 		return;
 	}
 	// the alive rows are not contiguous (the leftovers of the previous blocks' candidate sets sit between their
-	// sources): compact them, 256 rows per round, at most 8 rounds
+	// sources): compact them, 256 rows per round, at most 8 rounds.  A round fetches the rows' alive marks AND their
+	// window words (whether or not they turn out to be candidates): one memory round trip for the first two rounds,
+	// which nearly always suffice (256 rows fall to a block, ~64 of its candidates are left over).
 	int have_c = 0;
+	auto fetch = [&](int round, int &d, uint4 &lo, uint4 &hi, i64 &i) {
+		i = (i64)first + round * 256 + t;
+		const i64 ic = i < rows ? i : rows - 1;
+		d = died[ic];
+		const uint4 *src = reinterpret_cast<const uint4 *>(Wb_in + ic * GF2_GMAX);
+		lo = src[0]; hi = src[1];
+	};
+	int dA, dB; uint4 loA, hiA, loB, hiB; i64 iA, iB;
+	fetch(0, dA, loA, hiA, iA);
+	fetch(1, dB, loB, hiB, iB);
 	for (int round = 0; round < 8 && have_c < GF2_FAST_NC; round++) {
-		const i64 i = (i64)first + round * 256 + t;
-		const bool alive = i < rows && died[i < rows ? i : rows - 1] == GF2_NEVER;
+		if (round >= 2) fetch(round, dA, loA, hiA, iA);
+		const int d = round == 1 ? dB : dA;
+		const uint4 lo = round == 1 ? loB : loA, hi = round == 1 ? hiB : hiA;
+		const i64 i = round == 1 ? iB : iA;
+		const bool alive = i < rows && d == GF2_NEVER;
 		const u64 bal = __ballot(alive);
 		if (lane == 0) wcnt[wv] = __popcll(bal);
 		__syncthreads();
 		int before = have_c, total = 0;
 #pragma unroll
 		for (int q = 0; q < 4; q++) { if (q < wv) before += wcnt[q]; total += wcnt[q]; }
-		const int pos = before + __popcll(bal & lanemask_lt(lane));
-		if (alive && pos < GF2_FAST_NC) crow[pos] = (int)i;
+		const int c = before + __popcll(bal & lanemask_lt(lane));
+		if (alive && c < GF2_FAST_NC) {
+			crow[c] = (int)i;
+			cw[c * 4 + 0] = ((u64)lo.y << 32) | lo.x; cw[c * 4 + 1] = ((u64)lo.w << 32) | lo.z;
+			cw[c * 4 + 2] = ((u64)hi.y << 32) | hi.x; cw[c * 4 + 3] = ((u64)hi.w << 32) | hi.z;
+			used[c] = 0;
+		}
 		have_c += total;
 		__syncthreads();
 	}
@@ -1135,17 +1155,11 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_
 		give_up();
 		return;
 	}
-	for (int c = t; c < GF2_FAST_NC; c += 256) {
-		const uint4 *src = reinterpret_cast<const uint4 *>(Wb_in + (i64)crow[c] * GF2_GMAX);
-		const uint4 lo = src[0], hi = src[1];
-		cw[c * 4 + 0] = ((u64)lo.y << 32) | lo.x; cw[c * 4 + 1] = ((u64)lo.w << 32) | lo.z;
-		cw[c * 4 + 2] = ((u64)hi.y << 32) | hi.x; cw[c * 4 + 3] = ((u64)hi.w << 32) | hi.z;
-		used[c] = 0;
-	}
 	if (t == 0) ok = 1;
 	__syncthreads();
 	const int e_ = t >> 6, sl = t & 63;
-#pragma unroll 1
+	u64 Pk[GF2_GMAX] = { 0, 0, 0, 0 };                  // word e_ of pivot sl of panel g
+#pragma unroll
 	for (int g = 0; g < GF2_GMAX; g++) {
 		if (wv == 0) {
 			const int c = 64 * g + lane;
@@ -1173,14 +1187,17 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_
 			give_up();
 			return;
 		}
-		// the pivot rows' window words right of the panel: comb x source words (the sources' words sit in the tables' space)
+		// the pivot rows' window words right of the panel = comb x source words: the 64 source rows are folded into nibble
+		// tables (as k_block_trsm does) and every pivot row is 16 lookups by its combination mask
 		const bool use = e_ >= g;
-		L.Sw(e_)[sl] = use ? cw[srcs[g][sl] * 4 + e_] : 0ull;
+		L.Pb[e_][sl] = use ? cw[srcs[g][sl] * 4 + e_] : 0ull;
 		__syncthreads();
-		const u64 acc = use ? xor_over_bits(L.Sw(e_), L.Cm[sl], [](int q) { return q; }) : 0ull;
+		build_nibble_tables(L, t);
 		__syncthreads();
+		const u64 acc = use ? nibble_word(L.Tn, L.Cm[sl], e_) : 0ull;
+		Pk[g] = acc;
+		__syncthreads();                                    // (the tables are read by every thread before Pb changes under them)
 		L.Pb[e_][sl] = (e_ > g) ? acc : 0ull;               // (word g of pivot b is the single bit b: nothing to look up there)
-		Pfast[(g * GF2_GMAX + e_) * 64 + sl] = acc;
 		if (t < 64) {
 			PanelAux *A = aux + j0 + g;
 			A->slot_row[t] = crow[srcs[g][t]];
@@ -1214,7 +1231,7 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_
 	}
 #pragma unroll
 	for (int g = 0; g < GF2_GMAX; g++)
-		if (e_ >= g) M[tidx(crow[srcs[g][sl]], j0 + e_, srows)] = Pfast[(g * GF2_GMAX + e_) * 64 + sl];
+		if (e_ >= g) M[tidx(crow[srcs[g][sl]], j0 + e_, srows)] = Pk[g];
 	if (t < 64) {
 #pragma unroll
 		for (int g = 0; g < GF2_GMAX; g++) {
