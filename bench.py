@@ -147,7 +147,8 @@ def roofline_block(stats_list, sweep_ms_total: float, n: int, device: int, ceil:
     out = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, g, t),
-        "kernel": f"k_update<G={g},T={t}> (bulk update, {g} panels = {64 * g} pivots per pass)",
+        "kernel": (f"k_update16 (bulk update on 16-byte tiles, {g} panels = {64 * g} pivots = {g * t} byte-field tables per pass)"
+                   if s0["tile_words"] == 2 else f"k_update<G={g},T={t}> (bulk update, {g} panels = {64 * g} pivots per pass)"),
         "alg_bytes_total": alg_bytes, "kernel_ms_total": sweep_ms_total,
         # one pass applies G panels: HBM rate a one-panel-per-pass sweep would need for the same wall time
         "single_panel_equivalent_GBs": achieved * g,
@@ -382,8 +383,8 @@ def run_batch(args, world, rank, local_rank, dev):
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "kernel": f"k_update<G={g},T={s0['tables_per_sweep'] // g}> (bulk update of a gang: {s0.get('gang_systems', 0)} "
-                      f"systems x {64 * g} pivots per launch)",
+            "kernel": f"{'k_update16' if s0['tile_words'] == 2 else 'k_update'}<G={g},T={s0['tables_per_sweep'] // g}> (bulk update of a gang: "
+                      f"{s0.get('gang_systems', 0)} systems x {64 * g} pivots per launch)",
             "launches": launches, "alg_bytes_per_launch": alg_bytes / max(launches, 1),
             "avg_launch_ms": sweep_ms / max(launches, 1),
             "measured_rmw_stream_GBs": ceil["rmw_gbs"], "measured_read_stream_GBs": ceil["read_gbs"],

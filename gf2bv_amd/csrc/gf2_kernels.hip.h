@@ -2158,6 +2158,8 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		}
 	}
 
+	uint4 staged = make_uint4(0, 0, 0, 0);          // this thread's pivot-row segment of the NEXT span's tile, requested while
+	bool have_staged = false;                       // the current span streams (the build then starts without a memory round trip)
 	for (bool first_span = true; pos < pend; first_span = false) {
 		const int ct = (int)(pos / R);
 		const i64 r0 = pos - (i64)ct * R;
@@ -2184,7 +2186,7 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		const uint4 *Mq = reinterpret_cast<const uint4 *>(M) + tile * srows;       // this tile's slab, one uint4 per row
 		if (threadIdx.x < GF2_GMAX * 64) {
 			const int pr = prow[threadIdx.x];
-			uint4 v = Mq[pr >= 0 ? pr : 0];
+			uint4 v = have_staged ? staged : Mq[pr >= 0 ? pr : 0];
 			// words left of wlo belong to windows the panel path owns: their table bits stay zero
 			const bool k0 = pr >= 0 && 2 * tile >= wlo, k1 = pr >= 0 && 2 * tile + 1 >= wlo;
 			if (!k0) { v.x = 0; v.y = 0; }
@@ -2215,6 +2217,16 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		}
 		__syncthreads();
 
+		// the pivot rows of the next span's tile (pivot rows are never changed by this launch: zero multipliers)
+		have_staged = false;
+		if (pos < pend) {
+			const i64 ntile = owned_item((int)(pos / R), tile_begin, GF2_OWN_LOG - 1, world, wrank);
+			if (threadIdx.x < GF2_GMAX * 64) {
+				const int pr = prow[threadIdx.x];
+				staged = (reinterpret_cast<const uint4 *>(M) + ntile * srows)[pr >= 0 ? pr : 0];
+			}
+			have_staged = true;
+		}
 		// ---- stream the rows ----
 		// A wavefront takes 64 consecutive rows (1 KiB of the slab, 2 KiB of multipliers) per batch; the loads of
 		// batch i+1 are in flight while batch i does its 32 lookups.  No control flow around vector-memory
