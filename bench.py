@@ -481,10 +481,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the product path has no CPU fallback)")
+    # (tests on a one-GPU box: GF2BV_BENCH_DEVICE pins every rank to one GPU, GF2BV_BENCH_BACKEND=gloo replaces RCCL, which
+    # cannot put two ranks on one device; the driver's multi-GPU runs set neither)
+    if os.environ.get("GF2BV_BENCH_DEVICE") is not None:
+        local_rank = int(os.environ["GF2BV_BENCH_DEVICE"])
+    backend = os.environ.get("GF2BV_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     workload = args.workload if args.workload != "auto" else ("single" if world == 1 else "batch")
     out = {"single": run_single, "batch": run_batch, "sharded": run_sharded}[workload](args, world, rank, local_rank, dev)
     if rank == 0:

@@ -44,8 +44,15 @@ def gather_records(local: torch.Tensor, nsys: int, group=None) -> torch.Tensor:
     biggest = (nsys + world - 1) // world
     padded = torch.zeros(biggest, width, dtype=local.dtype, device=local.device)
     padded[: local.shape[0]] = local
-    parts = [torch.empty_like(padded) for _ in range(world)]
-    dist.all_gather(parts, padded, group=group)
+    if padded.is_cuda and dist.get_backend(group) == "gloo":
+        # gloo moves host memory only (tests: several ranks sharing one GPU); RCCL ("nccl") gathers device tensors directly
+        host = padded.cpu()
+        hparts = [torch.empty_like(host) for _ in range(world)]
+        dist.all_gather(hparts, host, group=group)
+        parts = [h.to(padded.device) for h in hparts]
+    else:
+        parts = [torch.empty_like(padded) for _ in range(world)]
+        dist.all_gather(parts, padded, group=group)
     out = torch.empty(nsys, width, dtype=local.dtype, device=local.device)
     for r in range(world):
         lo, hi = shard_bounds(nsys, world, r)

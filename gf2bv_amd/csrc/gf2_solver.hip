@@ -570,7 +570,11 @@ int pick_update_wgs(i64 est_rows, int ntiles, int nsys)
 	i64 want = 256;
 	if (const char *e = getenv("GF2BV_WGS")) { int v = atoi(e); if (v > 0) want = v; }
 	want = std::max<i64>(1, want / std::max(1, nsys));
-	const i64 cap = std::max<i64>(1, (i64)ntiles * TW / 8 * est_rows / 4096);
+	// (a span below ~min_rows rows of a 64-byte column is not worth a workgroup of its own: a table build costs as much
+	// as streaming ~1000 of them -- but small passes are latency, not throughput: the chip is mostly idle, so they take
+	// as many workgroups as have at least that much to do)
+	static const i64 min_rows = getenv("GF2BV_WG_MIN_ROWS") ? std::max(256, atoi(getenv("GF2BV_WG_MIN_ROWS"))) : 2048;
+	const i64 cap = std::max<i64>(1, (i64)ntiles * TW / 8 * est_rows / min_rows);
 	return (int)std::min(want, cap);
 }
 

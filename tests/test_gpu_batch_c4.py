@@ -104,3 +104,22 @@ def test_bench_sharded_mode_single_rank():
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["scaling"] == "strong" and line["parity_gate"]["residual_rows"] == 0 and line["parity_gate"]["all_solved"]
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_ranks_sharing_the_gpu():
+    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one process per rank): shard bounds,
+    barriers, max-over-ranks timing, the gather and the JSON line -- with both ranks pinned to this box's one GPU and gloo
+    standing in for RCCL (which cannot put two ranks on one device)."""
+    env = dict(os.environ, GF2BV_BENCH_DEVICE="0", GF2BV_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch-total", "9", "--batch-n", "4096"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=550, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                    # rank 0 only
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["systems_total"] == 9
+    assert line["parity_gate"]["all_ranks_ok"] and line["parity_gate"]["gathered_records"] == 9
+    assert "cpu_baseline" not in line and line["value"] > 0 and line["roofline"]["achieved"] > 0
