@@ -200,8 +200,15 @@ class PackedLinearSystem:
                 r = np.frombuffer((int(z) & ((1 << (64 * self._words)) - 1)).to_bytes(8 * self._words, "little"),
                                   dtype=np.uint64)
                 parts.append(r[None, :])
-        rows = np.concatenate(parts) if parts else np.zeros((0, self._words), dtype=np.uint64)
-        return rows[rows.any(axis=1)]                  # literal zeros carry no information
+        n = sum(len(x) for x in parts)
+        # (stacked into a buffer that is kept between calls: a fresh 50 MB allocation is paid for in page faults, several
+        # times the copy itself.  The returned array is a view of it, valid until the next call.)
+        buf = getattr(self, "_rowbuf", None)
+        if buf is None or len(buf) < n:
+            buf = self._rowbuf = np.empty((max(n, 1), self._words), dtype=np.uint64)
+        rows = np.concatenate(parts, out=buf[:n]) if parts else buf[:0]
+        nz = np.bitwise_or.reduce(rows, axis=1) != 0   # literal zeros carry no information
+        return rows if nz.all() else rows[nz]          # (the usual case costs no second copy of the ~50 MB of an MT19937 system)
 
     def get_eqs(self, zeros: Sequence) -> list:
         """the reference's list of equation ints (for callers that want it; the solve methods do not build it)"""
@@ -210,7 +217,8 @@ class PackedLinearSystem:
     # -- boundary call (reference :229-240) ------------------------------------------------------------
     def _solve_internal(self, zeros: Sequence, mode: int):
         rows = self.get_rows(zeros)
-        if len(rows) and ((rows[:, 0] == 1) & ~rows[:, 1:].any(axis=1)).any():     # the equation "1 = 0"
+        cand = np.flatnonzero(rows[:, 0] == 1) if len(rows) else ()                # the equation "1 = 0": word 0 is 1 ...
+        if len(cand) and (~rows[cand, 1:].any(axis=1)).any():                        # ... and nothing else is set
             return None
         if len(rows) < self._cols:                     # the boundary wants rows >= cols
             rows = np.concatenate([rows, np.zeros((self._cols - len(rows), self._words), dtype=np.uint64)])
