@@ -9,10 +9,12 @@ from tests.systems import random_system
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-configs = ["4x12", "4x16", "3x12", "2x12", "1x12", "1x8"]
+configs = ["0", "1", "2", "3", "4", "5"]          # instances of k_update16 (GF2_TW = 2 builds)
+knobs = [{}, {}, {"GF2BV_FAST": "0"}, {"GF2BV_OPTIMISTIC": "0"}, {"GF2BV_SELF_WAIT_US": "0"}, {"GF2BV_NARROW_RPT": "3"}]
 t0, n, worst = time.time(), 0, 0
 while time.time() - t0 < budget:
-    cols = rng.choice([rng.randint(1, 130), rng.randint(131, 700), rng.randint(700, 2600), 64 * rng.randint(1, 40), 256 * rng.randint(1, 10) + rng.choice([-1, 0, 1])])
+    cols = rng.choice([rng.randint(1, 130), rng.randint(131, 700), rng.randint(700, 2600), 64 * rng.randint(1, 40), 256 * rng.randint(1, 10) + rng.choice([-1, 0, 1]),
+                       rng.randint(2048, 4200)])               # (>= 8 blocks: the optimistic enqueue and its resume path)
     cols = max(cols, 1)
     rows = cols + rng.choice([0, 1, rng.randint(0, 64), rng.randint(0, cols), rng.randint(0, 3 * cols)])
     density = rng.choice([0.5, 0.5, 0.1, 0.02, 0.004])
@@ -21,6 +23,9 @@ while time.time() - t0 < budget:
     zero_rows = rng.choice([0, 0, rng.randint(0, rows // 2)])
     mode = rng.randint(0, 1)
     os.environ["GF2BV_UPDATE"] = rng.choice(configs)
+    for k in ("GF2BV_FAST", "GF2BV_OPTIMISTIC", "GF2BV_SELF_WAIT_US", "GF2BV_NARROW_RPT"):
+        os.environ.pop(k, None)
+    os.environ.update(rng.choice(knobs))
     eqs = random_system(rng, rows, cols, density, cap, consistent, min(zero_rows, rows - 1))
     rng.shuffle(eqs)
     aug = O.eqs_to_aug(eqs, cols)
