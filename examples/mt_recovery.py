@@ -2,17 +2,17 @@
 scenario of the reference's examples/mt.py with gf2bv_amd's own API and models)."""
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from gf2bv_amd import LinearSystem
+from gf2bv_amd import LinearSystem, PackedLinearSystem
 from gf2bv_amd.crypto import MT19937
 
 
-def recover(bs, samples=None):
+def recover(bs, samples=None, system=LinearSystem):
     rand = random.Random(3142)
     state = tuple(rand.getstate()[1][:-1])
     eff = ((bs - 1) & bs) or bs
     samples = 624 * 32 // eff if samples is None else samples
     out = [rand.getrandbits(bs) for _ in range(samples)]
-    lin = LinearSystem([32] * 624)
+    lin = system([32] * 624)
     mt = lin.gens()
     rng = MT19937(mt)
     t0 = time.perf_counter()
@@ -23,9 +23,10 @@ def recover(bs, samples=None):
     assert sol == state
     check = MT19937(sol)
     assert all(check.getrandbits(bs) == o for o in out)
-    print(f"bs={bs:5d} rows={len(lin.get_eqs(zeros)):6d} generate {t1 - t0:6.2f}s  solve_one {t2 - t1:6.3f}s  ok")
+    print(f"{system.__name__:18s} bs={bs:5d} generate {t1 - t0:6.2f}s  solve_one {t2 - t1:6.3f}s  ok")
 
 
 if __name__ == "__main__":
     for bs, samples in ((32, None), (17, None), (9, None), (1, None), (1337, 19968 // 1337 + 10), (137, 19968 // 137 + 60)):
         recover(bs, samples)
+        recover(bs, samples, PackedLinearSystem)       # the same scenario on bit matrices
