@@ -127,7 +127,19 @@ struct SolveState {
 	// block, nothing can factorise it: poison = its index + 1, and every later panel-path kernel returns at once
 	// (the bulk kernels of unpublished blocks find no pivots and do nothing) until the host resumes from that block.
 	int poison;
-	int pad[1];
+	int gate_timeout;    // a hand-over gate (k_gate) gave up waiting: the solve's results are void (the host reports an error)
+};
+
+// Hand-over between the panel stream and the bulk stream through memory instead of events.  An event wait costs a
+// barrier packet -- 4-7 us on an idle chip, 10-11 us measured inside a solve (tools/microbench_gap.hip), once per block
+// on EACH stream -- while a kernel that follows another in the same stream starts 1.4 us after it and sees a flag another
+// stream has written within ~1 us.  So each stream announces its progress in these counters and waits for the other's
+// with a one-wavefront kernel (k_gate) queued where the event wait used to be: the kernels behind it start as soon
+// as it ends, and a single spinning wavefront cannot starve anything.  Not part of SolveState: a column-slab solve imports
+// that from other ranks (and keeps the events: its hand-overs go through the host anyway).
+struct SyncFlags {
+	int narrow_done;     // panel stream: blocks whose multipliers are complete (block b's TRSM / update may start at b + 1)
+	int bulk_done;       // bulk stream: blocks whose bulk update is complete (block b's look-ahead needs b, i.e. block b - 1)
 };
 
 // Scratch of one search unit (wavefront).
@@ -354,11 +366,33 @@ k_win_scatter(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, const u6
 	M[tidx(i, j0 + g, srows)] = Wb[i * GF2_GMAX + g];
 }
 
+// (k_gate follows the definitions of GF2_ST / GF2_LD below)
 // Cross-workgroup scratch of the search units is exchanged with relaxed AGENT-scope atomics (write-through
 // stores, L2-coherent loads): no __threadfence(), whose release half would write back the whole
 // L2 -- megabytes of lines the concurrent bulk update is dirtying.
 #define GF2_ST(ptr, val) __hip_atomic_store((ptr), (val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #define GF2_LD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+// One wavefront per system: announce this stream's progress (set_* > 0), then wait until the other stream's counter has
+// reached need_*.  What the producer's kernels wrote is visible to the kernels behind the gate by the usual
+// kernel-boundary release / acquire: the producer's counter is written by ITS gate, which runs after them.  The wait is
+// bounded (GF2_GATE_TICKS of the 100 MHz clock; both gates of a block are enqueued before either can matter, so only a
+// launch failure on the other stream can leave one waiting): on expiry the solve is marked void and everything drains.
+#define GF2_GATE_TICKS 1500000000ull      // 15 s
+__global__ void __launch_bounds__(64)
+k_gate(SyncFlags *__restrict__ sf, SolveState *__restrict__ st, int set_narrow, int set_bulk, int need_narrow, int need_bulk,
+       SysStride ss)
+{
+	sf = sys_at(sf, blockIdx.y * ss.arena_bytes); st = sys_at(st, blockIdx.y * ss.arena_bytes);
+	if (threadIdx.x != 0) return;
+	if (set_narrow > 0) GF2_ST(&sf->narrow_done, set_narrow);
+	if (set_bulk > 0) GF2_ST(&sf->bulk_done, set_bulk);
+	const unsigned long long t0 = wall_clock64();
+	while (GF2_LD(&sf->narrow_done) < need_narrow || GF2_LD(&sf->bulk_done) < need_bulk) {
+		__builtin_amdgcn_s_sleep(2);
+		if (wall_clock64() - t0 > GF2_GATE_TICKS) { GF2_ST(&st->gate_timeout, 1); break; }
+	}
+}
 
 // -DGF2_STEP_PROBE (tools/probe_step.py builds a separate library with it): wall-clock (100 MHz) timestamps of
 // the phases of the panel steps of ONE block, per workgroup and per search unit.  Not compiled into the product.
@@ -369,6 +403,7 @@ __device__ int gf2_probe_j0 = -1;                                        // bloc
 __device__ unsigned long long gf2_probe_wg[GF2_GMAX + 1][GF2_PROBE_WGS][4];     // [step][workgroup][entry, params in, P built, end]
 __device__ unsigned long long gf2_probe_un[GF2_GMAX + 1][GF2_PROBE_UNITS][6];   // [step][unit][loop start, loop end, arrived, decided, published, chunks]
 __device__ unsigned long long gf2_probe_gj[4];                            // unit 0, last panel: gj_columns entry, after transpose, after pivot loop, exit
+__device__ unsigned long long gf2_probe_fast[32];                         // k_block_fast of that block: entry, candidates in, then per panel {search done, pivot rows formed, candidates narrowed}, published
 __device__ unsigned long long gf2_probe_upd[GF2_PROBE_WGS][6];           // k_update of that block: [workgroup][entry, first tables built, end, spans, table time, -]
 __device__ unsigned long long gf2_probe_wave[5][16];                      // k_update: end time of every wavefront of workgroups 8, 72, 136, 200
 #define GF2_PROBE_WG(k) do { if (probe_on && threadIdx.x == 0 && blockIdx.x < GF2_PROBE_WGS) gf2_probe_wg[probe_step][blockIdx.x][k] = wall_clock64(); } while (0)
@@ -1107,6 +1142,13 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_
 	__shared__ int wcnt[4];
 	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
 	const int first = st->first, r0 = st->rank;
+#ifdef GF2_STEP_PROBE
+	const bool fprobe = j0 == gf2_probe_j0 && blockIdx.y == 0 && t == 0;
+#define GF2_PROBE_FAST(k) do { if (fprobe) gf2_probe_fast[k] = wall_clock64(); } while (0)
+#else
+#define GF2_PROBE_FAST(k) do { } while (0)
+#endif
+	GF2_PROBE_FAST(0);
 	if (st->poison) return;
 	// fast_only: no general steps are enqueued behind this launch -- giving up poisons the rest of the enqueued work
 	auto give_up = [&]() { if (t == 0) { st->fast_off = 1; if (fast_only) st->poison = blk + 1; } };
@@ -1157,6 +1199,7 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_
 	}
 	if (t == 0) ok = 1;
 	__syncthreads();
+	GF2_PROBE_FAST(1);
 	const int e_ = t >> 6, sl = t & 63;
 	u64 Pk[GF2_GMAX] = { 0, 0, 0, 0 };                  // word e_ of pivot sl of panel g
 #pragma unroll
@@ -1187,6 +1230,7 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_
 			give_up();
 			return;
 		}
+		GF2_PROBE_FAST(2 + 3 * g);
 		// the pivot rows' window words right of the panel = comb x source words: the 64 source rows are folded into nibble
 		// tables (as k_block_trsm does) and every pivot row is 16 lookups by its combination mask
 		const bool use = e_ >= g;
@@ -1206,6 +1250,7 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_
 			for (int e = 0; e < GF2_GMAX; e++) A->src_mult[t][e] = (e < g) ? cw[srcs[g][t] * 4 + e] : 0ull;
 		}
 		__syncthreads();
+		GF2_PROBE_FAST(3 + 3 * g);
 		if (g + 1 < GF2_GMAX) {
 			build_nibble_tables(L, t);
 			__syncthreads();
@@ -1220,6 +1265,7 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_
 			}
 			__syncthreads();
 		}
+		GF2_PROBE_FAST(4 + 3 * g);
 	}
 	// ---- every panel is complete: publish the block ----
 	int nf = GF2_FAST_NC - 1;                               // first candidate that is still alive
@@ -1256,6 +1302,7 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_
 		st->fast_done = blk + 1;
 		st->fast_blocks++;
 	}
+	GF2_PROBE_FAST(14);
 }
 
 // The narrow halves of a block that k_block_fast has factorised, as a launch of its own (optimistic enqueue: no

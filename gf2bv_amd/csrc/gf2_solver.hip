@@ -370,6 +370,9 @@ struct Solver {
 	u64 *Wb = nullptr;            // 2 x rows x GMAX window words (the panel steps ping-pong between the halves)
 	u64 *Uwin = nullptr;          // rank x GMAX: pivot rows' words of the following window (k_prio_window -> k_unwind)
 	u64 *Pfast = nullptr;         // scratch of k_block_fast: the pivot rows' window words of a block, [panel][word][column]
+	SyncFlags *sf = nullptr;      // progress counters of the two streams (k_gate)
+	bool flag_sync = true;        // per-block hand-overs between the streams through sf + k_gate instead of events (GF2BV_FLAG_SYNC=0)
+	int sync_base = 0;            // the counters only grow: a pass that re-enqueues blocks (resume after a poisoned one) counts from here
 	bool fast_blocks = true;      // try the one-launch block search on dense blocks (GF2BV_FAST=0 disables)
 	bool optimistic = true;       // ... and drop the general panel steps behind it once block 0 has taken it (GF2BV_OPTIMISTIC=0)
 	int units = 0;
@@ -508,6 +511,9 @@ int solver_alloc(Solver &S)
 	if (const char *e = getenv("GF2BV_DEBUG_SYNC")) S.dbg_sync = atoi(e);
 	if (const char *e = getenv("GF2BV_EXT_EVENTS")) S.ext_events = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_FAST")) S.fast_blocks = atoi(e) != 0;
+	S.flag_sync = S.world == 1;           // (a column-slab solve hands over through the host between the pieces: events)
+	if (const char *e = getenv("GF2BV_FLAG_SYNC")) S.flag_sync = S.flag_sync && atoi(e) != 0;
+	if (getenv("GF2BV_SERIAL")) S.flag_sync = false;      // (one stream: the panel gate would wait for a gate queued behind it)
 	if (const char *e = getenv("GF2BV_OPTIMISTIC")) S.optimistic = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_SPARSE")) { int v = atoi(e); if (v >= 0 && v <= 2) S.sparse_mode = v; }
 	// narrow workgroups: as many rows each as keeps ~256 of them (all systems of a gang together) busy, at most 8 blocks
@@ -528,16 +534,17 @@ int solver_alloc(Solver &S)
 		const i64 R = std::max<i64>(1, S.rows), NP = std::max(1, S.npanels);
 		size_t off = 0;
 		auto carve = [&](size_t bytes) { size_t at = off; off += (bytes + 255) & ~(size_t)255; return at; };
-		const size_t o_st = carve(sizeof(SolveState)), o_pan = carve(sizeof(PanelRec) * NP), o_aux = carve(sizeof(PanelAux) * NP),
+		const size_t o_st = carve(sizeof(SolveState)), o_sf = carve(sizeof(SyncFlags)), o_pan = carve(sizeof(PanelRec) * NP), o_aux = carve(sizeof(PanelAux) * NP),
 		             o_fu = carve(sizeof(FindUnit) * (S.units + 1 + GF2_MAXGROUPS)), o_alive = carve(sizeof(int) * (size_t)R),
 		             o_piv = carve(sizeof(int) * (S.maxr + 64)), o_urow = carve(sizeof(int) * (S.maxr + 64)),
 		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * 2 * G * mult_rows(R)),
 		             o_wb = carve(sizeof(u64) * 2 * GF2_GMAX * R), o_uw = carve(sizeof(u64) * GF2_GMAX * (S.maxr + 64)),
 		             o_pf = carve(sizeof(u64) * GF2_GMAX * GF2_GMAX * 64);
 		S.arena_stride = off;
+		S.sync_base = 0;
 		HIPCHK(pool().alloc(&S.arena, off * S.nsys, S.device));
 		char *base = (char *)S.arena;
-		S.st = (SolveState *)(base + o_st); S.panels = (PanelRec *)(base + o_pan); S.aux = (PanelAux *)(base + o_aux);
+		S.st = (SolveState *)(base + o_st); S.sf = (SyncFlags *)(base + o_sf); S.panels = (PanelRec *)(base + o_pan); S.aux = (PanelAux *)(base + o_aux);
 		S.fu = (FindUnit *)(base + o_fu); S.died = (int *)(base + o_alive); S.pivcol = (int *)(base + o_piv);
 		S.urow = (int *)(base + o_urow); S.blk_first = (int *)(base + o_blk); S.mult = (u64 *)(base + o_mult);
 		S.Wb = (u64 *)(base + o_wb); S.Uwin = (u64 *)(base + o_uw); S.Pfast = (u64 *)(base + o_pf);
@@ -616,11 +623,11 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 	const i64 est_rows = std::max<i64>(256, S.rows - (i64)j0 * 64);      // alive rows of a dense system (the kernel uses the true bound)
 	const int wgs = pick_update_wgs(est_rows, ntiles, S.nsys);
 	hipEvent_t begun = nullptr, done = nullptr;
-	if (S.ext_events) { begun = ka; done = S.time_kernels ? kb : (last ? S.evPrio[b] : nullptr); }
+	if (S.ext_events) { begun = ka; done = S.time_kernels ? kb : (last && !S.flag_sync ? S.evPrio[b] : nullptr); }
 	HIPCHK(S.impl->update(dim3((unsigned)wgs, S.nsys), st, S.M, S.rows, S.srows, j0, gb, wlo, S.panels, S.aux, mset,
 	                      S.blk_first + b, tile_begin, ntiles, S.world, S.wrank, nw_lo, nw_hi, S.ss(), begun, done));
 	if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, st));
-	if (!last) return GF2BV_OK;
+	if (!last || S.flag_sync) return GF2BV_OK;
 	if (S.ext_events) *handoff = done;
 	else { HIPCHK(hipEventRecord(S.evPrio[b], st)); *handoff = S.evPrio[b]; }
 	return GF2BV_OK;
@@ -659,6 +666,15 @@ bool fast_block_possible(const Solver &S, const BlockGeom &g)
 	return S.fast_blocks && g.gb == GF2_GMAX && (i64)(g.j0 + g.gb) * 64 <= S.cols && S.rows >= GF2_FAST_NC;
 }
 
+// flag hand-over, panel stream: "block b factorised" (its multipliers are complete) -- and, where the look-ahead of block b
+// follows (every block but the last), the wait for the bulk update of block b - 1 that k_prio_window needs
+int panel_handover(Solver &S, int b)
+{
+	k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sA>>>(S.sf, S.st, S.sync_base + b + 1, 0, 0, b + 1 < S.nblocks ? S.sync_base + b : 0, S.ss());
+	HIPCHK(hipGetLastError());
+	return GF2BV_OK;
+}
+
 int enqueue_block_panel(Solver &S, int b, bool fast_only = false)
 {
 	const BlockGeom g = block_geom(S, b);
@@ -668,9 +684,10 @@ int enqueue_block_panel(Solver &S, int b, bool fast_only = false)
 		k_block_fast<<<dim3(1, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, 1, b, (const u64 *)half[0], S.st, S.died,
 		                                                      S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, S.Pfast, S.ss());
 		hipExtLaunchKernelGGL(k_narrow_all, dim3((row_blocks + S.narrow_rpt - 1) / S.narrow_rpt, S.nsys), dim3(256), 0, S.sA, nullptr,
-		                      S.ext_events ? S.evA[b] : nullptr, 0, (const u64 *)S.M, S.rows, S.srows, g.j0, b, (const u64 *)half[0],
+		                      S.ext_events && !S.flag_sync ? S.evA[b] : nullptr, 0, (const u64 *)S.M, S.rows, S.srows, g.j0, b, (const u64 *)half[0],
 		                      (const SolveState *)S.st, (const int *)S.died, (const PanelAux *)S.aux, g.mset, S.impl->T, S.narrow_rpt, S.ss());
 		HIPCHK(hipGetLastError());
+		if (S.flag_sync) return panel_handover(S, b);
 		if (!S.ext_events) HIPCHK(hipEventRecord(S.evA[b], S.sA));
 		return GF2BV_OK;
 	}
@@ -686,7 +703,7 @@ int enqueue_block_panel(Solver &S, int b, bool fast_only = false)
 		const int find_wgs = gf >= 0 ? (S.units + 3) / 4 : 0;
 		const unsigned wgs = (unsigned)find_wgs + (gp >= 0 ? (row_blocks + S.narrow_rpt - 1) / S.narrow_rpt : 0u);
 		// the block's last step carries the hand-off event as its own completion signal (no marker packet)
-		const bool ext = S.ext_events && s == g.gb && b != S.nblocks - 1;
+		const bool ext = S.ext_events && !S.flag_sync && s == g.gb && b != S.nblocks - 1;
 		hipExtLaunchKernelGGL(k_panel_step, dim3(wgs, S.nsys), dim3(256), 0, S.sA, nullptr, ext ? S.evA[b] : nullptr, 0,
 		                      S.M, S.rows, S.srows, g.j0, gp, gf, g.gb, colmask,
 		                      (const u64 *)half[s ? (s - 1) & 1 : 0], half[s & 1], S.st, S.died, S.fu, S.units, find_wgs,
@@ -696,7 +713,8 @@ int enqueue_block_panel(Solver &S, int b, bool fast_only = false)
 	if (b == S.nblocks - 1)
 		k_win_scatter<<<dim3((unsigned)((S.rows * g.gb + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, half[g.gb & 1], S.died, S.st, S.ss());
 	HIPCHK(hipGetLastError());
-	if (!(S.ext_events && b != S.nblocks - 1)) HIPCHK(hipEventRecord(S.evA[b], S.sA));
+	if (S.flag_sync) { int rc = panel_handover(S, b); if (rc) return rc; }
+	else if (!(S.ext_events && b != S.nblocks - 1)) HIPCHK(hipEventRecord(S.evA[b], S.sA));
 	if (S.dbg_sync & 1) HIPCHK(hipDeviceSynchronize());
 	return GF2BV_OK;
 }
@@ -706,7 +724,10 @@ int enqueue_block_panel(Solver &S, int b, bool fast_only = false)
 int enqueue_block_bulk(Solver &S, int b)
 {
 	const BlockGeom g = block_geom(S, b);
-	HIPCHK(hipStreamWaitEvent(S.sB, S.evA[b], 0));
+	if (S.flag_sync) {       // "bulk of blocks < b complete"; wait for block b's multipliers
+		k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sB>>>(S.sf, S.st, 0, S.sync_base + b, S.sync_base + b + 1, 0, S.ss());
+		HIPCHK(hipGetLastError());
+	} else HIPCHK(hipStreamWaitEvent(S.sB, S.evA[b], 0));
 	bool launched = false;
 	if (g.nt_all > 0) {
 		int rc = launch_trsm(S, S.sB, g.j0, g.gb, g.wlo, g.wlo, g.wlo + g.gnext);
@@ -738,7 +759,7 @@ int enqueue_block_bulk(Solver &S, int b)
 		}
 #endif
 	}
-	if (!launched) {
+	if (!launched && !S.flag_sync) {
 		HIPCHK(hipEventRecord(S.evPrio[b], S.sB));      // "bulk of block b complete" (no update launch of this rank carries it)
 		S.waitPrio[b] = S.evPrio[b];
 	}
@@ -752,7 +773,7 @@ int enqueue_block_prio(Solver &S, int b)
 	if (b + 1 >= S.nblocks) return GF2BV_OK;
 	const BlockGeom g = block_geom(S, b);
 	const unsigned row_blocks = (unsigned)((S.rows + 255) / 256);
-	if (b > 0) HIPCHK(hipStreamWaitEvent(S.sA, S.waitPrio[b - 1], 0));
+	if (b > 0 && !S.flag_sync) HIPCHK(hipStreamWaitEvent(S.sA, S.waitPrio[b - 1], 0));     // (flag hand-over: the gate behind block b's panel path has waited)
 	k_prio_window<<<dim3(row_blocks, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, g.wlo, std::max(g.gnext, 1),
 	                                                             S.panels, S.aux, g.mset, S.blk_first + b, S.Wb, S.Uwin,
 	                                                             S.impl->T, S.st, S.ss());
@@ -831,6 +852,7 @@ int enqueue_forward(Solver &S)
 		if (hst.poison) {                               // a block the fast search could not take: resume there, both paths
 			const int pb = hst.poison - 1;
 			HIPCHK(hipMemsetAsync(&S.st->poison, 0, sizeof(int), S.sA));
+			S.sync_base += S.nblocks + 1;
 			for (b = pb; b < S.nblocks; b++) {
 				if ((rc = enqueue_block_panel(S, b))) return rc;
 				if ((rc = enqueue_block_bulk(S, b))) return rc;
@@ -985,6 +1007,7 @@ int finish_end(Solver &S, gf2bv_result **out)
 	HIPCHK(hipStreamSynchronize(S.sB));
 	tr.mark("finish: sync");
 	const SolveState &hst = S.hst;
+	if (hst.gate_timeout) return fail(GF2BV_ERR_HIP, "a stream hand-over gate timed out on the device (a launch on the other stream failed?)");
 	const std::vector<u64> &hout = S.hout;
 	const std::vector<PanelRec> &hp = S.hp;
 	S.hpiv.resize(hst.rank);
@@ -1815,6 +1838,12 @@ int gf2bv_probe_read_gj(unsigned long long *w)
 {
 	HIPCHK(hipDeviceSynchronize());
 	HIPCHK(hipMemcpyFromSymbol(w, HIP_SYMBOL(gf2_probe_gj), sizeof(gf2_probe_gj)));
+	return GF2BV_OK;
+}
+int gf2bv_probe_read_fast(unsigned long long *w)
+{
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpyFromSymbol(w, HIP_SYMBOL(gf2_probe_fast), sizeof(gf2_probe_fast)));
 	return GF2BV_OK;
 }
 int gf2bv_probe_read_wave(unsigned long long *w)
