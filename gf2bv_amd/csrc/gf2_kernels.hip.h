@@ -135,8 +135,10 @@ struct SolveState {
 // on EACH stream -- while a kernel that follows another in the same stream starts 1.4 us after it and sees a flag another
 // stream has written within ~1 us.  So each stream announces its progress in these counters and waits for the other's
 // with a one-wavefront kernel (k_gate) queued where the event wait used to be: the kernels behind it start as soon
-// as it ends, and a single spinning wavefront cannot starve anything.  Not part of SolveState: a column-slab solve imports
-// that from other ranks (and keeps the events: its hand-overs go through the host anyway).
+// as it ends, and a single spinning wavefront cannot starve anything.  Every wait targets a counter written by a launch
+// that was SUBMITTED BEFORE the waiter (as an event wait does): the runtime may map several streams onto one hardware
+// queue, and whatever a waiter spins for must then be ahead of it in every queue.  Not part of SolveState: a column-slab
+// solve imports that from other ranks (and keeps the events: its hand-overs go through the host anyway).
 struct SyncFlags {
 	int narrow_done;     // panel stream: blocks whose multipliers are complete (block b's TRSM / update may start at b + 1)
 	int bulk_done;       // bulk stream: blocks whose bulk update is complete (block b's look-ahead needs b, i.e. block b - 1)

@@ -724,8 +724,9 @@ int enqueue_block_panel(Solver &S, int b, bool fast_only = false)
 int enqueue_block_bulk(Solver &S, int b)
 {
 	const BlockGeom g = block_geom(S, b);
-	if (S.flag_sync) {       // "bulk of blocks < b complete"; wait for block b's multipliers
-		k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sB>>>(S.sf, S.st, 0, S.sync_base + b, S.sync_base + b + 1, 0, S.ss());
+	if (S.flag_sync) {       // wait for block b's multipliers
+		if (S.nsys == 1) HIPCHK(hipStreamWaitValue32(S.sB, &S.sf->narrow_done, (uint32_t)(S.sync_base + b + 1), hipStreamWaitValueGte, 0xffffffffu));
+		else k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sB>>>(S.sf, S.st, 0, 0, S.sync_base + b + 1, 0, S.ss());
 		HIPCHK(hipGetLastError());
 	} else HIPCHK(hipStreamWaitEvent(S.sB, S.evA[b], 0));
 	bool launched = false;
@@ -758,6 +759,10 @@ int enqueue_block_bulk(Solver &S, int b)
 			launched = true;
 		}
 #endif
+	}
+	if (S.flag_sync) {       // "bulk of block b complete" (a launch of its own: the panel stream's gate, submitted later, waits for it)
+		k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sB>>>(S.sf, S.st, 0, S.sync_base + b + 1, 0, 0, S.ss());
+		HIPCHK(hipGetLastError());
 	}
 	if (!launched && !S.flag_sync) {
 		HIPCHK(hipEventRecord(S.evPrio[b], S.sB));      // "bulk of block b complete" (no update launch of this rank carries it)
@@ -853,6 +858,10 @@ int enqueue_forward(Solver &S)
 			const int pb = hst.poison - 1;
 			HIPCHK(hipMemsetAsync(&S.st->poison, 0, sizeof(int), S.sA));
 			S.sync_base += S.nblocks + 1;
+			if (S.flag_sync) {      // the bulk updates of the blocks before pb are complete: what block pb's look-ahead waits for
+				k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sB>>>(S.sf, S.st, 0, S.sync_base + pb, 0, 0, S.ss());
+				HIPCHK(hipGetLastError());
+			}
 			for (b = pb; b < S.nblocks; b++) {
 				if ((rc = enqueue_block_panel(S, b))) return rc;
 				if ((rc = enqueue_block_bulk(S, b))) return rc;

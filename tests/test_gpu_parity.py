@@ -485,6 +485,36 @@ def test_concurrent_solves_from_python_threads():
         assert (origin, basis) == (ref.origin, ref.basis)
 
 
+def test_stream_handover_through_memory_vs_events(monkeypatch):
+    """The two streams of a solve hand over through progress counters in device memory (k_gate / stream memory
+    operations) instead of events: same bits either way, also when a block poisons the optimistic enqueue and the host
+    resumes (rank cap in the middle), and with more concurrent solves than the runtime has hardware queues -- every wait
+    targets work submitted before the waiter, so sharing a queue cannot deadlock (a gate that gave up would surface as an
+    error from the solve)."""
+    from concurrent.futures import ThreadPoolExecutor
+    rng = random.Random(909)
+    jobs = []
+    for rows, cols, cap in ((2700, 2600, None), (5000, 4097, 2600), (2300, 2200, 2193)):
+        eqs = random_system(rng, rows, cols, .5, cap, True, 0)
+        aug = O.eqs_to_aug(eqs, cols)
+        want = O.solve_words(aug, rows, cols, 1)
+        monkeypatch.setenv("GF2BV_FLAG_SYNC", "0")
+        assert_same(hip.solve_words(aug, rows, cols, 1), want, 1)
+        monkeypatch.setenv("GF2BV_FLAG_SYNC", "1")
+        assert_same(hip.solve_words(aug, rows, cols, 1), want, 1)
+        jobs.append((aug, rows, cols, want))
+    monkeypatch.delenv("GF2BV_FLAG_SYNC", raising=False)
+
+    def run(job):
+        aug, rows, cols, _ = job
+        return hip.solve_words(aug, rows, cols, 1)
+
+    with ThreadPoolExecutor(12) as ex:
+        got = list(ex.map(run, jobs * 8))
+    for job, g in zip(jobs * 8, got):
+        assert_same(g, job[3], 1)
+
+
 def test_stream_ceiling_reports_sane_rates():
     c = hip.stream_ceiling(1 << 30)
     assert 1000 < c["rmw_gbs"] < 8000 and 1000 < c["read_gbs"] < 8000

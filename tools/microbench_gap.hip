@@ -33,9 +33,11 @@ int main()
 	const char *names[] = { "same stream, back to back", "K1 carries a completion event (ext launch)", "hipEventRecord between", "wait on a long-complete event between",
 	                        "completion event + wait on old event", "cross-stream: K1 completion event, s2 waits", "cross-stream: hipEventRecord, s2 waits",
 	                        "cross-stream: flag in memory, K2 spins", "K1 carries a TIMING completion event", "cross-stream: wait enqueued, then K1 launched (K2 queue idle)",
-	                        "K1; wait on an event of the other stream that completes while K1 runs; K2", "same, K1 also carries a completion event" };
+	                        "K1; wait on an event of the other stream that completes while K1 runs; K2", "same, K1 also carries a completion event",
+	                        "cross-stream: K1, hipStreamWriteValue32 | hipStreamWaitValue32, K2", "cross-stream: K1, hipStreamWriteValue32 | K2 spins",
+	                        "cross-stream: K1 stores the flag | hipStreamWaitValue32, K2", "same stream: K1, WriteValue32, K2 (cost of the write op)" };
 	for (int wg = 1; wg <= 256; wg *= 256)
-	for (int v = 0; v < 12; v++) {
+	for (int v = 0; v < 16; v++) {
 		std::vector<double> gaps;
 		for (int rep = 0; rep < 25; rep++) {
 			CK(hipMemsetAsync(flag, 0, 4, s1)); CK(hipStreamSynchronize(s1));
@@ -51,6 +53,10 @@ int main()
 			case 8: hipExtLaunchKernelGGL(k1, dim3(wg), dim3(256), 0, s1, nullptr, et, 0, stamp, (int *)nullptr, 30); k2<<<wg, 256, 0, s1>>>(stamp, nullptr); break;
 			case 9: hipExtLaunchKernelGGL(k1, dim3(wg), dim3(256), 0, s1, nullptr, e, 0, stamp, (int *)nullptr, 200); CK(hipStreamWaitEvent(s2, e, 0)); k2<<<wg, 256, 0, s2>>>(stamp, nullptr); break;
 			case 10: hipExtLaunchKernelGGL(k1, dim3(wg), dim3(256), 0, s2, nullptr, e, 0, stamp + 2, (int *)nullptr, 60); k1<<<wg, 256, 0, s1>>>(stamp, nullptr, 300); CK(hipStreamWaitEvent(s1, e, 0)); k2<<<wg, 256, 0, s1>>>(stamp, nullptr); break;
+			case 12: k1<<<wg, 256, 0, s1>>>(stamp, nullptr, 30); CK(hipStreamWriteValue32(s1, flag, 1, 0)); CK(hipStreamWaitValue32(s2, flag, 1, hipStreamWaitValueGte, 0xffffffffu)); k2<<<wg, 256, 0, s2>>>(stamp, nullptr); break;
+			case 13: k1<<<wg, 256, 0, s1>>>(stamp, nullptr, 30); CK(hipStreamWriteValue32(s1, flag, 1, 0)); k2<<<1, 64, 0, s2>>>(stamp, flag); break;
+			case 14: k1<<<wg, 256, 0, s1>>>(stamp, flag, 30); CK(hipStreamWaitValue32(s2, flag, 1, hipStreamWaitValueGte, 0xffffffffu)); k2<<<wg, 256, 0, s2>>>(stamp, nullptr); break;
+			case 15: k1<<<wg, 256, 0, s1>>>(stamp, nullptr, 30); CK(hipStreamWriteValue32(s1, flag, 1, 0)); k2<<<wg, 256, 0, s1>>>(stamp, nullptr); break;
 			case 11: hipExtLaunchKernelGGL(k1, dim3(wg), dim3(256), 0, s2, nullptr, e, 0, stamp + 2, (int *)nullptr, 60); hipExtLaunchKernelGGL(k1, dim3(wg), dim3(256), 0, s1, nullptr, et, 0, stamp, (int *)nullptr, 300); CK(hipStreamWaitEvent(s1, e, 0)); k2<<<wg, 256, 0, s1>>>(stamp, nullptr); break;
 			}
 			CK(hipDeviceSynchronize());
