@@ -381,6 +381,19 @@ k_win_scatter(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, const u6
 // bounded (GF2_GATE_TICKS of the 100 MHz clock; both gates of a block are enqueued before either can matter, so only a
 // launch failure on the other stream can leave one waiting): on expiry the solve is marked void and everything drains.
 #define GF2_GATE_TICKS 1500000000ull      // 15 s
+// A gate is a kernel that waits for a kernel of another stream: it needs the two streams to EXECUTE concurrently.  Counter
+// collection (rocprofv3 --pmc) and some debug settings run one kernel at a time, in which case the waiter would sit on the
+// device for its full time-out.  The host therefore probes once per device (streams_run_concurrently): the waiter is
+// submitted FIRST, the setter to the other stream after it; serialized execution shows as a waiter that gives up after
+// `ticks`, and the solves of this process keep the event hand-over.
+__global__ void k_probe_wait(int *flag, int *result, unsigned long long ticks)
+{
+	const unsigned long long t0 = wall_clock64();
+	int ok = 0;
+	while (!(ok = GF2_LD(flag)) && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(2);
+	*result = ok ? 1 : 2;
+}
+__global__ void k_probe_set(int *flag) { GF2_ST(flag, 1); }
 __global__ void __launch_bounds__(64)
 k_gate(SyncFlags *__restrict__ sf, SolveState *__restrict__ st, int set_narrow, int set_bulk, int need_narrow, int need_bulk,
        SysStride ss)
@@ -390,8 +403,10 @@ k_gate(SyncFlags *__restrict__ sf, SolveState *__restrict__ st, int set_narrow, 
 	if (set_narrow > 0) GF2_ST(&sf->narrow_done, set_narrow);
 	if (set_bulk > 0) GF2_ST(&sf->bulk_done, set_bulk);
 	const unsigned long long t0 = wall_clock64();
+	int polls = 0;
 	while (GF2_LD(&sf->narrow_done) < need_narrow || GF2_LD(&sf->bulk_done) < need_bulk) {
-		__builtin_amdgcn_s_sleep(2);
+		// (a long wait is the stream that is AHEAD waiting for the other one: nothing is lost by polling every ~2 us then)
+		if (++polls < 512) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(64);
 		if (wall_clock64() - t0 > GF2_GATE_TICKS) { GF2_ST(&st->gate_timeout, 1); break; }
 	}
 }

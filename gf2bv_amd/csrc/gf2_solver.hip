@@ -204,6 +204,8 @@ Pool &pool()
 
 // ---- kernel configurations -----------------------------------------------------------------
 // Bulk update: G panels fused per HBM pass, T grease tables per panel (balanced bit-fields).
+int streams_run_concurrently(int device, hipStream_t a, hipStream_t b, int *ok);
+
 struct UpdateImpl {
 	int G, T, lds_bytes, threads;
 	hipError_t (*update)(dim3, hipStream_t, u64 *, i64, i64, int, int, int, const PanelRec *, const PanelAux *,
@@ -529,6 +531,12 @@ int solver_alloc(Solver &S)
 		HIPCHK(pool().stream(&S.sB, S.device, true));
 		S.own_sB = true;
 	}
+	if (S.flag_sync && S.sB != S.sA) {
+		int ok = 0;
+		int rc = streams_run_concurrently(S.device, S.sA, S.sB, &ok);
+		if (rc) return rc;
+		S.flag_sync = ok != 0;
+	}
 	// one arena for all side arrays (a dozen hipMalloc/hipFree pairs cost more than a small solve)
 	{
 		const i64 R = std::max<i64>(1, S.rows), NP = std::max(1, S.npanels);
@@ -565,6 +573,32 @@ int solver_alloc(Solver &S)
 		HIPCHK(pool().event(&S.evA[b], false));
 		HIPCHK(pool().event(&S.evPrio[b], false));
 	}
+	return GF2BV_OK;
+}
+
+// Do kernels of two streams execute at the same time on this device, in this process?  (See k_probe_wait.)  Asked once per
+// device; GF2BV_FLAG_SYNC=0 skips the question and the flag hand-over with it.
+int streams_run_concurrently(int device, hipStream_t a, hipStream_t b, int *ok)
+{
+	static std::mutex mu;
+	static std::map<int, int> known;
+	std::lock_guard<std::mutex> lk(mu);
+	auto it = known.find(device);
+	if (it != known.end()) { *ok = it->second; return GF2BV_OK; }
+	int *d = nullptr;
+	HIPCHK(pool().alloc((void **)&d, 2 * sizeof(int), device));
+	struct Free { int *p; ~Free() { pool().release(p); } } guard{d};
+	HIPCHK(hipMemsetAsync(d, 0, 2 * sizeof(int), a));
+	HIPCHK(hipStreamSynchronize(a));
+	HIPCHK(hipStreamSynchronize(b));
+	k_probe_wait<<<dim3(1), dim3(1), 0, a>>>(d, d + 1, 200000ull);      // 2 ms
+	k_probe_set<<<dim3(1), dim3(1), 0, b>>>(d);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(a));
+	HIPCHK(hipStreamSynchronize(b));
+	int h[2] = { 0, 0 };
+	HIPCHK(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
+	*ok = known[device] = (h[1] == 1);
 	return GF2BV_OK;
 }
 
