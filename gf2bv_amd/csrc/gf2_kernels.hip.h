@@ -380,7 +380,7 @@ k_win_scatter(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, const u6
 // kernel-boundary release / acquire: the producer's counter is written by ITS gate, which runs after them.  The wait is
 // bounded (GF2_GATE_TICKS of the 100 MHz clock; both gates of a block are enqueued before either can matter, so only a
 // launch failure on the other stream can leave one waiting): on expiry the solve is marked void and everything drains.
-#define GF2_GATE_TICKS 1500000000ull      // 15 s
+#define GF2_GATE_TICKS 500000000ull       // 5 s (the longest legitimate wait is one bulk-update pass: ~20 ms at 524288^2)
 // A gate is a kernel that waits for a kernel of another stream: it needs the two streams to EXECUTE concurrently.  Counter
 // collection (rocprofv3 --pmc) and some debug settings run one kernel at a time, in which case the waiter would sit on the
 // device for its full time-out.  The host therefore probes once per device (streams_run_concurrently): the waiter is
@@ -407,7 +407,8 @@ k_gate(SyncFlags *__restrict__ sf, SolveState *__restrict__ st, int set_narrow, 
 	while (GF2_LD(&sf->narrow_done) < need_narrow || GF2_LD(&sf->bulk_done) < need_bulk) {
 		// (a long wait is the stream that is AHEAD waiting for the other one: nothing is lost by polling every ~2 us then)
 		if (++polls < 512) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(64);
-		if (wall_clock64() - t0 > GF2_GATE_TICKS) { GF2_ST(&st->gate_timeout, 1); break; }
+		// (one expired gate voids the solve: the later ones do not wait at all)
+		if (wall_clock64() - t0 > GF2_GATE_TICKS || GF2_LD(&st->gate_timeout)) { GF2_ST(&st->gate_timeout, 1); break; }
 	}
 }
 

@@ -38,12 +38,23 @@ int fail(int code, const char *what, hipError_t e = hipSuccess)
 }
 
 // Nothing may propagate through the C ABI: allocation failures of the host-side containers become GF2BV_ERR_NOMEM.
+// GF2BV_RETRY_EVENTS (internal, never returned through the C ABI): a stream hand-over gate gave up on the device -- kernels
+// of the two streams were not executing concurrently after all (a profiler attached since the probe, say).  The device
+// has been marked accordingly (streams_run_concurrently) and the solve is repeated once, with the event hand-over: the
+// input is never modified.
+#define GF2BV_RETRY_EVENTS (-77)
 template <class F>
 int guarded(F &&body)
 {
-	try { return body(); }
-	catch (const std::bad_alloc &) { return fail(GF2BV_ERR_NOMEM, "out of host memory"); }
-	catch (const std::exception &e) { return fail(GF2BV_ERR_HIP, e.what()); }
+	for (int attempt = 0;; attempt++) {
+		try {
+			const int rc = body();
+			if (rc != GF2BV_RETRY_EVENTS) return rc;
+			if (attempt) return fail(GF2BV_ERR_HIP, "a stream hand-over gate timed out on the device");
+		}
+		catch (const std::bad_alloc &) { return fail(GF2BV_ERR_NOMEM, "out of host memory"); }
+		catch (const std::exception &e) { return fail(GF2BV_ERR_HIP, e.what()); }
+	}
 }
 
 #define HIPCHK(call)                                                     \
@@ -205,6 +216,7 @@ Pool &pool()
 // ---- kernel configurations -----------------------------------------------------------------
 // Bulk update: G panels fused per HBM pass, T grease tables per panel (balanced bit-fields).
 int streams_run_concurrently(int device, hipStream_t a, hipStream_t b, int *ok);
+void forget_concurrency(int device);
 
 struct UpdateImpl {
 	int G, T, lds_bytes, threads;
@@ -578,13 +590,23 @@ int solver_alloc(Solver &S)
 
 // Do kernels of two streams execute at the same time on this device, in this process?  (See k_probe_wait.)  Asked once per
 // device; GF2BV_FLAG_SYNC=0 skips the question and the flag hand-over with it.
+struct ConcurrencyCache { std::mutex mu; std::map<int, int> known; };
+ConcurrencyCache &concurrency_cache() { static ConcurrencyCache c; return c; }
+void forget_concurrency(int device)       // a gate timed out although the probe had passed: events from now on
+{
+	ConcurrencyCache &c = concurrency_cache();
+	std::lock_guard<std::mutex> lk(c.mu);
+	c.known[device] = 0;
+}
 int streams_run_concurrently(int device, hipStream_t a, hipStream_t b, int *ok)
 {
-	static std::mutex mu;
-	static std::map<int, int> known;
+	std::mutex &mu = concurrency_cache().mu;
+	std::map<int, int> &known = concurrency_cache().known;
 	std::lock_guard<std::mutex> lk(mu);
 	auto it = known.find(device);
 	if (it != known.end()) { *ok = it->second; return GF2BV_OK; }
+	// (GF2BV_FLAG_SYNC=2: take concurrency for granted until a gate times out -- exercises the time-out / retry path)
+	if (getenv("GF2BV_FLAG_SYNC") && atoi(getenv("GF2BV_FLAG_SYNC")) == 2) { *ok = 1; return GF2BV_OK; }
 	int *d = nullptr;
 	HIPCHK(pool().alloc((void **)&d, 2 * sizeof(int), device));
 	struct Free { int *p; ~Free() { pool().release(p); } } guard{d};
@@ -759,8 +781,9 @@ int enqueue_block_bulk(Solver &S, int b)
 {
 	const BlockGeom g = block_geom(S, b);
 	if (S.flag_sync) {       // wait for block b's multipliers
-		if (S.nsys == 1) HIPCHK(hipStreamWaitValue32(S.sB, &S.sf->narrow_done, (uint32_t)(S.sync_base + b + 1), hipStreamWaitValueGte, 0xffffffffu));
-		else k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sB>>>(S.sf, S.st, 0, 0, S.sync_base + b + 1, 0, S.ss());
+		// (a gate, not hipStreamWaitValue32: that is a polling kernel as well on this runtime -- __amd_rocclr_streamOpsWait --
+		// but one without a time-out)
+		k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sB>>>(S.sf, S.st, 0, 0, S.sync_base + b + 1, 0, S.ss());
 		HIPCHK(hipGetLastError());
 	} else HIPCHK(hipStreamWaitEvent(S.sB, S.evA[b], 0));
 	bool launched = false;
@@ -1050,7 +1073,11 @@ int finish_end(Solver &S, gf2bv_result **out)
 	HIPCHK(hipStreamSynchronize(S.sB));
 	tr.mark("finish: sync");
 	const SolveState &hst = S.hst;
-	if (hst.gate_timeout) return fail(GF2BV_ERR_HIP, "a stream hand-over gate timed out on the device (a launch on the other stream failed?)");
+	if (hst.gate_timeout) {
+		if (!S.flag_sync) return fail(GF2BV_ERR_HIP, "a stream hand-over gate timed out on the device");
+		forget_concurrency(S.device);
+		return GF2BV_RETRY_EVENTS;
+	}
 	const std::vector<u64> &hout = S.hout;
 	const std::vector<PanelRec> &hp = S.hp;
 	S.hpiv.resize(hst.rank);
