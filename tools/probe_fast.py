@@ -18,7 +18,8 @@ blocks = [int(a) for a in args[1:]] or [8, n // 512, n // 256 - 16]
 lib = hip.lib(); stride = hip.padded_stride(n)
 buf = hip.DeviceBuffer(n * stride * 8)
 hip.synth_device(buf.ptr, n, n, stride, 1234); hip.solve_device(buf.ptr, n, n, stride, 0)
-names = ["entry", "candidates in LDS"] + [f"panel {g}: {x}" for g in range(4) for x in ("search done", "pivot rows formed", "candidates narrowed")] + ["published"]
+names = (["entry", "candidates in LDS"] + [f"panel {g}: {x}" for g in range(4) for x in ("search done", "pivot rows formed", "candidates narrowed")]
+         + ["published", "chain tail: inputs ready", "handed over", "end: before the release", "after"])
 for b in blocks:
     assert lib.gf2bv_probe_set(ctypes.c_int(b * 4)) == 0
     hip.solve_device(buf.ptr, n, n, stride, 0)
