@@ -142,37 +142,7 @@ struct SolveState {
 struct SyncFlags {
 	int narrow_done;     // panel stream: blocks whose multipliers are complete (block b's TRSM / update may start at b + 1)
 	int bulk_done;       // bulk stream: blocks whose bulk update is complete (block b's look-ahead needs b, i.e. block b - 1)
-	int chain_done;      // search chain (ChainArgs): blocks whose k_block_fast launch has ENDED
-	int win_done;        // panel stream: blocks whose look-ahead (k_prio_window) is complete for ALL rows
-	unsigned cnt_narrow, cnt_win;     // workgroups of the producing launch that have finished (signal_light)
 };
-
-// Search chain (dense systems, optimistic enqueue, the panel-bound part of a solve).  The panel path of a block is
-// k_block_fast -> narrow step of all rows -> look-ahead of all rows (k_prio_window), and the next block's search needs the
-// look-ahead's result for ~320 rows only.  In a chain the searches run back to back on a stream of their own:
-// k_block_fast(b) ends by carrying ITS OWN successors forward -- the 64 candidates it leaves over plus the next 256 alive
-// rows get block b's update on the window of block b + 1 (narrow step, 4-word TRSM and look-ahead on those rows, in
-// registers and LDS) -- and hands them to k_block_fast(b + 1) in a small buffer, while the full-width narrow step and
-// look-ahead of block b run beside block b + 1's search on the panel stream.  The tail must not need the bulk update of
-// block b - 1 (that update cannot even start before the narrow step of block b - 1, i.e. before this very launch): the
-// blocks around a chain run a look-ahead of depth TWO -- k_prio_window(b - 1) applies block b - 1 to the window of block b
-// (into the window buffer, as always) AND to the window of block b + 1 (in place), and the bulk update of block b - 1 leaves
-// both alone.  What the tail waits for (in the kernel, read with coherent loads): win_done -- the look-ahead of block
-// b - 1 is complete for all rows --, and before publishing narrow_done -- the narrow step of block b - 1 has read the alive
-// marks and fast_done.
-struct ChainArgs {
-	const int *in_rows;  // candidates handed over by the previous block's search: [GF2_FAST_NC] rows, [GF2_FAST_NC] = count
-	const u64 *in_words; // ... their window words, [GF2_FAST_NC][GF2_GMAX]
-	int *out_rows;       // the same for the next block (nullptr: no successor in the chain)
-	u64 *out_words;
-	SyncFlags *sf;       // nullptr: not a chain launch
-	int base;            // counters count from here (see Solver::sync_base)
-	int gnext;           // panels (words) of the next block's window
-};
-// A producing launch whose OUTPUT is written with write-through stores (GF2_ST) announces its own end: every workgroup waits
-// for its stores and counts itself in, the last one sets the flag -- no L2 write-back (an agent-scope release fence per
-// workgroup was measured: it writes back what the concurrent bulk update has dirtied, 32768^2 9.0 -> 11.1 ms).
-struct DoneSignal { unsigned *count; int *flag; int value; };
 
 // Scratch of one search unit (wavefront).
 struct FindUnit {
@@ -426,7 +396,7 @@ __global__ void k_probe_wait(int *flag, int *result, unsigned long long ticks)
 __global__ void k_probe_set(int *flag) { GF2_ST(flag, 1); }
 __global__ void __launch_bounds__(64)
 k_gate(SyncFlags *__restrict__ sf, SolveState *__restrict__ st, int set_narrow, int set_bulk, int need_narrow, int need_bulk,
-       int need_chain, SysStride ss)
+       SysStride ss)
 {
 	sf = sys_at(sf, blockIdx.y * ss.arena_bytes); st = sys_at(st, blockIdx.y * ss.arena_bytes);
 	if (threadIdx.x != 0) return;
@@ -434,40 +404,12 @@ k_gate(SyncFlags *__restrict__ sf, SolveState *__restrict__ st, int set_narrow, 
 	if (set_bulk > 0) GF2_ST(&sf->bulk_done, set_bulk);
 	const unsigned long long t0 = wall_clock64();
 	int polls = 0;
-	while (GF2_LD(&sf->narrow_done) < need_narrow || GF2_LD(&sf->bulk_done) < need_bulk || GF2_LD(&sf->chain_done) < need_chain) {
+	while (GF2_LD(&sf->narrow_done) < need_narrow || GF2_LD(&sf->bulk_done) < need_bulk) {
 		// (a long wait is the stream that is AHEAD waiting for the other one: nothing is lost by polling every ~2 us then)
 		if (++polls < 512) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(64);
 		// (one expired gate voids the solve: the later ones do not wait at all)
 		if (wall_clock64() - t0 > GF2_GATE_TICKS || GF2_LD(&st->gate_timeout)) { GF2_ST(&st->gate_timeout, 1); break; }
 	}
-}
-// ... the same wait inside a kernel (k_block_fast in a chain): thread 0 waits, the workgroup follows
-__device__ __forceinline__ void wait_flags(const SyncFlags *sf, SolveState *st, int need_narrow, int need_win)
-{
-	if (threadIdx.x == 0) {
-		const unsigned long long t0 = wall_clock64();
-		while (GF2_LD(&sf->narrow_done) < need_narrow || GF2_LD(&sf->win_done) < need_win) {
-			__builtin_amdgcn_s_sleep(1);
-			if (wall_clock64() - t0 > GF2_GATE_TICKS || GF2_LD(&st->gate_timeout)) { GF2_ST(&st->gate_timeout, 1); break; }
-		}
-	}
-	__syncthreads();
-}
-__device__ __forceinline__ void signal_light(DoneSignal sig, i64 arena_off, unsigned total_wgs)      // by ALL threads, at the very end
-{
-	if (!sig.count) return;                                 // (uniform)
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the write-through stores of this workgroup have landed
-	__syncthreads();
-	if (threadIdx.x == 0) {
-		unsigned *cnt = sys_at(sig.count, arena_off);
-		const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		if (old + 1 == total_wgs) { GF2_ST(cnt, 0u); GF2_ST(sys_at(sig.flag, arena_off), sig.value); }
-	}
-}
-__device__ __forceinline__ bool poisoned(const SolveState *st, int blk)     // this block's panel work is void: the host will redo it
-{
-	const int p = st->poison;
-	return p && blk >= p - 1;
 }
 
 // -DGF2_STEP_PROBE (tools/probe_step.py builds a separate library with it): wall-clock (100 MHz) timestamps of
@@ -1155,7 +1097,7 @@ __device__ __forceinline__ void build_nibble_tables(StepLds &L, int t)
 __device__ __forceinline__ void narrow_all_panels(StepLds &L, const u64 *__restrict__ M, i64 rows, i64 srows, int j0,
                                                   const u64 *__restrict__ Wb_in, const int *__restrict__ died,
                                                   const PanelAux *__restrict__ aux, u64 *__restrict__ multset, int upd_T,
-                                                  i64 rb, int rpt, bool wt = false)
+                                                  i64 rb, int rpt)
 {
 	__shared__ u64 Pall[GF2_GMAX - 1][GF2_GMAX][64];        // [panel][word][pivot bit]
 	const int t = threadIdx.x, e_ = t >> 6, sl = t & 63;
@@ -1189,27 +1131,25 @@ __device__ __forceinline__ void narrow_all_panels(StepLds &L, const u64 *__restr
 		}
 		if (i < rows) {
 #pragma unroll
-			for (int g = 0; g < GF2_GMAX; g++) {
-				const u64 v = mult_stored(upd_T, m[g], i);
-				if (wt) GF2_ST(&multset[midx(g, i, rows)], v);      // (the launch announces its own end: signal_light)
-				else multset[midx(g, i, rows)] = v;
-			}
+			for (int g = 0; g < GF2_GMAX; g++) multset[midx(g, i, rows)] = mult_stored(upd_T, m[g], i);
 		}
 	}
 }
 
-__device__ __forceinline__ void
-block_fast_body(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_only, int blk,
-                const u64 *__restrict__ Wb_in, SolveState *__restrict__ st, int *__restrict__ died,
-                PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol, int *__restrict__ urow,
-                int *__restrict__ blk_first_out, ChainArgs chain, SysStride ss)
+__global__ void __launch_bounds__(256)
+k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_only, int blk,
+             const u64 *__restrict__ Wb_in, SolveState *__restrict__ st, int *__restrict__ died,
+             PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol, int *__restrict__ urow,
+             int *__restrict__ blk_first_out, u64 *__restrict__ Pfast, SysStride ss)
 {
+	__builtin_amdgcn_s_setprio(3);
 	{
 		const i64 ao = blockIdx.y * ss.arena_bytes;
 		M += blockIdx.y * ss.m_words;
 		Wb_in = sys_at(Wb_in, ao); st = sys_at(st, ao); died = sys_at(died, ao); panels = sys_at(panels, ao);
 		aux = sys_at(aux, ao); pivcol = sys_at(pivcol, ao); urow = sys_at(urow, ao); blk_first_out = sys_at(blk_first_out, ao);
-	}       // (a chain is one system: no per-system offsets on its buffers)
+		(void)Pfast;                                        // (scratch of an earlier version: the pivot rows' words stay in registers)
+	}
 	__shared__ StepLds L;
 	__shared__ u64 cw[GF2_FAST_NC * GF2_GMAX];          // candidates' window words; word g becomes the multiplier once panel g is through
 	__shared__ unsigned char used[GF2_FAST_NC];         // dead on entry, or a source of an earlier panel
@@ -1218,8 +1158,6 @@ block_fast_body(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fa
 	__shared__ int ok;
 	__shared__ int crow[GF2_FAST_NC];                   // candidate -> row: the first GF2_FAST_NC ALIVE rows from the bound on
 	__shared__ int wcnt[4];
-	__shared__ int lo_idx[64];                          // chain: the candidates this block leaves over
-	__shared__ int nx_row[GF2_FAST_NC];                 // chain: the next block's candidates
 	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
 	const int first = st->first, r0 = st->rank;
 #ifdef GF2_STEP_PROBE
@@ -1241,18 +1179,6 @@ block_fast_body(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fa
 	// window words (whether or not they turn out to be candidates): one memory round trip for the first two rounds,
 	// which nearly always suffice (256 rows fall to a block, ~64 of its candidates are left over).
 	int have_c = 0;
-	if (chain.in_rows) {                                    // (uniform) handed over by the previous block's search
-		have_c = chain.in_rows[GF2_FAST_NC];
-		if (have_c >= GF2_FAST_NC)
-			for (int c = t; c < GF2_FAST_NC; c += 256) {
-				crow[c] = chain.in_rows[c];
-				const uint4 *src = reinterpret_cast<const uint4 *>(chain.in_words + (i64)c * GF2_GMAX);
-				const uint4 lo = src[0], hi = src[1];
-				cw[c * 4 + 0] = ((u64)lo.y << 32) | lo.x; cw[c * 4 + 1] = ((u64)lo.w << 32) | lo.z;
-				cw[c * 4 + 2] = ((u64)hi.y << 32) | hi.x; cw[c * 4 + 3] = ((u64)hi.w << 32) | hi.z;
-				used[c] = 0;
-			}
-	}
 	auto fetch = [&](int round, int &d, uint4 &lo, uint4 &hi, i64 &i) {
 		i = (i64)first + round * 256 + t;
 		const i64 ic = i < rows ? i : rows - 1;
@@ -1260,12 +1186,10 @@ block_fast_body(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fa
 		const uint4 *src = reinterpret_cast<const uint4 *>(Wb_in + ic * GF2_GMAX);
 		lo = src[0]; hi = src[1];
 	};
-	int dA = 0, dB = 0; uint4 loA = {}, hiA = {}, loB = {}, hiB = {}; i64 iA = 0, iB = 0;
-	if (!chain.in_rows) {
-		fetch(0, dA, loA, hiA, iA);
-		fetch(1, dB, loB, hiB, iB);
-	}
-	for (int round = 0; round < 8 && have_c < GF2_FAST_NC && !chain.in_rows; round++) {
+	int dA, dB; uint4 loA, hiA, loB, hiB; i64 iA, iB;
+	fetch(0, dA, loA, hiA, iA);
+	fetch(1, dB, loB, hiB, iB);
+	for (int round = 0; round < 8 && have_c < GF2_FAST_NC; round++) {
 		if (round >= 2) fetch(round, dA, loA, hiA, iA);
 		const int d = round == 1 ? dB : dA;
 		const uint4 lo = round == 1 ? loB : loA, hi = round == 1 ? hiB : hiA;
@@ -1362,8 +1286,6 @@ block_fast_body(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fa
 		GF2_PROBE_FAST(4 + 3 * g);
 	}
 	// ---- every panel is complete: publish the block ----
-	// (chain: the narrow step of the block before runs beside this launch and reads the alive marks and fast_done)
-	if (chain.sf) wait_flags(chain.sf, st, chain.base + blk, 0);
 	int nf = GF2_FAST_NC - 1;                               // first candidate that is still alive
 	if (wv == 0) {
 		for (int ch = GF2_FAST_CH - 1; ch >= 0; ch--) {
@@ -1399,179 +1321,6 @@ block_fast_body(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fa
 		st->fast_blocks++;
 	}
 	GF2_PROBE_FAST(14);
-	if (!chain.out_rows) return;                            // (uniform)
-	// ---- chain: carry the next block's candidates forward -- the GF2_FAST_NC - 256 candidates left over here, then the
-	// next alive rows -- through this block's update on the window of block blk + 1 ----
-	constexpr int NLO = GF2_FAST_NC - 64 * GF2_GMAX;       // leftovers: exactly this many (every panel took 64 sources)
-	static_assert(NLO == 64 && GF2_GMAX == 4, "thread <-> item mappings of the chain tail");
-	__syncthreads();
-	if (wv == 0) {
-		int before = 0;
-		for (int ch = 0; ch < GF2_FAST_CH; ch++) {
-			const bool free_ = !used[64 * ch + lane];
-			const u64 bal = __ballot(free_);
-			if (free_) lo_idx[before + __popcll(bal & lanemask_lt(lane))] = 64 * ch + lane;
-			before += __popcll(bal);
-		}
-	}
-	__syncthreads();
-	// what the tail needs of the candidates' words, into registers (cw becomes scratch): TRSM item = (slot r, window word w)
-	const int r = t >> 2, w = t & 3;
-	const int wlo = j0 + GF2_GMAX;
-	const bool live = w < chain.gnext;
-	u64 smul[GF2_GMAX][GF2_GMAX], comb[GF2_GMAX], lm[GF2_GMAX] = { 0, 0, 0, 0 };
-	int srow[GF2_GMAX];
-#pragma unroll
-	for (int g = 0; g < GF2_GMAX; g++) {
-		const int sc = srcs[g][r];
-		srow[g] = crow[sc];
-		comb[g] = combs[g][r];
-#pragma unroll
-		for (int e = 0; e < GF2_GMAX; e++) smul[g][e] = (e < g) ? cw[sc * 4 + e] : 0ull;
-	}
-	const int lrow = crow[lo_idx[t & 63]];                  // threads 0..63 own the leftovers
-	if (t < NLO) {
-#pragma unroll
-		for (int e = 0; e < GF2_GMAX; e++) lm[e] = cw[lo_idx[t] * 4 + e];
-	}
-	const int after = crow[GF2_FAST_NC - 1] + 1;            // the rows behind the last candidate have never been candidates
-	// input of the panel stream: the look-ahead of block blk - 1 for ALL rows -- this block's window in the window buffer and
-	// (depth two) the next block's window in the matrix
-	wait_flags(chain.sf, st, 0, chain.base + blk);
-	GF2_PROBE_FAST(15);
-	auto ld = [](const u64 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-	// the next 256 alive rows: marks + window words (coherent loads), compacted through cw
-	int have_n = 0;
-	for (int round = 0; round < 8 && have_n < 256; round++) {
-		const i64 i = (i64)after + round * 256 + t;
-		const i64 ic = i < rows ? i : rows - 1;
-		const int d = died[ic];
-		u64 x[GF2_GMAX];
-#pragma unroll
-		for (int e = 0; e < GF2_GMAX; e++) x[e] = ld(Wb_in + ic * GF2_GMAX + e);
-		const bool alive = i < rows && d == GF2_NEVER;
-		const u64 bal = __ballot(alive);
-		if (lane == 0) wcnt[wv] = __popcll(bal);
-		__syncthreads();
-		int before = have_n, total = 0;
-#pragma unroll
-		for (int q = 0; q < 4; q++) { if (q < wv) before += wcnt[q]; total += wcnt[q]; }
-		const int c = before + __popcll(bal & lanemask_lt(lane));
-		if (alive && c < 256) {
-			nx_row[NLO + c] = (int)i;
-#pragma unroll
-			for (int e = 0; e < GF2_GMAX; e++) cw[c * 4 + e] = x[e];
-		}
-		have_n += total;
-		__syncthreads();
-	}
-	if (have_n < 256) {                                     // (uniform) too few rows left: the next search gives up
-		if (t == 0) chain.out_rows[GF2_FAST_NC] = 0;
-		return;
-	}
-	const int nrow = nx_row[NLO + t];
-	u64 nm[GF2_GMAX];                                       // the new row's window words -> its multipliers
-#pragma unroll
-	for (int e = 0; e < GF2_GMAX; e++) nm[e] = cw[t * 4 + e];
-	// window words of block blk + 1: the sources' (TRSM items), the new rows', the leftovers'
-	u64 sv[GF2_GMAX], nv[GF2_GMAX], lv[GF2_GMAX];
-#pragma unroll
-	for (int g = 0; g < GF2_GMAX; g++) sv[g] = ld(M + tidx(srow[g], wlo + (live ? w : 0), srows));
-#pragma unroll
-	for (int e = 0; e < GF2_GMAX; e++) nv[e] = ld(M + tidx(nrow, wlo + (e < chain.gnext ? e : 0), srows));
-#pragma unroll
-	for (int e = 0; e < GF2_GMAX; e++) lv[e] = ld(M + tidx(lrow, wlo + (e < chain.gnext ? e : 0), srows));
-	// narrow the new rows (the candidates went through this inside the panel loop)
-#pragma unroll
-	for (int g = 0; g < GF2_GMAX - 1; g++) {
-		__syncthreads();
-		L.Pb[e_][sl] = (e_ > g) ? Pk[g] : 0ull;
-		__syncthreads();
-		build_nibble_tables(L, t);
-		__syncthreads();
-		if (nm[g]) {
-			u64 a4[GF2_GMAX];
-			nibble_rows(L.Tn, nm[g], a4);
-#pragma unroll
-			for (int e = 0; e < GF2_GMAX; e++) if (e > g) nm[e] ^= a4[e];
-		}
-	}
-	__syncthreads();
-	// the look-ahead on these rows (k_prio_window's method): S = the sources' words [panel][slot][word] in cw's space
-	u64 *const S = cw;
-#pragma unroll
-	for (int g = 0; g < GF2_GMAX; g++) S[(g * 64 + r) * GF2_GMAX + w] = live ? sv[g] : 0ull;
-	__syncthreads();
-	auto build_tables = [&](const u64 *rows64) {
-		const int n = t >> 4, v = t & 15;
-		u64 a[GF2_GMAX] = { 0, 0, 0, 0 };
-#pragma unroll
-		for (int k = 0; k < 4; k++) {
-			const u64 on = ((v >> k) & 1) ? ~0ull : 0ull;
-#pragma unroll
-			for (int e = 0; e < GF2_GMAX; e++) a[e] ^= rows64[(4 * n + k) * GF2_GMAX + e] & on;
-		}
-#pragma unroll
-		for (int e = 0; e < GF2_GMAX; e++) L.Tn[(n * 16 + v) * GF2_GMAX + e] = a[e];
-	};
-#pragma unroll
-	for (int g = 0; g < GF2_GMAX; g++) {
-		build_tables(&S[g * 64 * GF2_GMAX]);
-		__syncthreads();
-		const u64 acc = nibble_word(L.Tn, comb[g], w);      // pivot r of the panel = its combination of the sources
-		S[(g * 64 + r) * GF2_GMAX + w] = acc;                // (full panels: pivot k sits at bit k)
-		__syncthreads();
-		build_tables(&S[g * 64 * GF2_GMAX]);                // serves the later panels' sources and the rows
-		__syncthreads();
-#pragma unroll
-		for (int h = g + 1; h < GF2_GMAX; h++) S[(h * 64 + r) * GF2_GMAX + w] ^= nibble_word(L.Tn, smul[h][g], w);
-		if (nm[g]) {
-			u64 a4[GF2_GMAX];
-			nibble_rows(L.Tn, nm[g], a4);
-#pragma unroll
-			for (int e = 0; e < GF2_GMAX; e++) nv[e] ^= a4[e];
-		}
-		if (t < NLO && lm[g]) {
-			u64 a4[GF2_GMAX];
-			nibble_rows(L.Tn, lm[g], a4);
-#pragma unroll
-			for (int e = 0; e < GF2_GMAX; e++) lv[e] ^= a4[e];
-		}
-		__syncthreads();
-	}
-	// hand over: leftovers first (they precede the new rows in the matrix), words beyond the window are zero
-#pragma unroll
-	for (int e = 0; e < GF2_GMAX; e++) {
-		chain.out_words[(i64)(NLO + t) * GF2_GMAX + e] = e < chain.gnext ? nv[e] : 0ull;
-		if (t < NLO) chain.out_words[(i64)t * GF2_GMAX + e] = e < chain.gnext ? lv[e] : 0ull;
-	}
-	chain.out_rows[NLO + t] = nrow;
-	if (t < NLO) chain.out_rows[t] = lrow;
-	if (t == 0) chain.out_rows[GF2_FAST_NC] = GF2_FAST_NC;
-	GF2_PROBE_FAST(16);
-}
-__global__ void __launch_bounds__(256)
-k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_only, int blk,
-             const u64 *__restrict__ Wb_in, SolveState *__restrict__ st, int *__restrict__ died,
-             PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol, int *__restrict__ urow,
-             int *__restrict__ blk_first_out, ChainArgs chain, SysStride ss)
-{
-	__builtin_amdgcn_s_setprio(3);
-	block_fast_body(M, rows, srows, j0, gb, fast_only, blk, Wb_in, st, died, panels, aux, pivcol, urow, blk_first_out, chain, ss);
-	if (chain.sf) {       // this launch has ended (whichever way): what it published is released, the narrow step of the block may start
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__syncthreads();
-		if (threadIdx.x == 0) {
-#ifdef GF2_STEP_PROBE
-			if (j0 == gf2_probe_j0) gf2_probe_fast[17] = wall_clock64();
-#endif
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-			GF2_ST(&chain.sf->chain_done, chain.base + blk + 1);
-#ifdef GF2_STEP_PROBE
-			if (j0 == gf2_probe_j0) gf2_probe_fast[18] = wall_clock64();
-#endif
-		}
-	}
 }
 
 // The narrow halves of a block that k_block_fast has factorised, as a launch of its own (optimistic enqueue: no
@@ -1579,7 +1328,7 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_
 __global__ void __launch_bounds__(256)
 k_narrow_all(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int blk, const u64 *__restrict__ Wb_in,
              const SolveState *__restrict__ st, const int *__restrict__ died, const PanelAux *__restrict__ aux,
-             u64 *__restrict__ multset, int upd_T, int rpt, DoneSignal sig, SysStride ss)
+             u64 *__restrict__ multset, int upd_T, int rpt, SysStride ss)
 {
 	__builtin_amdgcn_s_setprio(3);
 	{
@@ -1587,12 +1336,9 @@ k_narrow_all(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int blk, co
 		M += blockIdx.y * ss.m_words;
 		Wb_in = sys_at(Wb_in, ao); st = sys_at(st, ao); died = sys_at(died, ao); aux = sys_at(aux, ao); multset = sys_at(multset, ao);
 	}
-	// (in a search chain the NEXT block's search runs beside this launch: it may have given up already -- this block is still
-	// good: poisoned() -- but it does not publish, i.e. move fast_done on, before this launch has announced its end)
+	if (st->poison || st->fast_done != blk + 1) return;
 	__shared__ StepLds L;
-	if (!(poisoned(st, blk) || st->fast_done != blk + 1))
-		narrow_all_panels(L, M, rows, srows, j0, Wb_in, died, aux, multset, upd_T, (i64)blockIdx.x, rpt, sig.count != nullptr);
-	signal_light(sig, blockIdx.y * ss.arena_bytes, gridDim.x);
+	narrow_all_panels(L, M, rows, srows, j0, Wb_in, died, aux, multset, upd_T, (i64)blockIdx.x, rpt);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1791,13 +1537,14 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 // stream owns them.  The block's pivot rows' share of them (part of U, needed by the back-substitution)
 // cannot be stored in place -- every workgroup here is still reading the source rows -- so workgroup 0
 // parks it in Uwin[pivot index][word] and k_unwind moves it into the matrix after the elimination.
-__device__ __forceinline__ void
-prio_window_body(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo, int gnext, int gnext2,
-                 const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
-                 const u64 *__restrict__ multset, const int *__restrict__ blk_first, u64 *__restrict__ Wb_out,
-                 u64 *__restrict__ Uwin, int upd_T, const SolveState *__restrict__ st, int blk, bool wt, SysStride ss)
+__global__ void __launch_bounds__(256)
+k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo, int gnext,
+              const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
+              const u64 *__restrict__ multset, const int *__restrict__ blk_first, u64 *__restrict__ Wb_out,
+              u64 *__restrict__ Uwin, int upd_T, const SolveState *__restrict__ st, SysStride ss)
 {
-	if (poisoned(sys_at(st, blockIdx.y * ss.arena_bytes), blk)) return;     // (the window buffer must stay what the resumed block needs)
+	__builtin_amdgcn_s_setprio(3);
+	if (sys_at(st, blockIdx.y * ss.arena_bytes)->poison) return;     // (the window buffer must stay what the resumed block needs)
 	{
 		const i64 ao = blockIdx.y * ss.arena_bytes;
 		M += blockIdx.y * ss.m_words;
@@ -1808,17 +1555,18 @@ prio_window_body(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int w
 	static_assert(W == 4, "thread <-> table entry mapping below");
 	// [panel][slot][word] source rows; once panel g's tables are built its slice is dead and takes the pivot rows
 	// BY BIT position ([panel][pivot bit][word], zero where the panel has no pivot) -- 17 KiB in all, so that a
-	// workgroup fits next to a bulk-update workgroup
+	// workgroup fits next to a bulk-update workgroup (160 KiB - 145 KiB of LDS)
 	__shared__ u64 S[GF2_GMAX * 64 * W];
 	u64 *const Pbit = S;
 	__shared__ u64 Tn[16 * 16 * W];            // nibble tables of 64 rows (see k_block_trsm)
 	__shared__ int Bk[GF2_GMAX * 64];          // [panel][pivot k] -> pivot bit
 	const int t = threadIdx.x;
 	const int r = t / W, w = t % W;            // TRSM item: (slot / pivot r, window word w)
+	const bool live = w < gnext;
 	const i64 first = *blk_first;
 	const i64 i = (i64)blockIdx.x * 256 + t;   // row of this thread
 	const i64 ic = i < rows ? i : rows - 1;
-	// trip 1: all parameters, this row's multipliers; trip 2 (per window): the source rows' and this row's window words
+	// trip 1: all parameters, this row's multipliers; trip 2: the source rows' and this row's window words
 	PanelRec rec[GF2_GMAX];
 	int srow[GF2_GMAX];
 	u64 comb[GF2_GMAX], smul[GF2_GMAX][GF2_GMAX], mrow[GF2_GMAX];
@@ -1833,6 +1581,9 @@ prio_window_body(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int w
 		mrow[g] = multset[midx(gc, ic, rows)];
 		if (g >= gb) { rec[g].p = 0; rec[g].mask = 0; mrow[g] = 0; }
 	}
+	u64 wv[W];
+#pragma unroll
+	for (int e = 0; e < W; e++) wv[e] = M[tidx(ic, wlo + (e < gnext ? e : 0), srows)];
 	// every row of this workgroup is dead (uniform); workgroup 0 still runs: it records the pivot rows' window words
 	if (blockIdx.x != 0 && (i64)(blockIdx.x + 1) * 256 <= first) return;
 	int anyp = 0;
@@ -1840,91 +1591,54 @@ prio_window_body(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int w
 	for (int g = 0; g < GF2_GMAX; g++) anyp |= rec[g].p;
 	if (anyp) {
 #pragma unroll
-		for (int g = 0; g < GF2_GMAX; g++)
+		for (int g = 0; g < GF2_GMAX; g++) {
+			const u64 v = M[tidx(r < rec[g].p ? srow[g] : 0, wlo + (live ? w : 0), srows)];
+			S[(g * 64 + r) * W + w] = (r < rec[g].p && live) ? v : 0ull;
 			if (w == 0 && ((rec[g].mask >> r) & 1)) Bk[g * 64 + __popcll(rec[g].mask & lanemask_lt(r))] = r;
-	}
-	const u64 anym = mrow[0] | mrow[1] | mrow[2] | mrow[3];
-	// part 0: the next block's window, matrix -> window buffer.  part 1 (look-ahead of depth two, see ChainArgs): the window
-	// after it, in place -- the bulk update of this block leaves both alone.
-	for (int part = 0; part < 2; part++) {
-		const int gn = part ? gnext2 : gnext;
-		if (gn <= 0) break;                                 // (uniform)
-		const int wl = part ? wlo + gnext : wlo;
-		const bool live = w < gn;
-		u64 wv[W];
+		}
+		__syncthreads();
+		auto build_tables = [&](const u64 *rows64) {
+			const int n = t >> 4, v = t & 15;
+			u64 a[W] = { 0, 0, 0, 0 };
 #pragma unroll
-		for (int e = 0; e < W; e++) wv[e] = M[tidx(ic, wl + (e < gn ? e : 0), srows)];
-		if (anyp) {
-			u64 sv[GF2_GMAX];
+			for (int k = 0; k < 4; k++) {
+				const u64 on = ((v >> k) & 1) ? ~0ull : 0ull;
 #pragma unroll
-			for (int g = 0; g < GF2_GMAX; g++) sv[g] = M[tidx(r < rec[g].p ? srow[g] : 0, wl + (live ? w : 0), srows)];
-			__syncthreads();                                // (part 1: the tables of part 0 are done with)
+				for (int e = 0; e < W; e++) a[e] ^= rows64[(4 * n + k) * W + e] & on;
+			}
 #pragma unroll
-			for (int g = 0; g < GF2_GMAX; g++) S[(g * 64 + r) * W + w] = (r < rec[g].p && live) ? sv[g] : 0ull;
+			for (int e = 0; e < W; e++) Tn[(n * 16 + v) * W + e] = a[e];
+		};
+#pragma unroll
+		for (int g = 0; g < GF2_GMAX; g++) {
+			if (g >= gb) break;
+			build_tables(&S[g * 64 * W]);
 			__syncthreads();
-			auto build_tables = [&](const u64 *rows64) {
-				const int n = t >> 4, v = t & 15;
-				u64 a[W] = { 0, 0, 0, 0 };
-#pragma unroll
-				for (int k = 0; k < 4; k++) {
-					const u64 on = ((v >> k) & 1) ? ~0ull : 0ull;
-#pragma unroll
-					for (int e = 0; e < W; e++) a[e] ^= rows64[(4 * n + k) * W + e] & on;
-				}
-#pragma unroll
-				for (int e = 0; e < W; e++) Tn[(n * 16 + v) * W + e] = a[e];
-			};
-#pragma unroll
-			for (int g = 0; g < GF2_GMAX; g++) {
-				if (g >= gb) break;
-				build_tables(&S[g * 64 * W]);
-				__syncthreads();
-				if (!((rec[g].mask >> r) & 1)) Pbit[(g * 64 + r) * W + w] = 0;      // bit r of the panel has no pivot
-				if (r < rec[g].p) {
-					const u64 acc = nibble_word(Tn, comb[g], w);
-					Pbit[(g * 64 + Bk[g * 64 + r]) * W + w] = acc;
-					if (blockIdx.x == 0 && live) {
-						u64 *const u = &Uwin[(i64)(rec[g].start + r) * (2 * GF2_GMAX) + part * GF2_GMAX + w];
-						if (wt) GF2_ST(u, acc); else *u = acc;
-					}
-				}
-				__syncthreads();
-				build_tables(&Pbit[g * 64 * W]);            // serves the later panels' sources AND this workgroup's rows
-				__syncthreads();
-#pragma unroll
-				for (int h = g + 1; h < GF2_GMAX; h++)
-					if (h < gb && r < rec[h].p) S[(h * 64 + r) * W + w] ^= nibble_word(Tn, smul[h][g], w);
-				if (i < rows && mrow[g]) {
-					u64 acc[W];
-					nibble_rows(Tn, mult_plain(upd_T, mrow[g], ic), acc);       // (stored rotated for the table kernel)
-#pragma unroll
-					for (int e = 0; e < W; e++) wv[e] ^= acc[e];
-				}
-				__syncthreads();
+			if (!((rec[g].mask >> r) & 1)) Pbit[(g * 64 + r) * W + w] = 0;      // bit r of the panel has no pivot
+			if (r < rec[g].p) {
+				const u64 acc = nibble_word(Tn, comb[g], w);
+				Pbit[(g * 64 + Bk[g * 64 + r]) * W + w] = acc;
+				if (blockIdx.x == 0 && live) Uwin[(i64)(rec[g].start + r) * GF2_GMAX + w] = acc;
 			}
-		}
-		if (i < rows) {
+			__syncthreads();
+			build_tables(&Pbit[g * 64 * W]);            // serves the later panels' sources AND this workgroup's rows
+			__syncthreads();
 #pragma unroll
-			for (int e = 0; e < W; e++) {
-				if (e >= gn) continue;
-				// (in place: only rows the block changes -- its own pivot rows are being read by every workgroup)
-				u64 *const dst = part ? (anym ? &M[tidx(i, wl + e, srows)] : (u64 *)nullptr) : &Wb_out[i * GF2_GMAX + e];
-				if (!dst) continue;
-				if (wt) GF2_ST(dst, wv[e]); else *dst = wv[e];
+			for (int h = g + 1; h < GF2_GMAX; h++)
+				if (h < gb && r < rec[h].p) S[(h * 64 + r) * W + w] ^= nibble_word(Tn, smul[h][g], w);
+			if (i < rows && mrow[g]) {
+				u64 acc[W];
+				nibble_rows(Tn, mult_plain(upd_T, mrow[g], ic), acc);       // (stored rotated for the table kernel)
+#pragma unroll
+				for (int e = 0; e < W; e++) wv[e] ^= acc[e];
 			}
+			__syncthreads();
 		}
 	}
-}
-__global__ void __launch_bounds__(256)
-k_prio_window(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo, int gnext, int gnext2,
-              const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
-              const u64 *__restrict__ multset, const int *__restrict__ blk_first, u64 *__restrict__ Wb_out,
-              u64 *__restrict__ Uwin, int upd_T, const SolveState *__restrict__ st, int blk, DoneSignal sig, SysStride ss)
-{
-	__builtin_amdgcn_s_setprio(3);
-	prio_window_body(M, rows, srows, j0, gb, wlo, gnext, gnext2, panels, aux, multset, blk_first, Wb_out, Uwin, upd_T, st, blk,
-	                 sig.count != nullptr, ss);
-	signal_light(sig, blockIdx.y * ss.arena_bytes, gridDim.x);
+	if (i >= rows) return;
+#pragma unroll
+	for (int e = 0; e < W; e++)
+		if (e < gnext) Wb_out[i * GF2_GMAX + e] = wv[e];
 }
 
 // After the elimination: pivot row k of block b gets its words of block b+1's window (parked in Uwin by
@@ -1932,7 +1646,7 @@ k_prio_window(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 __global__ void __launch_bounds__(256)
 k_unwind(u64 *__restrict__ M, i64 srows, int G, int npanels, int nblocks, const SolveState *__restrict__ st,
          const int *__restrict__ pivcol, const int *__restrict__ urow, const u64 *__restrict__ Uwin, int world, int wrank,
-         int deep_lo, int deep_hi, SysStride ss)
+         SysStride ss)
 {
 	{
 		const i64 ao = blockIdx.y * ss.arena_bytes;
@@ -1940,18 +1654,16 @@ k_unwind(u64 *__restrict__ M, i64 srows, int G, int npanels, int nblocks, const 
 		st = sys_at(st, ao); pivcol = sys_at(pivcol, ao); urow = sys_at(urow, ao); Uwin = sys_at(Uwin, ao);
 	}
 	const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	const i64 k = t / (2 * GF2_GMAX);
-	const int e = (int)(t % GF2_GMAX), part = (int)(t / GF2_GMAX) & 1;
+	const i64 k = t / GF2_GMAX;
+	const int e = (int)(t % GF2_GMAX);
 	if (k >= st->rank) return;
 	const int b = (pivcol[k] >> 6) / G;
-	if (b + 1 + part >= nblocks) return;                // the last block has no next window
-	// (blocks [deep_lo, deep_hi] ran a look-ahead of depth two: their pivot rows' words of the window after the next are parked too)
-	if (part && (b < deep_lo || b > deep_hi)) return;
-	const int wlo = (b + 1 + part) * G;
+	if (b + 1 >= nblocks) return;                       // the last block has no next window
+	const int wlo = (b + 1) * G;
 	const int gnext = (npanels - wlo < G) ? npanels - wlo : G;
 	// (column-slab solve: the window of block b + 1 was carried forward -- and Uwin filled -- by the rank that owns its tile)
 	if (world > 1 && ((wlo + e) >> GF2_OWN_LOG) % world != wrank) return;
-	if (e < gnext) M[tidx(urow[k], wlo + e, srows)] = Uwin[k * (2 * GF2_GMAX) + part * GF2_GMAX + e];
+	if (e < gnext) M[tidx(urow[k], wlo + e, srows)] = Uwin[k * GF2_GMAX + e];
 }
 
 // Column-slab solve (one system over several GPUs): a rank that did not factorise block b receives its records and

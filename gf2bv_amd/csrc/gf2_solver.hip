@@ -380,29 +380,13 @@ struct Solver {
 	FindUnit *fu = nullptr;
 	int *died = nullptr;          // per row: panel that made it a pivot source, GF2_NEVER while alive
 	int *pivcol = nullptr, *urow = nullptr, *blk_first = nullptr;
-	u64 *mult = nullptr;          // 3 sets x G x rows (block b uses set b % 3: in a search chain the narrow step of block b + 1
-	                              // may run while the bulk update of block b - 1 is still reading its set)
+	u64 *mult = nullptr;          // 2 sets x G x rows (ping-pong between consecutive blocks)
 	u64 *Wb = nullptr;            // 2 x rows x GMAX window words (the panel steps ping-pong between the halves)
-	u64 *Uwin = nullptr;          // rank x 2 GMAX: pivot rows' words of the following window(s) (k_prio_window -> k_unwind)
+	u64 *Uwin = nullptr;          // rank x GMAX: pivot rows' words of the following window (k_prio_window -> k_unwind)
 	u64 *Pfast = nullptr;         // scratch of k_block_fast: the pivot rows' window words of a block, [panel][word][column]
 	SyncFlags *sf = nullptr;      // progress counters of the two streams (k_gate)
 	bool flag_sync = true;        // per-block hand-overs between the streams through sf + k_gate instead of events (GF2BV_FLAG_SYNC=0)
 	int sync_base = 0;            // the counters only grow: a pass that re-enqueues blocks (resume after a poisoned one) counts from here
-	// search chain (ChainArgs): the searches of consecutive dense blocks back to back on a stream of their own
-	bool chain = true;            // GF2BV_CHAIN=0 disables
-	hipStream_t sC = nullptr;
-	hipEvent_t ev_chain = nullptr;
-	int *chain_rows = nullptr;    // 2 x (GF2_FAST_NC + 64) ints: candidates handed from one search to the next (ping-pong)
-	u64 *chain_words = nullptr;   // 2 x GF2_FAST_NC x GF2_GMAX
-	int chain_prev = -1;          // last block whose search handed candidates on
-	int chain_last = -1;          // last block whose search went to the chain stream
-	int chain_from = INT_MAX, chain_to = -1;     // blocks [chain_from, chain_to] are searched in a chain (set by enqueue_forward)
-	float chain_us = 45.f;        // ... those whose bulk update is estimated below this (GF2BV_CHAIN_US): the panel-bound part of a solve
-	bool is_chain(int b) const { return b >= chain_from && b <= chain_to; }
-	bool has_tail(int b) const { return is_chain(b) && is_chain(b + 1); }     // block b's search carries block b + 1's candidates forward
-	// ... on a window that must not wait for the bulk update of block b - 1: that block runs a look-ahead of depth two
-	// (k_prio_window takes the window after the next as well, its bulk update leaves both alone)
-	bool deep(int b) const { return has_tail(b + 1); }
 	bool fast_blocks = true;      // try the one-launch block search on dense blocks (GF2BV_FAST=0 disables)
 	bool optimistic = true;       // ... and drop the general panel steps behind it once block 0 has taken it (GF2BV_OPTIMISTIC=0)
 	int units = 0;
@@ -463,8 +447,6 @@ struct Solver {
 		for (hipEvent_t e : evA) P.release_event(e, false);
 		for (hipEvent_t e : evPrio) P.release_event(e, false);
 		kev.clear(); evA.clear(); evPrio.clear();
-		if (sC) { P.release_stream(sC, device, false); sC = nullptr; }
-		if (ev_chain) { P.release_event(ev_chain, false); ev_chain = nullptr; }
 		if (own_sB && sB) P.release_stream(sB, device, true);
 		sB = nullptr;
 		if (own_sA && sA) P.release_stream(sA, device, false);
@@ -546,8 +528,6 @@ int solver_alloc(Solver &S)
 	S.flag_sync = S.world == 1;           // (a column-slab solve hands over through the host between the pieces: events)
 	if (const char *e = getenv("GF2BV_FLAG_SYNC")) S.flag_sync = S.flag_sync && atoi(e) != 0;
 	if (getenv("GF2BV_SERIAL")) S.flag_sync = false;      // (one stream: the panel gate would wait for a gate queued behind it)
-	if (const char *e = getenv("GF2BV_CHAIN")) S.chain = atoi(e) != 0;
-	if (const char *e = getenv("GF2BV_CHAIN_US")) S.chain_us = (float)atof(e);
 	if (const char *e = getenv("GF2BV_OPTIMISTIC")) S.optimistic = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_SPARSE")) { int v = atoi(e); if (v >= 0 && v <= 2) S.sparse_mode = v; }
 	// narrow workgroups: as many rows each as keeps ~256 of them (all systems of a gang together) busy, at most 8 blocks
@@ -577,10 +557,9 @@ int solver_alloc(Solver &S)
 		const size_t o_st = carve(sizeof(SolveState)), o_sf = carve(sizeof(SyncFlags)), o_pan = carve(sizeof(PanelRec) * NP), o_aux = carve(sizeof(PanelAux) * NP),
 		             o_fu = carve(sizeof(FindUnit) * (S.units + 1 + GF2_MAXGROUPS)), o_alive = carve(sizeof(int) * (size_t)R),
 		             o_piv = carve(sizeof(int) * (S.maxr + 64)), o_urow = carve(sizeof(int) * (S.maxr + 64)),
-		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * 3 * G * mult_rows(R)),
-		             o_wb = carve(sizeof(u64) * 2 * GF2_GMAX * R), o_uw = carve(sizeof(u64) * 2 * GF2_GMAX * (S.maxr + 64)),
-		             o_pf = carve(sizeof(u64) * GF2_GMAX * GF2_GMAX * 64), o_cr = carve(sizeof(int) * 2 * (GF2_FAST_NC + 64)),
-		             o_cw = carve(sizeof(u64) * 2 * GF2_FAST_NC * GF2_GMAX);
+		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * 2 * G * mult_rows(R)),
+		             o_wb = carve(sizeof(u64) * 2 * GF2_GMAX * R), o_uw = carve(sizeof(u64) * GF2_GMAX * (S.maxr + 64)),
+		             o_pf = carve(sizeof(u64) * GF2_GMAX * GF2_GMAX * 64);
 		S.arena_stride = off;
 		S.sync_base = 0;
 		HIPCHK(pool().alloc(&S.arena, off * S.nsys, S.device));
@@ -589,8 +568,6 @@ int solver_alloc(Solver &S)
 		S.fu = (FindUnit *)(base + o_fu); S.died = (int *)(base + o_alive); S.pivcol = (int *)(base + o_piv);
 		S.urow = (int *)(base + o_urow); S.blk_first = (int *)(base + o_blk); S.mult = (u64 *)(base + o_mult);
 		S.Wb = (u64 *)(base + o_wb); S.Uwin = (u64 *)(base + o_uw); S.Pfast = (u64 *)(base + o_pf);
-		S.chain_rows = (int *)(base + o_cr); S.chain_words = (u64 *)(base + o_cw);
-		S.chain_prev = S.chain_last = -1; S.chain_from = INT_MAX; S.chain_to = -1;
 		// zero everything that is read before it is written: state, panel records, unit scratch, block bounds, multipliers
 		for (int s = 0; s < S.nsys; s++) {
 			char *b = base + (size_t)s * off;
@@ -721,7 +698,7 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 //     the two overlap: per-block time is max(panel path, bulk path), and B never idles when it is
 //     the longer one.
 // ---- one block of the forward elimination, in the three pieces the two streams interleave ----
-struct BlockGeom { int j0, gb, wlo, tb, nt_all, gnext, gnext2; u64 *mset; };
+struct BlockGeom { int j0, gb, wlo, tb, nt_all, gnext; u64 *mset; };
 BlockGeom block_geom(const Solver &S, int b)
 {
 	const int G = S.impl->G;
@@ -729,12 +706,11 @@ BlockGeom block_geom(const Solver &S, int b)
 	g.j0 = b * G;
 	g.gb = std::min(G, S.npanels - g.j0);
 	g.wlo = g.j0 + g.gb;
-	g.mset = S.mult + (i64)(b % 3) * G * mult_rows(S.rows);
+	g.mset = S.mult + (i64)(b & 1) * G * mult_rows(S.rows);
 	// trailing tiles; the next block's window [wlo, wlo + gnext) sits in the first one or two of them
 	g.tb = g.wlo / TW;
 	g.nt_all = (g.wlo < S.wt) ? (int)S.ntiles - g.tb : 0;
 	g.gnext = (b + 1 < S.nblocks) ? std::min(G, S.npanels - g.wlo) : 0;
-	g.gnext2 = S.deep(b) ? std::min(G, S.npanels - g.wlo - g.gnext) : 0;      // (look-ahead of depth two: see Solver::deep)
 	return g;
 }
 
@@ -750,7 +726,7 @@ bool fast_block_possible(const Solver &S, const BlockGeom &g)
 // follows (every block but the last), the wait for the bulk update of block b - 1 that k_prio_window needs
 int panel_handover(Solver &S, int b)
 {
-	k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sA>>>(S.sf, S.st, S.sync_base + b + 1, 0, 0, b + 1 < S.nblocks ? S.sync_base + b : 0, 0, S.ss());
+	k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sA>>>(S.sf, S.st, S.sync_base + b + 1, 0, 0, b + 1 < S.nblocks ? S.sync_base + b : 0, S.ss());
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
@@ -761,43 +737,12 @@ int enqueue_block_panel(Solver &S, int b, bool fast_only = false)
 	const unsigned row_blocks = (unsigned)((S.rows + 255) / 256);
 	u64 *const half[2] = { S.Wb, S.Wb + (i64)GF2_GMAX * S.rows };
 	if (fast_only) {
-		ChainArgs ca{};
-		hipStream_t strm = S.sA;
-		const bool chained = S.is_chain(b);
-		if (chained) {
-			if (!S.sC) HIPCHK(pool().stream(&S.sC, S.device, false));
-			if (S.chain_last != b - 1) {        // the chain starts here: behind everything the panel stream holds (block b - 1's look-ahead)
-				if (!S.ev_chain) HIPCHK(pool().event(&S.ev_chain, false));
-				HIPCHK(hipEventRecord(S.ev_chain, S.sA));
-				HIPCHK(hipStreamWaitEvent(S.sC, S.ev_chain, 0));
-			}
-			S.chain_last = b;
-			strm = S.sC;
-			ca.sf = S.sf; ca.base = S.sync_base; ca.gnext = g.gnext;
-			if (S.chain_prev == b - 1) {
-				ca.in_rows = S.chain_rows + (b & 1) * (GF2_FAST_NC + 64);
-				ca.in_words = S.chain_words + (i64)(b & 1) * GF2_FAST_NC * GF2_GMAX;
-			}
-			if (S.has_tail(b)) {
-				ca.out_rows = S.chain_rows + ((b + 1) & 1) * (GF2_FAST_NC + 64);
-				ca.out_words = S.chain_words + (i64)((b + 1) & 1) * GF2_FAST_NC * GF2_GMAX;
-				S.chain_prev = b;
-			}
-		}
-		k_block_fast<<<dim3(1, S.nsys), dim3(256), 0, strm>>>(S.M, S.rows, S.srows, g.j0, g.gb, 1, b, (const u64 *)half[0], S.st, S.died,
-		                                                      S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, ca, S.ss());
-		DoneSignal sig{};
-		if (chained) {
-			// panel stream: the narrow step needs this block's search to have ENDED (it announces that itself); the look-ahead
-			// behind it needs the bulk update of block b - 1 (whose completion also frees the multiplier set of block b - 3)
-			k_gate<<<dim3(1, 1), dim3(64), 0, S.sA>>>(S.sf, S.st, 0, 0, 0, S.sync_base + b, S.sync_base + b + 1, S.ss());
-			sig = DoneSignal{ &S.sf->cnt_narrow, &S.sf->narrow_done, S.sync_base + b + 1 };
-		}
+		k_block_fast<<<dim3(1, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, 1, b, (const u64 *)half[0], S.st, S.died,
+		                                                      S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, S.Pfast, S.ss());
 		hipExtLaunchKernelGGL(k_narrow_all, dim3((row_blocks + S.narrow_rpt - 1) / S.narrow_rpt, S.nsys), dim3(256), 0, S.sA, nullptr,
 		                      S.ext_events && !S.flag_sync ? S.evA[b] : nullptr, 0, (const u64 *)S.M, S.rows, S.srows, g.j0, b, (const u64 *)half[0],
-		                      (const SolveState *)S.st, (const int *)S.died, (const PanelAux *)S.aux, g.mset, S.impl->T, S.narrow_rpt, sig, S.ss());
+		                      (const SolveState *)S.st, (const int *)S.died, (const PanelAux *)S.aux, g.mset, S.impl->T, S.narrow_rpt, S.ss());
 		HIPCHK(hipGetLastError());
-		if (chained) return GF2BV_OK;       // (the narrow launch announces narrow_done; the gate before it has waited for the bulk stream)
 		if (S.flag_sync) return panel_handover(S, b);
 		if (!S.ext_events) HIPCHK(hipEventRecord(S.evA[b], S.sA));
 		return GF2BV_OK;
@@ -806,7 +751,7 @@ int enqueue_block_panel(Solver &S, int b, bool fast_only = false)
 	// block done (or, when it gave up, untouched)
 	if (fast_block_possible(S, g))
 		k_block_fast<<<dim3(1, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, 0, b, (const u64 *)half[0], S.st, S.died,
-		                                                      S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, ChainArgs{}, S.ss());
+		                                                      S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, S.Pfast, S.ss());
 	for (int s = 0; s <= g.gb; s++) {
 		const int gp = s - 1, gf = (s < g.gb) ? s : -1;
 		const i64 c0 = (i64)(g.j0 + std::max(gf, 0)) * 64;
@@ -838,19 +783,19 @@ int enqueue_block_bulk(Solver &S, int b)
 	if (S.flag_sync) {       // wait for block b's multipliers
 		// (a gate, not hipStreamWaitValue32: that is a polling kernel as well on this runtime -- __amd_rocclr_streamOpsWait --
 		// but one without a time-out)
-		k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sB>>>(S.sf, S.st, 0, 0, S.sync_base + b + 1, 0, 0, S.ss());
+		k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sB>>>(S.sf, S.st, 0, 0, S.sync_base + b + 1, 0, S.ss());
 		HIPCHK(hipGetLastError());
 	} else HIPCHK(hipStreamWaitEvent(S.sB, S.evA[b], 0));
 	bool launched = false;
 	if (g.nt_all > 0) {
-		int rc = launch_trsm(S, S.sB, g.j0, g.gb, g.wlo, g.wlo, g.wlo + g.gnext + g.gnext2);
+		int rc = launch_trsm(S, S.sB, g.j0, g.gb, g.wlo, g.wlo, g.wlo + g.gnext);
 		if (rc) return rc;
 #if GF2_TW == 2
 		// 16-byte tiles: the next block's window is whole tiles that are simply left out; when it ends in the middle of a
 		// tile (an odd number of window words: the block before a short last one) that tile takes the HALF instance first
 		// (the LAST block has no next window: its trailing words start at wlo, possibly in the middle of a tile whose first
 		// word is the block's own -- the table entries are zero there, see `keep` in k_update16 -- and nobody else writes it)
-		const int wend = g.wlo + g.gnext + g.gnext2;      // (the window(s) the look-ahead owns)
+		const int wend = g.wlo + g.gnext;
 		const int tfull = g.gnext > 0 ? (wend + 1) / 2 : g.wlo / 2;      // first tile with no window word
 		const i64 nfull = owned_count(tfull, S.ntiles, GF2_OWN_LOG - 1, S.world, S.wrank);
 		if ((wend & 1) && g.gnext > 0 && owned_count(wend / 2, wend / 2 + 1, GF2_OWN_LOG - 1, S.world, S.wrank) > 0) {
@@ -873,7 +818,7 @@ int enqueue_block_bulk(Solver &S, int b)
 #endif
 	}
 	if (S.flag_sync) {       // "bulk of block b complete" (a launch of its own: the panel stream's gate, submitted later, waits for it)
-		k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sB>>>(S.sf, S.st, 0, S.sync_base + b + 1, 0, 0, 0, S.ss());
+		k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sB>>>(S.sf, S.st, 0, S.sync_base + b + 1, 0, 0, S.ss());
 		HIPCHK(hipGetLastError());
 	}
 	if (!launched && !S.flag_sync) {
@@ -891,11 +836,9 @@ int enqueue_block_prio(Solver &S, int b)
 	const BlockGeom g = block_geom(S, b);
 	const unsigned row_blocks = (unsigned)((S.rows + 255) / 256);
 	if (b > 0 && !S.flag_sync) HIPCHK(hipStreamWaitEvent(S.sA, S.waitPrio[b - 1], 0));     // (flag hand-over: the gate behind block b's panel path has waited)
-	// (while a search chain is running the look-ahead announces its own end: the next search's tail waits for it)
-	const DoneSignal sig = S.chain_from != INT_MAX ? DoneSignal{ &S.sf->cnt_win, &S.sf->win_done, S.sync_base + b + 1 } : DoneSignal{};
-	k_prio_window<<<dim3(row_blocks, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, g.wlo, std::max(g.gnext, 1), g.gnext2,
+	k_prio_window<<<dim3(row_blocks, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, g.wlo, std::max(g.gnext, 1),
 	                                                             S.panels, S.aux, g.mset, S.blk_first + b, S.Wb, S.Uwin,
-	                                                             S.impl->T, S.st, b, sig, S.ss());
+	                                                             S.impl->T, S.st, S.ss());
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
@@ -917,9 +860,8 @@ int enqueue_forward_join(Solver &S)
 	HIPCHK(hipEventRecord(S.ev3, S.sB));
 	HIPCHK(hipStreamWaitEvent(S.sA, S.ev3, 0));
 	if (S.nblocks > 1 && S.maxr > 0)
-		k_unwind<<<dim3((unsigned)((S.maxr * 2 * GF2_GMAX + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(
-			S.M, S.srows, S.impl->G, S.npanels, S.nblocks, S.st, S.pivcol, S.urow, S.Uwin, S.world, S.wrank,
-			S.chain_from == INT_MAX ? INT_MAX : S.chain_from - 1, S.chain_to - 2, S.ss());
+		k_unwind<<<dim3((unsigned)((S.maxr * GF2_GMAX + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(
+			S.M, S.srows, S.impl->G, S.npanels, S.nblocks, S.st, S.pivcol, S.urow, S.Uwin, S.world, S.wrank, S.ss());
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
@@ -960,18 +902,6 @@ int enqueue_forward(Solver &S)
 		// rows left when the block starts: at most 64 leftover candidates sit below the bound besides the pivots found
 		return fast_block_possible(S, block_geom(S, blk)) && S.rows - (i64)blk * 64 * S.impl->G >= GF2_FAST_NC + 128;
 	};
-	if (optimistic && S.chain && S.flag_sync && TW == 2) {
-		// the chain takes the fast_only blocks whose bulk update is short: while the update is the longer path the panel path
-		// is hidden behind it anyway
-		for (int q = b + 1; q < S.nblocks && fast_only_ok(q); q++) {
-			const BlockGeom gq = block_geom(S, q - 1);
-			const double us = (double)std::max<i64>(256, S.rows - (i64)gq.j0 * 64) * (double)std::max(0, gq.nt_all) * 32.0 / 4.0e6;
-			if (us >= S.chain_us) continue;
-			if (S.chain_from == INT_MAX) S.chain_from = q;
-			S.chain_to = q;
-		}
-		if (S.chain_to - S.chain_from < 4) { S.chain_from = INT_MAX; S.chain_to = -1; }
-	}
 	for (; b < S.nblocks; b++) {
 		if ((rc = enqueue_block_panel(S, b, optimistic && fast_only_ok(b)))) return rc;
 		if ((rc = enqueue_block_bulk(S, b))) return rc;
@@ -981,14 +911,12 @@ int enqueue_forward(Solver &S)
 	if (optimistic) {
 		HIPCHK(hipMemcpyAsync(&hst, S.st, sizeof hst, hipMemcpyDeviceToHost, S.sA));
 		HIPCHK(hipStreamSynchronize(S.sA));
-		if (S.sC) HIPCHK(hipStreamSynchronize(S.sC));       // (a poisoned chain drains at once; otherwise the panel stream has waited for it)
 		if (hst.poison) {                               // a block the fast search could not take: resume there, both paths
 			const int pb = hst.poison - 1;
 			HIPCHK(hipMemsetAsync(&S.st->poison, 0, sizeof(int), S.sA));
 			S.sync_base += S.nblocks + 1;
-			S.chain_from = INT_MAX; S.chain_to = -1;            // (the first pass has unwound the parked words of its deep blocks)
 			if (S.flag_sync) {      // the bulk updates of the blocks before pb are complete: what block pb's look-ahead waits for
-				k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sB>>>(S.sf, S.st, 0, S.sync_base + pb, 0, 0, 0, S.ss());
+				k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sB>>>(S.sf, S.st, 0, S.sync_base + pb, 0, 0, S.ss());
 				HIPCHK(hipGetLastError());
 			}
 			for (b = pb; b < S.nblocks; b++) {
@@ -1890,6 +1818,33 @@ int gf2bv_residual_device(const void *d_aug, int64_t rows, int64_t cols, int64_t
 	(void)hipFree(dx); (void)hipFree(dbad);
 	*bad_rows = (int64_t)h;
 	return GF2BV_OK;
+}
+
+// Registers (VGPRs per lane) and static LDS of the kernels that must fit on a CU TOGETHER: the default bulk-update instance
+// and the panel-path kernels that run beside it.  out[2 k], out[2 k + 1] = registers, LDS bytes of kernel k (see
+// gf2bv_hip.h for the order).
+int gf2bv_kernel_resources(int device, int32_t *out, int n)
+{
+	return guarded([&]() -> int {
+	if (!out || n < 10) return fail(GF2BV_ERR_ARG, "need room for 5 kernels");
+	int rc = check_device(device);
+	if (rc) return rc;
+	HIPCHK(hipSetDevice(device));
+#if GF2_TW == 2
+	const void *fn[5] = { (const void *)k_update16<512, false, 3, true, 512>, (const void *)k_block_fast, (const void *)k_narrow_all,
+	                      (const void *)k_prio_window, (const void *)k_panel_step };
+#else
+	const void *fn[5] = { (const void *)k_update<4, 12, 768>, (const void *)k_block_fast, (const void *)k_narrow_all,
+	                      (const void *)k_prio_window, (const void *)k_panel_step };
+#endif
+	for (int k = 0; k < 5; k++) {
+		hipFuncAttributes a{};
+		HIPCHK(hipFuncGetAttributes(&a, fn[k]));
+		out[2 * k] = a.numRegs;
+		out[2 * k + 1] = (int32_t)a.sharedSizeBytes;
+	}
+	return GF2BV_OK;
+	});
 }
 
 int gf2bv_stream_ceiling_device(int device, int64_t bytes, double *rmw_gbs, double *read_gbs)

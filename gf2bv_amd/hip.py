@@ -34,7 +34,7 @@ EXPORTS = [
     "gf2bv_slab_payload_bytes", "gf2bv_slab_factor", "gf2bv_slab_apply", "gf2bv_slab_finish_local", "gf2bv_slab_solve",
     "gf2bv_slab_close",
     "gf2bv_synth_device", "gf2bv_residual_device",
-    "gf2bv_stream_ceiling_device",
+    "gf2bv_stream_ceiling_device", "gf2bv_kernel_resources",
     "gf2bv_device_alloc", "gf2bv_device_free", "gf2bv_device_upload", "gf2bv_device_download",
 ]
 
@@ -111,6 +111,7 @@ def lib():
         L.gf2bv_synth_device.argtypes = [vp, i64, i64, i64, ctypes.c_uint64, i32, vp]
         L.gf2bv_residual_device.argtypes = [vp, i64, i64, i64, vp, i32, vp, ctypes.POINTER(i64)]
         L.gf2bv_stream_ceiling_device.argtypes = [i32, i64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        L.gf2bv_kernel_resources.argtypes = [i32, ctypes.POINTER(ctypes.c_int32), i32]
         L.gf2bv_device_alloc.argtypes = [i32, i64, pp]
         L.gf2bv_device_free.argtypes = [i32, vp]
         L.gf2bv_device_upload.argtypes = [i32, vp, vp, i64]
@@ -283,6 +284,14 @@ def stream_ceiling(nbytes: int = 2 << 30, device: int = 0) -> dict:
     rmw, rd = ctypes.c_double(0), ctypes.c_double(0)
     _check(lib().gf2bv_stream_ceiling_device(device, nbytes, ctypes.byref(rmw), ctypes.byref(rd)))
     return {"rmw_gbs": rmw.value, "read_gbs": rd.value}
+
+
+def kernel_resources(device: int = 0) -> dict:
+    """VGPRs per lane and static LDS bytes of the bulk-update kernel and of the panel kernels that run beside it."""
+    out = (ctypes.c_int32 * 10)()
+    _check(lib().gf2bv_kernel_resources(device, out, 10))
+    names = ("update", "block_fast", "narrow_all", "prio_window", "panel_step")
+    return {nm: {"vgprs": int(out[2 * k]), "lds": int(out[2 * k + 1])} for k, nm in enumerate(names)}
 
 
 class DeviceBuffer:

@@ -199,6 +199,13 @@ int gf2bv_residual_device(const void *d_aug, int64_t rows, int64_t cols, int64_t
  * read_gbs = read-only.  Reported by bench.py next to the 8 TB/s spec peak. */
 int gf2bv_stream_ceiling_device(int device, int64_t bytes, double *rmw_gbs, double *read_gbs);
 
+/* Registers per lane and static LDS bytes of the kernels that must fit on a compute unit TOGETHER -- the panel path of
+ * block b+1 runs beside the bulk update of block b, and a panel kernel that does not fit next to an update workgroup
+ * (two wavefronts per SIMD, 128 KiB of tables) silently waits for one to retire: out[0..1] the default bulk-update
+ * instance, then k_block_fast, k_narrow_all, k_prio_window, k_panel_step (registers, LDS each; n >= 10).  A test holds the
+ * budget: registers <= 512 - 2 x round_up(update's, 8), LDS <= 160 KiB - update's. */
+int gf2bv_kernel_resources(int device, int32_t *out, int n);
+
 /* plain device buffer helpers so a host language without a HIP binding can stage data */
 int gf2bv_device_alloc(int device, int64_t bytes, void **d_ptr);
 int gf2bv_device_free(int device, void *d_ptr);

@@ -515,6 +515,22 @@ def test_stream_handover_through_memory_vs_events(monkeypatch):
         assert_same(g, job[3], 1)
 
 
+def test_panel_kernels_fit_beside_the_bulk_update():
+    """The panel path of block b + 1 runs BESIDE the bulk update of block b: its kernels must fit into
+    what an update workgroup leaves of a CU -- 512 VGPRs per SIMD lane minus the update's two wavefronts, 160 KiB of LDS
+    minus its tables.  A kernel that outgrows that still gives the right bits, it just cannot start before an update
+    workgroup retires (seen once: k_block_fast at 217 VGPRs and 180-280 us per launch in the bulk-bound part of 65536^2)."""
+    res = hip.kernel_resources()
+    upd = res["update"]
+    if hip.solve_words(np.zeros((1, 1), dtype=np.uint64), 1, 1, 0).stats["tile_words"] != 2:
+        pytest.skip("budget of the 16-byte-tile layout")
+    free_vgprs = 512 - 2 * ((upd["vgprs"] + 7) // 8 * 8)
+    free_lds = 160 * 1024 - upd["lds"]
+    for name in ("block_fast", "narrow_all", "prio_window", "panel_step"):
+        assert res[name]["vgprs"] <= free_vgprs, (name, res)
+        assert res[name]["lds"] <= free_lds, (name, res)
+
+
 def test_stream_ceiling_reports_sane_rates():
     c = hip.stream_ceiling(1 << 30)
     assert 1000 < c["rmw_gbs"] < 8000 and 1000 < c["read_gbs"] < 8000
