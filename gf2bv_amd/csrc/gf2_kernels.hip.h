@@ -134,7 +134,8 @@ struct SolveState {
 // barrier packet -- 4-7 us on an idle chip, 10-11 us measured inside a solve (tools/microbench_gap.hip), once per block
 // on EACH stream -- while a kernel that follows another in the same stream starts 1.4 us after it and sees a flag another
 // stream has written within ~1 us.  So each stream announces its progress in these counters and waits for the other's
-// with a one-wavefront kernel (k_gate) queued where the event wait used to be: the kernels behind it start as soon
+// with a one-wavefront kernel (k_gate) queued where the event wait used to be (the narrow launch of a dense block announces
+// narrow_done itself, signal_light): the kernels behind it start as soon
 // as it ends, and a single spinning wavefront cannot starve anything.  Every wait targets a counter written by a launch
 // that was SUBMITTED BEFORE the waiter (as an event wait does): the runtime may map several streams onto one hardware
 // queue, and whatever a waiter spins for must then be ahead of it in every queue.  Not part of SolveState: a column-slab
@@ -142,7 +143,13 @@ struct SolveState {
 struct SyncFlags {
 	int narrow_done;     // panel stream: blocks whose multipliers are complete (block b's TRSM / update may start at b + 1)
 	int bulk_done;       // bulk stream: blocks whose bulk update is complete (block b's look-ahead needs b, i.e. block b - 1)
+	unsigned cnt_narrow; // workgroups of the running k_narrow_all that have finished (signal_light)
 };
+// A producing launch whose OUTPUT is written with write-through stores (GF2_ST) announces its own end: every workgroup waits
+// for its stores and counts itself in, the last one sets the flag -- no launch for the announcement, no L2 write-back (an
+// agent-scope release fence per workgroup was measured instead: it writes back what the concurrent bulk update has dirtied,
+// 32768^2 9.0 -> 11.1 ms; k_update16 alone announcing bulk_done that way: 65536^2 +3 %).
+struct DoneSignal { unsigned *count; int *flag; int value; };
 
 // Scratch of one search unit (wavefront).
 struct FindUnit {
@@ -409,6 +416,17 @@ k_gate(SyncFlags *__restrict__ sf, SolveState *__restrict__ st, int set_narrow, 
 		if (++polls < 512) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(64);
 		// (one expired gate voids the solve: the later ones do not wait at all)
 		if (wall_clock64() - t0 > GF2_GATE_TICKS || GF2_LD(&st->gate_timeout)) { GF2_ST(&st->gate_timeout, 1); break; }
+	}
+}
+__device__ __forceinline__ void signal_light(DoneSignal sig, i64 arena_off, unsigned total_wgs)      // by ALL threads, at the very end
+{
+	if (!sig.count) return;                                 // (uniform)
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the write-through stores of this workgroup have landed
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		unsigned *cnt = sys_at(sig.count, arena_off);
+		const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (old + 1 == total_wgs) { GF2_ST(cnt, 0u); GF2_ST(sys_at(sig.flag, arena_off), sig.value); }
 	}
 }
 
@@ -1097,7 +1115,7 @@ __device__ __forceinline__ void build_nibble_tables(StepLds &L, int t)
 __device__ __forceinline__ void narrow_all_panels(StepLds &L, const u64 *__restrict__ M, i64 rows, i64 srows, int j0,
                                                   const u64 *__restrict__ Wb_in, const int *__restrict__ died,
                                                   const PanelAux *__restrict__ aux, u64 *__restrict__ multset, int upd_T,
-                                                  i64 rb, int rpt)
+                                                  i64 rb, int rpt, bool wt = false)
 {
 	__shared__ u64 Pall[GF2_GMAX - 1][GF2_GMAX][64];        // [panel][word][pivot bit]
 	const int t = threadIdx.x, e_ = t >> 6, sl = t & 63;
@@ -1131,7 +1149,11 @@ __device__ __forceinline__ void narrow_all_panels(StepLds &L, const u64 *__restr
 		}
 		if (i < rows) {
 #pragma unroll
-			for (int g = 0; g < GF2_GMAX; g++) multset[midx(g, i, rows)] = mult_stored(upd_T, m[g], i);
+			for (int g = 0; g < GF2_GMAX; g++) {
+				const u64 v = mult_stored(upd_T, m[g], i);
+				if (wt) GF2_ST(&multset[midx(g, i, rows)], v);      // (the launch announces its own end: signal_light)
+				else multset[midx(g, i, rows)] = v;
+			}
 		}
 	}
 }
@@ -1328,7 +1350,7 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_
 __global__ void __launch_bounds__(256)
 k_narrow_all(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int blk, const u64 *__restrict__ Wb_in,
              const SolveState *__restrict__ st, const int *__restrict__ died, const PanelAux *__restrict__ aux,
-             u64 *__restrict__ multset, int upd_T, int rpt, SysStride ss)
+             u64 *__restrict__ multset, int upd_T, int rpt, DoneSignal sig, SysStride ss)
 {
 	__builtin_amdgcn_s_setprio(3);
 	{
@@ -1336,9 +1358,10 @@ k_narrow_all(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int blk, co
 		M += blockIdx.y * ss.m_words;
 		Wb_in = sys_at(Wb_in, ao); st = sys_at(st, ao); died = sys_at(died, ao); aux = sys_at(aux, ao); multset = sys_at(multset, ao);
 	}
-	if (st->poison || st->fast_done != blk + 1) return;
 	__shared__ StepLds L;
-	narrow_all_panels(L, M, rows, srows, j0, Wb_in, died, aux, multset, upd_T, (i64)blockIdx.x, rpt);
+	if (!(st->poison || st->fast_done != blk + 1))
+		narrow_all_panels(L, M, rows, srows, j0, Wb_in, died, aux, multset, upd_T, (i64)blockIdx.x, rpt, sig.count != nullptr);
+	signal_light(sig, blockIdx.y * ss.arena_bytes, gridDim.x);      // (narrow_done: the bulk stream's gate waits for it)
 }
 
 __global__ void __launch_bounds__(256)

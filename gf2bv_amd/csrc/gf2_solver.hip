@@ -724,9 +724,9 @@ bool fast_block_possible(const Solver &S, const BlockGeom &g)
 
 // flag hand-over, panel stream: "block b factorised" (its multipliers are complete) -- and, where the look-ahead of block b
 // follows (every block but the last), the wait for the bulk update of block b - 1 that k_prio_window needs
-int panel_handover(Solver &S, int b)
+int panel_handover(Solver &S, int b)      // general panel steps: a launch for the announcement (k_narrow_all makes its own)
 {
-	k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sA>>>(S.sf, S.st, S.sync_base + b + 1, 0, 0, b + 1 < S.nblocks ? S.sync_base + b : 0, S.ss());
+	k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sA>>>(S.sf, S.st, S.sync_base + b + 1, 0, 0, 0, S.ss());
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
@@ -741,9 +741,10 @@ int enqueue_block_panel(Solver &S, int b, bool fast_only = false)
 		                                                      S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, S.Pfast, S.ss());
 		hipExtLaunchKernelGGL(k_narrow_all, dim3((row_blocks + S.narrow_rpt - 1) / S.narrow_rpt, S.nsys), dim3(256), 0, S.sA, nullptr,
 		                      S.ext_events && !S.flag_sync ? S.evA[b] : nullptr, 0, (const u64 *)S.M, S.rows, S.srows, g.j0, b, (const u64 *)half[0],
-		                      (const SolveState *)S.st, (const int *)S.died, (const PanelAux *)S.aux, g.mset, S.impl->T, S.narrow_rpt, S.ss());
+		                      (const SolveState *)S.st, (const int *)S.died, (const PanelAux *)S.aux, g.mset, S.impl->T, S.narrow_rpt,
+		                      S.flag_sync ? DoneSignal{ &S.sf->cnt_narrow, &S.sf->narrow_done, S.sync_base + b + 1 } : DoneSignal{}, S.ss());
 		HIPCHK(hipGetLastError());
-		if (S.flag_sync) return panel_handover(S, b);
+		if (S.flag_sync) return GF2BV_OK;       // (the narrow launch announces narrow_done itself)
 		if (!S.ext_events) HIPCHK(hipEventRecord(S.evA[b], S.sA));
 		return GF2BV_OK;
 	}
@@ -780,10 +781,11 @@ int enqueue_block_panel(Solver &S, int b, bool fast_only = false)
 int enqueue_block_bulk(Solver &S, int b)
 {
 	const BlockGeom g = block_geom(S, b);
-	if (S.flag_sync) {       // wait for block b's multipliers
-		// (a gate, not hipStreamWaitValue32: that is a polling kernel as well on this runtime -- __amd_rocclr_streamOpsWait --
-		// but one without a time-out)
-		k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sB>>>(S.sf, S.st, 0, 0, S.sync_base + b + 1, 0, S.ss());
+	if (S.flag_sync) {       // "bulk updates of the blocks before b complete"; wait for block b's multipliers
+		// (submitted AFTER the launch that announces narrow_done and BEFORE the panel stream's gate that waits for bulk_done:
+		// every wait targets earlier-submitted work.  A gate, not hipStreamWaitValue32: that is a polling kernel as well on this
+		// runtime -- __amd_rocclr_streamOpsWait -- but one without a time-out)
+		k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sB>>>(S.sf, S.st, 0, S.sync_base + b, S.sync_base + b + 1, 0, S.ss());
 		HIPCHK(hipGetLastError());
 	} else HIPCHK(hipStreamWaitEvent(S.sB, S.evA[b], 0));
 	bool launched = false;
@@ -817,10 +819,6 @@ int enqueue_block_bulk(Solver &S, int b)
 		}
 #endif
 	}
-	if (S.flag_sync) {       // "bulk of block b complete" (a launch of its own: the panel stream's gate, submitted later, waits for it)
-		k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sB>>>(S.sf, S.st, 0, S.sync_base + b + 1, 0, 0, S.ss());
-		HIPCHK(hipGetLastError());
-	}
 	if (!launched && !S.flag_sync) {
 		HIPCHK(hipEventRecord(S.evPrio[b], S.sB));      // "bulk of block b complete" (no update launch of this rank carries it)
 		S.waitPrio[b] = S.evPrio[b];
@@ -835,7 +833,11 @@ int enqueue_block_prio(Solver &S, int b)
 	if (b + 1 >= S.nblocks) return GF2BV_OK;
 	const BlockGeom g = block_geom(S, b);
 	const unsigned row_blocks = (unsigned)((S.rows + 255) / 256);
-	if (b > 0 && !S.flag_sync) HIPCHK(hipStreamWaitEvent(S.sA, S.waitPrio[b - 1], 0));     // (flag hand-over: the gate behind block b's panel path has waited)
+	if (b > 0 && !S.flag_sync) HIPCHK(hipStreamWaitEvent(S.sA, S.waitPrio[b - 1], 0));
+	if (b > 0 && S.flag_sync) {      // the bulk update of block b - 1: announced by the bulk stream's gate of block b (submitted before this one)
+		k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sA>>>(S.sf, S.st, 0, 0, 0, S.sync_base + b, S.ss());
+		HIPCHK(hipGetLastError());
+	}
 	k_prio_window<<<dim3(row_blocks, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, g.wlo, std::max(g.gnext, 1),
 	                                                             S.panels, S.aux, g.mset, S.blk_first + b, S.Wb, S.Uwin,
 	                                                             S.impl->T, S.st, S.ss());
@@ -915,10 +917,6 @@ int enqueue_forward(Solver &S)
 			const int pb = hst.poison - 1;
 			HIPCHK(hipMemsetAsync(&S.st->poison, 0, sizeof(int), S.sA));
 			S.sync_base += S.nblocks + 1;
-			if (S.flag_sync) {      // the bulk updates of the blocks before pb are complete: what block pb's look-ahead waits for
-				k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sB>>>(S.sf, S.st, 0, S.sync_base + pb, 0, 0, S.ss());
-				HIPCHK(hipGetLastError());
-			}
 			for (b = pb; b < S.nblocks; b++) {
 				if ((rc = enqueue_block_panel(S, b))) return rc;
 				if ((rc = enqueue_block_bulk(S, b))) return rc;
