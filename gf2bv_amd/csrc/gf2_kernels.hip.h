@@ -385,8 +385,9 @@ k_win_scatter(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, const u6
 // One wavefront per system: announce this stream's progress (set_* > 0), then wait until the other stream's counter has
 // reached need_*.  What the producer's kernels wrote is visible to the kernels behind the gate by the usual
 // kernel-boundary release / acquire: the producer's counter is written by ITS gate, which runs after them.  The wait is
-// bounded (GF2_GATE_TICKS of the 100 MHz clock; both gates of a block are enqueued before either can matter, so only a
-// launch failure on the other stream can leave one waiting): on expiry the solve is marked void and everything drains.
+// bounded (GF2_GATE_TICKS of the 100 MHz clock; what a gate waits for has always been submitted before it, so only a
+// launch failure on the other stream, or a device that runs one kernel at a time, can leave one waiting): on expiry the
+// solve is marked void, everything drains and the host repeats the solve with events.
 #define GF2_GATE_TICKS 500000000ull       // 5 s (the longest legitimate wait is one bulk-update pass: ~20 ms at 524288^2)
 // A gate is a kernel that waits for a kernel of another stream: it needs the two streams to EXECUTE concurrently.  Counter
 // collection (rocprofv3 --pmc) and some debug settings run one kernel at a time, in which case the waiter would sit on the
