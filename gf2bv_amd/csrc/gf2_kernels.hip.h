@@ -1561,14 +1561,8 @@ k_panel_step(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gp, int gf, i
 // stream owns them.  The block's pivot rows' share of them (part of U, needed by the back-substitution)
 // cannot be stored in place -- every workgroup here is still reading the source rows -- so workgroup 0
 // parks it in Uwin[pivot index][word] and k_unwind moves it into the matrix after the elimination.
-// PART 0: the next block's window (wlo = its first word, gnext = its words), matrix -> window buffer.  PART 1 (look-ahead of
-// depth two, a second launch behind the first; see Solver::deep): the window after it, IN PLACE (Mw) -- the TRSM and the
-// bulk update of this block leave both windows alone, the pivot rows park their words of both in Uwin.  (Two launches, not
-// one kernel doing both windows: as a loop or as two inlined instances the compiler kept 186 to 400 registers live
-// against 70, and a look-ahead workgroup no longer fitted beside the bulk update -- see gf2bv_kernel_resources.)
-template <int PART>
 __global__ void __launch_bounds__(256)
-k_prio_window(const u64 *__restrict__ M, u64 *Mw, i64 rows, i64 srows, int j0, int gb, int wlo, int gnext,
+k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo, int gnext,
               const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
               const u64 *__restrict__ multset, const int *__restrict__ blk_first, u64 *__restrict__ Wb_out,
               u64 *__restrict__ Uwin, int upd_T, const SolveState *__restrict__ st, SysStride ss)
@@ -1577,7 +1571,7 @@ k_prio_window(const u64 *__restrict__ M, u64 *Mw, i64 rows, i64 srows, int j0, i
 	if (sys_at(st, blockIdx.y * ss.arena_bytes)->poison) return;     // (the window buffer must stay what the resumed block needs)
 	{
 		const i64 ao = blockIdx.y * ss.arena_bytes;
-		M += blockIdx.y * ss.m_words; Mw += blockIdx.y * ss.m_words;
+		M += blockIdx.y * ss.m_words;
 		panels = sys_at(panels, ao); aux = sys_at(aux, ao); multset = sys_at(multset, ao); blk_first = sys_at(blk_first, ao);
 		Wb_out = sys_at(Wb_out, ao); Uwin = sys_at(Uwin, ao);
 	}
@@ -1648,7 +1642,7 @@ k_prio_window(const u64 *__restrict__ M, u64 *Mw, i64 rows, i64 srows, int j0, i
 			if (r < rec[g].p) {
 				const u64 acc = nibble_word(Tn, comb[g], w);
 				Pbit[(g * 64 + Bk[g * 64 + r]) * W + w] = acc;
-				if (blockIdx.x == 0 && live) Uwin[(i64)(rec[g].start + r) * (2 * GF2_GMAX) + PART * GF2_GMAX + w] = acc;
+				if (blockIdx.x == 0 && live) Uwin[(i64)(rec[g].start + r) * GF2_GMAX + w] = acc;
 			}
 			__syncthreads();
 			build_tables(&Pbit[g * 64 * W]);            // serves the later panels' sources AND this workgroup's rows
@@ -1666,11 +1660,9 @@ k_prio_window(const u64 *__restrict__ M, u64 *Mw, i64 rows, i64 srows, int j0, i
 		}
 	}
 	if (i >= rows) return;
-	// (in place: only rows the block changes -- its own pivot rows are being read by every workgroup)
-	if (PART && !(mrow[0] | mrow[1] | mrow[2] | mrow[3])) return;
 #pragma unroll
 	for (int e = 0; e < W; e++)
-		if (e < gnext) { if (PART) Mw[tidx(i, wlo + e, srows)] = wv[e]; else Wb_out[i * GF2_GMAX + e] = wv[e]; }
+		if (e < gnext) Wb_out[i * GF2_GMAX + e] = wv[e];
 }
 
 // After the elimination: pivot row k of block b gets its words of block b+1's window (parked in Uwin by
@@ -1678,7 +1670,7 @@ k_prio_window(const u64 *__restrict__ M, u64 *Mw, i64 rows, i64 srows, int j0, i
 __global__ void __launch_bounds__(256)
 k_unwind(u64 *__restrict__ M, i64 srows, int G, int npanels, int nblocks, const SolveState *__restrict__ st,
          const int *__restrict__ pivcol, const int *__restrict__ urow, const u64 *__restrict__ Uwin, int world, int wrank,
-         int deep_lo, int deep_hi, SysStride ss)
+         SysStride ss)
 {
 	{
 		const i64 ao = blockIdx.y * ss.arena_bytes;
@@ -1686,18 +1678,16 @@ k_unwind(u64 *__restrict__ M, i64 srows, int G, int npanels, int nblocks, const 
 		st = sys_at(st, ao); pivcol = sys_at(pivcol, ao); urow = sys_at(urow, ao); Uwin = sys_at(Uwin, ao);
 	}
 	const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	const i64 k = t / (2 * GF2_GMAX);
-	const int e = (int)(t % GF2_GMAX), part = (int)(t / GF2_GMAX) & 1;
+	const i64 k = t / GF2_GMAX;
+	const int e = (int)(t % GF2_GMAX);
 	if (k >= st->rank) return;
 	const int b = (pivcol[k] >> 6) / G;
-	if (b + 1 + part >= nblocks) return;                // the last block has no next window
-	// (blocks [deep_lo, deep_hi] ran a look-ahead of depth two: their pivot rows' words of the window after the next are parked too)
-	if (part && (b < deep_lo || b > deep_hi)) return;
-	const int wlo = (b + 1 + part) * G;
+	if (b + 1 >= nblocks) return;                       // the last block has no next window
+	const int wlo = (b + 1) * G;
 	const int gnext = (npanels - wlo < G) ? npanels - wlo : G;
 	// (column-slab solve: the window of block b + 1 was carried forward -- and Uwin filled -- by the rank that owns its tile)
 	if (world > 1 && ((wlo + e) >> GF2_OWN_LOG) % world != wrank) return;
-	if (e < gnext) M[tidx(urow[k], wlo + e, srows)] = Uwin[k * (2 * GF2_GMAX) + part * GF2_GMAX + e];
+	if (e < gnext) M[tidx(urow[k], wlo + e, srows)] = Uwin[k * GF2_GMAX + e];
 }
 
 // Column-slab solve (one system over several GPUs): a rank that did not factorise block b receives its records and

@@ -380,21 +380,13 @@ struct Solver {
 	FindUnit *fu = nullptr;
 	int *died = nullptr;          // per row: panel that made it a pivot source, GF2_NEVER while alive
 	int *pivcol = nullptr, *urow = nullptr, *blk_first = nullptr;
-	u64 *mult = nullptr;          // 3 sets x G x rows (block b uses set b % 3: in a search chain the narrow step of block b + 1
-	                              // may run while the bulk update of block b - 1 is still reading its set)
+	u64 *mult = nullptr;          // 2 sets x G x rows (ping-pong between consecutive blocks)
 	u64 *Wb = nullptr;            // 2 x rows x GMAX window words (the panel steps ping-pong between the halves)
-	u64 *Uwin = nullptr;          // rank x 2 GMAX: pivot rows' words of the following window(s) (k_prio_window -> k_unwind)
+	u64 *Uwin = nullptr;          // rank x GMAX: pivot rows' words of the following window (k_prio_window -> k_unwind)
 	u64 *Pfast = nullptr;         // scratch of k_block_fast: the pivot rows' window words of a block, [panel][word][column]
 	SyncFlags *sf = nullptr;      // progress counters of the two streams (k_gate)
 	bool flag_sync = true;        // per-block hand-overs between the streams through sf + k_gate instead of events (GF2BV_FLAG_SYNC=0)
 	int sync_base = 0;            // the counters only grow: a pass that re-enqueues blocks (resume after a poisoned one) counts from here
-	// Look-ahead of depth two on blocks [deep_lo, deep_hi]: k_prio_window also takes the window AFTER the next (in place), the
-	// TRSM and the bulk update of the block leave both windows alone, the pivot rows park their words of both (Uwin).  A
-	// property of the single block -- every window still receives every block's update exactly once -- so deep and ordinary
-	// blocks mix freely.  Set for the blocks in front of a search chain (whose tail then never waits for a bulk update);
-	// GF2BV_DEEP=1 forces it on every block that has two full windows behind it (tests).
-	int deep_lo = INT_MAX, deep_hi = -1;
-	bool deep(int b) const { return b >= deep_lo && b <= deep_hi; }
 	bool fast_blocks = true;      // try the one-launch block search on dense blocks (GF2BV_FAST=0 disables)
 	bool optimistic = true;       // ... and drop the general panel steps behind it once block 0 has taken it (GF2BV_OPTIMISTIC=0)
 	int units = 0;
@@ -565,8 +557,8 @@ int solver_alloc(Solver &S)
 		const size_t o_st = carve(sizeof(SolveState)), o_sf = carve(sizeof(SyncFlags)), o_pan = carve(sizeof(PanelRec) * NP), o_aux = carve(sizeof(PanelAux) * NP),
 		             o_fu = carve(sizeof(FindUnit) * (S.units + 1 + GF2_MAXGROUPS)), o_alive = carve(sizeof(int) * (size_t)R),
 		             o_piv = carve(sizeof(int) * (S.maxr + 64)), o_urow = carve(sizeof(int) * (S.maxr + 64)),
-		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * 3 * G * mult_rows(R)),
-		             o_wb = carve(sizeof(u64) * 2 * GF2_GMAX * R), o_uw = carve(sizeof(u64) * 2 * GF2_GMAX * (S.maxr + 64)),
+		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * 2 * G * mult_rows(R)),
+		             o_wb = carve(sizeof(u64) * 2 * GF2_GMAX * R), o_uw = carve(sizeof(u64) * GF2_GMAX * (S.maxr + 64)),
 		             o_pf = carve(sizeof(u64) * GF2_GMAX * GF2_GMAX * 64);
 		S.arena_stride = off;
 		S.sync_base = 0;
@@ -706,7 +698,7 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 //     the two overlap: per-block time is max(panel path, bulk path), and B never idles when it is
 //     the longer one.
 // ---- one block of the forward elimination, in the three pieces the two streams interleave ----
-struct BlockGeom { int j0, gb, wlo, tb, nt_all, gnext, gnext2; u64 *mset; };
+struct BlockGeom { int j0, gb, wlo, tb, nt_all, gnext; u64 *mset; };
 BlockGeom block_geom(const Solver &S, int b)
 {
 	const int G = S.impl->G;
@@ -714,12 +706,11 @@ BlockGeom block_geom(const Solver &S, int b)
 	g.j0 = b * G;
 	g.gb = std::min(G, S.npanels - g.j0);
 	g.wlo = g.j0 + g.gb;
-	g.mset = S.mult + (i64)(b % 3) * G * mult_rows(S.rows);
+	g.mset = S.mult + (i64)(b & 1) * G * mult_rows(S.rows);
 	// trailing tiles; the next block's window [wlo, wlo + gnext) sits in the first one or two of them
 	g.tb = g.wlo / TW;
 	g.nt_all = (g.wlo < S.wt) ? (int)S.ntiles - g.tb : 0;
 	g.gnext = (b + 1 < S.nblocks) ? std::min(G, S.npanels - g.wlo) : 0;
-	g.gnext2 = S.deep(b) ? std::min(G, S.npanels - g.wlo - g.gnext) : 0;
 	return g;
 }
 
@@ -799,14 +790,14 @@ int enqueue_block_bulk(Solver &S, int b)
 	} else HIPCHK(hipStreamWaitEvent(S.sB, S.evA[b], 0));
 	bool launched = false;
 	if (g.nt_all > 0) {
-		int rc = launch_trsm(S, S.sB, g.j0, g.gb, g.wlo, g.wlo, g.wlo + g.gnext + g.gnext2);
+		int rc = launch_trsm(S, S.sB, g.j0, g.gb, g.wlo, g.wlo, g.wlo + g.gnext);
 		if (rc) return rc;
 #if GF2_TW == 2
 		// 16-byte tiles: the next block's window is whole tiles that are simply left out; when it ends in the middle of a
 		// tile (an odd number of window words: the block before a short last one) that tile takes the HALF instance first
 		// (the LAST block has no next window: its trailing words start at wlo, possibly in the middle of a tile whose first
 		// word is the block's own -- the table entries are zero there, see `keep` in k_update16 -- and nobody else writes it)
-		const int wend = g.wlo + g.gnext + g.gnext2;      // (the window(s) the look-ahead owns)
+		const int wend = g.wlo + g.gnext;
 		const int tfull = g.gnext > 0 ? (wend + 1) / 2 : g.wlo / 2;      // first tile with no window word
 		const i64 nfull = owned_count(tfull, S.ntiles, GF2_OWN_LOG - 1, S.world, S.wrank);
 		if ((wend & 1) && g.gnext > 0 && owned_count(wend / 2, wend / 2 + 1, GF2_OWN_LOG - 1, S.world, S.wrank) > 0) {
@@ -847,13 +838,9 @@ int enqueue_block_prio(Solver &S, int b)
 		k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sA>>>(S.sf, S.st, 0, 0, 0, S.sync_base + b, S.ss());
 		HIPCHK(hipGetLastError());
 	}
-	k_prio_window<0><<<dim3(row_blocks, S.nsys), dim3(256), 0, S.sA>>>((const u64 *)S.M, S.M, S.rows, S.srows, g.j0, g.gb, g.wlo, std::max(g.gnext, 1),
-	                                                                S.panels, S.aux, g.mset, S.blk_first + b, S.Wb, S.Uwin,
-	                                                                S.impl->T, S.st, S.ss());
-	if (g.gnext2 > 0)        // look-ahead of depth two: the window after the next, in place
-		k_prio_window<1><<<dim3(row_blocks, S.nsys), dim3(256), 0, S.sA>>>((const u64 *)S.M, S.M, S.rows, S.srows, g.j0, g.gb, g.wlo + g.gnext, g.gnext2,
-		                                                                S.panels, S.aux, g.mset, S.blk_first + b, S.Wb, S.Uwin,
-		                                                                S.impl->T, S.st, S.ss());
+	k_prio_window<<<dim3(row_blocks, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, g.wlo, std::max(g.gnext, 1),
+	                                                             S.panels, S.aux, g.mset, S.blk_first + b, S.Wb, S.Uwin,
+	                                                             S.impl->T, S.st, S.ss());
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
@@ -875,8 +862,8 @@ int enqueue_forward_join(Solver &S)
 	HIPCHK(hipEventRecord(S.ev3, S.sB));
 	HIPCHK(hipStreamWaitEvent(S.sA, S.ev3, 0));
 	if (S.nblocks > 1 && S.maxr > 0)
-		k_unwind<<<dim3((unsigned)((S.maxr * 2 * GF2_GMAX + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(
-			S.M, S.srows, S.impl->G, S.npanels, S.nblocks, S.st, S.pivcol, S.urow, S.Uwin, S.world, S.wrank, S.deep_lo, S.deep_hi, S.ss());
+		k_unwind<<<dim3((unsigned)((S.maxr * GF2_GMAX + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(
+			S.M, S.srows, S.impl->G, S.npanels, S.nblocks, S.st, S.pivcol, S.urow, S.Uwin, S.world, S.wrank, S.ss());
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
@@ -913,13 +900,6 @@ int enqueue_forward(Solver &S)
 		optimistic = hst.fast_done == 1;
 		b = 1;
 	}
-	S.deep_lo = INT_MAX; S.deep_hi = -1;
-	if (getenv("GF2BV_DEEP") && atoi(getenv("GF2BV_DEEP")) && TW == 2 && S.world == 1) {
-		// every block from b on that has two FULL windows behind it (a partial second window would end inside a tile)
-		const int G = S.impl->G;
-		const int last = (S.npanels - 3 * G) / G;           // block q: windows [G(q+1), G(q+2)) and [G(q+2), G(q+3)) exist in full
-		if (last >= b) { S.deep_lo = b; S.deep_hi = last; }
-	}
 	auto fast_only_ok = [&](int blk) {
 		// rows left when the block starts: at most 64 leftover candidates sit below the bound besides the pivots found
 		return fast_block_possible(S, block_geom(S, blk)) && S.rows - (i64)blk * 64 * S.impl->G >= GF2_FAST_NC + 128;
@@ -937,7 +917,6 @@ int enqueue_forward(Solver &S)
 			const int pb = hst.poison - 1;
 			HIPCHK(hipMemsetAsync(&S.st->poison, 0, sizeof(int), S.sA));
 			S.sync_base += S.nblocks + 1;
-			S.deep_lo = INT_MAX; S.deep_hi = -1;                // (the first pass has unwound the parked words of its deep blocks)
 			for (b = pb; b < S.nblocks; b++) {
 				if ((rc = enqueue_block_panel(S, b))) return rc;
 				if ((rc = enqueue_block_bulk(S, b))) return rc;
@@ -1851,10 +1830,10 @@ int gf2bv_kernel_resources(int device, int32_t *out, int n)
 	HIPCHK(hipSetDevice(device));
 #if GF2_TW == 2
 	const void *fn[5] = { (const void *)k_update16<512, false, 3, true, 512>, (const void *)k_block_fast, (const void *)k_narrow_all,
-	                      (const void *)k_prio_window<0>, (const void *)k_panel_step };
+	                      (const void *)k_prio_window, (const void *)k_panel_step };
 #else
 	const void *fn[5] = { (const void *)k_update<4, 12, 768>, (const void *)k_block_fast, (const void *)k_narrow_all,
-	                      (const void *)k_prio_window<0>, (const void *)k_panel_step };
+	                      (const void *)k_prio_window, (const void *)k_panel_step };
 #endif
 	for (int k = 0; k < 5; k++) {
 		hipFuncAttributes a{};

@@ -515,29 +515,6 @@ def test_stream_handover_through_memory_vs_events(monkeypatch):
         assert_same(g, job[3], 1)
 
 
-def test_look_ahead_of_depth_two(monkeypatch):
-    """GF2BV_DEEP=1: every block with two full windows behind it lets k_prio_window carry BOTH forward (the second one in
-    place), its TRSM and bulk update leave both alone and its pivot rows park their words of both -- same bits as the
-    ordinary look-ahead, for dense systems (one-launch block search, incl. a rank cap that poisons the optimistic enqueue
-    and resumes), sparse ones (general panel steps) and a gang."""
-    rng = random.Random(222)
-    monkeypatch.setenv("GF2BV_DEEP", "1")
-    for rows, cols, cap, dens in ((2700, 2600, None, .5), (5000, 4097, 2600, .5), (3000, 2900, 2893, .5), (2600, 2500, None, .02), (1500, 1029, None, .5)):
-        eqs = random_system(rng, rows, cols, dens, cap, True, 0)
-        aug = O.eqs_to_aug(eqs, cols)
-        for mode in (0, 1):
-            assert_same(hip.solve_words(aug, rows, cols, mode), O.solve_words(aug, rows, cols, mode), mode)
-    n = 3072
-    stride = hip.padded_stride(n)
-    bufs = hip.DeviceBuffer(4 * n * stride * 8)
-    for i in range(4):
-        hip.synth_device(bufs.ptr + i * n * stride * 8, n, n, stride, 700 + i)
-    sols = hip.solve_batch_device(bufs.ptr, 4, n * stride, n, n, stride, 1)
-    for i, s in enumerate(sols):
-        assert_same(s, O.solve_words(O.gen_synthetic(n, n, 700 + i), n, n, 1), 1)
-    bufs.free()
-
-
 def test_panel_kernels_fit_beside_the_bulk_update():
     """The panel path of block b + 1 runs BESIDE the bulk update of block b: its kernels must fit into
     what an update workgroup leaves of a CU -- 512 VGPRs per SIMD lane minus the update's two wavefronts, 160 KiB of LDS
