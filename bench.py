@@ -3,18 +3,23 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload single|batch] [--n 65536]
 
-Two workloads, both through the C ABI, inputs resident in HBM before the timed region:
+Workloads, all through the C ABI, inputs resident in HBM before the timed region:
 
-  single (default at N = 1; BASELINE.json configs[1]): one "step" = one complete solve_one of a synthetic dense
-      65536 x 65536 full-rank system (tile-major copy + forward elimination + consistency check + back-substitution +
-      export) by gf2bv_solve_device.  The default N = 1 run adds, as extra fields that are never `value`:
-      `target_262144` (the north-star size, 2 steps after 1 warm-up), `batch_throughput` (one GPU's share of configs[3])
-      and `cpu_baseline`.
-  batch  (default at N > 1; BASELINE.json configs[3]): 512 independent 32768 x 32768 systems, sharded in contiguous
-      blocks over the ranks (gf2bv_amd.batch.shard_bounds), every rank solving its block with
-      gf2bv_solve_batch_device (lock-step gangs) -- no collective on the data path -- then ONE all_gather of the
-      fixed-size records [status, rank, origin] (RCCL over xGMI).  One "step" = the whole 512-system job; the total is
-      fixed, so "scaling" is "strong".
+  single (the default at EVERY N; BASELINE.json configs[1]): one "step" = one complete solve_one of a synthetic dense
+      65536 x 65536 full-rank system PER GPU (tile-major copy + forward elimination + consistency check +
+      back-substitution + export) by gf2bv_solve_device; at N > 1 every rank solves its own system (generator seed +
+      rank), one all_gather of the solutions at the end -- per-GPU work is fixed, "scaling" is "weak", and the lines of
+      N = 1, 2, 4, 8 are the SAME workload, so the driver's scaling curve compares like with like.
+      Every default line also carries `batch_c4`: BASELINE.json configs[3], the job of 512 independent 32768 x 32768
+      systems sharded in contiguous blocks over the N ranks (1 warm-up + 1 timed step; at N = 1 all 512 on the one GPU,
+      73 GB resident -- the anchor of the strong-scaling curve `batch_c4.systems_per_s` over N), with its own roofline
+      block.  The N = 1 line adds `target_262144` (the north-star size, 2 steps after 1 warm-up) and `cpu_baseline`.
+      None of these extras is ever `value`.
+  batch  (`--workload batch`; BASELINE.json configs[3] as the line's own `value`): 512 independent 32768 x 32768
+      systems, sharded in contiguous blocks over the ranks (gf2bv_amd.batch.shard_bounds), every rank solving its
+      block with gf2bv_solve_batch_device (lock-step gangs) -- no collective on the data path -- then ONE all_gather of
+      the fixed-size records [status, rank, origin] (RCCL over xGMI).  One "step" = the whole 512-system job; the total
+      is fixed, so "scaling" is "strong".
 
 Launched for N > 1 as `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU).
 Rank 0 prints ONE JSON line carrying
@@ -52,17 +57,17 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", choices=["auto", "single", "batch", "sharded"], default="auto",
-                    help="auto = single at N = 1 (configs[1]), batch at N > 1 (configs[3]); sharded = ONE --n system with its "
-                         "columns over the ranks (SURVEY 8f-1, strong scaling)")
+                    help="auto = single at every N (configs[1] per GPU, weak scaling) with the configs[3] job as the extra block "
+                         "`batch_c4`; batch = configs[3] as the line itself; sharded = ONE --n system with its columns over "
+                         "the ranks (SURVEY 8f-1, strong scaling)")
     ap.add_argument("--n", type=int, default=65536, help="single: system size N (rows = cols)")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=None, help="size of the bounded CPU-baseline sample (default: 65536 single / 32768 batch)")
     ap.add_argument("--batch-total", type=int, default=512, help="batch: systems in the whole job (sharded over the ranks)")
     ap.add_argument("--batch-n", type=int, default=32768)
-    ap.add_argument("--batch-systems", type=int, default=64,
-                    help="single: also time a gang batch of this many --batch-n systems = one GPU's share of configs[3] "
-                         "(0 = skip); extra field, not `value`")
+    ap.add_argument("--no-batch-c4", action="store_true",
+                    help="single: skip the `batch_c4` block (the configs[3] job of --batch-total x --batch-n systems over the ranks)")
     ap.add_argument("--target-n", type=int, default=262144,
                     help="single: also run the north-star size (1 warm-up + 2 steps) as `target_262144` (0 = skip)")
     ap.add_argument("--no-kernel-events", action="store_true",
@@ -184,9 +189,12 @@ def timed_single(mat: torch.Tensor, n: int, stride: int, steps: int, warmup: int
         s = step()
         stats.append(s)
         sols[k].copy_(torch.from_numpy(s.origin.view(np.int64)))
-    if world > 1:
-        gathered = [torch.empty_like(sols) for _ in range(world)]
-        dist.all_gather(gathered, sols)          # the single end-of-job gather (RCCL over xGMI)
+    if world > 1:                                # the single end-of-job gather (RCCL over xGMI)
+        if dist.get_backend() == "gloo":         # (tests: ranks sharing one GPU; gloo gathers host memory only)
+            host = sols.cpu()
+            dist.all_gather([torch.empty_like(host) for _ in range(world)], host)
+        else:
+            dist.all_gather([torch.empty_like(sols) for _ in range(world)], sols)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -197,27 +205,6 @@ def timed_single(mat: torch.Tensor, n: int, stride: int, steps: int, warmup: int
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     return elapsed, stats, sols
-
-
-def batch_throughput(n: int, nsys: int, device: int, dev) -> dict:
-    """BASELINE configs[3], one GPU's share (64 of the 512 systems at 8 GPUs): nsys independent n x n systems resident in
-    HBM, solved by gf2bv_solve_batch_device (lock-step gangs) through gf2bv_amd.batch -- the function the N > 1 run
-    uses on every rank; every solution checked by the residual kernel."""
-    mats = batch.synth_shard(n, [BATCH_SEED0 + i for i in range(nsys)], device)
-    stride = hip.padded_stride(n)
-    best, sols = None, None
-    for _ in range(2):                                   # first pass warms the allocator
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        _, sols = batch.solve_shard(n, mats, device)
-        dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    bad = sum(hip.residual_device(mats[i].data_ptr(), n, n, stride, s.origin, device=device) for i, s in enumerate(sols))
-    xors = float(sum(s.stats["row_xors"] for s in sols))
-    del mats
-    return {"n": n, "systems": nsys, "ms_per_system": best / nsys * 1e3, "systems_per_s": nsys / best,
-            "row_xors_per_s": xors / best, "residual_rows": int(bad), "all_solved": all(s.solved for s in sols),
-            "gang_systems": int(sols[0].stats.get("gang_systems", 0))}
 
 
 def run_single(args, world, rank, local_rank, dev):
@@ -241,6 +228,10 @@ def run_single(args, world, rank, local_rank, dev):
         dist.all_reduce(agg)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     del mat
+    c4 = None
+    if not args.no_batch_c4 and args.batch_total > 0:
+        torch.cuda.empty_cache()
+        c4 = batch_job(args, world, rank, local_rank, dev, steps=1, warmup=1)       # every rank takes part (barriers, gather)
     if rank != 0:
         return None
     s0 = stats[-1].stats
@@ -260,7 +251,8 @@ def run_single(args, world, rank, local_rank, dev):
         "config": {
             "workload": f"synthetic dense {n}x{n} GF(2) solve_one, planted RHS, seed {seed}"
                         + (" (full rank)" if n in FULL_RANK_SEEDS and args.seed is None else ""),
-            "systems_per_step_per_gpu": 1, "parallelism": f"independent systems x{world}",
+            "systems_per_step_per_gpu": 1,
+            "parallelism": f"independent systems x{world}" + (", one all_gather of the solutions at the end" if world > 1 else ""),
             "tables_per_sweep": s0["tables_per_sweep"], "table_bits": s0["table_bits"],
             "tile_words": s0["tile_words"], "rank": int(stats[-1].rank),
         },
@@ -275,8 +267,8 @@ def run_single(args, world, rank, local_rank, dev):
     }
     if world == 1 and args.target_n > 0 and n == 65536:
         out[f"target_{args.target_n}"] = target_leg(args.target_n, local_rank, dev, ceil)
-    if world == 1 and args.batch_systems > 0:
-        out["batch_throughput"] = batch_throughput(args.batch_n, args.batch_systems, local_rank, dev)
+    if c4 is not None:
+        out["batch_c4"] = c4
     if world == 1 and not args.no_cpu_baseline:
         m = args.cpu_n or 65536
         cb = cpu_baseline(m, seed)
@@ -315,8 +307,9 @@ def target_leg(n: int, device: int, dev, ceil: dict) -> dict:
             "roofline": roofline}
 
 
-def run_batch(args, world, rank, local_rank, dev):
-    """BASELINE configs[3]: args.batch_total independent n x n systems, contiguous blocks per rank, one gather."""
+def batch_job(args, world, rank, local_rank, dev, steps: int, warmup: int):
+    """BASELINE configs[3]: args.batch_total independent n x n systems, contiguous blocks per rank, one gather.
+    `warmup` untimed + `steps` timed passes of the whole job; returns the measurement dict on rank 0, None elsewhere."""
     n, total = args.batch_n, args.batch_total
     lo, hi = batch.shard_bounds(total, world, rank)
     seeds = [BATCH_SEED0 + i for i in range(lo, hi)]
@@ -330,7 +323,7 @@ def run_batch(args, world, rank, local_rank, dev):
         allrec = batch.gather_records(recs, total)              # the single end-of-job collective (no-op at N = 1)
         return allrec, sols
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     torch.cuda.synchronize(dev)
     if world > 1:
@@ -338,7 +331,7 @@ def run_batch(args, world, rank, local_rank, dev):
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     allrec, sols, all_sols = None, None, []
-    for _ in range(args.steps):
+    for _ in range(steps):
         allrec, sols = step()
         all_sols.extend(sols)
     torch.cuda.synchronize(dev)
@@ -366,11 +359,12 @@ def run_batch(args, world, rank, local_rank, dev):
                         float(sum(s.stats["ms_sweep"] / max(s.stats.get("gang_systems", 1), 1) for s in all_sols)),
                         float(sum(s.stats["n_sweeps"] / max(s.stats.get("gang_systems", 1), 1) for s in all_sols))],
                        dtype=torch.float64, device=dev)
-    per_rank = torch.tensor([float(hi - lo) * args.steps / elapsed], dtype=torch.float64, device=dev)
+    per_rank = torch.tensor([float(hi - lo) * steps / elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(agg)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     del mats
+    torch.cuda.empty_cache()
     if rank != 0:
         return None
     row_xors, alg_bytes, sweep_ms, launches = (float(x) for x in agg.tolist())
@@ -383,38 +377,47 @@ def run_batch(args, world, rank, local_rank, dev):
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "kernel": f"{'k_update16' if s0['tile_words'] == 2 else 'k_update'}<G={g},T={s0['tables_per_sweep'] // g}> (bulk update of a gang: "
+            "kernel": f"k_update16<G={g},T={s0['tables_per_sweep'] // g}> (bulk update of a gang: "
                       f"{s0.get('gang_systems', 0)} systems x {64 * g} pivots per launch)",
             "launches": launches, "alg_bytes_per_launch": alg_bytes / max(launches, 1),
             "avg_launch_ms": sweep_ms / max(launches, 1),
             "measured_rmw_stream_GBs": ceil["rmw_gbs"], "measured_read_stream_GBs": ceil["read_gbs"],
-            "frac_of_measured_rmw": achieved / ceil["rmw_gbs"],
+            # end to end: the job's algorithmic bytes over its wall time (all ranks), against N x 8 TB/s
+            "end_to_end_frac": alg_bytes / steps / (elapsed / steps) / 1e9 / (HBM_PEAK_GBS * world),
             "note": "summed over all ranks; two gangs are in flight per GPU (a gang's back-substitution and export overlap "
                     "the next gang's elimination), so a launch's duration includes the share of the chip the other gang took",
         }
-    out = {
-        "metric": "GF(2) row-XORs/s (batch of independent dense NxN solve_one, sharded)", "value": row_xors / elapsed,
-        "unit": "row-XORs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+    return {
+        "value": row_xors / elapsed, "unit": "row-XORs/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3, "scaling": "strong",
         "config": {
             "workload": f"batch of {total} independent synthetic dense {n}x{n} GF(2) solve_one systems (seeds {BATCH_SEED0}..), "
-                        f"contiguous blocks of {total}/{world} per GPU, one all_gather of [status, rank, origin] records at the end",
+                        f"contiguous blocks per GPU, one all_gather of [status, rank, origin] records at the end",
             "systems_total": total, "systems_per_gpu": (total + world - 1) // world, "n": n,
             "parallelism": f"independent systems, shard x{world}, gangs of {s0.get('gang_systems', 0)}",
             "tables_per_sweep": s0["tables_per_sweep"], "table_bits": s0["table_bits"], "tile_words": s0["tile_words"],
             "collective": ("all_gather over nccl (RCCL)" if world > 1 else "none (single rank)"),
         },
-        "systems_per_s": total * args.steps / elapsed,
-        "ms_per_system_per_gpu": elapsed / args.steps / ((total + world - 1) // world) * 1e3,
+        "systems_per_s": total * steps / elapsed,
+        "ms_per_system_per_gpu": elapsed / steps / ((total + world - 1) // world) * 1e3,
         "rank0_systems_per_s": float(per_rank.item()),
         "parity_gate": {"residual_rows_rank0": int(bad), "all_ranks_ok": bool(ok.item()),
                         "gathered_records": int(allrec.shape[0])},
-        "row_panels_per_s": total * args.steps * n * ((n + 63) // 64) / 2 / elapsed,
+        "row_panels_per_s": total * steps * n * ((n + 63) // 64) / 2 / elapsed,
         "roofline": roofline,
     }
+
+
+def run_batch(args, world, rank, local_rank, dev):
+    """`--workload batch`: the configs[3] job as the line's own value."""
+    job = batch_job(args, world, rank, local_rank, dev, args.steps, args.warmup)
+    if rank != 0:
+        return None
+    out = {"metric": "GF(2) row-XORs/s (batch of independent dense NxN solve_one, sharded)"}
+    out.update(job)
+    out.update({"higher_is_better": True, "vs_baseline": None, "dtype": "u64", "data": "synthetic"})
     if world == 1 and not args.no_cpu_baseline:
-        m = args.cpu_n or n
+        m = args.cpu_n or args.batch_n
         cb = cpu_baseline(m, BATCH_SEED0)
         out["parity_gate"]["gpu_equals_cpu_oracle_on_sample"] = gpu_equals_oracle(cb, m, BATCH_SEED0, local_rank)
         out["cpu_baseline"] = cb
@@ -493,7 +496,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
-    workload = args.workload if args.workload != "auto" else ("single" if world == 1 else "batch")
+    workload = args.workload if args.workload != "auto" else "single"
     out = {"single": run_single, "batch": run_batch, "sharded": run_sharded}[workload](args, world, rank, local_rank, dev)
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -9,7 +9,17 @@ There is no CPU fallback: importing works anywhere, solving needs the GPU.
 from ._internal import AffineSpace, m4ri_solve, mul_bit_quad, to_bits, tuple_where, xor_tuple
 from .bitvec import BitVec
 from .linsys import DimensionTooLargeError, LinearSystem, QuadraticSystem, Zeros
-from .packed import PackedBitVec, PackedLinearSystem
+
+
+def __getattr__(name):
+    # the packed front-end needs numpy (>= 1.20; np.bitwise_count of 2.x is used when present): imported on first use so
+    # that the package itself has no import-time dependency beyond the standard library
+    if name in ("PackedBitVec", "PackedLinearSystem", "packed"):
+        import importlib
+        mod = importlib.import_module(".packed", __name__)
+        return mod if name == "packed" else getattr(mod, name)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
+
 
 __all__ = [
     "AffineSpace", "BitVec", "DimensionTooLargeError", "LinearSystem", "PackedBitVec", "PackedLinearSystem",

@@ -90,6 +90,7 @@ void space_dealloc(AffineSpaceObject *self)
 }
 
 PyObject *space_dimension(AffineSpaceObject *self, void *) { return PyLong_FromLongLong(self->dim); }
+PyObject *space_device(AffineSpaceObject *self, void *) { return PyLong_FromLong(self->device); }
 PyObject *space_origin(AffineSpaceObject *self, void *) { return words_to_pylong(self->origin, self->words); }
 PyObject *space_basis(AffineSpaceObject *self, void *)
 {
@@ -241,6 +242,7 @@ PyGetSetDef space_getset[] = {
 	{"dimension", (getter)space_dimension, nullptr, "Dimension of the affine space", nullptr},
 	{"origin", (getter)space_origin, nullptr, "Origin of the affine space", nullptr},
 	{"basis", (getter)space_basis, nullptr, "Basis of the affine space", nullptr},
+	{"device", (getter)space_device, nullptr, "GPU whose solve produced the space (-1: built on the host); not in the reference", nullptr},
 	{nullptr, nullptr, nullptr, nullptr, nullptr}};
 
 PyMethodDef space_methods[] = {
@@ -269,7 +271,7 @@ PyType_Spec slow_spec = {"_internal.AffineSpaceIteratorSlow", sizeof(SpaceIterOb
                          Py_TPFLAGS_DEFAULT | Py_TPFLAGS_DISALLOW_INSTANTIATION, slow_slots};
 
 // Result handle -> None / int / AffineSpace (_internal.c:440-501); frees the handle.
-PyObject *result_to_py(gf2bv_result *res, long mode)
+PyObject *result_to_py(gf2bv_result *res, long mode, int device)
 {
 	if (gf2bv_result_status(res) != GF2BV_STATUS_SOLVED) {
 		gf2bv_result_free(res);
@@ -286,7 +288,7 @@ PyObject *result_to_py(gf2bv_result *res, long mode)
 		if (sp) {
 			sp->dim = gf2bv_result_dimension(res);
 			sp->words = words;
-			sp->device = 0;
+			sp->device = device;
 			sp->origin = (uint64_t *)calloc((size_t)(words ? words : 1), sizeof(uint64_t));
 			sp->basis = (uint64_t *)calloc((size_t)((sp->dim * words) > 0 ? sp->dim * words : 1), sizeof(uint64_t));
 			if (!sp->origin || !sp->basis) {
@@ -301,6 +303,53 @@ PyObject *result_to_py(gf2bv_result *res, long mode)
 	}
 	gf2bv_result_free(res);
 	return ret;
+}
+
+// Which GPU a solve runs on.  The reference's m4ri_solve has no such notion (one core of the host); here every solve entry
+// takes an OPTIONAL trailing `device` argument (an index below device_count()), and without it uses the module default
+// (set_default_device; initially the environment variable GF2BV_DEVICE, else 0).  AffineSpace remembers the device of
+// its solve: large walks are materialised there.
+int g_default_device = -1;
+int default_device()
+{
+	if (g_default_device < 0) {
+		const char *e = getenv("GF2BV_DEVICE");
+		g_default_device = e ? atoi(e) : 0;
+		if (g_default_device < 0) g_default_device = 0;
+	}
+	return g_default_device;
+}
+bool parse_device(PyObject *obj, int *device)
+{
+	if (obj == Py_None) { *device = default_device(); return true; }
+	const long d = PyLong_AsLong(obj);
+	if (d == -1 && PyErr_Occurred()) return false;
+	const int n = gf2bv_device_count();
+	if (d < 0 || (n > 0 && d >= n)) { PyErr_Format(PyExc_ValueError, "device %ld out of range (%d visible)", d, n); return false; }
+	*device = (int)d;
+	return true;
+}
+// devices: None = every visible device, an int, or a sequence of ints (repeats allowed)
+bool parse_devices(PyObject *obj, std::vector<int> *devs)
+{
+	devs->clear();
+	if (obj == Py_None) {
+		const int n = gf2bv_device_count();
+		for (int d = 0; d < (n > 0 ? n : 1); d++) devs->push_back(d);
+		return true;
+	}
+	if (PyLong_Check(obj)) { int d; if (!parse_device(obj, &d)) return false; devs->push_back(d); return true; }
+	PyObject *seq = PySequence_Fast(obj, "devices must be None, an int or a sequence of ints");
+	if (!seq) return false;
+	const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
+	for (Py_ssize_t i = 0; i < n; i++) {
+		int d;
+		if (!parse_device(PySequence_Fast_GET_ITEM(seq, i), &d)) { Py_DECREF(seq); return false; }
+		devs->push_back(d);
+	}
+	Py_DECREF(seq);
+	if (devs->empty()) { PyErr_SetString(PyExc_ValueError, "devices must not be empty"); return false; }
+	return true;
 }
 
 // cols / mode checks shared by m4ri_solve and m4ri_solve_many (_internal.c:372-395)
@@ -383,7 +432,9 @@ struct DigitGather {
 // m4ri_solve(equations, cols, mode) -- gf2bv/_internal.c:359-502
 PyObject *py_m4ri_solve(PyObject *, PyObject *const *args, Py_ssize_t nargs)
 {
-	if (nargs != 3) { PyErr_SetString(PyExc_TypeError, "m4ri_solve requires 3 arguments"); return nullptr; }
+	if (nargs != 3 && nargs != 4) { PyErr_SetString(PyExc_TypeError, "m4ri_solve requires 3 arguments"); return nullptr; }
+	int device = default_device();
+	if (nargs == 4 && !parse_device(args[3], &device)) return nullptr;
 	PyObject *list = args[0];
 	if (!PyList_Check(list)) {
 		PyErr_SetString(PyExc_TypeError, "The first argument equations must be a list");
@@ -405,14 +456,14 @@ PyObject *py_m4ri_solve(PyObject *, PyObject *const *args, Py_ssize_t nargs)
 	gf2bv_result *res = nullptr;
 	int rc;
 	Py_BEGIN_ALLOW_THREADS          // same place the reference drops the GIL (_internal.c:429)
-	rc = gf2bv_solve_digits(dg.digits, dg.off.data(), PyLong_SHIFT, rows, cols, (int)mode, 0, &res);
+	rc = gf2bv_solve_digits(dg.digits, dg.off.data(), PyLong_SHIFT, rows, cols, (int)mode, device, &res);
 	Py_END_ALLOW_THREADS
 	if (rc != GF2BV_OK) {
 		PyErr_Format(rc == GF2BV_ERR_ARG ? PyExc_ValueError : PyExc_RuntimeError,
 		             "gf2bv_amd: HIP solve failed (%d): %s", rc, gf2bv_last_error());
 		return nullptr;
 	}
-	return result_to_py(res, mode);
+	return result_to_py(res, mode, device);
 }
 
 // m4ri_solve_packed(buffer, rows, words, cols, mode) -> None | int | AffineSpace.
@@ -423,7 +474,9 @@ PyObject *py_m4ri_solve(PyObject *, PyObject *const *args, Py_ssize_t nargs)
 // gf2bv/_internal.c:403-426 does bit by bit.  Same checks, same result types as m4ri_solve.
 PyObject *py_m4ri_solve_packed(PyObject *, PyObject *const *args, Py_ssize_t nargs)
 {
-	if (nargs != 5) { PyErr_SetString(PyExc_TypeError, "m4ri_solve_packed requires 5 arguments"); return nullptr; }
+	if (nargs != 5 && nargs != 6) { PyErr_SetString(PyExc_TypeError, "m4ri_solve_packed requires 5 arguments"); return nullptr; }
+	int device = default_device();
+	if (nargs == 6 && !parse_device(args[5], &device)) return nullptr;
 	const Py_ssize_t rows = PyLong_AsSsize_t(args[1]), words = PyLong_AsSsize_t(args[2]);
 	if ((rows == -1 || words == -1) && PyErr_Occurred()) return nullptr;
 	Py_ssize_t cols;
@@ -447,7 +500,7 @@ PyObject *py_m4ri_solve_packed(PyObject *, PyObject *const *args, Py_ssize_t nar
 	gf2bv_result *res = nullptr;
 	int rc;
 	Py_BEGIN_ALLOW_THREADS
-	rc = gf2bv_solve_digits(static_cast<const uint32_t *>(view.buf), off.data(), 32, rows, cols, (int)mode, 0, &res);
+	rc = gf2bv_solve_digits(static_cast<const uint32_t *>(view.buf), off.data(), 32, rows, cols, (int)mode, device, &res);
 	Py_END_ALLOW_THREADS
 	PyBuffer_Release(&view);
 	if (rc != GF2BV_OK) {
@@ -455,16 +508,20 @@ PyObject *py_m4ri_solve_packed(PyObject *, PyObject *const *args, Py_ssize_t nar
 		             "gf2bv_amd: HIP solve failed (%d): %s", rc, gf2bv_last_error());
 		return nullptr;
 	}
-	return result_to_py(res, mode);
+	return result_to_py(res, mode, device);
 }
 
-// m4ri_solve_many(list_of_equation_lists, cols, mode) -> list of (None | int | AffineSpace).
+// m4ri_solve_many(list_of_equation_lists, cols, mode[, devices]) -> list of (None | int | AffineSpace).
 // New entry (no counterpart in the reference): independent systems of one shape -- one per output
 // bit / per instance in the recovery examples -- are solved as lock-step gangs by one call; every
-// element of the result is what m4ri_solve would return for that system.
+// element of the result is what m4ri_solve would return for that system.  `devices`: None (default) = every
+// visible GPU, an int, or a sequence of device indices -- the systems are sharded in contiguous blocks over them,
+// one host thread per entry inside the library (gf2bv_solve_batch_digits_multi), results in input order.
 PyObject *py_m4ri_solve_many(PyObject *, PyObject *const *args, Py_ssize_t nargs)
 {
-	if (nargs != 3) { PyErr_SetString(PyExc_TypeError, "m4ri_solve_many requires 3 arguments"); return nullptr; }
+	if (nargs != 3 && nargs != 4) { PyErr_SetString(PyExc_TypeError, "m4ri_solve_many requires 3 arguments"); return nullptr; }
+	std::vector<int> devs;
+	if (!parse_devices(nargs == 4 ? args[3] : Py_None, &devs)) return nullptr;
 	PyObject *systems = args[0];
 	if (!PyList_Check(systems)) {
 		PyErr_SetString(PyExc_TypeError, "The first argument must be a list of equation lists");
@@ -499,7 +556,8 @@ PyObject *py_m4ri_solve_many(PyObject *, PyObject *const *args, Py_ssize_t nargs
 	std::vector<gf2bv_result *> res((size_t)nsys, nullptr);
 	int rc;
 	Py_BEGIN_ALLOW_THREADS
-	rc = gf2bv_solve_batch_digits(dg.digits, dg.off.data(), PyLong_SHIFT, nsys, rows, cols, (int)mode, 0, res.data());
+	rc = gf2bv_solve_batch_digits_multi(dg.digits, dg.off.data(), PyLong_SHIFT, nsys, rows, cols, (int)mode, devs.data(),
+	                                    (int)devs.size(), res.data());
 	Py_END_ALLOW_THREADS
 	if (rc != GF2BV_OK) {
 		for (gf2bv_result *r : res) if (r) gf2bv_result_free(r);
@@ -510,7 +568,11 @@ PyObject *py_m4ri_solve_many(PyObject *, PyObject *const *args, Py_ssize_t nargs
 	PyObject *out = PyList_New(nsys);
 	Py_ssize_t done = 0;
 	for (; out && done < nsys; done++) {
-		PyObject *item = result_to_py(res[done], mode);      // frees res[done]
+		// (the share -> device map of gf2bv_solve_batch_digits_multi: share k = systems floor(nsys k / n) ..)
+		const Py_ssize_t nsh = std::min<Py_ssize_t>((Py_ssize_t)devs.size(), nsys);
+		Py_ssize_t share = 0;
+		while (share + 1 < nsh && nsys * (share + 1) / nsh <= done) share++;
+		PyObject *item = result_to_py(res[done], mode, devs[(size_t)share]);      // frees res[done]
 		if (!item) { done++; Py_CLEAR(out); break; }
 		PyList_SET_ITEM(out, done, item);
 	}
@@ -678,15 +740,24 @@ PyObject *py_space_from_ints(PyObject *, PyObject *const *args, Py_ssize_t nargs
 }
 
 PyObject *py_device_count(PyObject *, PyObject *) { return PyLong_FromLong(gf2bv_device_count()); }
+PyObject *py_get_default_device(PyObject *, PyObject *) { return PyLong_FromLong(default_device()); }
+PyObject *py_set_default_device(PyObject *, PyObject *arg)
+{
+	int d;
+	if (arg == Py_None) { PyErr_SetString(PyExc_TypeError, "device must be an int"); return nullptr; }
+	if (!parse_device(arg, &d)) return nullptr;
+	g_default_device = d;
+	Py_RETURN_NONE;
+}
 
 #define FAST(fn) (PyCFunction)(void (*)(void))(fn)
 PyMethodDef module_methods[] = {
 	{"m4ri_solve", FAST(py_m4ri_solve), METH_FASTCALL,
-	 "m4ri_solve(equations, cols, mode)\n--\n\nSolve the linear system on the MI355X; None when inconsistent."},
+	 "m4ri_solve(equations, cols, mode, device=None)\n--\n\nSolve the linear system on the MI355X; None when inconsistent."},
 	{"m4ri_solve_packed", FAST(py_m4ri_solve_packed), METH_FASTCALL,
-	 "m4ri_solve_packed(buffer, rows, words, cols, mode)\n--\n\nm4ri_solve on equations already packed as rows x words 64-bit words (equation-int bit order)."},
+	 "m4ri_solve_packed(buffer, rows, words, cols, mode, device=None)\n--\n\nm4ri_solve on equations already packed as rows x words 64-bit words (equation-int bit order)."},
 	{"m4ri_solve_many", FAST(py_m4ri_solve_many), METH_FASTCALL,
-	 "m4ri_solve_many(systems, cols, mode)\n--\n\nSolve a list of same-shape systems in one batched call; list of m4ri_solve results."},
+	 "m4ri_solve_many(systems, cols, mode, devices=None)\n--\n\nSolve a list of same-shape systems in one batched call, sharded over the given (default: all visible) GPUs; list of m4ri_solve results."},
 	{"to_bits", FAST(py_to_bits), METH_FASTCALL, "to_bits(n, a)\n--\n\nLow n bits of a, LSB first."},
 	{"mul_bit_quad", FAST(py_mul_bit_quad), METH_FASTCALL, "mul_bit_quad(n, a, b, v, basis)\n--\n\n"},
 	{"xor_tuple", FAST(py_xor_tuple), METH_FASTCALL, "xor_tuple(a, b)\n--\n\nElement-wise xor."},
@@ -694,6 +765,8 @@ PyMethodDef module_methods[] = {
 	{"eqs_to_sage_mat_helper", FAST(py_sage_helper), METH_FASTCALL, "not available in gf2bv_amd"},
 	{"_space_from_ints", FAST(py_space_from_ints), METH_FASTCALL, "test hook: AffineSpace from ints"},
 	{"device_count", py_device_count, METH_NOARGS, "number of visible HIP devices"},
+	{"get_default_device", py_get_default_device, METH_NOARGS, "the device solves run on when no `device` argument is given"},
+	{"set_default_device", py_set_default_device, METH_O, "set_default_device(d)\n--\n\nselect the GPU for solves without a `device` argument"},
 	{nullptr, nullptr, 0, nullptr}};
 
 PyModuleDef module_def = {PyModuleDef_HEAD_INIT, "_internal", "gf2bv_amd native boundary (HIP solver)", -1,

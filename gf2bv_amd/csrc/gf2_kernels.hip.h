@@ -422,7 +422,11 @@ k_gate(SyncFlags *__restrict__ sf, SolveState *__restrict__ st, int set_narrow, 
 __device__ __forceinline__ void signal_light(DoneSignal sig, i64 arena_off, unsigned total_wgs)      // by ALL threads, at the very end
 {
 	if (!sig.count) return;                                 // (uniform)
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // the write-through stores of this workgroup have landed
+	// every thread waits for ITS write-through stores to be acknowledged before the barrier: a workgroup-scope release
+	// fence compiles to lgkmcnt(0) only (no vmcnt wait outside tgsplit mode), so without this the counter below could
+	// be published while other wavefronts' multiplier stores are still in flight
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 	__syncthreads();
 	if (threadIdx.x == 0) {
 		unsigned *cnt = sys_at(sig.count, arena_off);

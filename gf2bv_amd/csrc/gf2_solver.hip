@@ -1330,16 +1330,26 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 			for (i64 q = t; q < ngangs && rcs[t] == GF2BV_OK; q += NS) {
 				try {
 				const i64 s0 = q * gang;
-				Solver S;
-				S.t_begin = std::chrono::steady_clock::now();
-				S.device = device;
-				S.sA = st;
-				S.nsys = (int)std::min<i64>(gang, nsys - s0);
-				S.src = (const u64 *)d_aug + s0 * sys_stride_words;
-				S.src_sys_words = sys_stride_words;
-				S.rows = rows; S.cols = cols; S.stride = stride_words; S.mode = mode;
-				S.time_kernels = time_kernels != 0;
-				int rc = solve_gang(S, &out[s0]);
+				const int ns = (int)std::min<i64>(gang, nsys - s0);
+				int rc = GF2BV_OK;
+				// an expired hand-over gate voids THIS gang only: its results (if any were built) are dropped and the
+				// gang runs once more with events -- the device is marked by then; other gangs' results stay
+				for (int attempt = 0; attempt < 2; attempt++) {
+					Solver S;
+					S.t_begin = std::chrono::steady_clock::now();
+					S.device = device;
+					S.sA = st;
+					S.nsys = ns;
+					S.src = (const u64 *)d_aug + s0 * sys_stride_words;
+					S.src_sys_words = sys_stride_words;
+					S.rows = rows; S.cols = cols; S.stride = stride_words; S.mode = mode;
+					S.time_kernels = time_kernels != 0;
+					rc = solve_gang(S, &out[s0]);
+					if (rc != GF2BV_RETRY_EVENTS) break;
+					for (int k = 0; k < ns; k++) { delete out[s0 + k]; out[s0 + k] = nullptr; }
+					(void)hipStreamSynchronize(st);
+				}
+				if (rc == GF2BV_RETRY_EVENTS) { rc = GF2BV_ERR_HIP; g_err = "a stream hand-over gate timed out on the device"; }
 				if (rc != GF2BV_OK) { rcs[t] = rc; errs[t] = g_err; }
 				} catch (const std::bad_alloc &) { rcs[t] = GF2BV_ERR_NOMEM; errs[t] = "out of host memory"; }
 				(void)hipStreamSynchronize(st);
@@ -1395,21 +1405,28 @@ int gf2bv_solve_words(const uint64_t *aug, int64_t rows, int64_t cols, int64_t s
 	});
 }
 
-int gf2bv_solve_batch_digits(const uint32_t *digits, const int64_t *digit_off, int bits_per_digit, int64_t nsys,
-                             int64_t rows, int64_t cols, int mode, int device, gf2bv_result **out)
+// One device's share of a digits batch.  digit_off[] holds ABSOLUTE digit positions (a later share of a larger batch does
+// not start at 0): only digits[digit_off[0] .. digit_off[nsys * rows]) are uploaded and the pack kernel sees them through a
+// rebased pointer.
+static int batch_digits_on(const uint32_t *digits, const int64_t *digit_off, int bits_per_digit, int64_t nsys,
+                           int64_t rows, int64_t cols, int mode, int device, gf2bv_result **out)
 {
+	bool again = false;
 	return guarded([&]() -> int {
 	if (!out || !digit_off || nsys < 0) return fail(GF2BV_ERR_ARG, "null pointer");
-	for (i64 s = 0; s < nsys; s++) out[s] = nullptr;
+	for (i64 s = 0; s < nsys; s++) { if (again) delete out[s]; out[s] = nullptr; }      // (a retry drops what the voided attempt built)
+	again = true;
 	int rc = check_shape(rows, cols, mode);
 	if (rc) return rc;
 	if (bits_per_digit < 1 || bits_per_digit > 32) return fail(GF2BV_ERR_ARG, "bits_per_digit must be 1..32");
 	rc = check_device(device);
 	if (rc) return rc;
 	if (nsys == 0) return GF2BV_OK;
+	HIPCHK(hipSetDevice(device));
 	const i64 wt = (cols + 1 + 63) / 64, ntiles = tiles_for(wt), srows = slab_rows(rows);
 	const i64 m_stride = ntiles * TW * srows;
-	const i64 nrows_all = nsys * rows, ndig = digit_off[nrows_all];
+	const i64 nrows_all = nsys * rows, dig0 = digit_off[0], ndig = digit_off[nrows_all] - dig0;
+	if (ndig < 0) return fail(GF2BV_ERR_ARG, "digit offsets must not decrease");
 	// all digits and offsets go up once; every gang packs its own systems straight into tile-major slabs
 	struct Staged {
 		uint32_t *dig = nullptr; i64 *off = nullptr; hipStream_t st = nullptr; int device = 0;
@@ -1424,7 +1441,7 @@ int gf2bv_solve_batch_digits(const uint32_t *digits, const int64_t *digit_off, i
 	HIPCHK(pool().stream(&G.st, device, 0));
 	HIPCHK(pool().alloc((void **)&G.dig, sizeof(uint32_t) * std::max<i64>(1, ndig), device));
 	HIPCHK(pool().alloc((void **)&G.off, sizeof(i64) * (nrows_all + 1), device));
-	if (ndig) HIPCHK(hipMemcpyAsync(G.dig, digits, sizeof(uint32_t) * ndig, hipMemcpyHostToDevice, G.st));
+	if (ndig) HIPCHK(hipMemcpyAsync(G.dig, digits + dig0, sizeof(uint32_t) * ndig, hipMemcpyHostToDevice, G.st));
 	HIPCHK(hipMemcpyAsync(G.off, digit_off, sizeof(i64) * (nrows_all + 1), hipMemcpyHostToDevice, G.st));
 	const i64 gang = pick_gang(nsys, rows, cols);
 	for (i64 s0 = 0; s0 < nsys; s0 += gang) {
@@ -1439,13 +1456,54 @@ int gf2bv_solve_batch_digits(const uint32_t *digits, const int64_t *digit_off, i
 		const i64 total = rows * ntiles * TW;
 		if (total > 0)
 			k_pack_digits<<<dim3((unsigned)((ntiles * TW + 255) / 256), (unsigned)std::min<i64>(rows, 65535), S.nsys), dim3(256), 0, S.sA>>>(
-				G.dig, G.off + s0 * rows, bits_per_digit, (i64)rows, (i64)cols, ntiles * TW, srows, S.M, SysStride{m_stride, 0});
+				G.dig - dig0, G.off + s0 * rows, bits_per_digit, (i64)rows, (i64)cols, ntiles * TW, srows, S.M, SysStride{m_stride, 0});
 		HIPCHK(hipGetLastError());
 		rc = solve_gang(S, &out[s0]);
 		if (rc) return rc;
 	}
 	return GF2BV_OK;
 	});
+}
+
+int gf2bv_solve_batch_digits(const uint32_t *digits, const int64_t *digit_off, int bits_per_digit, int64_t nsys,
+                             int64_t rows, int64_t cols, int mode, int device, gf2bv_result **out)
+{
+	return batch_digits_on(digits, digit_off, bits_per_digit, nsys, rows, cols, mode, device, out);
+}
+
+// The same batch over SEVERAL devices (the reference solves one system per m4ri_solve call on one core; independent
+// systems -- one per output bit / per instance in the recovery examples -- are this path's natural shard unit):
+// entry k of devices[] takes the k-th contiguous share of the systems on its own host thread (a device may be listed more
+// than once: its shares then run as concurrent gangs on it), results land in out[] in input order.  No collective and no
+// torch: one process drives every GPU of the node.
+int gf2bv_solve_batch_digits_multi(const uint32_t *digits, const int64_t *digit_off, int bits_per_digit, int64_t nsys,
+                                   int64_t rows, int64_t cols, int mode, const int *devices, int ndevices,
+                                   gf2bv_result **out)
+{
+	if (!out || !digit_off || !devices || nsys < 0 || ndevices < 1) return fail(GF2BV_ERR_ARG, "null pointer");
+	for (i64 s = 0; s < nsys; s++) out[s] = nullptr;
+	for (int k = 0; k < ndevices; k++) { int rc = check_device(devices[k]); if (rc) return rc; }
+	const int nshares = (int)std::min<i64>(ndevices, std::max<i64>(nsys, 1));
+	if (nshares == 1) return batch_digits_on(digits, digit_off, bits_per_digit, nsys, rows, cols, mode, devices[0], out);
+	std::vector<int> rcs((size_t)nshares, GF2BV_OK);
+	std::vector<std::string> errs((size_t)nshares);
+	std::vector<std::thread> th;
+	try {
+		for (int k = 0; k < nshares; k++) {
+			const i64 lo = nsys * k / nshares, hi = nsys * (k + 1) / nshares;
+			th.emplace_back([&, k, lo, hi]() {
+				rcs[k] = batch_digits_on(digits, digit_off + lo * rows, bits_per_digit, hi - lo, rows, cols, mode, devices[k], out + lo);
+				if (rcs[k] != GF2BV_OK) errs[k] = g_err;
+			});
+		}
+	} catch (const std::exception &) { for (auto &t : th) t.join(); for (i64 s = 0; s < nsys; s++) { delete out[s]; out[s] = nullptr; } return fail(GF2BV_ERR_NOMEM, "could not start a host thread per device"); }
+	for (auto &t : th) t.join();
+	for (int k = 0; k < nshares; k++)
+		if (rcs[k] != GF2BV_OK) {
+			for (i64 s = 0; s < nsys; s++) { delete out[s]; out[s] = nullptr; }
+			return fail(rcs[k], errs[k].c_str());
+		}
+	return GF2BV_OK;
 }
 
 int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bits_per_digit, int64_t rows,
@@ -1695,7 +1753,10 @@ int gf2bv_slab_solve(gf2bv_slab *h, gf2bv_result **out)
 	int rc = enqueue_check_rhs(S);
 	if (rc == GF2BV_OK) rc = enqueue_backward_single(S);
 	if (rc) return rc;
-	return solver_finish(S, out);
+	rc = solver_finish(S, out);
+	// (the elimination state of a slab handle cannot be replayed from here: an expired gate is an error, not a retry)
+	if (rc == GF2BV_RETRY_EVENTS) return fail(GF2BV_ERR_HIP, "a stream hand-over gate timed out on the device");
+	return rc;
 	});
 }
 

@@ -26,7 +26,7 @@ STATUS_INCONSISTENT = 1
 EXPORTS = [
     "gf2bv_version", "gf2bv_device_count", "gf2bv_last_error",
     "gf2bv_solve_digits", "gf2bv_solve_words", "gf2bv_solve_device", "gf2bv_solve_batch_device",
-    "gf2bv_solve_batch_digits",
+    "gf2bv_solve_batch_digits", "gf2bv_solve_batch_digits_multi",
     "gf2bv_result_status", "gf2bv_result_rank", "gf2bv_result_dimension", "gf2bv_result_words",
     "gf2bv_result_origin", "gf2bv_result_basis", "gf2bv_result_pivots", "gf2bv_result_stats",
     "gf2bv_result_free", "gf2bv_space_combine", "gf2bv_space_open", "gf2bv_space_enumerate", "gf2bv_space_buffer", "gf2bv_space_close",
@@ -77,6 +77,7 @@ def lib():
         L.gf2bv_solve_device.argtypes = [vp, i64, i64, i64, i32, i32, vp, i32, pp]
         L.gf2bv_solve_batch_device.argtypes = [vp, i64, i64, i64, i64, i64, i32, i32, vp, i32, pp]
         L.gf2bv_solve_batch_digits.argtypes = [vp, vp, i32, i64, i64, i64, i32, i32, pp]
+        L.gf2bv_solve_batch_digits_multi.argtypes = [vp, vp, i32, i64, i64, i64, i32, vp, i32, pp]
         for name, res in (("gf2bv_result_status", i32), ("gf2bv_result_rank", i64),
                           ("gf2bv_result_dimension", i64), ("gf2bv_result_words", i64)):
             getattr(L, name).restype = res
@@ -224,13 +225,20 @@ def _take_all(hs, nsys: int, rc: int, mode: int) -> list:
 
 
 def solve_batch_digits(digits: np.ndarray, offsets: np.ndarray, bits_per_digit: int, nsys: int, rows: int,
-                       cols: int, mode: int = MODE_SINGLE, device: int = 0) -> list:
-    """nsys equal-shape systems as digit arrays; offsets has nsys*rows + 1 entries (system-major)."""
+                       cols: int, mode: int = MODE_SINGLE, device: int = 0, devices=None) -> list:
+    """nsys equal-shape systems as digit arrays; offsets has nsys*rows + 1 entries (system-major).
+    `devices` (a sequence of device indices, repeats allowed) shards the systems in contiguous blocks over them, one
+    host thread per entry (gf2bv_solve_batch_digits_multi); default: everything on `device`."""
     digits = np.ascontiguousarray(digits, dtype=np.uint32)
     offsets = np.ascontiguousarray(offsets, dtype=np.int64)
     hs = (ctypes.c_void_p * max(nsys, 1))()
-    rc = lib().gf2bv_solve_batch_digits(digits.ctypes.data, offsets.ctypes.data, bits_per_digit, nsys, rows, cols,
-                                        mode, device, hs)
+    if devices is None:
+        rc = lib().gf2bv_solve_batch_digits(digits.ctypes.data, offsets.ctypes.data, bits_per_digit, nsys, rows, cols,
+                                            mode, device, hs)
+    else:
+        devs = np.ascontiguousarray(list(devices), dtype=np.int32)
+        rc = lib().gf2bv_solve_batch_digits_multi(digits.ctypes.data, offsets.ctypes.data, bits_per_digit, nsys, rows,
+                                                  cols, mode, devs.ctypes.data, len(devs), hs)
     return _take_all(hs, nsys, rc, mode)
 
 

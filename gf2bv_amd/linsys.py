@@ -123,7 +123,9 @@ class LinearSystem:
     # Independent instances of the same LinearSystem (one zeros list per instance / per output bit) go to
     # the GPU as ONE call: _internal.m4ri_solve_many -> gf2bv_solve_batch_digits, lock-step gangs.
     # Element i of the result is exactly what the single-system method returns for zeros_list[i].
-    def _solve_internal_many(self, zeros_list: Sequence[Zeros], mode: int) -> list:
+    # `devices`: None = every visible GPU (the systems are sharded in contiguous blocks over them inside the library, one
+    # host thread per device, no collective -- gf2bv_solve_batch_digits_multi), an int, or a sequence of device indices.
+    def _solve_internal_many(self, zeros_list: Sequence[Zeros], mode: int, devices=None) -> list:
         eqs_list = [self.get_eqs(z) for z in zeros_list]
         live = [i for i, eqs in enumerate(eqs_list) if 1 not in eqs]      # "1 = 0" is decided on the host
         rows = max([self._cols] + [len(eqs_list[i]) for i in live])
@@ -131,18 +133,19 @@ class LinearSystem:
             eqs_list[i].extend([0] * (rows - len(eqs_list[i])))
         out: list = [None] * len(eqs_list)
         if live:
-            for i, res in zip(live, m4ri_solve_many([eqs_list[i] for i in live], self._cols, mode)):
+            for i, res in zip(live, m4ri_solve_many([eqs_list[i] for i in live], self._cols, mode, devices)):
                 out[i] = res
         return out
 
-    def solve_raw_one_many(self, zeros_list: Sequence[Zeros]) -> list:
-        return self._solve_internal_many(zeros_list, 0)
+    def solve_raw_one_many(self, zeros_list: Sequence[Zeros], devices=None) -> list:
+        return self._solve_internal_many(zeros_list, 0, devices)
 
-    def solve_raw_space_many(self, zeros_list: Sequence[Zeros]) -> list:
-        return self._solve_internal_many(zeros_list, 1)
+    def solve_raw_space_many(self, zeros_list: Sequence[Zeros], devices=None) -> list:
+        return self._solve_internal_many(zeros_list, 1, devices)
 
-    def solve_one_many(self, zeros_list: Sequence[Zeros]) -> list:
-        return [None if raw is None else self.convert_sol(raw) for raw in self._solve_internal_many(zeros_list, 0)]
+    def solve_one_many(self, zeros_list: Sequence[Zeros], devices=None) -> list:
+        return [None if raw is None else self.convert_sol(raw)
+                for raw in self._solve_internal_many(zeros_list, 0, devices)]
 
     def evaluate(self, bv: BitVec, sol: tuple) -> int:
         raw, shift = 0, 0

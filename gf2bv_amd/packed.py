@@ -16,6 +16,7 @@ gf2bv_amd.crypto run on it unchanged); ``get_eqs`` still returns the reference's
 """
 from __future__ import annotations
 
+import operator
 from typing import Iterable, Optional, Sequence
 
 import numpy as np
@@ -26,9 +27,20 @@ from .linsys import DimensionTooLargeError
 
 
 def _const_bits(n: int, value: int) -> np.ndarray:
-    """low n bits of |value| ... of value in two's complement, LSB first, as uint64 0/1 (to_bits of the reference)"""
-    value &= (1 << n) - 1
+    """low n bits of the MAGNITUDE of value, LSB first, as uint64 0/1 -- to_bits of the reference walks the digits of
+    |a| (gf2bv/_internal.c:504-531), so a negative constant contributes abs(value), not its two's complement"""
+    value = abs(int(value)) & ((1 << n) - 1)
     return np.array([(value >> i) & 1 for i in range(n)], dtype=np.uint64)
+
+
+def _popcount64(a: np.ndarray) -> np.ndarray:
+    if hasattr(np, "bitwise_count"):                   # numpy >= 2.0
+        return np.bitwise_count(a)
+    b = a.view(np.uint8).reshape(a.shape + (8,))       # numpy 1.x: per-byte table
+    return _POP8[b].sum(axis=-1)
+
+
+_POP8 = np.array([bin(i).count("1") for i in range(256)], dtype=np.uint64)
 
 
 class PackedBitVec(BitVec):
@@ -63,7 +75,12 @@ class PackedBitVec(BitVec):
     def __getitem__(self, key):
         if isinstance(key, slice):
             return PackedBitVec(self._rows[key])
-        return PackedBitVec(self._rows[key:key + 1] if key != -1 else self._rows[-1:])
+        i = operator.index(key)
+        n = self._rows.shape[0]
+        if not -n <= i < n:                            # (also what ends `for b in bv`: BitVec has no __iter__)
+            raise IndexError("PackedBitVec index out of range")
+        i %= n
+        return PackedBitVec(self._rows[i:i + 1])
 
     # -- xor (reference :39-49) ----------------------------------------------------------------
     def __xor__(self, other):
@@ -76,14 +93,12 @@ class PackedBitVec(BitVec):
     def __rshift__(self, n: int):
         if n == 0:
             return self
-        n = min(n, len(self))
-        return PackedBitVec(np.concatenate([self._rows[n:], self._zero_rows(n)]))
+        return PackedBitVec(np.concatenate([self._rows[n:], self._zero_rows(n)]))      # (n > len grows it, as bits[n:] + (0,) * n does)
 
     def __lshift__(self, n: int):
         if n == 0:
             return self
-        n = min(n, len(self))
-        return PackedBitVec(np.concatenate([self._zero_rows(n), self._rows[:len(self) - n]]))
+        return PackedBitVec(np.concatenate([self._zero_rows(n), self._rows[:-n]]))
 
     def lshift_ext(self, n: int):
         return PackedBitVec(np.concatenate([self._zero_rows(n), self._rows]))
@@ -161,7 +176,7 @@ class PackedBitVec(BitVec):
     def evaluate(self, s: int) -> int:
         W = self._rows.shape[1]
         point = np.frombuffer((((s << 1) | 1) & ((1 << (64 * W)) - 1)).to_bytes(8 * W, "little"), dtype=np.uint64)
-        par = np.bitwise_count(self._rows & point[None, :]).sum(axis=1) & 1
+        par = _popcount64(self._rows & point[None, :]).sum(axis=1) & 1
         return int(sum(int(b) << i for i, b in enumerate(par)))
 
 
@@ -190,6 +205,11 @@ class PackedLinearSystem:
 
     # -- zeros -> one [n, W] array (the packed twin of get_eqs, reference :214-227) ------------------
     def get_rows(self, zeros: Sequence) -> np.ndarray:
+        """the stacked non-zero rows of ``zeros`` as a fresh [n, W] array (the solve methods use the shared buffer of
+        ``_stack_rows`` instead and never keep it)"""
+        return self._stack_rows(zeros).copy()
+
+    def _stack_rows(self, zeros: Sequence) -> np.ndarray:
         parts = []
         for z in zeros:
             if isinstance(z, PackedBitVec):
@@ -202,7 +222,7 @@ class PackedLinearSystem:
                 parts.append(r[None, :])
         n = sum(len(x) for x in parts)
         # (stacked into a buffer that is kept between calls: a fresh 50 MB allocation is paid for in page faults, several
-        # times the copy itself.  The returned array is a view of it, valid until the next call.)
+        # times the copy itself.  The returned array is a view of it, valid until the next call: internal use only.)
         buf = getattr(self, "_rowbuf", None)
         if buf is None or len(buf) < n:
             buf = self._rowbuf = np.empty((max(n, 1), self._words), dtype=np.uint64)
@@ -212,11 +232,11 @@ class PackedLinearSystem:
 
     def get_eqs(self, zeros: Sequence) -> list:
         """the reference's list of equation ints (for callers that want it; the solve methods do not build it)"""
-        return [int.from_bytes(r.tobytes(), "little") for r in self.get_rows(zeros)]
+        return [int.from_bytes(r.tobytes(), "little") for r in self._stack_rows(zeros)]
 
     # -- boundary call (reference :229-240) ------------------------------------------------------------
     def _solve_internal(self, zeros: Sequence, mode: int):
-        rows = self.get_rows(zeros)
+        rows = self._stack_rows(zeros)
         cand = np.flatnonzero(rows[:, 0] == 1) if len(rows) else ()                # the equation "1 = 0": word 0 is 1 ...
         if len(cand) and (~rows[cand, 1:].any(axis=1)).any():                        # ... and nothing else is set
             return None

@@ -120,6 +120,17 @@ int gf2bv_solve_batch_digits(const uint32_t *digits, const int64_t *digit_off, i
                              int64_t nsys, int64_t rows, int64_t cols, int mode, int device,
                              gf2bv_result **out);
 
+/* The same batch over SEVERAL devices of the node, from one process and without any collective: entry k of
+ * devices[0..ndevices) takes the k-th contiguous share of the systems (floor(nsys*k/ndevices) ..) on its own host thread,
+ * uploads only its share of the digits and runs it as lock-step gangs there; out[] is in input order and identical to
+ * what the one-device call returns.  A device may be listed more than once (its shares then run as concurrent gangs).
+ * The reference solves one system per m4ri_solve call (gf2bv/_internal.c:359-502): independent systems -- one per
+ * output bit / per instance in the recovery examples -- are the natural shard unit; this is what
+ * m4ri_solve_many(..., devices=None) binds, None = every visible device. */
+int gf2bv_solve_batch_digits_multi(const uint32_t *digits, const int64_t *digit_off, int bits_per_digit,
+                                   int64_t nsys, int64_t rows, int64_t cols, int mode,
+                                   const int *devices, int ndevices, gf2bv_result **out);
+
 /* ---- result accessors (AffineSpace getters, gf2bv/_internal.c:206-240) -------------------- */
 int     gf2bv_result_status(const gf2bv_result *r);      /* GF2BV_STATUS_* */
 int64_t gf2bv_result_rank(const gf2bv_result *r);

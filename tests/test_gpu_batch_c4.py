@@ -108,18 +108,37 @@ def test_bench_sharded_mode_single_rank():
 
 @pytest.mark.timeout(600)
 def test_bench_two_ranks_sharing_the_gpu():
-    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one process per rank): shard bounds,
-    barriers, max-over-ranks timing, the gather and the JSON line -- with both ranks pinned to this box's one GPU and gloo
-    standing in for RCCL (which cannot put two ranks on one device)."""
+    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one process per rank): the default line is
+    the N = 1 workload on every rank (weak scaling: one system per GPU per step) plus the configs[3] job sharded over the
+    ranks as `batch_c4` -- shard bounds, barriers, max-over-ranks timing, the gathers and the JSON line -- with both ranks
+    pinned to this box's one GPU and gloo standing in for RCCL (which cannot put two ranks on one device)."""
     env = dict(os.environ, GF2BV_BENCH_DEVICE="0", GF2BV_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--batch-total", "9", "--batch-n", "4096"]
+           "--n", "8192", "--batch-total", "9", "--batch-n", "4096"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=550, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1                                    # rank 0 only
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["systems_total"] == 9
-    assert line["parity_gate"]["all_ranks_ok"] and line["parity_gate"]["gathered_records"] == 9
-    assert "cpu_baseline" not in line and line["value"] > 0 and line["roofline"]["achieved"] > 0
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "8192x8192" in line["config"]["workload"]
+    assert line["parity_gate"]["all_ranks_ok"] and line["parity_gate"]["residual_rows"] == 0
+    assert "cpu_baseline" not in line and "target_262144" not in line and line["value"] > 0 and line["roofline"]["achieved"] > 0
+    c4 = line["batch_c4"]
+    assert c4["n_gpus"] == 2 and c4["scaling"] == "strong" and c4["config"]["systems_total"] == 9
+    assert c4["parity_gate"]["all_ranks_ok"] and c4["parity_gate"]["gathered_records"] == 9
+    assert c4["systems_per_s"] > 0 and c4["roofline"]["achieved"] > 0
+
+
+@pytest.mark.timeout(600)
+def test_bench_default_line_carries_the_scale_anchor():
+    """N = 1: the same line shape (headline + `batch_c4` with its roofline), here at reduced sizes."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--n", "8192", "--batch-total", "6",
+           "--batch-n", "4096", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=550, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["parity_gate"]["residual_rows"] == 0
+    c4 = line["batch_c4"]
+    assert c4["n_gpus"] == 1 and c4["config"]["systems_total"] == 6 and c4["parity_gate"]["all_ranks_ok"]
+    assert c4["roofline"]["frac"] > 0 and c4["roofline"]["end_to_end_frac"] > 0

@@ -291,6 +291,35 @@ def test_batched_list_of_int_boundary(monkeypatch):
             assert (sp.dimension, sp.origin, sp.basis) == (ref.dimension, ref.origin, ref.basis)
 
 
+def test_batch_sharded_over_devices_from_the_python_boundary(monkeypatch):
+    """m4ri_solve_many(..., devices): contiguous shares, one host thread per listed device inside the library
+    (gf2bv_solve_batch_digits_multi).  The box has one GPU, so the device list names it twice or three times -- the shares
+    then run as concurrent gangs on it -- and the answer must equal the one-device call and the oracle, in input order."""
+    monkeypatch.setenv("GF2BV_GANG", "2")
+    rng = random.Random(404)
+    cols = 190
+    systems = [random_system(rng, 230, cols, .5, cap) for cap in (None, 64, 189, 1, None, 100, None)] + [[0] * 230]
+    assert _internal.device_count() >= 1 and _internal.get_default_device() == 0
+    for mode in (0, 1):
+        one = _internal.m4ri_solve_many(systems, cols, mode, 0)
+        for devs in ([0, 0], [0, 0, 0], None, [0] * 11):
+            got = _internal.m4ri_solve_many(systems, cols, mode, devs)
+            for eqs, g, w in zip(systems, got, one):
+                o = O.m4ri_solve(list(eqs), cols, mode)
+                if mode == 0 or w is None:
+                    assert g == w == o
+                else:
+                    assert (g.dimension, g.origin, g.basis) == (w.dimension, w.origin, w.basis) == (o.dimension, o.origin, o.basis)
+                    assert g.device == 0
+    assert m4ri_solve(list(systems[0]), cols, 0, 0) == m4ri_solve(list(systems[0]), cols, 0)
+    with pytest.raises(ValueError, match="out of range"):
+        _internal.m4ri_solve_many(systems, cols, 0, [0, _internal.device_count()])
+    lin = LinearSystem([8, 8])
+    a, b = lin.gens()
+    zl = [[a ^ b ^ k, b ^ (k * 7 & 255)] for k in range(9)]
+    assert lin.solve_one_many(zl, devices=[0, 0]) == [lin.solve_one(z) for z in zl]
+
+
 def test_randomised_shapes_and_configs(monkeypatch):
     """A seeded sweep over shapes, densities, rank caps, zero rows, modes and k_update configurations
     (tests/manual/stress_parity.py runs the open-ended version of this on the GPU box)."""

@@ -136,10 +136,31 @@ def test_m4ri_solve_many_argument_errors():
     with pytest.raises(TypeError, match="must be integers"):
         many([[1, 2], [1, None]], 2, 0)
     assert many([], 3, 1) == []
+    with pytest.raises(TypeError, match="requires 3 arguments"):
+        many([[1, 2]], 2, 0, None, 1)
+    with pytest.raises(ValueError, match="must not be empty"):
+        many([[1, 2]], 2, 0, [])
+    with pytest.raises(ValueError, match="out of range"):
+        many([[1, 2]], 2, 0, [-1])
+    with pytest.raises(TypeError):
+        many([[1, 2]], 2, 0, ["gpu0"])
     # "1 = 0" systems are decided on the host, the others would go to the GPU together
     lin = LinearSystem([2])
     (v,) = lin.gens()
     assert lin.solve_one_many([[1], [v ^ v, 1]]) == [None, None]
+
+
+def test_device_selection_surface():
+    """round 3: every solve entry takes an optional trailing device; the module keeps a default (GF2BV_DEVICE or 0)"""
+    assert _internal.get_default_device() == 0
+    with pytest.raises(ValueError, match="out of range"):
+        _internal.set_default_device(-3)
+    with pytest.raises(ValueError, match="out of range"):
+        _internal.m4ri_solve([1, 2], 2, 0, -1)
+    with pytest.raises(TypeError, match="requires 3 arguments"):
+        _internal.m4ri_solve([1, 2], 2, 0, 0, 0)
+    sp = _internal._space_from_ints(4, 1, (5,))
+    assert sp.device == -1                       # host-built: walked on the host
 
 
 def test_solve_fails_loudly_without_gpu():

@@ -98,3 +98,38 @@ def test_get_rows_drops_zeros_and_takes_bare_ints():
     rows = pk.get_rows(zeros_p)
     assert rows.shape == (len(lin.get_eqs(zeros_t)), 1) and rows.dtype == np.uint64
     assert pk.solve_one([pa ^ pa ^ 1]) is None              # "1 = 0" is decided on the host, like the reference
+
+
+def test_iteration_indexing_and_negative_constants_follow_the_tuple_front_end():
+    """an out-of-range index ends iteration (BitVec has no __iter__: Python walks __getitem__ until
+    IndexError); negative constants contribute their MAGNITUDE as the reference's to_bits does (_internal.c:504-531);
+    shifts by more than the length grow the vector like bits[n:] + (0,) * n."""
+    lin, pk = _pair([8, 5])
+    a, b = lin.gens()
+    pa, pb = pk.gens()
+    assert len(list(pa)) == len(pa) == 8
+    assert [x._bits for x in pa] == [x._bits for x in a]
+    for i in (-8, -1, 0, 7):
+        _same(a[i], pa[i])
+    for bad in (8, -9, 100):
+        with pytest.raises(IndexError):
+            pa[bad]
+        with pytest.raises(IndexError):
+            a[bad]
+    for v in (-1, -2, -0x55, -(1 << 40)):
+        _same(v ^ a, v ^ pa)
+        _same(a & v, pa & v)
+        _same(a | v, pa | v)
+        _same(a & ~v, pa & ~v)
+    for n in (9, 13):
+        _same(a >> n, pa >> n)
+        _same(a << n, pa << n)
+
+
+def test_get_rows_returns_an_array_of_its_own():
+    lin, pk = _pair([16])
+    (x,) = pk.gens()
+    r1 = pk.get_rows([x ^ 0x1234])
+    keep = r1.copy()
+    r2 = pk.get_rows([x ^ 0xFFFF])
+    assert (r1 == keep).all() and not (r1 == r2).all()
