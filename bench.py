@@ -60,7 +60,9 @@ def parse():
                     help="auto = single at every N (configs[1] per GPU, weak scaling) with the configs[3] job as the extra block "
                          "`batch_c4`; batch = configs[3] as the line itself; sharded = ONE --n system with its columns over "
                          "the ranks (SURVEY 8f-1, strong scaling)")
-    ap.add_argument("--n", type=int, default=65536, help="single: system size N (rows = cols)")
+    ap.add_argument("--n", "--size", dest="n", type=int, default=65536,
+                    help="single: system size N (rows = cols); spell it --size under torch.distributed.run, whose own parser "
+                         "takes a bare --n for an abbreviation of its options")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=None, help="size of the bounded CPU-baseline sample (default: 65536 single / 32768 batch)")

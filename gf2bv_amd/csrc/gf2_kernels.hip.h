@@ -2339,6 +2339,8 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 			H.m0 = mq[row * 2]; H.m1 = mq[row * 2 + 1];
 #ifdef GF2_MB_L2               /* tools/microbench_update16.hip: keep the row data L2-resident to time the table work alone */
 			H.d = Mw[row & 4095];
+#elif defined(GF2_NT_LOAD)     /* cache-policy experiments (tools/microbench_update16.hip) */
+			{ const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Mw + row)); H.d = make_uint4(t.x, t.y, t.z, t.w); }
 #else
 			H.d = Mw[row];
 #endif
@@ -2373,7 +2375,11 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 			const i64 q = H.row;
 #endif
 			if (HALF) reinterpret_cast<u64 *>(Mw + q)[1] = ((u64)acc.w << 32) | acc.z;
+#ifdef GF2_NT_STORE
+			else { const u32x4 t = { acc.x, acc.y, acc.z, acc.w }; __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(Mw + q)); }
+#else
 			else Mw[q] = acc;
+#endif
 		};
 		if (nb > 0) {
 			// DEPTH batches in flight per wave (loads DEPTH-1 batches ahead); PIPE: the lookups of round r+1 -- also

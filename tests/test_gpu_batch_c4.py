@@ -115,7 +115,7 @@ def test_bench_two_ranks_sharing_the_gpu():
     env = dict(os.environ, GF2BV_BENCH_DEVICE="0", GF2BV_BENCH_BACKEND="gloo")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--n", "8192", "--batch-total", "9", "--batch-n", "4096"]
+           "--size", "8192", "--batch-total", "9", "--batch-n", "4096"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=550, cwd=ROOT, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]

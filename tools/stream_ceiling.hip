@@ -43,6 +43,36 @@ __global__ void __launch_bounds__(TB) u4_rmw_range(u4 *a, size_t per_wg, unsigne
 		for (int u = 0; u < 4; u++) p[i + (size_t)u * TB] = v[u] ^ k;
 	}
 }
+// the same with non-temporal loads (NL) and / or stores (NS)
+template <bool NL, bool NS>
+__global__ void __launch_bounds__(TB) u4_rmw_range_nt(u4 *a, size_t per_wg, unsigned k)
+{
+	u4 *p = a + (size_t)blockIdx.x * per_wg;
+	for (size_t i = threadIdx.x; i < per_wg; i += 4 * TB) {
+		u4 v[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++) v[u] = NL ? __builtin_nontemporal_load(p + i + (size_t)u * TB) : p[i + (size_t)u * TB];
+#pragma unroll
+		for (int u = 0; u < 4; u++) { if (NS) __builtin_nontemporal_store(v[u] ^ k, p + i + (size_t)u * TB); else p[i + (size_t)u * TB] = v[u] ^ k; }
+	}
+}
+// ... and with a second, cache-resident read stream of twice the bytes beside it (the bulk update reads 32 B of
+// multipliers, an 8 MiB array shared by all workgroups, per 16 B of row data)
+template <bool NL, bool NS>
+__global__ void __launch_bounds__(TB) u4_rmw_range_side(u4 *a, size_t per_wg, const u4 *side, size_t side_mask, unsigned k)
+{
+	u4 *p = a + (size_t)blockIdx.x * per_wg;
+	for (size_t i = threadIdx.x; i < per_wg; i += 2 * TB) {
+		u4 v[2], m[4];
+#pragma unroll
+		for (int u = 0; u < 2; u++) {
+			v[u] = NL ? __builtin_nontemporal_load(p + i + (size_t)u * TB) : p[i + (size_t)u * TB];
+			m[2 * u] = side[(2 * (i + (size_t)u * TB)) & side_mask]; m[2 * u + 1] = side[(2 * (i + (size_t)u * TB) + 1) & side_mask];
+		}
+#pragma unroll
+		for (int u = 0; u < 2; u++) { const u4 r = v[u] ^ m[2 * u] ^ m[2 * u + 1] ^ k; if (NS) __builtin_nontemporal_store(r, p + i + (size_t)u * TB); else p[i + (size_t)u * TB] = r; }
+	}
+}
 __global__ void __launch_bounds__(256) u4_read_gs(const u4 *a, size_t n, unsigned *out) { unsigned acc = 0; for (size_t i = (size_t)blockDim.x * blockIdx.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) { u4 v = a[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; } if (acc == 0x12345) out[0] = acc; }
 __global__ void __launch_bounds__(TB) u4_write(u4 *a, unsigned k) { const size_t i = (size_t)blockDim.x * blockIdx.x + threadIdx.x; a[i] = (u4){k, k, k, k}; }
 
@@ -91,6 +121,20 @@ int main(int argc, char **argv)
 		{ char nm[64]; snprintf(nm, sizeof nm, "rmw grid-stride %d x 256", blocks); timeit(nm, 2.0 * bytes, [&] { u4_rmw_gs<<<blocks, 256>>>((u4 *)A, n4, 5); }); }
 	for (int wgs : {256, 512, 1024})
 		{ char nm[64]; snprintf(nm, sizeof nm, "rmw contiguous range per workgroup, %d wgs", wgs); timeit(nm, 2.0 * bytes, [&] { u4_rmw_range<<<wgs, TB>>>((u4 *)A, n4 / wgs, 5); }); }
+	for (int wgs : {256, 1024}) {
+		char nm[80];
+		snprintf(nm, sizeof nm, "rmw range, nt loads + nt stores, %d wgs", wgs); timeit(nm, 2.0 * bytes, [&] { u4_rmw_range_nt<true, true><<<wgs, TB>>>((u4 *)A, n4 / wgs, 5); });
+		snprintf(nm, sizeof nm, "rmw range, nt loads only, %d wgs", wgs); timeit(nm, 2.0 * bytes, [&] { u4_rmw_range_nt<true, false><<<wgs, TB>>>((u4 *)A, n4 / wgs, 5); });
+		snprintf(nm, sizeof nm, "rmw range, nt stores only, %d wgs", wgs); timeit(nm, 2.0 * bytes, [&] { u4_rmw_range_nt<false, true><<<wgs, TB>>>((u4 *)A, n4 / wgs, 5); });
+	}
+	printf("-- (5b) the same range form beside a cache-resident read stream of 2x the bytes (8 MiB array), rate = row bytes only\n");
+	for (int wgs : {256}) {
+		char nm[80];
+		const size_t smask = (8u << 20) / 16 - 1;
+		snprintf(nm, sizeof nm, "rmw range + side stream, plain, %d wgs", wgs); timeit(nm, 2.0 * bytes, [&] { u4_rmw_range_side<false, false><<<wgs, TB>>>((u4 *)A, n4 / wgs, (const u4 *)B, smask, 5); });
+		snprintf(nm, sizeof nm, "rmw range + side stream, nt rows, %d wgs", wgs); timeit(nm, 2.0 * bytes, [&] { u4_rmw_range_side<true, true><<<wgs, TB>>>((u4 *)A, n4 / wgs, (const u4 *)B, smask, 5); });
+		snprintf(nm, sizeof nm, "rmw range + side stream, nt stores, %d wgs", wgs); timeit(nm, 2.0 * bytes, [&] { u4_rmw_range_side<false, true><<<wgs, TB>>>((u4 *)A, n4 / wgs, (const u4 *)B, smask, 5); });
+	}
 	printf("-- (6) one direction only\n");
 	timeit("read  grid-stride 8192 x 256", 1.0 * bytes, [&] { u4_read_gs<<<8192, 256>>>((u4 *)A, n4, o); });
 	timeit("write one per thread", 1.0 * bytes, [&] { u4_write<<<n4 / TB, TB>>>((u4 *)A, 7); });
