@@ -154,8 +154,7 @@ def roofline_block(stats_list, sweep_ms_total: float, n: int, device: int, ceil:
     out = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, g, t),
-        "kernel": (f"k_update16 (bulk update on 16-byte tiles, {g} panels = {64 * g} pivots = {g * t} byte-field tables per pass)"
-                   if s0["tile_words"] == 2 else f"k_update<G={g},T={t}> (bulk update, {g} panels = {64 * g} pivots per pass)"),
+        "kernel": f"k_update16 (bulk update on 16-byte tiles, {g} panels = {64 * g} pivots = {g * t} byte-field tables per pass)",
         "alg_bytes_total": alg_bytes, "kernel_ms_total": sweep_ms_total,
         # one pass applies G panels: HBM rate a one-panel-per-pass sweep would need for the same wall time
         "single_panel_equivalent_GBs": achieved * g,

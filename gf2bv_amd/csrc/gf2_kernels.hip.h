@@ -35,15 +35,10 @@ typedef unsigned long long u64;   // matches HIP's 64-bit atomics and __ballot
 typedef long long i64;
 
 #define GF2_GMAX 4                // max panels per block
-#ifndef GF2_TW
-#define GF2_TW 2                  // 64-bit words per column tile: 2 (16-byte row segments: the byte-field bulk update
-                                  // k_update16, one lane per row segment -- the product since round 2), or 8 / 16
-                                  // (64- / 128-byte segments: the 5/6-bit-field k_update of round 1, -DGF2_TW=8 for A/B runs)
-#endif
-#define GF2_TW_LOG (GF2_TW == 16 ? 4 : GF2_TW == 8 ? 3 : 1)
-#define GF2_LPR (GF2_TW / 2)      // lanes per row segment, 16 bytes each
-#define GF2_IL (16 / GF2_LPR)     // table entries interleaved in one 256-byte LDS slot: 4 (TW=8), 2 (TW=16), 16 (TW=2)
-static_assert(GF2_TW == 2 || GF2_TW == 8 || GF2_TW == 16, "tile width");
+#define GF2_TW 2                  // 64-bit words per column tile: 16-byte row segments, one lane per row segment (k_update16).
+                                  // (Round 1 used 8-word tiles; that kernel family is archived in tools/archive_round1/.)
+#define GF2_TW_LOG 1
+#define GF2_LPR 1                 // lanes per row segment, 16 bytes each
 #define GF2_OWN_LOG 3             // column-slab solves: the unit of ownership is 8 words (one or four tiles)
 #define GF2_FEW_UNITS 8           // search units used while panels are easy (dense systems)
 #ifndef GF2_BATCH
@@ -66,13 +61,6 @@ __device__ __forceinline__ long long tidx(long long row, long long word, long lo
 {
 	return ((word >> GF2_TW_LOG) * srows + row) * GF2_TW + (word & (GF2_TW - 1));
 }
-// Which part of a 256-byte table slot a row reads first (see k_update): a function of the row index only,
-// so the panel path can store every row's multiplier already rotated for it.
-__host__ __device__ __forceinline__ int rowq(long long row)
-{
-	return GF2_IL == 2 ? (int)(row & 1) : (int)((row >> 1) & 3);
-}
-
 // One record per 64-column panel, written by the search half of k_panel_step.
 struct PanelRec {
 	int start;      // global index of this panel's first pivot (= rank before the panel)
@@ -183,79 +171,28 @@ __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirs
 __device__ __forceinline__ u64 lanemask_lt(int lane) { return lane ? (~0ull >> (64 - lane)) : 0ull; }
 __device__ __forceinline__ uint4 xor4(uint4 a, uint4 b) { return make_uint4(a.x ^ b.x, a.y ^ b.y, a.z ^ b.z, a.w ^ b.w); }
 
-// Balanced split of the 64 pivot bits of a panel into T bit-fields (grease tables), taken in GROUPS of
-// GF2_IL consecutive tables of equal width (a group shares its 256-byte LDS slots, see k_update).
-template <int T>
-struct Fields {
-	static constexpr int IL = GF2_IL;
-	static constexpr int LO = 64 / T;                 // small field width
-	static constexpr int NBIG = 64 - T * LO;          // the first NBIG fields are one bit wider
-	static constexpr int NG = T / IL;                 // groups
-	static_assert(T % IL == 0 && NBIG % IL == 0, "tables must form equal-width groups");
-	__host__ __device__ static constexpr int width(int t) { return t < NBIG ? LO + 1 : LO; }
-	__host__ __device__ static constexpr int shift(int t) { return t < NBIG ? t * (LO + 1) : NBIG * (LO + 1) + (t - NBIG) * LO; }
-	// first 256-byte slot of group m inside a panel (slot i of a group = entry i of each of its IL tables)
-	__host__ __device__ static constexpr int groupoff(int m)
-	{
-		return IL * m < NBIG ? m * (1 << (LO + 1)) : (NBIG / IL) * (1 << (LO + 1)) + (m - NBIG / IL) * (1 << LO);
-	}
-	static constexpr int SLOTS = (NBIG / IL) * (1 << (LO + 1)) + ((T - NBIG) / IL) * (1 << LO);   // per panel
-	// Rotate the fields of every group by q positions: field s of the result = field (s+q) % IL of m.
-	// q = rowq(row).  The panel path stores multipliers in this form; rot_fields(x, (IL-q) % IL) undoes it.
-	__host__ __device__ static inline u64 rot_fields(u64 m, int q)
-	{
-		if (q == 0) return m;
-		u64 r = 0;
-#pragma unroll
-		for (int g = 0; g < NG; g++) {
-			const int w = width(IL * g), sh = shift(IL * g), gw = IL * w;
-			const u64 gm = gw >= 64 ? ~0ull : ((1ull << gw) - 1);
-			const u64 grp = (m >> sh) & gm;
-			r |= (((grp >> (q * w)) | (grp << ((IL - q) * w))) & gm) << sh;
-		}
-		return r;
-	}
-};
-
-
-// rot_fields for a table count chosen at run time (the panel path is not templated on the update config)
-__device__ __forceinline__ u64 rot_fields_rt(int T, u64 m, int q)
-{
-#if GF2_TW == 2
-	(void)T; (void)q;
-	return m;                     // (not used by the 16-byte-tile layout: see mult_stored / mult_plain)
-#else
-	switch (T) {
-	case 8: return Fields<8>::rot_fields(m, q);
-	case 12: return Fields<12>::rot_fields(m, q);
-#if GF2_IL == 2
-	case 10: return Fields<10>::rot_fields(m, q);
-	case 14: return Fields<14>::rot_fields(m, q);
-#endif
-	default: return Fields<16>::rot_fields(m, q);
-	}
-#endif
-}
-
 // ---- where a row's multipliers live, and in which form -----------------------------------------------------------
-// TW = 8 / 16: one array per panel, multset[g * R + row], fields rotated by rowq(row) for the table layout of k_update.
-// TW = 2 (k_update16): 32 bytes per row, multset[row * 4 + (g ^ rq_hi)], bytes rotated by rq_lo (rq = row & 15): two
-// 16-byte loads per row, and a lookup address is one v_perm_b32 (see k_update16).  R = rows (padded to 64 for TW = 2:
-// the bulk update reads whole wavefronts of rows; the padding stays zero).
-__host__ __device__ __forceinline__ i64 mult_rows(i64 rows) { return GF2_TW == 2 ? ((rows + 63) & ~(i64)63) : rows; }
+// 32 bytes per row, multset[row * 4 + (g ^ rq_hi)], bytes rotated by rq_lo (rq = row & 15): two 16-byte loads per row, and a
+// lookup address is one v_perm_b32 (see k_update16).  R = rows padded to 64: the bulk update reads whole wavefronts of
+// rows; the padding stays zero.  (`T`, the table count per panel, is 8 everywhere since round 2; the parameter remains
+// in the panel kernels' signatures.)
+__host__ __device__ __forceinline__ i64 mult_rows(i64 rows) { return (rows + 63) & ~(i64)63; }
 __host__ __device__ __forceinline__ i64 midx(int g, i64 row, i64 rows)
 {
-	return GF2_TW == 2 ? row * 4 + (g ^ (int)((row >> 3) & 1)) : (i64)g * rows + row;
+	(void)rows;
+	return row * 4 + (g ^ (int)((row >> 3) & 1));
 }
 __device__ __forceinline__ u64 mult_stored(int T, u64 m, i64 row)           // plain bit order -> stored form
 {
-	if (GF2_TW == 2) { const int sh = 8 * (int)(row & 7); return sh ? ((m >> sh) | (m << (64 - sh))) : m; }
-	return rot_fields_rt(T, m, rowq(row));
+	(void)T;
+	const int sh = 8 * (int)(row & 7);
+	return sh ? ((m >> sh) | (m << (64 - sh))) : m;
 }
 __device__ __forceinline__ u64 mult_plain(int T, u64 v, i64 row)            // stored form -> plain bit order
 {
-	if (GF2_TW == 2) { const int sh = 8 * (int)(row & 7); return sh ? ((v << sh) | (v >> (64 - sh))) : v; }
-	return rot_fields_rt(T, v, (GF2_IL - rowq(row)) % GF2_IL);
+	(void)T;
+	const int sh = 8 * (int)(row & 7);
+	return sh ? ((v << sh) | (v >> (64 - sh))) : v;
 }
 
 // Gang execution: several systems of one shape are eliminated in lock-step by the same launches;
@@ -1674,7 +1611,7 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 __global__ void __launch_bounds__(256)
 k_unwind(u64 *__restrict__ M, i64 srows, int G, int npanels, int nblocks, const SolveState *__restrict__ st,
          const int *__restrict__ pivcol, const int *__restrict__ urow, const u64 *__restrict__ Uwin, int world, int wrank,
-         SysStride ss)
+         int tl_K, int tl_bend, SysStride ss)
 {
 	{
 		const i64 ao = blockIdx.y * ss.arena_bytes;
@@ -1687,11 +1624,35 @@ k_unwind(u64 *__restrict__ M, i64 srows, int G, int npanels, int nblocks, const 
 	if (k >= st->rank) return;
 	const int b = (pivcol[k] >> 6) / G;
 	if (b + 1 >= nblocks) return;                       // the last block has no next window
+	if (tl_K > 0 && b < tl_bend && (b + 1) % tl_K == 0) return;     // ... nor has the last block of an outer panel (two-level)
 	const int wlo = (b + 1) * G;
 	const int gnext = (npanels - wlo < G) ? npanels - wlo : G;
 	// (column-slab solve: the window of block b + 1 was carried forward -- and Uwin filled -- by the rank that owns its tile)
 	if (world > 1 && ((wlo + e) >> GF2_OWN_LOG) % world != wrank) return;
 	if (e < gnext) M[tidx(urow[k], wlo + e, srows)] = Uwin[k * GF2_GMAX + e];
+}
+
+// Column-slab solve: the records of one block <-> the broadcast payload, ONE launch each way (five copy packets per block
+// and direction cost more than the block's panel path on small systems).  Up to 5 segments of 4-byte units; the multiplier
+// set (the bulk of it, 16-byte aligned on both sides) goes as uint4.
+struct SlabSeg { const void *src; void *dst; unsigned bytes; };
+struct SlabSegs { SlabSeg s[5]; };
+__global__ void __launch_bounds__(256)
+k_slab_copy(SlabSegs segs)
+{
+	const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+#pragma unroll
+	for (int k = 0; k < 5; k++) {
+		const SlabSeg g = segs.s[k];
+		if (!g.bytes) continue;
+		if (((g.bytes | (unsigned)(size_t)g.src | (unsigned)(size_t)g.dst) & 15u) == 0) {
+			const uint4 *a = static_cast<const uint4 *>(g.src); uint4 *b = static_cast<uint4 *>(g.dst);
+			for (size_t i = tid; i < g.bytes / 16; i += nth) b[i] = a[i];
+		} else {
+			const unsigned *a = static_cast<const unsigned *>(g.src); unsigned *b = static_cast<unsigned *>(g.dst);
+			for (size_t i = tid; i < g.bytes / 4; i += nth) b[i] = a[i];
+		}
+	}
 }
 
 // Column-slab solve (one system over several GPUs): a rank that did not factorise block b receives its records and
@@ -1816,355 +1777,16 @@ k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int group_
 }
 
 // The bulk update of one block on a set of column tiles:
-//     row[tile] ^= XOR_{g<gb} XOR_{t<T} tab[g][t][ field t of mult_g[row] ]
-// Tables ("Method of the Four Russians") of all gb panels for one tile live in LDS.
+//     row[tile] ^= XOR_{g<gb} XOR_{t<8} tab[g][t][ byte t of mult_g[row] ]
+// Tables ("Method of the Four Russians") of all gb panels for one tile live in LDS: 16-BYTE column tiles, BYTE bit-fields.
 //
-// Lane mapping: a row segment (GF2_TW words) is covered by LPR = GF2_TW/2 consecutive lanes, 16 bytes each
-// (global_load_dwordx4 / ds_read_b128 / global_store_dwordx4); a wavefront covers 64/LPR rows and, the
-// matrix being tile-major, reads/writes ONE contiguous KiB per instruction.
-//
-// LDS layout (bank-conflict free).  ds_read_b128 is serviced 16 lanes at a time; the 16 lanes of a
-// service group belong to IL = 16/LPR different rows whose rowq() values are all different (LPR = 8:
-// one even + one odd row; LPR = 4: rows {0,3,5,6} / {1,2,4,7} of each 8, rowq = (row>>1)&3).  A table
-// entry covers 1/IL of the 64 banks, so IL different entries would collide at random -- unless each of
-// those rows is steered to a different part of the bank row.  Tables are therefore stored in groups of
-// IL: slot i of a group = [entry i of table 0 | ... | entry i of table IL-1] = 256 B = all 64 banks, and
-// at step s a row with rowq = q looks up table (q+s) % IL of the group.  Every ds_read_b128 touches each
-// bank exactly once (SQ_LDS_BANK_CONFLICT ~ 0).  The multipliers arrive already rotated (field s holds
-// what the row needs at step s), so no per-lookup select is needed.
-//
-#if GF2_TW != 2
-// Rows whose multipliers are all 0 (dead rows, the block's own sources, sparse rows) are not written back.
-template <int G, int T>
-struct UpdateCfg {
-	static constexpr int TW = GF2_TW;
-	static constexpr int LPR = GF2_LPR;
-	static constexpr int SLOTS = Fields<T>::SLOTS;                  // 256-byte slots per panel
-	static constexpr int LDS_BYTES = G * SLOTS * 256 + G * 64 * 4;
-};
-
-// (register budget of a 1024-thread workgroup -- 128 VGPRs -- also when launched with fewer threads: a 768-thread
-// instance then leaves a quarter of every SIMD's register file to the panel kernels)
-template <int G, int T, int NT>
-__global__ void __launch_bounds__(1024)
-k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
-         const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
-         const u64 *__restrict__ multset, const int *__restrict__ blk_first,
-         int tile_begin, int ntiles, int world, int wrank, int nw_lo, int nw_hi, SysStride ss)
-{
-	// Words [nw_lo, nw_hi) -- the next block's window -- are never WRITTEN here: the panel stream owns them
-	// (k_prio_window has carried them into Wb, and the next block's panel steps store its pivot rows there
-	// while this launch is still running).
-	{
-		const i64 ao = blockIdx.y * ss.arena_bytes;
-		M += blockIdx.y * ss.m_words;
-		panels = sys_at(panels, ao); aux = sys_at(aux, ao); multset = sys_at(multset, ao); blk_first = sys_at(blk_first, ao);
-	}
-	typedef UpdateCfg<G, T> C;
-	typedef Fields<T> F;
-	constexpr int TW = C::TW, LPR = C::LPR, SLOTS = C::SLOTS, IL = F::IL;
-	// STATIC shared memory (up to 129 KiB; gfx950 has 160 KiB per CU): the tables then start at LDS address 0
-	// known to the compiler, and a lookup address is (field << 8 | lane constant) with nothing to add --
-	// two VALU instructions per lookup (shift, v_and_or) instead of three
-	__shared__ __attribute__((aligned(256))) uint4 tab[G * SLOTS * 16];
-	__shared__ int prow[G * 64];                    // [G][64] physical row of pivot bit, -1 if none
-	__shared__ uint4 stage[G * 64 * LPR];           // the tile's segment of every pivot row, [panel][pivot bit][lane] (zero: no pivot)
-	const int lr = threadIdx.x % LPR;
-	const int rr = threadIdx.x / LPR;
-	constexpr int RPP = NT / LPR;
-
-#ifdef GF2_STEP_PROBE
-	const bool uprobe = j0 == gf2_probe_j0 && blockIdx.y == 0 && threadIdx.x == 0 && blockIdx.x < GF2_PROBE_WGS;
-	unsigned long long up_t0 = 0, up_tab = 0, up_spans = 0;
-	if (uprobe) { up_t0 = wall_clock64(); gf2_probe_upd[blockIdx.x][0] = up_t0; }
-#endif
-	int anyp = 0;
-	for (int g = 0; g < gb; g++) anyp |= panels[j0 + g].p;
-	if (!anyp) return;                          // a block without pivots changes nothing
-	// Work = (tile, alive row) pairs, tile-major: ntiles x R of them.  Every workgroup takes ONE contiguous
-	// span of that line -- equal spans, so the launch has no tail of half-empty rounds whatever ntiles is
-	// (129 tiles x 8 row ranges were 4.03 rounds of 256 workgroups) -- and rebuilds its tables when the span
-	// crosses into the next tile (1 + span/R builds per workgroup).  Span starts are multiples of 1024 rows from
-	// a multiple of 8, so a lane's rowq is a constant (rows just below the bound are dead: zero multipliers).
-	const i64 rlo = (i64)(*blk_first) & ~(i64)7;
-	constexpr int ALIGN = RPP * 4;
-	const i64 R = (rows - rlo + ALIGN - 1) / ALIGN * ALIGN;
-	const i64 total = (i64)ntiles * R;
-	i64 chunk = (total + gridDim.x - 1) / gridDim.x;
-	chunk = (chunk + ALIGN - 1) / ALIGN * ALIGN;
-	i64 pos = (i64)blockIdx.x * chunk;
-	const i64 pend = (pos + chunk < total) ? pos + chunk : total;
-	for (bool first_span = true; pos < pend; first_span = false) {
-	const int ct = (int)(pos / R);
-	const i64 r0 = pos - (i64)ct * R;
-	const i64 span = (R - r0 < pend - pos) ? R - r0 : pend - pos;
-	pos += span;
-	const i64 tile = owned_item(ct, tile_begin, GF2_OWN_LOG - GF2_TW_LOG, world, wrank);     // (column-slab solve: the tiles this rank owns)
-	const i64 w0 = tile * TW;
-	const i64 rbeg = rlo + r0;
-	if (rbeg >= rows) continue;                 // padding at the end of a tile's line
-	const i64 rend = (rbeg + span < rows) ? rbeg + span : rows;
-	if (!first_span) __syncthreads();           // the previous span's rows are done with the tables
-#ifdef GF2_STEP_PROBE
-	unsigned long long up_a = 0;
-	if (uprobe) { up_a = wall_clock64(); if (up_spans == 1) gf2_probe_upd[blockIdx.x][5] = up_a; }
-#endif
-	// ---- tables ----
-	if (first_span) {                           // which physical row holds pivot bit b of panel g: the same for every tile
-		for (int t = threadIdx.x; t < gb * 64; t += NT) {
-			const int g = t >> 6, b = t & 63;
-			const PanelRec rec = panels[j0 + g];
-			prow[t] = ((rec.mask >> b) & 1) ? aux[j0 + g].slot_row[__popcll(rec.mask & ((1ull << b) - 1))] : -1;
-		}
-		__syncthreads();
-	}
-	// words below wlo belong to windows the panel path owns: their table slots stay zero
-	const uint4 keep = make_uint4((w0 + 2 * lr >= wlo) ? ~0u : 0u, (w0 + 2 * lr >= wlo) ? ~0u : 0u,
-	                              (w0 + 2 * lr + 1 >= wlo) ? ~0u : 0u, (w0 + 2 * lr + 1 >= wlo) ? ~0u : 0u);
-	const uint4 *Mq = reinterpret_cast<const uint4 *>(M) + tile * srows * LPR;    // this tile's slab, LPR x uint4 per row
-#ifdef GF2_STEP_PROBE
-	if (uprobe && blockIdx.x == 8 && first_span) gf2_probe_wave[4][0] = wall_clock64();
-#endif
-	// The pivot rows' segments come in with ONE load per thread, all in flight together, and the entries are then
-	// combined from LDS.  (A workgroup whose span crosses into the next tile rebuilds its tables while the other
-	// 255 keep HBM saturated: entries that fetched their <= 3 rows one after the other paid the loaded memory
-	// latency 24 times in a row -- measured +325 us on a 420 us pass for those workgroups, i.e. for the launch.)
-	for (int t = threadIdx.x; t < gb * 64 * LPR; t += NT) {
-		const int pr = prow[t / LPR];
-		uint4 v = Mq[(i64)(pr >= 0 ? pr : 0) * LPR + lr];
-		if (pr < 0) v = make_uint4(0, 0, 0, 0);
-		v.x &= keep.x; v.y &= keep.y; v.z &= keep.z; v.w &= keep.w;
-		stage[t] = v;
-	}
-	__syncthreads();
-#ifdef GF2_STEP_PROBE
-	if (uprobe && blockIdx.x == 8 && first_span) gf2_probe_wave[4][1] = wall_clock64();
-#endif
-	// A table entry is the XOR of the pivot rows selected by its index.  Pass 0: the PURE entries -- index bits only in
-	// the low half or only in the high half of the field -- straight from the staged rows (<= 3 of them); pass 1: the
-	// mixed ones = low ^ high.  Each pass enumerates exactly its own entries, and what an item is (group, table,
-	// index) depends on the thread alone, not on the panel: decoded once, used for every panel.  (The first version
-	// walked all 2048 entries in both passes and decoded each from scratch: 21 iterations of index arithmetic for
-	// 8 us of the 9-13 us a build took; tools/probe_step.py prints the phases.)
-	for (int pass = 0; pass < 2; pass++) {
-		int per_panel = 0;                              // entries of this pass per panel
-#pragma unroll
-		for (int m = 0; m < F::NG; m++) {
-			const int w = F::width(IL * m), kl = w >> 1, nlo = (1 << kl) - 1, nhi = (1 << (w - kl)) - 1;
-			per_panel += IL * (pass == 0 ? 1 + nlo + nhi : nlo * nhi);
-		}
-		for (int it = threadIdx.x; it < per_panel * LPR; it += NT) {
-			int e = it / LPR;                           // (lane lr = it % LPR = threadIdx.x % LPR)
-			int off = 0, lo = 0, hi = 0, sh = 0;        // tab index of the entry inside a panel, index halves, field position
-#pragma unroll
-			for (int m = 0; m < F::NG; m++) {
-				const int w = F::width(IL * m), kl = w >> 1, nlo = (1 << kl) - 1, nhi = (1 << (w - kl)) - 1;
-				const int cnt = IL * (pass == 0 ? 1 + nlo + nhi : nlo * nhi);
-				if (e >= 0 && e < cnt) {
-					const int k = e / IL, part = e % IL;
-					if (pass == 0) { lo = k <= nlo ? k : 0; hi = k <= nlo ? 0 : (k - nlo) << kl; }
-					else { lo = 1 + k % nlo; hi = (1 + k / nlo) << kl; }
-					off = (F::groupoff(m) + (lo | hi)) * 16 + part * LPR + lr;
-					sh = F::shift(IL * m + part);
-				}
-				e -= cnt;                               // (negative once found)
-			}
-			const int idx = lo | hi;
-			for (int g = 0; g < gb; g++) {
-				if (pass == 0) {
-					uint4 acc = make_uint4(0, 0, 0, 0);
-					int bits = idx;
-					while (bits) {
-						const int l = __ffs(bits) - 1; bits &= bits - 1;
-						acc = xor4(acc, stage[(g * 64 + sh + l) * LPR + lr]);
-					}
-					tab[g * SLOTS * 16 + off] = acc;
-				} else {
-					const int base = g * SLOTS * 16 + off - idx * 16;
-					tab[base + idx * 16] = xor4(tab[base + lo * 16], tab[base + hi * 16]);
-				}
-			}
-		}
-		__syncthreads();
-#ifdef GF2_STEP_PROBE
-		if (uprobe && blockIdx.x == 8 && first_span) gf2_probe_wave[4][2 + pass] = wall_clock64();
-#endif
-	}
-
-#ifdef GF2_STEP_PROBE
-	if (uprobe) { const unsigned long long now = wall_clock64(); up_tab += now - up_a; if (up_spans++ == 0) gf2_probe_upd[blockIdx.x][1] = now; }
-#endif
-	// ---- stream the rows ----
-	// Per lane: U rows per half-batch; the global loads (multipliers + data) of half-batch h+1 are issued
-	// before half-batch h is computed and stored, so every wavefront always has HBM requests in flight
-	// while it works through its LDS lookups.  Table reads go out 8 at a time before the first XOR;
-	// three-input XORs (v_bitop3) fold two entries at once.
-	uint4 *Mw = reinterpret_cast<uint4 *>(M) + tile * srows * LPR;
-	const int q = rowq(rr);                         // rbeg and the row steps are multiples of 8
-	// byte offset inside a 256-byte slot at step s (< 256), plus the 64-KiB page of the group (the ds_read
-	// immediate holds 16 bits)
-	constexpr int PAGES = (G * SLOTS * 256 + 65535) / 65536;
-	unsigned cbyte[PAGES][IL];
-#pragma unroll
-	for (int pg = 0; pg < PAGES; pg++)
-#pragma unroll
-		for (int sidx = 0; sidx < IL; sidx++) {
-			unsigned c = ((unsigned)(((q + sidx) % IL) * LPR + lr) * 16u) | ((unsigned)pg << 16);
-			// opaque to the optimiser: otherwise it peels the page bit off again and spends v_and + v_add per lookup
-			asm volatile("" : "+v"(c));
-			cbyte[pg][sidx] = c;
-		}
-	const char *tabb = reinterpret_cast<const char *>(tab);
-	constexpr int U = (G >= 4) ? 1 : GF2_UROWS;      // rows per lane per half-batch (register budget: 128 VGPRs at 1024 threads)
-	constexpr int GPB = 8 / IL;                     // groups per batch -> 8 table reads in flight per lane
-	struct Half { u64 m[U][G]; uint4 d[U]; int qx[U]; bool on[U]; };
-	// FAST (compile-time tag): the half-batch lies entirely inside the row range, all G panels are present and
-	// there is no window to deposit.  Then every global load and the store are UNCONDITIONAL -- no control flow
-	// around vector-memory instructions -- which is what lets the compiler wait with vmcnt(N > 0): with loads
-	// under per-lane or per-launch conditions it cannot count what is outstanding, falls back to vmcnt(0) right
-	// after issuing the prefetch, and the software pipeline degenerates to load -> wait -> compute.
-	typedef std::integral_constant<bool, true> FastT;
-	typedef std::integral_constant<bool, false> SafeT;
-	// rows of a half-batch: base + u * rstride + roff (static split: rstride = RPP, roff = rr; dynamic: 16, lane's row)
-	auto load_half = [&](auto tag, Half &H, i64 base, int rstride, int roff) {
-		constexpr bool FAST = decltype(tag)::value;
-#pragma unroll
-		for (int u = 0; u < U; u++) {
-			const i64 row = base + (i64)u * rstride + roff;
-#ifdef GF2_MB_L2               /* tools/microbench_update.hip: keep the row data L2-resident to time the table work alone */
-			H.qx[u] = (int)((row & 1023) * LPR + lr);
-#else
-			H.qx[u] = (int)(row * LPR + lr);
-#endif
-		}
-#pragma unroll
-		for (int u = 0; u < U; u++) {
-			const i64 row = base + (i64)u * rstride + roff;
-			u64 any = 0;
-#pragma unroll
-			for (int g = 0; g < G; g++) {
-				u64 v;
-				if (FAST) v = multset[(i64)g * rows + row];
-				else v = (row < rend && g < gb) ? multset[(i64)g * rows + row] : 0ull;
-				any |= v;
-				H.m[u][g] = v;
-			}
-			H.on[u] = any != 0;
-		}
-		// the data load does NOT wait for the multipliers (no dependent second memory round trip):
-		// every row of the range is fetched; rows that turn out to have zero multipliers are written back
-		// unchanged (FAST) or not at all
-#pragma unroll
-		for (int u = 0; u < U; u++)
-			if (FAST || base + (i64)u * rstride + roff < rend) H.d[u] = Mw[H.qx[u]];
-	};
-	// this lane's two words against the no-write range (only the tile that holds the next window is affected)
-	const bool nw0 = (int)(w0 + 2 * lr) >= nw_lo && (int)(w0 + 2 * lr) < nw_hi;
-	const bool nw1 = (int)(w0 + 2 * lr + 1) >= nw_lo && (int)(w0 + 2 * lr + 1) < nw_hi;
-	const bool nw_tile = (int)w0 < nw_hi && (int)(w0 + TW) > nw_lo;        // uniform per workgroup
-	const bool nw_lanes = ((nw_lo | nw_hi) & 1) == 0;                       // the range covers whole lanes (always for G = 4)
-	const int qdummy = (int)((srows - 1) * LPR + lr);                       // padding row of the slab (rows < srows - 1)
-	auto compute_half = [&](auto tag, Half &H, i64 base) {
-		constexpr bool FAST = decltype(tag)::value;
-#pragma unroll
-		for (int u = 0; u < U; u++) {
-			if (!FAST && !H.on[u]) continue;
-			uint4 acc = H.d[u];
-			if (!FAST || H.on[u]) {
-#ifndef GF2_MB_NOLOOKUP        /* tools/microbench_update.hip: time the HBM stream without the table work */
-#pragma unroll
-			for (int g = 0; g < G; g++) {
-				if (!FAST && g >= gb) break;        // tables of absent panels were never built (uniform branch)
-				const unsigned mlo = (unsigned)H.m[u][g], mhi = (unsigned)(H.m[u][g] >> 32);
-#pragma unroll
-				for (int m0 = 0; m0 < F::NG; m0 += GPB) {
-					uint4 v[8];
-#pragma unroll
-					for (int h = 0; h < GPB; h++) {
-#pragma unroll
-						for (int sidx = 0; sidx < IL; sidx++) {
-							const int gm = m0 + h;
-							if (gm >= F::NG) continue;
-							// byte offset inside the group = field * 256 + (slot part, lane) * 16: the field is moved to
-							// bit 8 with ONE shift (or alignbit across the 32-bit boundary), then masked and merged with the
-							// lane constant in ONE three-operand op (v_bitop3 / v_and_or); the group base is a compile-time
-							// immediate of the ds_read
-							const int sh = F::shift(IL * gm + sidx), wd = F::width(IL * gm);
-							const unsigned fm = ((1u << wd) - 1) << 8;
-							unsigned x;
-							if (sh >= 32) x = (sh - 32 >= 8) ? (mhi >> (sh - 40)) : (mhi << (40 - sh));
-							else if (sh + wd <= 32) x = (sh >= 8) ? (mlo >> (sh - 8)) : (mlo << (8 - sh));
-							else x = __builtin_amdgcn_alignbit(mhi, mlo, sh - 8);      // sh >= 8 whenever a field straddles
-							const int goff = (g * SLOTS + F::groupoff(gm)) * 256;     // byte offset of the group (constant after unrolling)
-							const unsigned at = (x & fm) | cbyte[goff >> 16][sidx];    // one v_and_or_b32
-							v[h * IL + sidx] = *reinterpret_cast<const uint4 *>(tabb + (goff & 0xffff) + at);
-						}
-					}
-					const int nv = ((F::NG - m0 < GPB) ? (F::NG - m0) : GPB) * IL;     // entries actually read (even; folds after unrolling)
-#pragma unroll
-					for (int h = 0; h < 4; h++) {
-						if (h >= nv / 2) break;
-						acc.x = __builtin_amdgcn_bitop3_b32(acc.x, v[2 * h].x, v[2 * h + 1].x, 0x96);
-						acc.y = __builtin_amdgcn_bitop3_b32(acc.y, v[2 * h].y, v[2 * h + 1].y, 0x96);
-						acc.z = __builtin_amdgcn_bitop3_b32(acc.z, v[2 * h].z, v[2 * h + 1].z, 0x96);
-						acc.w = __builtin_amdgcn_bitop3_b32(acc.w, v[2 * h].w, v[2 * h + 1].w, 0x96);
-					}
-				}
-			}
-#endif
-			}
-			// FAST: a lane whose two words belong to the next window (whole lanes: the range is lane-aligned there)
-			// stores to the slab's padding row instead -- a select on the index, no control flow around the store
-			if (FAST) Mw[nw0 ? qdummy : H.qx[u]] = acc;
-			else if (!(nw0 | nw1)) Mw[H.qx[u]] = acc;
-			else {                                      // the window's tile: 8-byte stores of the words that may be written
-				u64 *dst = reinterpret_cast<u64 *>(Mw + H.qx[u]);
-				if (!nw0) dst[0] = ((u64)acc.y << 32) | acc.x;
-				if (!nw1) dst[1] = ((u64)acc.w << 32) | acc.z;
-			}
-		}
-	};
-	constexpr i64 STEP = (i64)RPP * U;
-	Half A, B;
-	i64 base = rbeg;
-	load_half(SafeT(), A, base, RPP, rr);
-	if (gb == G && (!nw_tile || nw_lanes))              // full blocks: the branch-free pipeline
-		for (; base + 3 * STEP <= rend; base += 2 * STEP) {
-			load_half(FastT(), B, base + STEP, RPP, rr);
-			compute_half(FastT(), A, base);
-			load_half(FastT(), A, base + 2 * STEP, RPP, rr);
-			compute_half(FastT(), B, base + STEP);
-		}
-	// (Handing the rows out dynamically, 16 at a time per wavefront from an LDS counter, makes the four wavefronts of
-	// a SIMD finish together -- with this static split they finish at 515 / 570 / 655 / 750 us of a 750 us pass,
-	// oldest first -- but the pass is not shorter: the SIMD is issue-bound whatever the number of waves left.
-	// Same chip, same run: 262144^2 -1 %, 131072^2 +-0, 65536^2 +7 % (the early finishers make room for the panel
-	// kernels).  Not kept.)
-	for (; base < rend; base += 2 * STEP) {                 // the range's tail, the window's tile, partial blocks
-		load_half(SafeT(), B, base + STEP, RPP, rr);    // rows >= rend load nothing (on = false)
-		compute_half(SafeT(), A, base);
-		load_half(SafeT(), A, base + 2 * STEP, RPP, rr);
-		compute_half(SafeT(), B, base + STEP);
-	}
-	}       // spans
-#ifdef GF2_STEP_PROBE
-	if (j0 == gf2_probe_j0 && blockIdx.y == 0 && (threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 8 && blockIdx.x < 256)
-		gf2_probe_wave[blockIdx.x >> 6][threadIdx.x >> 6] = wall_clock64();
-	if (uprobe) { gf2_probe_upd[blockIdx.x][2] = wall_clock64(); gf2_probe_upd[blockIdx.x][3] = up_spans; gf2_probe_upd[blockIdx.x][4] = up_tab; }
-#endif
-}
-
-#else   // GF2_TW == 2
-// ------------------------------------------------------------------------------------------
-// Bulk update, second form: 16-BYTE column tiles and BYTE bit-fields.
-//
-// The LDS holds G x T x 2^k x E bytes of tables (G panels, T = 64/k fields of k bits, entries of E bytes =
-// the tile width); the lookups a row segment costs are G x T whatever E is.  k_update above spends its
-// 128 KiB on E = 64: T = 12 fields of 5-6 bits, 48 lookups of 64 B per 64-byte segment -- 24 bytes of LDS
-// reads per byte of HBM traffic, and the LDS + VALU issue is what binds it.  Here E = 16:
-// a tile is TWO words wide, a lane owns a whole row segment, k = 8: 32 tables of 256 entries = 128 KiB, 32
-// lookups of 16 B per 16-byte segment -- 16 bytes of LDS per HBM byte -- and the address of a lookup is ONE
-// v_perm_b32 (field byte -> bits 8..15, lane constant -> bits 0..7, 64-KiB page -> bit 16).
+// The LDS holds G x T x 2^k x E bytes of tables (G panels, T = 64/k fields of k bits, entries of E bytes = the tile width);
+// the lookups a row segment costs are G x T whatever E is.  E = 16: a tile is TWO words wide, a lane owns a whole row
+// segment (global_load_dwordx4 / ds_read_b128 / global_store_dwordx4; a wavefront = 64 consecutive rows = ONE contiguous KiB
+// of the tile-major matrix per instruction), k = 8: 32 tables of 256 entries = 128 KiB, 32 lookups of 16 B per 16-byte
+// segment -- 16 bytes of LDS per HBM byte -- and the address of a lookup is ONE v_perm_b32 (field byte -> bits 8..15, lane
+// constant -> bits 0..7, 64-KiB page -> bit 16).  (Round 1 spent the same 128 KiB on 64-byte entries, 12 five/six-bit
+// tables per panel: tools/archive_round1/.)
 //
 // LDS layout: two groups (pages) of 16 tables = panels {0,1} and {2,3}; slot `idx` of a group = 256 B =
 // [entry idx of table 0 | ... | table 15] = all 64 banks; table 8 * (panel & 1) + byte.  ds_read_b128 is
@@ -2177,9 +1799,9 @@ k_update(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 //
 // Measured (tools/microbench_update16.hip, MI355X): the table work (0.32-0.35 ms per GiB pass) hides completely under
 // the stream; the stream carries 32 bytes of multipliers per 16 bytes of row data (L2 hits, ~0.045 ms per GiB of them):
-// 4.1 TB/s per pass in isolation against 3.99 for k_update<4,12,768> -- and, being bound by the memory side and not by
-// LDS + VALU issue, it does not slow down when the next block's panel steps share its CUs (the 64-byte-tile kernel
-// loses 7-12 % of its isolated rate inside a solve).
+// 4.1 TB/s per pass in isolation against 3.99 for round 1's 64-byte-tile kernel -- and, being bound by the memory side and
+// not by LDS + VALU issue, it does not slow down when the next block's panel steps share its CUs (the 64-byte-tile kernel
+// lost 7-12 % of its isolated rate inside a solve).
 __host__ __device__ __forceinline__ int mult_slot(int g, i64 row) { return g ^ (int)((row >> 3) & 1); }
 __host__ __device__ __forceinline__ u64 mult_rot(u64 m, i64 row)
 {
@@ -2419,7 +2041,255 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	}       // spans
 }
 
-#endif  // GF2_TW
+
+// ==========================================================================================
+// TWO-LEVEL ELIMINATION (round 3): outer panels of K blocks
+// ==========================================================================================
+// Large systems are bound by the bulk update, and the bulk update by its memory side: every 16-byte segment update costs an
+// HBM round trip of the segment (32 B) plus 32 B of multipliers (profiles/r03_costing.txt).  M4RI's _mzd_pluq is
+// block-recursive for the same reason (gf2bv/_internal.c:431-433): the trailing matrix should see MANY pivots per trip.
+// Here: K consecutive blocks (an OUTER PANEL, K x 256 columns) are first eliminated on the panel's own column tiles only --
+// the unchanged blocked elimination above, its bulk updates restricted to those tiles -- and then applied to everything
+// right of the panel in ONE pass: k_outer_trsm brings the panel's <= K x 256 pivot rows up to date there, k_update16k
+// keeps row segments in REGISTERS across the K blocks, rebuilding the tables per block.  Memory-side traffic per segment
+// update falls from 64 B to 32 + 32 / K; isolated: 4.7 / 5.4 / 5.7 TB/s of 256-pivot sweep-words for K = 2 / 4 / 8 against
+// 3.8 - 3.95 for k_update16 on the same box (profiles/r03_kloop.txt).
+#define GF2_KMAX 8                /* blocks per outer panel at most */
+#ifndef GF2_KSEG
+#define GF2_KSEG 16               /* row segments a lane of k_update16k keeps in registers (x 512 lanes = 8192 rows per table build):
+                                     251 VGPRs, two wavefronts per SIMD; tests hold it to zero scratch (gf2bv_kernel_resources) */
+#endif
+
+// Pivot rows of an outer panel on one group of WPW = 4 words right of it: panel q (of `npan` = nblk x 4, in elimination
+// order) first forms its final pivot rows P_q = comb_q x S_q from its source rows (as k_block_trsm), then every LATER
+// panel's sources take their share of it: S_q2 ^= mult x P_q -- with the multipliers the panel path recorded: inside a
+// block PanelAux::src_mult, across blocks the per-row multipliers of the earlier block's set (the later block's sources
+// were ordinary alive rows then).  Sequential in q, latency-bound, one workgroup per word group: ~2 % of an outer pass.
+template <int WPW>
+__global__ void __launch_bounds__(64 * WPW)
+k_outer_trsm(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int npan, int group_begin,
+             const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
+             const u64 *__restrict__ mult, i64 set_words, int set0, int nsets, int upd_T)
+{
+	static_assert(WPW == 4, "thread <-> table entry mapping below");
+	constexpr int NP = GF2_KMAX * GF2_GMAX;
+	__shared__ u64 S[NP * 64 * WPW];           // [panel][slot][word] source rows (64 KiB)
+	__shared__ u64 Pb[64 * WPW];               // current panel's pivot rows by pivot BIT, zero where there is none
+	__shared__ u64 Tn[16 * 16 * WPW];          // nibble tables of 64 rows
+	__shared__ int srowL[NP * 64];             // physical row of (panel, slot), -1 beyond the panel's pivots
+	__shared__ int Bk[64];                     // pivot k -> pivot bit (current panel)
+	const i64 w0 = ((i64)group_begin + blockIdx.x) * WPW;
+	const int t = threadIdx.x, r = t / WPW, w = t % WPW;
+	for (int q = w; q < npan; q += WPW) srowL[q * 64 + r] = (r < panels[j0 + q].p) ? aux[j0 + q].slot_row[r] : -1;
+	__syncthreads();
+	for (int q = 0; q < npan; q++) {
+		const int sr = srowL[q * 64 + r];
+		S[(q * 64 + r) * WPW + w] = sr >= 0 ? M[tidx(sr, w0 + w, srows)] : 0ull;
+	}
+	auto build_tables = [&](const u64 *rows64) {
+		const int n = t >> 4, v = t & 15;
+		u64 a[WPW] = { 0, 0, 0, 0 };
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const u64 on = ((v >> k) & 1) ? ~0ull : 0ull;
+#pragma unroll
+			for (int e = 0; e < WPW; e++) a[e] ^= rows64[(4 * n + k) * WPW + e] & on;
+		}
+#pragma unroll
+		for (int e = 0; e < WPW; e++) Tn[(n * 16 + v) * WPW + e] = a[e];
+	};
+	auto lookup = [&](u64 m) {
+		u64 acc = 0;
+#pragma unroll
+		for (int n = 0; n < 16; n++) {
+			const unsigned half = n < 8 ? (unsigned)m : (unsigned)(m >> 32);
+			acc ^= Tn[(n * 16 + ((half >> (4 * (n & 7))) & 15u)) * WPW + w];
+		}
+		return acc;
+	};
+	__syncthreads();
+	for (int q = 0; q < npan; q++) {
+		const PanelRec rec = panels[j0 + q];
+		if (rec.p == 0) continue;                      // (uniform)
+		const u64 comb = aux[j0 + q].comb[r];
+		build_tables(&S[q * 64 * WPW]);
+		Pb[r * WPW + w] = 0;
+		if (w == 0 && ((rec.mask >> r) & 1)) Bk[__popcll(rec.mask & lanemask_lt(r))] = r;
+		__syncthreads();
+		if (r < rec.p) {
+			const u64 acc = lookup(comb);
+			Pb[Bk[r] * WPW + w] = acc;
+			M[tidx(srowL[q * 64 + r], w0 + w, srows)] = acc;
+		}
+		__syncthreads();
+		if (q + 1 >= npan) break;
+		build_tables(Pb);
+		__syncthreads();
+		const int g = q % GF2_GMAX, blk = q / GF2_GMAX;
+		const u64 *mset = mult + (i64)((set0 + blk) % nsets) * set_words;
+		for (int q2 = q + 1; q2 < npan; q2++) {
+			const int row2 = srowL[q2 * 64 + r];
+			if (row2 < 0) continue;
+			const u64 m = (q2 / GF2_GMAX == blk) ? aux[j0 + q2].src_mult[r][g] : mult_plain(upd_T, mset[midx(g, row2, rows)], row2);
+			if (m) S[(q2 * 64 + r) * WPW + w] ^= lookup(m);
+		}
+		__syncthreads();
+	}
+}
+
+// The outer pass: all `nblk` blocks of an outer panel (first panel j0) applied to the column tiles [tile_begin, tile_begin +
+// ntiles) right of it.  A workgroup of 8 wavefronts takes items (chunk of SEG x 512 rows, tile), chunk-major so that
+// concurrently running workgroups share the same rows' multipliers (L2 hits); every lane keeps SEG row segments of the tile
+// in registers, and per block: tables of the block's 256 pivot-row segments (prefetched during the previous block), 32
+// lookups per segment with that block's 32 B of multipliers (prefetched two segments ahead).  Rows are loaded once and
+// stored once per nblk blocks, and only rows that are alive after the panel are stored at all: the panel's own pivot
+// rows (final since k_outer_trsm) and older ones have nothing to take.
+template <int SEG>
+__global__ void __launch_bounds__(512)
+k_update16k(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int nblk,
+            const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
+            const u64 *__restrict__ mult, i64 set_words, int set0, int nsets,
+            const int *__restrict__ blk_first, const int *__restrict__ died, int tile_begin, int ntiles)
+{
+	constexpr int NT = 512, NW = 8;
+	__shared__ __attribute__((aligned(256))) uint4 tab[2 * 256 * 16];      // 128 KiB, must sit at LDS address 0 (checked below)
+	__shared__ uint4 stage[GF2_GMAX * 64];
+	__shared__ int prow[GF2_KMAX * GF2_GMAX * 64];                        // [block][panel][pivot bit] -> physical row, -1 if none
+	__shared__ int anyb[GF2_KMAX];
+	if ((unsigned)(size_t)tab != 0u) __builtin_trap();
+	const int lane = threadIdx.x & 63;
+	const int wvu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // wave-uniform by construction: keep it scalar
+	if (threadIdx.x < GF2_KMAX) anyb[threadIdx.x] = 0;
+	__syncthreads();
+	for (int t = threadIdx.x; t < nblk * GF2_GMAX * 64; t += NT) {
+		const int q = t >> 6, b = t & 63;
+		const PanelRec rec = panels[j0 + q];
+		int pr = -1;
+		if ((rec.mask >> b) & 1) { pr = aux[j0 + q].slot_row[__popcll(rec.mask & ((1ull << b) - 1))]; anyb[q / GF2_GMAX] = 1; }
+		prow[t] = pr;
+	}
+	__syncthreads();
+	int first_blk = -1, last_blk = -1;
+	for (int k = 0; k < nblk; k++) if (anyb[k]) { if (first_blk < 0) first_blk = k; last_blk = k; }
+	if (first_blk < 0) return;
+	unsigned KC[6];
+	{
+		const int rq_lo = lane & 7, rq_hi = (lane >> 3) & 1;
+#pragma unroll
+		for (int v = 0; v < 6; v++) {
+			unsigned k = 1u << 24;
+#pragma unroll
+			for (int b = 0; b < 3; b++) {
+				const int s = 3 * v + b;
+				if (s < 16) k |= (unsigned)(16 * (8 * ((s >> 3) ^ rq_hi) + (((s & 7) + rq_lo) & 7))) << (8 * b);
+			}
+			asm volatile("" : "+v"(k));
+			KC[v] = k;
+		}
+	}
+	const i64 rlo = (i64)(*blk_first) & ~(i64)63;      // rows below were pivots before this panel began
+	const i64 R64 = (rows + 63) & ~(i64)63;
+	constexpr i64 CH = (i64)SEG * NT;
+	const i64 nch = (R64 - rlo + CH - 1) / CH;
+	const i64 items = nch * ntiles;
+	const uint4 *mbase = reinterpret_cast<const uint4 *>(mult);
+	for (i64 it = blockIdx.x; it < items; it += gridDim.x) {
+		const i64 tile = tile_begin + it % ntiles;
+		const i64 r0 = rlo + (it / ntiles) * CH;
+		uint4 *Mw = reinterpret_cast<uint4 *>(M) + tile * srows;
+		// Every address below = a wave-uniform base (scalar registers) + the lane: a wavefront's 64 rows of batch j start at
+		// rb(j), a multiple of 64, so a batch lies wholly inside or wholly beyond the padded row range and the clamp is a
+		// scalar select (per-lane clamps cost a 64-bit VGPR pair per batch and the kernel spilled 1700 registers).
+		const i64 rb0 = r0 + (i64)wvu * 64;
+		auto rbase = [&](int j) { const i64 rb = rb0 + (i64)j * (NW * 64); return rb < R64 ? rb : R64 - 64; };
+		uint4 d[SEG];
+		unsigned alive = 0;
+#pragma unroll
+		for (int j = 0; j < SEG; j++) {
+			const i64 rb = rbase(j);
+			d[j] = Mw[rb + lane];
+			const i64 rl = rb + lane;
+			const int dd = died[rl < rows ? rl : rows - 1];
+			if (rb0 + (i64)j * (NW * 64) < R64 && rl < rows && dd == GF2_NEVER) alive |= 1u << j;
+		}
+		uint4 staged = make_uint4(0, 0, 0, 0);
+		if (threadIdx.x < GF2_GMAX * 64) { const int pr = prow[first_blk * 256 + threadIdx.x]; staged = pr >= 0 ? Mw[pr] : make_uint4(0, 0, 0, 0); }
+#pragma unroll 1
+		for (int k = first_blk; k <= last_blk; k++) {
+			if (!anyb[k]) continue;          // (uniform.  A loop that steps from block to block through the LDS flags made the
+			                                  // register allocator spill 1600 registers; this form compiles to 251 VGPRs, no scratch)
+			__syncthreads();                            // the previous block's (or item's) lookups are done with the tables
+			if (threadIdx.x < GF2_GMAX * 64) stage[threadIdx.x] = staged;
+			__syncthreads();
+			for (int e = threadIdx.x; e < 2 * 31 * 16; e += NT) {            // entries with bits in one nibble only
+				const int sub = e & 15, q = (e >> 4) % 31, grp = (e >> 4) / 31;
+				const int idx = q <= 15 ? q : (q - 15) << 4;
+				const uint4 *st = stage + (2 * grp + (sub >> 3)) * 64 + 8 * (sub & 7);
+				uint4 acc = make_uint4(0, 0, 0, 0);
+				int bits = idx;
+				while (bits) { const int l = __ffs(bits) - 1; bits &= bits - 1; acc = xor4(acc, st[l]); }
+				tab[grp * 4096 + idx * 16 + sub] = acc;
+			}
+			__syncthreads();
+			for (int e = threadIdx.x; e < 2 * 225 * 16; e += NT) {           // mixed = low-nibble entry ^ high-nibble entry
+				const int sub = e & 15, q = (e >> 4) % 225, grp = (e >> 4) / 225;
+				const int lo = 1 + q % 15, hi = (1 + q / 15) << 4;
+				uint4 *tb = tab + grp * 4096 + sub;
+				tb[(lo | hi) * 16] = xor4(tb[lo * 16], tb[hi * 16]);
+			}
+			{
+				const int kn = k + 1;                       // (a block without pivots stages zeros and is skipped)
+				if (kn <= last_blk && threadIdx.x < GF2_GMAX * 64) {
+					const int pr = prow[kn * 256 + threadIdx.x];
+					staged = pr >= 0 ? Mw[pr] : make_uint4(0, 0, 0, 0);
+				}
+			}
+			__syncthreads();
+			const uint4 *mq = mbase + (i64)((set0 + k) % nsets) * (set_words / 2);
+			uint4 m0[2], m1[2];
+			auto loadm = [&](int j, int slot) {
+				const uint4 *mr = mq + (rbase(j < SEG ? j : SEG - 1) + lane) * 2;
+				m0[slot] = mr[0]; m1[slot] = mr[1];
+			};
+			auto issue = [&](u32x4 *v, const uint4 &a0, const uint4 &a1, int r) {
+				const unsigned mw[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+				const int grp = r >> 1, hf = r & 1;
+#pragma unroll
+				for (int q = 0; q < 8; q++) {
+					const int s = 8 * hf + q;
+					const unsigned sel = (unsigned)(s % 3) | ((4u + (unsigned)(q & 3)) << 8) | ((grp ? 3u : 12u) << 16) | (12u << 24);
+					const unsigned at = __builtin_amdgcn_perm(mw[2 * (2 * grp + hf) + (q >> 2)], KC[s / 3], sel);
+					v[q] = *(lds_u4_ptr)(size_t)at;
+				}
+			};
+			auto fold = [&](uint4 &acc, const u32x4 *v) {
+#pragma unroll
+				for (int h = 0; h < 4; h++) {
+					acc.x = __builtin_amdgcn_bitop3_b32(acc.x, v[2 * h].x, v[2 * h + 1].x, 0x96);
+					acc.y = __builtin_amdgcn_bitop3_b32(acc.y, v[2 * h].y, v[2 * h + 1].y, 0x96);
+					acc.z = __builtin_amdgcn_bitop3_b32(acc.z, v[2 * h].z, v[2 * h + 1].z, 0x96);
+					acc.w = __builtin_amdgcn_bitop3_b32(acc.w, v[2 * h].w, v[2 * h + 1].w, 0x96);
+				}
+			};
+			u32x4 va[8], vb[8];
+			loadm(0, 0); loadm(1, 1);
+			issue(va, m0[0], m1[0], 0);
+#pragma unroll
+			for (int j = 0; j < SEG; j++) {
+				const int c = j & 1;
+				issue(vb, m0[c], m1[c], 1); fold(d[j], va);
+				issue(va, m0[c], m1[c], 2); fold(d[j], vb);
+				issue(vb, m0[c], m1[c], 3); fold(d[j], va);
+				const uint4 n0 = m0[c ^ 1], n1 = m1[c ^ 1];
+				loadm(j + 2, c);                        // (past the end: re-reads the last rows' multipliers, unused)
+				issue(va, n0, n1, 0); fold(d[j], vb);   // (past the end: a harmless extra round)
+			}
+		}
+#pragma unroll
+		for (int j = 0; j < SEG; j++)
+			if ((alive >> j) & 1) Mw[rb0 + (i64)j * (NW * 64) + lane] = d[j];
+	}
+}
 
 // ==========================================================================================
 // BACK-SUBSTITUTION

@@ -100,7 +100,7 @@ struct Pool {
 	struct Big { void *p = nullptr; size_t bytes = 0; };
 	std::map<int, Big> big_free;                                      // device -> idle large buffer
 	std::unordered_map<void *, std::pair<int, size_t>> big_live;      // handed-out large buffers
-	static bool keep_big() { static const bool k = !(getenv("GF2BV_KEEP_BIG") && atoi(getenv("GF2BV_KEEP_BIG")) == 0); return k; }
+	static bool keep_big() { return true; }
 
 	static size_t bucket(size_t bytes)
 	{
@@ -224,22 +224,6 @@ struct UpdateImpl {
 	                     const u64 *, const int *, int, int, int, int, int, int, SysStride, hipEvent_t, hipEvent_t);
 };
 
-#if GF2_TW != 2
-template <int G, int T, int NT>
-hipError_t launch_update(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows, int j0, int gb, int wlo,
-                         const PanelRec *panels, const PanelAux *aux, const u64 *multset, const int *blk_first,
-                         int tile_begin, int ntiles, int world, int wrank, int nw_lo, int nw_hi, SysStride ss, hipEvent_t begun,
-                         hipEvent_t done)
-{
-	// the tables are static shared memory (see k_update): no dynamic LDS, no attribute to raise
-	// `begun` / `done` (optional): timing and hand-off events ride on this kernel's own start / completion signals
-	// instead of marker packets around it
-	hipExtLaunchKernelGGL((k_update<G, T, NT>), grid, dim3(NT), 0, s, begun, done, 0, M, rows, srows, j0, gb, wlo, panels, aux,
-	                      multset, blk_first, tile_begin, ntiles, world, wrank, nw_lo, nw_hi, ss);
-	return hipGetLastError();
-}
-#define UPDATE_IMPL(G, T, NT) { G, T, UpdateCfg<G, T>::LDS_BYTES, NT, launch_update<G, T, NT> }
-#else
 // 16-byte tiles: G = 4 panels, T = 8 byte fields per panel.  nw_lo < 0 selects the HALF instance (only the tile's second
 // word is stored: its first one belongs to the next block's window); the window's whole tiles are simply not launched.
 template <int NT, int DEPTH, bool PIPE, int LB>
@@ -258,9 +242,7 @@ hipError_t launch_update16(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows
 	return hipGetLastError();
 }
 #define UPDATE16_IMPL(NT, D, P, LB) { 4, 8, 2 * 256 * 256 + GF2_GMAX * 64 * 20, NT, launch_update16<NT, D, P, LB> }
-#endif
 
-#if GF2_TW == 2
 const UpdateImpl kUpdates[] = {
 	// default: 8 wavefronts (two per SIMD, 157 VGPRs: three batches of 64 rows in flight per wavefront, the lookups of
 	// round r+1 issued before the XORs of round r); the kernel is bound by the memory side, so more wavefronts buy
@@ -273,48 +255,13 @@ const UpdateImpl kUpdates[] = {
 	UPDATE16_IMPL(768, 3, true, 768),
 	UPDATE16_IMPL(640, 2, true, 640),
 };
-#elif GF2_TW == 8
-const UpdateImpl kUpdates[] = {
-	// default: 4 panels (256 pivots) per pass, 5/6-bit fields: 48 lookups, 128 KiB of tables; 12 wavefronts with the
-	// register budget of 16, so that a quarter of every SIMD's register file (and 15 KiB of LDS) stays free and the
-	// panel steps of the next block run NEXT TO the bulk update instead of queueing for a CU behind it
-	UPDATE_IMPL(4, 12, 768),
-	UPDATE_IMPL(4, 12, 1024),   // 16 wavefronts: the same pass time in isolation (the SIMDs are issue-bound with 3 waves as with 4)
-	UPDATE_IMPL(4, 12, 512),
-	UPDATE_IMPL(4, 16, 1024),   // 4 panels, nibble fields: 64 lookups, 64 KiB
-	UPDATE_IMPL(3, 12, 1024),   // 3 panels, 36 lookups, 96 KiB
-	UPDATE_IMPL(2, 12, 1024),   // 2 panels, 24 lookups, 64 KiB
-	UPDATE_IMPL(2, 16, 1024),
-	UPDATE_IMPL(1, 12, 1024),
-	UPDATE_IMPL(1, 16, 1024),
-	UPDATE_IMPL(1, 8, 1024),    // 1 panel, byte fields: 8 lookups, 128 KiB
-};
-#else
-const UpdateImpl kUpdates[] = {
-	UPDATE_IMPL(4, 16, 1024),   // default: 4 panels (256 pivots) per pass, 64 lookups, 128 KiB LDS
-	UPDATE_IMPL(3, 16, 1024),   // 3 panels, 48 lookups, 96 KiB
-	UPDATE_IMPL(3, 14, 1024),   // 3 panels, 42 lookups, 132 KiB
-	UPDATE_IMPL(2, 12, 1024),   // 2 panels, 24 lookups, 128 KiB
-	UPDATE_IMPL(2, 14, 1024),   // 2 panels, 28 lookups, 88 KiB
-	UPDATE_IMPL(2, 16, 1024),   // 2 panels, 32 lookups, 64 KiB
-	UPDATE_IMPL(1, 10, 1024),   // 1 panel, 10 lookups, 112 KiB
-	UPDATE_IMPL(1, 12, 1024),   // 1 panel, 12 lookups, 64 KiB
-	UPDATE_IMPL(1, 16, 1024),   // 1 panel, 16 lookups, 32 KiB
-};
-#endif
 
 const UpdateImpl *pick_update()
 {
 	const UpdateImpl *chosen = &kUpdates[0];
-	if (const char *e = getenv("GF2BV_UPDATE")) {      // "GxT" or "GxTxTHREADS", e.g. 3x16 or 2x16x512
-		int g = 0, t = 0, nt = 0;
-		if (sscanf(e, "%dx%dx%d", &g, &t, &nt) >= 2)
-			for (const UpdateImpl &c : kUpdates)
-				if (c.G == g && c.T == t && (nt == 0 || c.threads == nt)) { chosen = &c; break; }
-		if (GF2_TW == 2) {                               // "NT" alone picks among the 16-byte-tile instances, in table order
-			int idx = atoi(e);
-			if (idx >= 0 && idx < (int)(sizeof kUpdates / sizeof kUpdates[0]) && !strchr(e, 'x')) chosen = &kUpdates[idx];
-		}
+	if (const char *e = getenv("GF2BV_UPDATE")) {      // index into the table above (tests run every instance)
+		const int idx = atoi(e);
+		if (idx >= 0 && idx < (int)(sizeof kUpdates / sizeof kUpdates[0])) chosen = &kUpdates[idx];
 	}
 	return chosen;
 }
@@ -380,7 +327,14 @@ struct Solver {
 	FindUnit *fu = nullptr;
 	int *died = nullptr;          // per row: panel that made it a pivot source, GF2_NEVER while alive
 	int *pivcol = nullptr, *urow = nullptr, *blk_first = nullptr;
-	u64 *mult = nullptr;          // 2 sets x G x rows (ping-pong between consecutive blocks)
+	u64 *mult = nullptr;          // nsets sets x G x rows: block b writes / reads set b % nsets (2 = ping-pong; an outer panel of the
+	                              // two-level elimination keeps all its K blocks' multipliers until its outer pass: nsets = K)
+	int nsets = 2;
+	// two-level elimination (large systems; see k_update16k): blocks [0, tl_bend) go in outer panels of tl_K blocks
+	int tl_K = 0, tl_bend = 0;
+	i64 tile_hi = 0;              // bulk kernels touch tiles < tile_hi (= ntiles; the outer panel's end while it is eliminated)
+	hipEvent_t evOuter = nullptr;
+	bool ends_outer_panel(int b) const { return tl_K > 0 && b < tl_bend && (b + 1) % tl_K == 0; }
 	u64 *Wb = nullptr;            // 2 x rows x GMAX window words (the panel steps ping-pong between the halves)
 	u64 *Uwin = nullptr;          // rank x GMAX: pivot rows' words of the following window (k_prio_window -> k_unwind)
 	u64 *Pfast = nullptr;         // scratch of k_block_fast: the pivot rows' window words of a block, [panel][word][column]
@@ -443,6 +397,7 @@ struct Solver {
 		st = nullptr; panels = nullptr; aux = nullptr; fu = nullptr; died = nullptr; pivcol = nullptr;
 		urow = nullptr; blk_first = nullptr; mult = nullptr; Wb = nullptr;
 		for (hipEvent_t *e : { &ev0, &ev1, &ev2, &ev3, &evx }) { P.release_event(*e, true); *e = nullptr; }
+		P.release_event(evOuter, false); evOuter = nullptr;
 		for (hipEvent_t e : kev) P.release_event(e, true);
 		for (hipEvent_t e : evA) P.release_event(e, false);
 		for (hipEvent_t e : evPrio) P.release_event(e, false);
@@ -502,6 +457,36 @@ int check_device(int device)
 	return GF2BV_OK;
 }
 
+// Two-level elimination (k_outer_trsm + k_update16k): which blocks go in outer panels, and of how many blocks.
+// An outer panel costs its inner elimination (K panel paths of ~90 us with nothing to hide behind: the outer pass has no
+// look-ahead yet) and saves (1 - ~0.73) of K bulk passes over what lies right of it, so it pays while that remainder is
+// large: default K = 4 while more than 1.5 GiB remain (nothing at 65536^2, the first 57 % of the pivots = 92 % of the bulk
+// work at 262144^2).  GF2BV_TWO_LEVEL=0 turns it off, =K (2..8) forces K from the first block on for every full panel
+// whatever the size (tests).  Single systems on one GPU only: gangs and column-slab solves keep the one-level schedule.
+void plan_two_level(Solver &S)
+{
+	S.tl_K = 0; S.tl_bend = 0; S.nsets = 2;
+	if (S.world != 1 || S.nsys != 1 || S.impl->G != GF2_GMAX) return;
+	int K = 4;
+	double min_bytes = 1.5 * 1073741824.0;
+	if (const char *e = getenv("GF2BV_TWO_LEVEL"); e && *e) {
+		const int v = atoi(e);
+		if (v <= 0) return;
+		K = std::min(GF2_KMAX, std::max(2, v));
+		min_bytes = 0;
+	}
+	const int G = S.impl->G;
+	int bend = 0;
+	for (int b0 = 0; b0 + K < S.nblocks; b0 += K) {            // (the last block never ends an outer panel: it may be short)
+		const i64 rows_left = S.rows - (i64)(b0 + K) * 64 * G, words_left = S.wt - (i64)(b0 + K) * G;
+		if ((i64)(b0 + K) * 64 * G > S.cols || rows_left <= 0 || words_left <= 0) break;
+		if ((double)rows_left * (double)words_left * 8.0 < min_bytes) break;
+		bend = b0 + K;
+	}
+	if (!bend) return;
+	S.tl_K = K; S.tl_bend = bend; S.nsets = K;
+}
+
 int solver_alloc(Solver &S)
 {
 	S.wt = (S.cols + 1 + 63) / 64;
@@ -520,21 +505,19 @@ int solver_alloc(Solver &S)
 	}
 	const int G = S.impl->G;
 	S.nblocks = (S.npanels + G - 1) / G;
+	S.tile_hi = S.ntiles;
+	plan_two_level(S);
 	S.units = (int)std::min<i64>(256, std::max<i64>(1, (S.rows + 255) / 256));
-	if (const char *e = getenv("GF2BV_UNITS")) { int v = atoi(e); if (v >= 1 && v <= 256) S.units = std::min(S.units, v); }
 	if (const char *e = getenv("GF2BV_DEBUG_SYNC")) S.dbg_sync = atoi(e);
-	if (const char *e = getenv("GF2BV_EXT_EVENTS")) S.ext_events = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_FAST")) S.fast_blocks = atoi(e) != 0;
 	S.flag_sync = S.world == 1;           // (a column-slab solve hands over through the host between the pieces: events)
 	if (const char *e = getenv("GF2BV_FLAG_SYNC")) S.flag_sync = S.flag_sync && atoi(e) != 0;
 	if (getenv("GF2BV_SERIAL")) S.flag_sync = false;      // (one stream: the panel gate would wait for a gate queued behind it)
 	if (const char *e = getenv("GF2BV_OPTIMISTIC")) S.optimistic = atoi(e) != 0;
-	if (const char *e = getenv("GF2BV_SPARSE")) { int v = atoi(e); if (v >= 0 && v <= 2) S.sparse_mode = v; }
 	// narrow workgroups: as many rows each as keeps ~256 of them (all systems of a gang together) busy, at most 8 blocks
 	{
 		const i64 blocks = (S.rows + 255) / 256 * std::max(1, S.nsys);
 		S.narrow_rpt = (int)std::min<i64>(8, std::max<i64>(1, blocks / 256));
-		if (const char *e = getenv("GF2BV_NARROW_RPT")) { int v = atoi(e); if (v >= 1 && v <= 64) S.narrow_rpt = v; }
 	}
 	if (const char *e = getenv("GF2BV_SELF_WAIT_US")) { int v = atoi(e); if (v >= 0 && v <= 1000000) S.self_wait = v * 100; }
 	if (getenv("GF2BV_SERIAL")) { S.sB = S.sA; S.own_sB = false; }     // ablation: no look-ahead overlap
@@ -557,7 +540,7 @@ int solver_alloc(Solver &S)
 		const size_t o_st = carve(sizeof(SolveState)), o_sf = carve(sizeof(SyncFlags)), o_pan = carve(sizeof(PanelRec) * NP), o_aux = carve(sizeof(PanelAux) * NP),
 		             o_fu = carve(sizeof(FindUnit) * (S.units + 1 + GF2_MAXGROUPS)), o_alive = carve(sizeof(int) * (size_t)R),
 		             o_piv = carve(sizeof(int) * (S.maxr + 64)), o_urow = carve(sizeof(int) * (S.maxr + 64)),
-		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * 2 * G * mult_rows(R)),
+		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * S.nsets * G * mult_rows(R)),
 		             o_wb = carve(sizeof(u64) * 2 * GF2_GMAX * R), o_uw = carve(sizeof(u64) * GF2_GMAX * (S.maxr + 64)),
 		             o_pf = carve(sizeof(u64) * GF2_GMAX * GF2_GMAX * 64);
 		S.arena_stride = off;
@@ -580,6 +563,7 @@ int solver_alloc(Solver &S)
 	HIPCHK(pool().event(&S.ev1, true));
 	HIPCHK(pool().event(&S.ev2, true));
 	HIPCHK(pool().event(&S.ev3, true));
+	if (S.tl_K) HIPCHK(pool().event(&S.evOuter, false));
 	S.evA.resize(S.nblocks); S.evPrio.resize(S.nblocks); S.waitPrio.assign(S.nblocks, nullptr);
 	for (int b = 0; b < S.nblocks; b++) {
 		HIPCHK(pool().event(&S.evA[b], false));
@@ -631,12 +615,11 @@ int streams_run_concurrently(int device, hipStream_t a, hipStream_t b, int *ok)
 int pick_update_wgs(i64 est_rows, int ntiles, int nsys)
 {
 	i64 want = 256;
-	if (const char *e = getenv("GF2BV_WGS")) { int v = atoi(e); if (v > 0) want = v; }
 	want = std::max<i64>(1, want / std::max(1, nsys));
 	// (a span below ~min_rows rows of a 64-byte column is not worth a workgroup of its own: a table build costs as much
 	// as streaming ~1000 of them -- but small passes are latency, not throughput: the chip is mostly idle, so they take
 	// as many workgroups as have at least that much to do)
-	static const i64 min_rows = getenv("GF2BV_WG_MIN_ROWS") ? std::max(256, atoi(getenv("GF2BV_WG_MIN_ROWS"))) : 2048;
+	constexpr i64 min_rows = 2048;
 	const i64 cap = std::max<i64>(1, (i64)ntiles * TW / 8 * est_rows / min_rows);
 	return (int)std::min(want, cap);
 }
@@ -656,7 +639,7 @@ i64 owned_count(i64 first, i64 end, int ulog, int world, int wrank)
 int launch_trsm(Solver &S, hipStream_t st, int j0, int gb, int wlo, int nw_lo, int nw_hi)
 {
 	constexpr int WPW = 4;
-	const i64 g0 = wlo / WPW, g1 = S.ntiles * TW / WPW;
+	const i64 g0 = wlo / WPW, g1 = S.tile_hi * TW / WPW;
 	const i64 ng = owned_count(g0, g1, GF2_OWN_LOG - 2, S.world, S.wrank);
 	if (ng <= 0) return GF2BV_OK;
 	k_block_trsm<TW, WPW><<<dim3((unsigned)ng, S.nsys), dim3(64 * WPW), 0, st>>>(S.M, S.srows, j0, gb, wlo, (int)g0, S.world, S.wrank,
@@ -706,11 +689,13 @@ BlockGeom block_geom(const Solver &S, int b)
 	g.j0 = b * G;
 	g.gb = std::min(G, S.npanels - g.j0);
 	g.wlo = g.j0 + g.gb;
-	g.mset = S.mult + (i64)(b & 1) * G * mult_rows(S.rows);
+	g.mset = S.mult + (i64)(b % S.nsets) * G * mult_rows(S.rows);
 	// trailing tiles; the next block's window [wlo, wlo + gnext) sits in the first one or two of them
+	// (two-level: the bulk kernels stop at the outer panel's end, and its last block has no next window to carry forward --
+	// the outer pass covers that window like every other tile right of the panel)
 	g.tb = g.wlo / TW;
-	g.nt_all = (g.wlo < S.wt) ? (int)S.ntiles - g.tb : 0;
-	g.gnext = (b + 1 < S.nblocks) ? std::min(G, S.npanels - g.wlo) : 0;
+	g.nt_all = (g.wlo < S.wt) ? (int)S.tile_hi - g.tb : 0;
+	g.gnext = (b + 1 < S.nblocks && !S.ends_outer_panel(b)) ? std::min(G, S.npanels - g.wlo) : 0;
 	return g;
 }
 
@@ -792,14 +777,13 @@ int enqueue_block_bulk(Solver &S, int b)
 	if (g.nt_all > 0) {
 		int rc = launch_trsm(S, S.sB, g.j0, g.gb, g.wlo, g.wlo, g.wlo + g.gnext);
 		if (rc) return rc;
-#if GF2_TW == 2
 		// 16-byte tiles: the next block's window is whole tiles that are simply left out; when it ends in the middle of a
 		// tile (an odd number of window words: the block before a short last one) that tile takes the HALF instance first
 		// (the LAST block has no next window: its trailing words start at wlo, possibly in the middle of a tile whose first
 		// word is the block's own -- the table entries are zero there, see `keep` in k_update16 -- and nobody else writes it)
 		const int wend = g.wlo + g.gnext;
 		const int tfull = g.gnext > 0 ? (wend + 1) / 2 : g.wlo / 2;      // first tile with no window word
-		const i64 nfull = owned_count(tfull, S.ntiles, GF2_OWN_LOG - 1, S.world, S.wrank);
+		const i64 nfull = owned_count(tfull, S.tile_hi, GF2_OWN_LOG - 1, S.world, S.wrank);
 		if ((wend & 1) && g.gnext > 0 && owned_count(wend / 2, wend / 2 + 1, GF2_OWN_LOG - 1, S.world, S.wrank) > 0) {
 			rc = launch_update_timed(S, S.sB, b, g.j0, g.gb, g.wlo, g.mset, wend / 2, 1, -1, 0, nfull <= 0, &S.waitPrio[b]);
 			if (rc) return rc;
@@ -810,14 +794,6 @@ int enqueue_block_bulk(Solver &S, int b)
 			if (rc) return rc;
 			launched = true;
 		}
-#else
-		const i64 nt = owned_count(g.tb, S.ntiles, GF2_OWN_LOG - GF2_TW_LOG, S.world, S.wrank);
-		if (nt > 0) {
-			rc = launch_update_timed(S, S.sB, b, g.j0, g.gb, g.wlo, g.mset, g.tb, (int)nt, g.wlo, g.wlo + g.gnext, true, &S.waitPrio[b]);
-			if (rc) return rc;
-			launched = true;
-		}
-#endif
 	}
 	if (!launched && !S.flag_sync) {
 		HIPCHK(hipEventRecord(S.evPrio[b], S.sB));      // "bulk of block b complete" (no update launch of this rank carries it)
@@ -830,7 +806,7 @@ int enqueue_block_bulk(Solver &S, int b)
 // stream A: the next block's window (needs the bulk update of block b-1, nothing newer)
 int enqueue_block_prio(Solver &S, int b)
 {
-	if (b + 1 >= S.nblocks) return GF2BV_OK;
+	if (b + 1 >= S.nblocks || S.ends_outer_panel(b)) return GF2BV_OK;
 	const BlockGeom g = block_geom(S, b);
 	const unsigned row_blocks = (unsigned)((S.rows + 255) / 256);
 	if (b > 0 && !S.flag_sync) HIPCHK(hipStreamWaitEvent(S.sA, S.waitPrio[b - 1], 0));
@@ -863,7 +839,7 @@ int enqueue_forward_join(Solver &S)
 	HIPCHK(hipStreamWaitEvent(S.sA, S.ev3, 0));
 	if (S.nblocks > 1 && S.maxr > 0)
 		k_unwind<<<dim3((unsigned)((S.maxr * GF2_GMAX + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(
-			S.M, S.srows, S.impl->G, S.npanels, S.nblocks, S.st, S.pivcol, S.urow, S.Uwin, S.world, S.wrank, S.ss());
+			S.M, S.srows, S.impl->G, S.npanels, S.nblocks, S.st, S.pivcol, S.urow, S.Uwin, S.world, S.wrank, S.tl_K, S.tl_bend, S.ss());
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
@@ -877,28 +853,93 @@ int enqueue_check_rhs(Solver &S)
 	return GF2BV_OK;
 }
 
+// Two-level elimination, the outer step of the panel of blocks [b0, b1): pivot rows brought up to date on every tile right
+// of the panel (k_outer_trsm), then all its blocks applied there in one pass (k_update16k).  Bulk stream; evOuter = done.
+int enqueue_outer_apply(Solver &S, int b0, int b1)
+{
+	const int G = S.impl->G;
+	const i64 w_begin = (i64)b1 * G;
+	const i64 t_begin = w_begin / TW, nt = S.ntiles - t_begin;
+	if (nt > 0) {
+		const i64 set_words = (i64)G * mult_rows(S.rows);
+		const i64 g_begin = w_begin / 4, ng = S.ntiles * TW / 4 - g_begin;
+		k_outer_trsm<4><<<dim3((unsigned)ng), dim3(256), 0, S.sB>>>(S.M, S.rows, S.srows, b0 * G, (b1 - b0) * G, (int)g_begin, S.panels, S.aux,
+		                                                             S.mult, set_words, b0 % S.nsets, S.nsets, S.impl->T);
+		HIPCHK(hipGetLastError());
+		hipEvent_t ka = nullptr, kb = nullptr;
+		if (S.time_kernels) {
+			HIPCHK(pool().event(&ka, true)); HIPCHK(pool().event(&kb, true));
+			S.kev.push_back(ka); S.kev.push_back(kb);
+			if (!S.ext_events) HIPCHK(hipEventRecord(ka, S.sB));
+		}
+		hipExtLaunchKernelGGL((k_update16k<GF2_KSEG>), dim3(256), dim3(512), 0, S.sB, S.ext_events ? ka : nullptr, S.ext_events ? kb : nullptr, 0,
+		                      S.M, S.rows, S.srows, b0 * G, b1 - b0, (const PanelRec *)S.panels, (const PanelAux *)S.aux, (const u64 *)S.mult,
+		                      set_words, b0 % S.nsets, S.nsets, (const int *)(S.blk_first + b0), (const int *)S.died, (int)t_begin, (int)nt);
+		HIPCHK(hipGetLastError());
+		if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, S.sB));
+	}
+	HIPCHK(hipEventRecord(S.evOuter, S.sB));
+	if (S.dbg_sync & 2) HIPCHK(hipDeviceSynchronize());
+	return GF2BV_OK;
+}
+
+// panel stream: the window of block b straight from the matrix (block 0; the first block behind an outer pass, which has
+// brought that window up to date like every other tile)
+int enqueue_window_gather(Solver &S, int b)
+{
+	const BlockGeom g = block_geom(S, b);
+	k_win_gather<<<dim3((unsigned)((S.rows * g.gb + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, S.Wb, S.ss());
+	HIPCHK(hipGetLastError());
+	return GF2BV_OK;
+}
+
 int enqueue_forward(Solver &S)
 {
 	int rc = enqueue_forward_begin(S, true);
 	if (rc) return rc;
+	int b = 0;
+	// Two-level part (large single systems, plan_two_level): outer panels of tl_K blocks.  Inside a panel the blocks run
+	// exactly as below -- both streams, look-ahead from block to block -- with the bulk kernels confined to the panel's own
+	// tiles (tile_hi); then the outer step; the next panel's first window is gathered behind it.  Both panel paths stay
+	// enqueued per block (no optimistic enqueue here: these blocks are far from panel-bound).
+	if (S.tl_K) {
+		const int G = S.impl->G;
+		for (int p0 = 0; p0 < S.tl_bend; p0 += S.tl_K) {
+			const int p1 = p0 + S.tl_K;
+			if (p0 > 0) {
+				HIPCHK(hipStreamWaitEvent(S.sA, S.evOuter, 0));
+				if ((rc = enqueue_window_gather(S, p0))) return rc;
+			}
+			S.tile_hi = (i64)p1 * G / TW;
+			for (b = p0; b < p1; b++) {
+				if ((rc = enqueue_block_panel(S, b))) return rc;
+				if ((rc = enqueue_block_bulk(S, b))) return rc;
+				if ((rc = enqueue_block_prio(S, b))) return rc;
+			}
+			S.tile_hi = S.ntiles;
+			if ((rc = enqueue_outer_apply(S, p0, p1))) return rc;
+		}
+		b = S.tl_bend;
+		HIPCHK(hipStreamWaitEvent(S.sA, S.evOuter, 0));
+		if (b < S.nblocks && (rc = enqueue_window_gather(S, b))) return rc;
+	}
 	// Optimistic enqueue for dense systems.  k_block_fast decides ON THE DEVICE whether a block goes the fast way, so the
 	// general panel steps have to be enqueued behind it all the same, and on a fast block they are G + 1 empty launches
-	// of ~4.5 us each on the critical path.  One look at the device settles it for the usual case: block 0 is enqueued
+	// of ~4.5 us each on the critical path.  One look at the device settles it for the usual case: the first block is enqueued
 	// both ways and the host waits for its panel path (a ~50 us stall, once per solve); if the fast search took it, the
 	// blocks that can take it at all (full blocks with enough rows left) get k_block_fast + k_narrow_all only.  Should the
 	// search give up on one of them after all, it poisons the panel path from there on (SolveState::poison) and the
 	// host resumes from that block with both paths -- the matrix and the window buffer are exactly as that block needs.
 	bool optimistic = false;
-	int b = 0;
 	SolveState hst{};
-	if (S.fast_blocks && S.optimistic && S.nsys == 1 && S.world == 1 && S.nblocks >= 8 && fast_block_possible(S, block_geom(S, 0))) {
-		if ((rc = enqueue_block_panel(S, 0))) return rc;
-		if ((rc = enqueue_block_bulk(S, 0))) return rc;
-		if ((rc = enqueue_block_prio(S, 0))) return rc;
+	if (S.fast_blocks && S.optimistic && S.nsys == 1 && S.world == 1 && S.nblocks - b >= 8 && fast_block_possible(S, block_geom(S, b))) {
+		if ((rc = enqueue_block_panel(S, b))) return rc;
+		if ((rc = enqueue_block_bulk(S, b))) return rc;
+		if ((rc = enqueue_block_prio(S, b))) return rc;
 		HIPCHK(hipMemcpyAsync(&hst, S.st, sizeof hst, hipMemcpyDeviceToHost, S.sA));
 		HIPCHK(hipStreamSynchronize(S.sA));
-		optimistic = hst.fast_done == 1;
-		b = 1;
+		optimistic = hst.fast_done == b + 1;
+		b++;
 	}
 	auto fast_only_ok = [&](int blk) {
 		// rows left when the block starts: at most 64 leftover candidates sit below the bound besides the pivots found
@@ -1616,6 +1657,17 @@ struct gf2bv_slab {
 	size_t payload_bytes = 0;
 	size_t o_blk = 0, o_pan = 0, o_aux = 0, o_mult = 0;
 	int next_prio = 0;         // k_prio_window(b) has been enqueued for all b < next_prio (on this rank, where it owns the next window)
+	// stream-ordered factor / apply (gf2bv_slab_factor_on / _apply_on): hand-overs between the caller's collective stream and
+	// the library's panel stream
+	// the panel stream, per payload buffer (block parity): [records exported, collective enqueued, records imported]
+	hipEvent_t ev_factored[2] = { nullptr, nullptr }, ev_bcast[2] = { nullptr, nullptr }, ev_imported[2] = { nullptr, nullptr };
+	bool bcast_seen[2] = { false, false }, import_seen[2] = { false, false };
+	~gf2bv_slab()
+	{
+		if (S.sA) (void)hipStreamSynchronize(S.sA);       // (nothing that waits on these events may still be queued)
+		if (S.sB) (void)hipStreamSynchronize(S.sB);
+		for (int k = 0; k < 2; k++) for (hipEvent_t e : { ev_factored[k], ev_bcast[k], ev_imported[k] }) pool().release_event(e, false);
+	}
 };
 
 namespace {
@@ -1656,6 +1708,9 @@ int gf2bv_slab_open(void *d_aug, int64_t rows, int64_t cols, int64_t stride_word
 	(void)carve(sizeof(SolveState)); h->o_blk = carve(sizeof(int)); h->o_pan = carve(sizeof(PanelRec) * G);
 	h->o_aux = carve(sizeof(PanelAux) * G); h->o_mult = carve(sizeof(u64) * G * mult_rows(R));
 	h->payload_bytes = off;
+	for (int k = 0; k < 2; k++)
+		for (hipEvent_t *e : { &h->ev_factored[k], &h->ev_bcast[k], &h->ev_imported[k] })
+			if (pool().event(e, false) != hipSuccess) { delete h; return fail(GF2BV_ERR_HIP, "hipEventCreate"); }
 	*out = h;
 	return GF2BV_OK;
 	});
@@ -1671,10 +1726,38 @@ int64_t gf2bv_slab_blocks(const gf2bv_slab *h) { return h ? h->S.nblocks : -1; }
 int gf2bv_slab_owner(const gf2bv_slab *h, int block) { return h ? slab_owner_of_block(h->S, block) : -1; }
 int64_t gf2bv_slab_payload_bytes(const gf2bv_slab *h) { return h ? (int64_t)h->payload_bytes : -1; }
 
-// Owner of block b: (carry its window forward,) factorise it, export the records into d_payload; returns when they are there.
-int gf2bv_slab_factor(gf2bv_slab *h, int b, void *d_payload)
+// records of block b <-> payload, one launch on `st` (export: to_payload)
+static int slab_copy_records(gf2bv_slab *h, int b, char *P, bool to_payload, hipStream_t st)
 {
-	return guarded([&]() -> int {
+	Solver &S = h->S;
+	const BlockGeom g = block_geom(S, b);
+	const int G = S.impl->G;
+	static_assert(sizeof(SolveState) % 4 == 0 && sizeof(PanelRec) % 4 == 0 && sizeof(PanelAux) % 4 == 0, "4-byte copy units");
+	struct { void *rec; size_t off, bytes; } seg[5] = {
+		{ S.st, 0, sizeof(SolveState) }, { S.blk_first + b, h->o_blk, sizeof(int) }, { S.panels + g.j0, h->o_pan, sizeof(PanelRec) * g.gb },
+		{ S.aux + g.j0, h->o_aux, sizeof(PanelAux) * g.gb }, { g.mset, h->o_mult, sizeof(u64) * G * mult_rows(S.rows) } };
+	SlabSegs sg;
+	size_t total = 0;
+	for (int k = 0; k < 5; k++) {
+		sg.s[k].src = to_payload ? seg[k].rec : (void *)(P + seg[k].off);
+		sg.s[k].dst = to_payload ? (void *)(P + seg[k].off) : seg[k].rec;
+		sg.s[k].bytes = (unsigned)seg[k].bytes;
+		total += seg[k].bytes;
+	}
+	const unsigned wgs = (unsigned)std::min<size_t>(256, std::max<size_t>(1, total / 16 / 256 / 4));
+	k_slab_copy<<<dim3(wgs), dim3(256), 0, st>>>(sg);
+	HIPCHK(hipGetLastError());
+	return GF2BV_OK;
+}
+
+// Owner of block b: (carry its window forward,) factorise it, export the records into d_payload.
+// Synchronous form (host_sync): returns when the payload is complete.  Stream-ordered form: `stream` is the stream the
+// caller's collective runs on; the export is ONE launch on the panel stream behind the panel path, `stream` is made to wait
+// for it and the call returns at once -- a broadcast enqueued on `stream` afterwards sends finished records, and the panel
+// stream never waits for the collective: the caller alternates TWO payload buffers (block b uses buffer b & 1), so that the
+// export of block b + 1 does not have to wait for the broadcast of block b (only for that of block b - 1, long gone).
+static int slab_factor_on(gf2bv_slab *h, int b, void *d_payload, hipStream_t stream, bool host_sync)
+{
 	if (!h || !d_payload || b < 0 || b >= h->S.nblocks) return fail(GF2BV_ERR_ARG, "bad block");
 	Solver &S = h->S;
 	if (slab_owner_of_block(S, b) != S.wrank) return fail(GF2BV_ERR_ARG, "this rank does not own the block's window");
@@ -1684,46 +1767,66 @@ int gf2bv_slab_factor(gf2bv_slab *h, int b, void *d_payload)
 	// rank's bulk update of block b-2, nothing newer: the look-ahead of the single-GPU solve, per owner
 	if (b > 0 && (rc = enqueue_block_prio(S, b - 1))) return rc;
 	if ((rc = enqueue_block_panel(S, b))) return rc;
-	const BlockGeom g = block_geom(S, b);
-	char *P = (char *)d_payload;
-	const int G = S.impl->G;
-	HIPCHK(hipMemcpyAsync(P, S.st, sizeof(SolveState), hipMemcpyDeviceToDevice, S.sA));
-	HIPCHK(hipMemcpyAsync(P + h->o_blk, S.blk_first + b, sizeof(int), hipMemcpyDeviceToDevice, S.sA));
-	HIPCHK(hipMemcpyAsync(P + h->o_pan, S.panels + g.j0, sizeof(PanelRec) * g.gb, hipMemcpyDeviceToDevice, S.sA));
-	HIPCHK(hipMemcpyAsync(P + h->o_aux, S.aux + g.j0, sizeof(PanelAux) * g.gb, hipMemcpyDeviceToDevice, S.sA));
-	HIPCHK(hipMemcpyAsync(P + h->o_mult, g.mset, sizeof(u64) * G * mult_rows(S.rows), hipMemcpyDeviceToDevice, S.sA));
-	HIPCHK(hipStreamSynchronize(S.sA));
+	if (S.world == 1 && !host_sync) return GF2BV_OK;       // nobody imports: the records stay where they are
+	const int par = b & 1;
+	// the buffer of this parity: last read by the broadcast of block b - 2 on the caller's stream (recorded in slab_apply_on)
+	if (!host_sync && h->bcast_seen[par]) HIPCHK(hipStreamWaitEvent(S.sA, h->ev_bcast[par], 0));
+	if ((rc = slab_copy_records(h, b, (char *)d_payload, true, S.sA))) return rc;
+	if (host_sync) HIPCHK(hipStreamSynchronize(S.sA));
+	else {
+		HIPCHK(hipEventRecord(h->ev_factored[par], S.sA));
+		HIPCHK(hipStreamWaitEvent(stream, h->ev_factored[par], 0));
+	}
 	return GF2BV_OK;
-	});
 }
 
-// Every rank: take block b's records (the other ranks import them from the broadcast payload), then TRSM + bulk update of
-// the tiles this rank owns.  Asynchronous.
-int gf2bv_slab_apply(gf2bv_slab *h, int b, const void *d_payload)
+// Every rank: take block b's records (the other ranks import them from the broadcast payload, which `stream` has produced),
+// then TRSM + bulk update of the tiles this rank owns.  Asynchronous.
+static int slab_apply_on(gf2bv_slab *h, int b, const void *d_payload, hipStream_t stream, bool host_sync)
 {
-	return guarded([&]() -> int {
 	if (!h || !d_payload || b < 0 || b >= h->S.nblocks) return fail(GF2BV_ERR_ARG, "bad block");
 	Solver &S = h->S;
 	HIPCHK(hipSetDevice(S.device));
 	const BlockGeom g = block_geom(S, b);
+	const int par = b & 1;
+	if (!host_sync && S.world > 1) {               // "the collective of block b has read / written buffer b & 1"
+		HIPCHK(hipEventRecord(h->ev_bcast[par], stream));
+		h->bcast_seen[par] = true;
+	}
 	if (slab_owner_of_block(S, b) != S.wrank) {
-		const char *P = (const char *)d_payload;
-		const int G = S.impl->G;
-		// the multiplier set (b & 1) was last read by this rank's bulk update of block b-2
-		if (b >= 2) HIPCHK(hipStreamWaitEvent(S.sA, S.waitPrio[b - 2], 0));
-		HIPCHK(hipMemcpyAsync(S.st, P, sizeof(SolveState), hipMemcpyDeviceToDevice, S.sA));
-		HIPCHK(hipMemcpyAsync(S.blk_first + b, P + h->o_blk, sizeof(int), hipMemcpyDeviceToDevice, S.sA));
-		HIPCHK(hipMemcpyAsync(S.panels + g.j0, P + h->o_pan, sizeof(PanelRec) * g.gb, hipMemcpyDeviceToDevice, S.sA));
-		HIPCHK(hipMemcpyAsync(S.aux + g.j0, P + h->o_aux, sizeof(PanelAux) * g.gb, hipMemcpyDeviceToDevice, S.sA));
-		HIPCHK(hipMemcpyAsync(g.mset, P + h->o_mult, sizeof(u64) * G * mult_rows(S.rows), hipMemcpyDeviceToDevice, S.sA));
+		if (!host_sync) HIPCHK(hipStreamWaitEvent(S.sA, h->ev_bcast[par], 0));      // the payload is what `stream` holds now
+		// the multiplier set of block b was last read by this rank's bulk update of block b - nsets
+		if (b >= S.nsets) HIPCHK(hipStreamWaitEvent(S.sA, S.waitPrio[b - S.nsets], 0));
+		int rc = slab_copy_records(h, b, (char *)const_cast<void *>(d_payload), false, S.sA);
+		if (rc) return rc;
 		k_import_marks<<<dim3(1), dim3(256), 0, S.sA>>>(g.j0, g.gb, S.panels, S.aux, S.died, S.pivcol, S.urow);
 		HIPCHK(hipGetLastError());
 		HIPCHK(hipEventRecord(S.evA[b], S.sA));
-		// the payload buffer may be reused by the caller once this returns
-		HIPCHK(hipStreamSynchronize(S.sA));
+		// the payload buffer may be overwritten once the import has read it: after this returns (host_sync), or by what the
+		// caller enqueues on `stream` behind the wait below -- placed one call LATER (the import of the previous block: the
+		// buffer it read is the one the next-but-one collective writes), so that the collective stream stays a block ahead
+		if (host_sync) HIPCHK(hipStreamSynchronize(S.sA));
+		else { HIPCHK(hipEventRecord(h->ev_imported[par], S.sA)); h->import_seen[par] = true; }
 	}
+	if (!host_sync && h->import_seen[par ^ 1]) HIPCHK(hipStreamWaitEvent(stream, h->ev_imported[par ^ 1], 0));
 	return enqueue_block_bulk(S, b);
-	});
+}
+
+int gf2bv_slab_factor(gf2bv_slab *h, int b, void *d_payload)
+{
+	return guarded([&]() -> int { return slab_factor_on(h, b, d_payload, nullptr, true); });
+}
+int gf2bv_slab_apply(gf2bv_slab *h, int b, const void *d_payload)
+{
+	return guarded([&]() -> int { return slab_apply_on(h, b, d_payload, nullptr, true); });
+}
+int gf2bv_slab_factor_on(gf2bv_slab *h, int b, void *d_payload, void *stream)
+{
+	return guarded([&]() -> int { return slab_factor_on(h, b, d_payload, (hipStream_t)stream, false); });
+}
+int gf2bv_slab_apply_on(gf2bv_slab *h, int b, const void *d_payload, void *stream)
+{
+	return guarded([&]() -> int { return slab_apply_on(h, b, d_payload, (hipStream_t)stream, false); });
 }
 
 // After the last block: this rank's tiles are final (pivot rows' parked window words moved in); synchronous.
@@ -1886,21 +1989,22 @@ int gf2bv_kernel_resources(int device, int32_t *out, int n)
 {
 	return guarded([&]() -> int {
 	if (!out || n < 10) return fail(GF2BV_ERR_ARG, "need room for 5 kernels");
+	for (int k = 0; k < n; k++) out[k] = 0;
 	int rc = check_device(device);
 	if (rc) return rc;
 	HIPCHK(hipSetDevice(device));
-#if GF2_TW == 2
 	const void *fn[5] = { (const void *)k_update16<512, false, 3, true, 512>, (const void *)k_block_fast, (const void *)k_narrow_all,
 	                      (const void *)k_prio_window, (const void *)k_panel_step };
-#else
-	const void *fn[5] = { (const void *)k_update<4, 12, 768>, (const void *)k_block_fast, (const void *)k_narrow_all,
-	                      (const void *)k_prio_window, (const void *)k_panel_step };
-#endif
 	for (int k = 0; k < 5; k++) {
 		hipFuncAttributes a{};
 		HIPCHK(hipFuncGetAttributes(&a, fn[k]));
 		out[2 * k] = a.numRegs;
 		out[2 * k + 1] = (int32_t)a.sharedSizeBytes;
+	}
+	if (n >= 13) {                 // the outer pass of the two-level elimination: registers, LDS, scratch bytes per lane (must be 0)
+		hipFuncAttributes a{};
+		HIPCHK(hipFuncGetAttributes(&a, (const void *)k_update16k<GF2_KSEG>));
+		out[10] = a.numRegs; out[11] = (int32_t)a.sharedSizeBytes; out[12] = (int32_t)a.localSizeBytes;
 	}
 	return GF2BV_OK;
 	});

@@ -31,7 +31,8 @@ EXPORTS = [
     "gf2bv_result_origin", "gf2bv_result_basis", "gf2bv_result_pivots", "gf2bv_result_stats",
     "gf2bv_result_free", "gf2bv_space_combine", "gf2bv_space_open", "gf2bv_space_enumerate", "gf2bv_space_buffer", "gf2bv_space_close",
     "gf2bv_slab_work_words", "gf2bv_slab_tiles", "gf2bv_slab_open", "gf2bv_slab_blocks", "gf2bv_slab_owner",
-    "gf2bv_slab_payload_bytes", "gf2bv_slab_factor", "gf2bv_slab_apply", "gf2bv_slab_finish_local", "gf2bv_slab_solve",
+    "gf2bv_slab_payload_bytes", "gf2bv_slab_factor", "gf2bv_slab_apply", "gf2bv_slab_factor_on", "gf2bv_slab_apply_on",
+    "gf2bv_slab_finish_local", "gf2bv_slab_solve",
     "gf2bv_slab_close",
     "gf2bv_synth_device", "gf2bv_residual_device",
     "gf2bv_stream_ceiling_device", "gf2bv_kernel_resources",
@@ -105,6 +106,8 @@ def lib():
         L.gf2bv_slab_payload_bytes.restype = i64
         L.gf2bv_slab_factor.argtypes = [vp, i32, vp]
         L.gf2bv_slab_apply.argtypes = [vp, i32, vp]
+        L.gf2bv_slab_factor_on.argtypes = [vp, i32, vp, vp]
+        L.gf2bv_slab_apply_on.argtypes = [vp, i32, vp, vp]
         L.gf2bv_slab_finish_local.argtypes = [vp]
         L.gf2bv_slab_solve.argtypes = [vp, pp]
         L.gf2bv_slab_close.argtypes = [vp]
@@ -296,10 +299,12 @@ def stream_ceiling(nbytes: int = 2 << 30, device: int = 0) -> dict:
 
 def kernel_resources(device: int = 0) -> dict:
     """VGPRs per lane and static LDS bytes of the bulk-update kernel and of the panel kernels that run beside it."""
-    out = (ctypes.c_int32 * 10)()
-    _check(lib().gf2bv_kernel_resources(device, out, 10))
+    out = (ctypes.c_int32 * 13)()
+    _check(lib().gf2bv_kernel_resources(device, out, 13))
     names = ("update", "block_fast", "narrow_all", "prio_window", "panel_step")
-    return {nm: {"vgprs": int(out[2 * k]), "lds": int(out[2 * k + 1])} for k, nm in enumerate(names)}
+    res = {nm: {"vgprs": int(out[2 * k]), "lds": int(out[2 * k + 1])} for k, nm in enumerate(names)}
+    res["update_outer"] = {"vgprs": int(out[10]), "lds": int(out[11]), "scratch": int(out[12])}      # k_update16k (two-level)
+    return res
 
 
 class DeviceBuffer:

@@ -35,17 +35,29 @@ class HipSlabEngine:
                                           device_index, ctypes.byref(h)))
         self.h = h
         self.nblocks = int(self.L.gf2bv_slab_blocks(h))
-        self.payload = torch.empty(int(self.L.gf2bv_slab_payload_bytes(h)) // 8, dtype=torch.int64, device=self.dev)
+        # two payload buffers: block b uses buffer b & 1 on every rank, so the export of block b + 1 never waits for the
+        # broadcast of block b (gf2bv_slab_factor_on)
+        nw = int(self.L.gf2bv_slab_payload_bytes(h)) // 8
+        self.payloads = [torch.zeros(nw, dtype=torch.int64, device=self.dev) for _ in range(2)]
 
     def owner(self, b: int) -> int:
         return int(self.L.gf2bv_slab_owner(self.h, b))
 
+    def _stream(self):
+        # the stream torch.distributed enqueues its collectives behind: the library orders its own streams against it
+        # with events (gf2bv_slab_factor_on / _apply_on), no call waits for the device
+        return torch.cuda.current_stream(self.dev).cuda_stream or None
+
+    def recv_buffer(self, b: int) -> torch.Tensor:
+        return self.payloads[b & 1]
+
     def factor(self, b: int) -> torch.Tensor:
-        self.hip._check(self.L.gf2bv_slab_factor(self.h, b, self.payload.data_ptr()))
-        return self.payload
+        buf = self.payloads[b & 1]
+        self.hip._check(self.L.gf2bv_slab_factor_on(self.h, b, buf.data_ptr(), self._stream()))
+        return buf
 
     def apply(self, b: int, payload: torch.Tensor):
-        self.hip._check(self.L.gf2bv_slab_apply(self.h, b, payload.data_ptr()))
+        self.hip._check(self.L.gf2bv_slab_apply_on(self.h, b, payload.data_ptr(), self._stream()))
 
     def finish_local(self):
         self.hip._check(self.L.gf2bv_slab_finish_local(self.h))
@@ -76,16 +88,15 @@ def _broadcast(t: torch.Tensor, src: int, group=None):
         dist.broadcast(t, src=src, group=group)
 
 
-def run_schedule(engine, group=None):
-    """The column-slab schedule on an initialised process group; returns rank 0's result (None elsewhere)."""
+def run_schedule(engine, group=None, always_broadcast: bool = False):
+    """The column-slab schedule on an initialised process group; returns rank 0's result (None elsewhere).
+    `always_broadcast`: issue the per-block collective at world size 1 as well (tests: the RCCL path on a one-GPU box)."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     for b in range(engine.nblocks):
         src = engine.owner(b)
-        payload = engine.factor(b) if src == rank else engine.payload
-        if world > 1:
-            _broadcast(payload, src, group)                 # the ONE collective of the block
-            if payload.is_cuda:
-                torch.cuda.current_stream(payload.device).synchronize()
+        payload = engine.factor(b) if src == rank else (engine.recv_buffer(b) if hasattr(engine, "recv_buffer") else engine.payload)
+        if world > 1 or always_broadcast:
+            _broadcast(payload, src, group)                 # the ONE collective of the block (stream-ordered on the GPU)
         engine.apply(b, payload)
     engine.finish_local()
     if world > 1:
@@ -100,12 +111,13 @@ def run_schedule(engine, group=None):
     return engine.solve() if rank == 0 else None
 
 
-def solve_one_sharded(aug: torch.Tensor, rows: int, cols: int, stride: int, device_index: int, group=None):
+def solve_one_sharded(aug: torch.Tensor, rows: int, cols: int, stride: int, device_index: int, group=None,
+                      always_broadcast: bool = False):
     """solve_one of the system `aug` (row-major augmented words, int64 tensor on this rank's GPU, the same on every
     rank) with its columns sharded over the ranks of `group`.  rank 0 returns a hip.Solution, the others None."""
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     eng = HipSlabEngine(aug.data_ptr(), rows, cols, stride, world, rank, device_index)
     try:
-        return run_schedule(eng, group)
+        return run_schedule(eng, group, always_broadcast)
     finally:
         eng.close()

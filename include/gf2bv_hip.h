@@ -175,6 +175,16 @@ int     gf2bv_slab_owner(const gf2bv_slab *h, int block);
 int64_t gf2bv_slab_payload_bytes(const gf2bv_slab *h);
 int     gf2bv_slab_factor(gf2bv_slab *h, int block, void *d_payload);
 int     gf2bv_slab_apply(gf2bv_slab *h, int block, const void *d_payload);
+/* The same two steps ordered against the caller's collective stream instead of the host (`stream`: the HIP stream the
+ * broadcast of d_payload is enqueued on).  The caller alternates TWO payload buffers: block b uses buffer b & 1 on every
+ * rank.  _factor_on exports the records with one launch on the library's panel stream, makes `stream` wait for it and
+ * returns at once: a broadcast enqueued on `stream` afterwards sends finished records, and the panel stream never waits
+ * for the collective.  _apply_on imports what `stream` holds when it is called (non-owners), and orders `stream` behind the
+ * import of the PREVIOUS block (whose buffer the next collective will write).  No call waits for the device: the broadcast
+ * of block b + 1 overlaps the bulk update of block b on every rank.  At world size 1 nothing is exported at all.
+ * (gf2bv_amd/slab.py runs this form.) */
+int     gf2bv_slab_factor_on(gf2bv_slab *h, int block, void *d_payload, void *stream);
+int     gf2bv_slab_apply_on(gf2bv_slab *h, int block, const void *d_payload, void *stream);
 int     gf2bv_slab_finish_local(gf2bv_slab *h);
 int     gf2bv_slab_solve(gf2bv_slab *h, gf2bv_result **out);
 void    gf2bv_slab_close(gf2bv_slab *h);
@@ -214,7 +224,9 @@ int gf2bv_stream_ceiling_device(int device, int64_t bytes, double *rmw_gbs, doub
  * block b+1 runs beside the bulk update of block b, and a panel kernel that does not fit next to an update workgroup
  * (two wavefronts per SIMD, 128 KiB of tables) silently waits for one to retire: out[0..1] the default bulk-update
  * instance, then k_block_fast, k_narrow_all, k_prio_window, k_panel_step (registers, LDS each; n >= 10).  A test holds the
- * budget: registers <= 512 - 2 x round_up(update's, 8), LDS <= 160 KiB - update's. */
+ * budget: registers <= 512 - 2 x round_up(update's, 8), LDS <= 160 KiB - update's.  With n >= 13: out[10..12] = registers,
+ * LDS and SCRATCH bytes per lane of k_update16k, the outer pass of the two-level elimination (it keeps 16 row segments per
+ * lane in registers: scratch must be 0). */
 int gf2bv_kernel_resources(int device, int32_t *out, int n);
 
 /* plain device buffer helpers so a host language without a HIP binding can stage data */

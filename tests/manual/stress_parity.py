@@ -10,7 +10,8 @@ from tests.systems import random_system
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 configs = ["0", "1", "2", "3", "4", "5"]          # instances of k_update16 (GF2_TW = 2 builds)
-knobs = [{}, {}, {"GF2BV_FAST": "0"}, {"GF2BV_OPTIMISTIC": "0"}, {"GF2BV_SELF_WAIT_US": "0"}, {"GF2BV_NARROW_RPT": "3"}, {"GF2BV_FLAG_SYNC": "0"}]
+knobs = [{}, {}, {"GF2BV_FAST": "0"}, {"GF2BV_OPTIMISTIC": "0"}, {"GF2BV_SELF_WAIT_US": "0"}, {"GF2BV_FLAG_SYNC": "0"},
+         {"GF2BV_TWO_LEVEL": "2"}, {"GF2BV_TWO_LEVEL": "3"}, {"GF2BV_TWO_LEVEL": "4"}, {"GF2BV_TWO_LEVEL": "8"}, {"GF2BV_TWO_LEVEL": "2", "GF2BV_FLAG_SYNC": "0"}]
 t0, n, worst = time.time(), 0, 0
 while time.time() - t0 < budget:
     cols = rng.choice([rng.randint(1, 130), rng.randint(131, 700), rng.randint(700, 2600), 64 * rng.randint(1, 40), 256 * rng.randint(1, 10) + rng.choice([-1, 0, 1]),
@@ -23,7 +24,7 @@ while time.time() - t0 < budget:
     zero_rows = rng.choice([0, 0, rng.randint(0, rows // 2)])
     mode = rng.randint(0, 1)
     os.environ["GF2BV_UPDATE"] = rng.choice(configs)
-    for k in ("GF2BV_FAST", "GF2BV_OPTIMISTIC", "GF2BV_SELF_WAIT_US", "GF2BV_NARROW_RPT", "GF2BV_FLAG_SYNC"):
+    for k in ("GF2BV_FAST", "GF2BV_OPTIMISTIC", "GF2BV_SELF_WAIT_US", "GF2BV_FLAG_SYNC", "GF2BV_TWO_LEVEL"):
         os.environ.pop(k, None)
     os.environ.update(rng.choice(knobs))
     eqs = random_system(rng, rows, cols, density, cap, consistent, min(zero_rows, rows - 1))
@@ -41,6 +42,7 @@ while time.time() - t0 < budget:
     n += 1
     worst = max(worst, rows)
     if not ok:
-        print(f"MISMATCH rows={rows} cols={cols} density={density} cap={cap} consistent={consistent} zero_rows={zero_rows} mode={mode} cfg={os.environ['GF2BV_UPDATE']}")
+        print(f"MISMATCH rows={rows} cols={cols} density={density} cap={cap} consistent={consistent} zero_rows={zero_rows} mode={mode} cfg={os.environ['GF2BV_UPDATE']} "
+              f"knobs={ {k: v for k, v in os.environ.items() if k.startswith('GF2BV_')} }")
         sys.exit(1)
 print(f"{n} random systems identical to the oracle in {time.time() - t0:.1f} s (largest {worst} rows)")

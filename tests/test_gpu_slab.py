@@ -49,8 +49,13 @@ def _worker(rank, world, port, n, seed, q, shape=None):
         if rank == 0:
             ref = hip.solve_device(aug.data_ptr(), rows, cols, stride, 0)
             bad = hip.residual_device(aug.data_ptr(), rows, cols, stride, sol.origin) if sol.solved else 0
+            # the CPU oracle on the same words (replaces the single _mzd_pluq call, gf2bv/_internal.c:431-433)
+            from oracle import gf2_oracle as O
+            host = aug.cpu().numpy().view(np.uint64).reshape(rows, stride)
+            want = O.solve_words(np.ascontiguousarray(host), rows, cols, 0, algo=1)
             q.put((sol.status, sol.rank, sol.origin.copy(), sol.pivots.copy(), ref.status, ref.rank, ref.origin.copy(),
-                   ref.pivots.copy(), bad))
+                   ref.pivots.copy(), bad, int(want["status"]), int(want["rank"]), np.array(want["origin"]).copy(),
+                   np.array(want["pivcols"]).copy()))
         else:
             assert sol is None
         dist.barrier()
@@ -71,10 +76,36 @@ def _run(world, n, seed, shape=None):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    st, rk, org, piv, rst, rrk, rorg, rpiv, bad = got
+    st, rk, org, piv, rst, rrk, rorg, rpiv, bad, ost, ork, oorg, opiv = got
     assert (st, rk) == (rst, rrk) and bad == 0
     assert np.array_equal(org, rorg) and np.array_equal(piv, rpiv)
+    # ... and word for word what the oracle says: status, rank, column rank profile, origin
+    assert (st, rk) == (ost, ork) and np.array_equal(piv, opiv)
+    if st == 0:
+        assert np.array_equal(org, oorg)
     return st, rk
+
+
+def test_schedule_over_rccl_world_size_1():
+    """The schedule with the backend of the multi-GPU run ("nccl" = RCCL) on this box's one GPU: the per-block broadcast of the
+    DEVICE payload tensor is issued although there is nobody to receive it, so dist.broadcast on device memory, the stream
+    ordering around it and the import of the records are the code the 8-GPU run executes.  Checked against the oracle."""
+    from oracle import gf2_oracle as O
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        for (n, seed) in ((4096, 21), (2500, 22)):
+            aug, stride = _system(n, seed, dev)
+            sol = slab.solve_one_sharded(aug, n, n, stride, 0, always_broadcast=True)
+            want = O.solve_words(O.gen_synthetic(n, n, seed), n, n, 0, algo=1)
+            assert sol.status == want["status"] and sol.rank == want["rank"]
+            assert np.array_equal(sol.pivots, want["pivcols"]) and np.array_equal(sol.origin, want["origin"])
+    finally:
+        dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("world,n,seed", [(1, 3000, 11), (2, 4096, 12), (2, 5000, 13), (3, 6200, 14)])

@@ -165,8 +165,9 @@ void run(uint4 *M, i64 rows, int ntiles, uint4 *piv, uint4 *mult, bool check, co
 	}
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 	auto launch = [&] { k_kloop<S, K><<<dim3(256), dim3(512)>>>(M, rr, ntiles, piv, mult); };
-	launch(); CK(hipDeviceSynchronize());
-	const int reps = 5;
+	CK(hipMemset(M, 0x5a, (size_t)rr * ntiles * 16));          // the same contents for every variant
+	launch(); launch(); CK(hipDeviceSynchronize());
+	const int reps = getenv("MB_REPS") ? atoi(getenv("MB_REPS")) : 10;
 	CK(hipEventRecord(e0)); for (int r = 0; r < reps; r++) launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
 	float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
 	const double seg_bytes = (double)rr * ntiles * 16;
@@ -193,15 +194,21 @@ int main(int argc, char **argv)
 	CK(hipMemcpy(mult, hm.data(), hm.size() * 8, hipMemcpyHostToDevice));
 	printf("# K-loop bulk update: %lld rows x %d tiles of 16 B = %.2f GiB; multipliers %.1f MiB per block\n", (long long)rows, ntiles,
 	       (double)rows * ntiles * 16 / 1073741824.0, (double)rows * 32 / 1048576.0);
-	run<8, 1>(M, rows, ntiles, piv, mult, true, hp, plain);
-	run<8, 2>(M, rows, ntiles, piv, mult, false, hp, plain);
-	run<8, 4>(M, rows, ntiles, piv, mult, true, hp, plain);
-	run<8, 8>(M, rows, ntiles, piv, mult, false, hp, plain);
-	run<12, 2>(M, rows, ntiles, piv, mult, false, hp, plain);
-	run<12, 4>(M, rows, ntiles, piv, mult, true, hp, plain);
-	run<12, 8>(M, rows, ntiles, piv, mult, false, hp, plain);
-	run<16, 2>(M, rows, ntiles, piv, mult, false, hp, plain);
-	run<16, 4>(M, rows, ntiles, piv, mult, true, hp, plain);
-	run<16, 8>(M, rows, ntiles, piv, mult, false, hp, plain);
+	const bool chk = !getenv("MB_NOCHECK");
+	for (int round = 0; round < 2; round++) {                  // twice: the second round shows what order / clocks do to the figures
+		run<8, 1>(M, rows, ntiles, piv, mult, chk && !round, hp, plain);
+		run<8, 2>(M, rows, ntiles, piv, mult, false, hp, plain);
+		run<8, 4>(M, rows, ntiles, piv, mult, chk && !round, hp, plain);
+		run<8, 8>(M, rows, ntiles, piv, mult, false, hp, plain);
+		run<12, 2>(M, rows, ntiles, piv, mult, false, hp, plain);
+		run<12, 4>(M, rows, ntiles, piv, mult, chk && !round, hp, plain);
+		run<12, 8>(M, rows, ntiles, piv, mult, false, hp, plain);
+		run<16, 1>(M, rows, ntiles, piv, mult, false, hp, plain);
+		run<16, 2>(M, rows, ntiles, piv, mult, false, hp, plain);
+		run<16, 3>(M, rows, ntiles, piv, mult, false, hp, plain);
+		run<16, 4>(M, rows, ntiles, piv, mult, chk && !round, hp, plain);
+		run<16, 6>(M, rows, ntiles, piv, mult, false, hp, plain);
+		run<16, 8>(M, rows, ntiles, piv, mult, false, hp, plain);
+	}
 	return 0;
 }
