@@ -154,17 +154,37 @@ def roofline_block(stats_list, sweep_ms_total: float, n: int, device: int, ceil:
     out = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, g, t),
-        "kernel": f"k_update16 (bulk update on 16-byte tiles, {g} panels = {64 * g} pivots = {g * t} byte-field tables per pass)",
+        "kernel": (f"k_update16 (bulk update on 16-byte tiles, {g} panels = {64 * g} pivots = {g * t} byte-field tables per pass)"
+                   + (f" + k_update16k (outer passes of the two-level elimination: {s0['outer_blocks']} of the {s0['n_sweeps']} blocks, "
+                      f"several blocks per trip through HBM)" if s0.get("outer_blocks") else "")),
+        "unit_of_work": "sweep-word = one 64-bit word taking one block of 256 pivots = 16 B (SURVEY 8d)",
         "alg_bytes_total": alg_bytes, "kernel_ms_total": sweep_ms_total,
+        # what the launches moved through HBM (read + written): below the algorithmic bytes where outer passes of the
+        # two-level elimination apply several blocks per trip
+        "hbm_bytes_total": 16.0 * float(sum(s.get("hbm_words", s["sweep_words"]) for s in stats_list)),
+        "bulk_launches": int(sum(s.get("bulk_launches", s["n_sweeps"]) for s in stats_list)),
+        "outer_blocks_per_solve": int(s0.get("outer_blocks", 0)),
         # one pass applies G panels: HBM rate a one-panel-per-pass sweep would need for the same wall time
         "single_panel_equivalent_GBs": achieved * g,
     }
     if ceil:
-        out.update({"measured_rmw_stream_GBs": ceil["rmw_gbs"], "measured_read_stream_GBs": ceil["read_gbs"],
-                    "frac_of_measured_rmw": achieved / ceil["rmw_gbs"]})
+        # same-run context, not a ceiling: this library's own persistent-workgroup streams (profiles/r03_stream_ceiling.txt has
+        # the independent references: an in-place stream reaches 6.4 TB/s = 0.80 of spec as one element per thread)
+        out.update({"persistent_rmw_stream_GBs": ceil["rmw_gbs"], "persistent_read_stream_GBs": ceil["read_gbs"]})
     if note:
         out["note"] = note
     return out, launches
+
+
+def finish_roofline(roofline: dict, s0: dict, blocks: int):
+    """per-block and per-launch figures of a roofline block (`blocks` = 256-pivot blocks applied over the timed solves)"""
+    nl = max(roofline["bulk_launches"], 1)
+    roofline["passes"] = s0["n_sweeps"]                   # blocks of 256 pivots per solve
+    roofline["alg_bytes_per_pass"] = roofline["alg_bytes_total"] / max(blocks, 1)
+    roofline["avg_pass_ms"] = roofline["kernel_ms_total"] / max(blocks, 1)
+    roofline["alg_bytes_per_launch"] = roofline["alg_bytes_total"] / nl
+    roofline["hbm_bytes_per_launch"] = roofline["hbm_bytes_total"] / nl
+    roofline["avg_launch_ms"] = roofline["kernel_ms_total"] / nl
 
 
 def timed_single(mat: torch.Tensor, n: int, stride: int, steps: int, warmup: int, device: int, dev, world: int,
@@ -241,9 +261,7 @@ def run_single(args, world, rank, local_rank, dev):
     roofline = None
     if rl:
         roofline, launches = rl
-        roofline["passes"] = s0["n_sweeps"]
-        roofline["alg_bytes_per_pass"] = roofline["alg_bytes_total"] / max(launches, 1)
-        roofline["avg_pass_ms"] = roofline["kernel_ms_total"] / max(launches, 1)
+        finish_roofline(roofline, s0, launches)
     out = {
         "metric": "GF(2) row-XORs/s (solve_one, dense NxN)", "value": float(agg.item()) / elapsed,
         "unit": "row-XORs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -297,9 +315,7 @@ def target_leg(n: int, device: int, dev, ceil: dict) -> dict:
     del mat
     s0 = stats[-1].stats
     roofline, launches = roofline_block([s.stats for s in stats], float(sum(s.stats["ms_sweep"] for s in stats)), n, device, ceil)
-    roofline["passes"] = s0["n_sweeps"]
-    roofline["alg_bytes_per_pass"] = roofline["alg_bytes_total"] / max(launches, 1)
-    roofline["avg_pass_ms"] = roofline["kernel_ms_total"] / max(launches, 1)
+    finish_roofline(roofline, s0, launches)
     return {"n": n, "seed": seed, "steps": steps, "warmup": 1, "ms_per_step": elapsed / steps * 1e3,
             "row_xors_per_s": float(sum(s.stats["row_xors"] for s in stats)) / elapsed,
             "rank": int(stats[-1].rank), "residual_rows": int(bad), "all_solved": all(s.solved for s in stats),
@@ -382,7 +398,7 @@ def batch_job(args, world, rank, local_rank, dev, steps: int, warmup: int):
                       f"{s0.get('gang_systems', 0)} systems x {64 * g} pivots per launch)",
             "launches": launches, "alg_bytes_per_launch": alg_bytes / max(launches, 1),
             "avg_launch_ms": sweep_ms / max(launches, 1),
-            "measured_rmw_stream_GBs": ceil["rmw_gbs"], "measured_read_stream_GBs": ceil["read_gbs"],
+            "persistent_rmw_stream_GBs": ceil["rmw_gbs"], "persistent_read_stream_GBs": ceil["read_gbs"],
             # end to end: the job's algorithmic bytes over its wall time (all ranks), against N x 8 TB/s
             "end_to_end_frac": alg_bytes / steps / (elapsed / steps) / 1e9 / (HBM_PEAK_GBS * world),
             "note": "summed over all ranks; two gangs are in flight per GPU (a gang's back-substitution and export overlap "

@@ -2065,11 +2065,18 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 // panel's sources take their share of it: S_q2 ^= mult x P_q -- with the multipliers the panel path recorded: inside a
 // block PanelAux::src_mult, across blocks the per-row multipliers of the earlier block's set (the later block's sources
 // were ordinary alive rows then).  Sequential in q, latency-bound, one workgroup per word group: ~2 % of an outer pass.
-template <int WPW>
+// IDENT (round 3, the form the solver uses): the same chain run on the IDENTITY instead of a word group of the matrix --
+// source slot (q, s) starts as unit vector 64 q + s -- and the pivot rows written, not into the matrix, but as rows of the
+// bit matrix T with P = T x S: the row operations of the chain are the same for every column, so T (npan x 64 square, 2048 bits
+// for K = 8) depends on the panel's records alone; it is formed ONCE per outer panel by npan / 4 workgroups (workgroup j' =
+// the four words = the 256 source slots of block j') and applied to every tile by k_outer_apply, a table pass without any
+// chain.  T is stored as K multiplier sets of a 2048-row system (Tm[j'][i][4], row i = pivot k of panel q at i = 64 q + k, in
+// the stored form of midx / mult_stored), which is what the lookup code of the bulk update reads.
+template <int WPW, bool IDENT>
 __global__ void __launch_bounds__(64 * WPW)
 k_outer_trsm(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int npan, int group_begin,
              const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
-             const u64 *__restrict__ mult, i64 set_words, int set0, int nsets, int upd_T)
+             const u64 *__restrict__ mult, i64 set_words, int set0, int nsets, int upd_T, u64 *__restrict__ Tm)
 {
 	static_assert(WPW == 4, "thread <-> table entry mapping below");
 	constexpr int NP = GF2_KMAX * GF2_GMAX;
@@ -2078,14 +2085,21 @@ k_outer_trsm(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int npan, int gro
 	__shared__ u64 Tn[16 * 16 * WPW];          // nibble tables of 64 rows
 	__shared__ int srowL[NP * 64];             // physical row of (panel, slot), -1 beyond the panel's pivots
 	__shared__ int Bk[64];                     // pivot k -> pivot bit (current panel)
+	__shared__ u64 mL[NP * 64];                // [later panel q2][slot]: multipliers of (q2, slot) w.r.t. the current panel
 	const i64 w0 = ((i64)group_begin + blockIdx.x) * WPW;
 	const int t = threadIdx.x, r = t / WPW, w = t % WPW;
 	for (int q = w; q < npan; q += WPW) srowL[q * 64 + r] = (r < panels[j0 + q].p) ? aux[j0 + q].slot_row[r] : -1;
 	__syncthreads();
 	for (int q = 0; q < npan; q++) {
 		const int sr = srowL[q * 64 + r];
-		S[(q * 64 + r) * WPW + w] = sr >= 0 ? M[tidx(sr, w0 + w, srows)] : 0ull;
+		if (IDENT) S[(q * 64 + r) * WPW + w] = (sr >= 0 && q == (int)w0 + w) ? (1ull << r) : 0ull;
+		else S[(q * 64 + r) * WPW + w] = sr >= 0 ? M[tidx(sr, w0 + w, srows)] : 0ull;
 	}
+	// (IDENT) row i = 64 q + k of T, words of this workgroup's block, in the stored multiplier form of a 2048-row system
+	auto put_T = [&](int q, u64 v) {
+		const i64 i = (i64)q * 64 + r;
+		Tm[((i64)blockIdx.x * (NP * 64) + i) * GF2_GMAX + (w ^ (int)((i >> 3) & 1))] = mult_stored(upd_T, v, i);
+	};
 	auto build_tables = [&](const u64 *rows64) {
 		const int n = t >> 4, v = t & 15;
 		u64 a[WPW] = { 0, 0, 0, 0 };
@@ -2107,67 +2121,121 @@ k_outer_trsm(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int npan, int gro
 		}
 		return acc;
 	};
+	// the multipliers of every later panel's sources with respect to panel q: requested by ALL threads at once (<= 8 each) at
+	// the start of step q - 1, kept in registers while that step runs, and put into LDS at its end -- one memory round trip per
+	// step, hidden behind the step's table builds.  (One by one inside the q2 loop they were 31 + 30 + ... dependent round
+	// trips: 0.72 ms per outer panel of 8 blocks; fetched straight into LDS at the top of the step, 0.62.)
+	constexpr int MPT = NP * 64 / (64 * WPW);          // multipliers per thread at most
+	u64 mreg[MPT];
+	auto fetch_mults = [&](int q) {
+		const int g = q % GF2_GMAX, blk = q / GF2_GMAX;
+		const u64 *mset = mult + (i64)((set0 + blk) % nsets) * set_words;
+#pragma unroll
+		for (int u = 0; u < MPT; u++) {
+			const int i = t + u * 64 * WPW;
+			u64 m = 0;
+			if (i < (npan - q - 1) * 64) {
+				const int q2 = q + 1 + i / 64, sl = i % 64;
+				const int row2 = srowL[q2 * 64 + sl];
+				if (row2 >= 0) m = (q2 / GF2_GMAX == blk) ? aux[j0 + q2].src_mult[sl][g] : mult_plain(upd_T, mset[midx(g, row2, rows)], row2);
+			}
+			mreg[u] = m;
+		}
+	};
+	auto put_mults = [&](int q) {
+#pragma unroll
+		for (int u = 0; u < MPT; u++) {
+			const int i = t + u * 64 * WPW;
+			if (i < (npan - q - 1) * 64) mL[(q + 1 + i / 64) * 64 + i % 64] = mreg[u];
+		}
+	};
+	fetch_mults(0);
+	put_mults(0);
 	__syncthreads();
 	for (int q = 0; q < npan; q++) {
 		const PanelRec rec = panels[j0 + q];
-		if (rec.p == 0) continue;                      // (uniform)
-		const u64 comb = aux[j0 + q].comb[r];
-		build_tables(&S[q * 64 * WPW]);
-		Pb[r * WPW + w] = 0;
-		if (w == 0 && ((rec.mask >> r) & 1)) Bk[__popcll(rec.mask & lanemask_lt(r))] = r;
-		__syncthreads();
-		if (r < rec.p) {
-			const u64 acc = lookup(comb);
-			Pb[Bk[r] * WPW + w] = acc;
-			M[tidx(srowL[q * 64 + r], w0 + w, srows)] = acc;
-		}
-		__syncthreads();
-		if (q + 1 >= npan) break;
-		build_tables(Pb);
-		__syncthreads();
-		const int g = q % GF2_GMAX, blk = q / GF2_GMAX;
-		const u64 *mset = mult + (i64)((set0 + blk) % nsets) * set_words;
-		for (int q2 = q + 1; q2 < npan; q2++) {
-			const int row2 = srowL[q2 * 64 + r];
-			if (row2 < 0) continue;
-			const u64 m = (q2 / GF2_GMAX == blk) ? aux[j0 + q2].src_mult[r][g] : mult_plain(upd_T, mset[midx(g, row2, rows)], row2);
-			if (m) S[(q2 * 64 + r) * WPW + w] ^= lookup(m);
-		}
+		if (q + 1 < npan) fetch_mults(q + 1);          // (registers; LDS at the end of this step)
+		if (rec.p != 0) {                               // (uniform)
+			const u64 comb = aux[j0 + q].comb[r];
+			build_tables(&S[q * 64 * WPW]);
+			Pb[r * WPW + w] = 0;
+			if (w == 0 && ((rec.mask >> r) & 1)) Bk[__popcll(rec.mask & lanemask_lt(r))] = r;
+			__syncthreads();
+			u64 acc = 0;
+			if (r < rec.p) {
+				acc = lookup(comb);
+				Pb[Bk[r] * WPW + w] = acc;
+				if (!IDENT) M[tidx(srowL[q * 64 + r], w0 + w, srows)] = acc;
+			}
+			if (IDENT) put_T(q, acc);
+			__syncthreads();
+			if (q + 1 >= npan) break;
+			build_tables(Pb);
+			__syncthreads();
+			for (int q2 = q + 1; q2 < npan; q2++) {
+				const u64 m = mL[q2 * 64 + r];
+				if (m) S[(q2 * 64 + r) * WPW + w] ^= lookup(m);
+			}
+		} else if (IDENT) put_T(q, 0ull);
+		__syncthreads();                                // every read of this step's multipliers is done
+		if (q + 1 < npan) put_mults(q + 1);
 		__syncthreads();
 	}
 }
 
+// Row lists of an outer panel, one tiny launch per panel (so that the many workgroups of the outer kernels start with a
+// coalesced read instead of a chain of dependent record loads each).  With NQ = GF2_KMAX x GF2_GMAX x 64:
+//   out[0 .. NQ)        [panel q][pivot BIT b]  -> physical row of that pivot, -1 if none      (tables of k_update16k)
+//   out[NQ .. NQ + KMAX) block k has pivots
+//   out[NQ + KMAX .. )  [panel q][slot / pivot k] -> slot_row of the panel, -1 beyond its p: the SOURCE row of slot k (tables
+//                       of k_outer_apply) and at the same time the row pivot k is stored in (its output rows)
+#define GF2_OUTER_LISTS (2 * GF2_KMAX * GF2_GMAX * 64 + GF2_KMAX)
+__global__ void __launch_bounds__(256)
+k_outer_prow(int j0, int nblk, const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux, int *__restrict__ out)
+{
+	constexpr int NQ = GF2_KMAX * GF2_GMAX * 64;
+	__shared__ int anyb[GF2_KMAX];
+	if (threadIdx.x < GF2_KMAX) anyb[threadIdx.x] = 0;
+	__syncthreads();
+	for (int t = threadIdx.x; t < NQ; t += blockDim.x) {
+		int pr = -1, sr = -1;
+		if (t < nblk * GF2_GMAX * 64) {
+			const int q = t >> 6, b = t & 63;
+			const PanelRec rec = panels[j0 + q];
+			if ((rec.mask >> b) & 1) { pr = aux[j0 + q].slot_row[__popcll(rec.mask & ((1ull << b) - 1))]; anyb[q / GF2_GMAX] = 1; }
+			if (b < rec.p) sr = aux[j0 + q].slot_row[b];
+		}
+		out[t] = pr;
+		out[NQ + GF2_KMAX + t] = sr;
+	}
+	__syncthreads();
+	if (threadIdx.x < GF2_KMAX) out[NQ + threadIdx.x] = anyb[threadIdx.x];
+}
+
 // The outer pass: all `nblk` blocks of an outer panel (first panel j0) applied to the column tiles [tile_begin, tile_begin +
-// ntiles) right of it.  A workgroup of 8 wavefronts takes items (chunk of SEG x 512 rows, tile), chunk-major so that
-// concurrently running workgroups share the same rows' multipliers (L2 hits); every lane keeps SEG row segments of the tile
+// ntiles) right of it.  A workgroup of 8 wavefronts takes items (tile, chunk of SEG x 512 rows); every lane keeps SEG row segments of the tile
 // in registers, and per block: tables of the block's 256 pivot-row segments (prefetched during the previous block), 32
 // lookups per segment with that block's 32 B of multipliers (prefetched two segments ahead).  Rows are loaded once and
 // stored once per nblk blocks, and only rows that are alive after the panel are stored at all: the panel's own pivot
 // rows (final since k_outer_trsm) and older ones have nothing to take.
 template <int SEG>
 __global__ void __launch_bounds__(512)
-k_update16k(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int nblk,
-            const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
+k_update16k(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__restrict__ gprow,
             const u64 *__restrict__ mult, i64 set_words, int set0, int nsets,
-            const int *__restrict__ blk_first, const int *__restrict__ died, int tile_begin, int ntiles)
+            const int *__restrict__ blk_first, const int *__restrict__ died, int j_end, int tile_begin, int ntiles)
 {
 	constexpr int NT = 512, NW = 8;
+	static_assert(GF2_KMAX * GF2_GMAX * 64 % 512 == 0, "k_outer_apply: whole pivots per lane");
 	__shared__ __attribute__((aligned(256))) uint4 tab[2 * 256 * 16];      // 128 KiB, must sit at LDS address 0 (checked below)
 	__shared__ uint4 stage[GF2_GMAX * 64];
 	__shared__ int prow[GF2_KMAX * GF2_GMAX * 64];                        // [block][panel][pivot bit] -> physical row, -1 if none
 	__shared__ int anyb[GF2_KMAX];
 	if ((unsigned)(size_t)tab != 0u) __builtin_trap();
 	const int lane = threadIdx.x & 63;
+	const unsigned ulane = (unsigned)lane;
 	const int wvu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // wave-uniform by construction: keep it scalar
-	if (threadIdx.x < GF2_KMAX) anyb[threadIdx.x] = 0;
-	__syncthreads();
-	for (int t = threadIdx.x; t < nblk * GF2_GMAX * 64; t += NT) {
-		const int q = t >> 6, b = t & 63;
-		const PanelRec rec = panels[j0 + q];
-		int pr = -1;
-		if ((rec.mask >> b) & 1) { pr = aux[j0 + q].slot_row[__popcll(rec.mask & ((1ull << b) - 1))]; anyb[q / GF2_GMAX] = 1; }
-		prow[t] = pr;
-	}
+	for (int t = threadIdx.x; t < nblk * GF2_GMAX * 64; t += NT) prow[t] = gprow[t];
+	if (threadIdx.x < GF2_KMAX) anyb[threadIdx.x] = gprow[GF2_KMAX * GF2_GMAX * 64 + threadIdx.x];
 	__syncthreads();
 	int first_blk = -1, last_blk = -1;
 	for (int k = 0; k < nblk; k++) if (anyb[k]) { if (first_blk < 0) first_blk = k; last_blk = k; }
@@ -2193,31 +2261,38 @@ k_update16k(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int nblk,
 	const i64 nch = (R64 - rlo + CH - 1) / CH;
 	const i64 items = nch * ntiles;
 	const uint4 *mbase = reinterpret_cast<const uint4 *>(mult);
-	for (i64 it = blockIdx.x; it < items; it += gridDim.x) {
-		const i64 tile = tile_begin + it % ntiles;
-		const i64 r0 = rlo + (it / ntiles) * CH;
-		uint4 *Mw = reinterpret_cast<uint4 *>(M) + tile * srows;
-		// Every address below = a wave-uniform base (scalar registers) + the lane: a wavefront's 64 rows of batch j start at
-		// rb(j), a multiple of 64, so a batch lies wholly inside or wholly beyond the padded row range and the clamp is a
-		// scalar select (per-lane clamps cost a 64-bit VGPR pair per batch and the kernel spilled 1700 registers).
-		const i64 rb0 = r0 + (i64)wvu * 64;
-		auto rbase = [&](int j) { const i64 rb = rb0 + (i64)j * (NW * 64); return rb < R64 ? rb : R64 - 64; };
+	i64 it = blockIdx.x;
+	if (it >= items) return;
+	// Every address below = a wave-uniform 64-bit base (scalar registers) + a 32-BIT lane offset (batch j of a wavefront =
+	// rows base + 512 j + lane): nothing per batch lives in a 64-bit VGPR pair -- with per-lane 64-bit row indices, clamped to
+	// the row range, the compiler kept 16 address pairs per stream across the block loop and spilled up to 1700 registers.
+	// Instead of clamping, batches past the padded row range (only in a tile's last chunk) simply run: they read up to
+	// 8192 rows into the next tile / the next multiplier set (the solver leaves that much slack behind the matrix and
+	// the multiplier sets), take garbage and are never stored -- a lane stores only if its row is alive.
+	// tile-major items: neighbouring workgroups take neighbouring row chunks of ONE tile.
+	auto item_rows = [&](i64 item) { return rlo + (item % nch) * CH + (i64)wvu * 64; };
+	auto item_tile = [&](i64 item) { return reinterpret_cast<uint4 *>(M) + ((i64)tile_begin + item / nch) * srows; };
+	for (; it < items; it += gridDim.x) {
+		uint4 *Mw = item_tile(it);
+		const i64 rb0 = item_rows(it);
+		uint4 *Mrow = Mw + rb0;
 		uint4 d[SEG];
+#pragma unroll
+		for (int j = 0; j < SEG; j++) d[j] = (Mrow + j * (NW * 64))[ulane];
 		unsigned alive = 0;
 #pragma unroll
 		for (int j = 0; j < SEG; j++) {
-			const i64 rb = rbase(j);
-			d[j] = Mw[rb + lane];
-			const i64 rl = rb + lane;
+			const i64 rl = rb0 + j * (NW * 64) + lane;
 			const int dd = died[rl < rows ? rl : rows - 1];
-			if (rb0 + (i64)j * (NW * 64) < R64 && rl < rows && dd == GF2_NEVER) alive |= 1u << j;
+			// alive BEHIND this panel: never a pivot source, or one of a later panel (the next panel may already be under way)
+			if (rl < rows && dd >= j_end) alive |= 1u << j;
 		}
 		uint4 staged = make_uint4(0, 0, 0, 0);
 		if (threadIdx.x < GF2_GMAX * 64) { const int pr = prow[first_blk * 256 + threadIdx.x]; staged = pr >= 0 ? Mw[pr] : make_uint4(0, 0, 0, 0); }
 #pragma unroll 1
 		for (int k = first_blk; k <= last_blk; k++) {
 			if (!anyb[k]) continue;          // (uniform.  A loop that steps from block to block through the LDS flags made the
-			                                  // register allocator spill 1600 registers; this form compiles to 251 VGPRs, no scratch)
+			                                  // register allocator spill 1600 registers; this form compiles without scratch)
 			__syncthreads();                            // the previous block's (or item's) lookups are done with the tables
 			if (threadIdx.x < GF2_GMAX * 64) stage[threadIdx.x] = staged;
 			__syncthreads();
@@ -2247,9 +2322,10 @@ k_update16k(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int nblk,
 			__syncthreads();
 			const uint4 *mq = mbase + (i64)((set0 + k) % nsets) * (set_words / 2);
 			uint4 m0[2], m1[2];
+			const uint4 *mrow = mq + rb0 * 2;
 			auto loadm = [&](int j, int slot) {
-				const uint4 *mr = mq + (rbase(j < SEG ? j : SEG - 1) + lane) * 2;
-				m0[slot] = mr[0]; m1[slot] = mr[1];
+				const uint4 *mr = mrow + (j < SEG ? j : SEG - 1) * (NW * 64 * 2);      // (scalar) + one lane offset shared by all batches
+				m0[slot] = mr[2 * ulane]; m1[slot] = mr[2 * ulane + 1];
 			};
 			auto issue = [&](u32x4 *v, const uint4 &a0, const uint4 &a1, int r) {
 				const unsigned mw[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
@@ -2285,9 +2361,115 @@ k_update16k(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int nblk,
 				issue(va, n0, n1, 0); fold(d[j], vb);   // (past the end: a harmless extra round)
 			}
 		}
+		// (Requesting the next item's segments while the last block is applied -- each into the registers of the segment just
+		// stored -- was built and measured: the two copies of the lookup loop cost ~80 spilled registers and the kernel ran
+		// 12 % slower, 3.87 against 4.38 TB/s for K = 4; tools/microbench_update16k.hip.)
 #pragma unroll
 		for (int j = 0; j < SEG; j++)
-			if ((alive >> j) & 1) Mw[rb0 + (i64)j * (NW * 64) + lane] = d[j];
+			if ((alive >> j) & 1) (Mrow + j * (NW * 64))[ulane] = d[j];
+	}
+}
+
+// P = T x S on one column tile: the final pivot rows of an outer panel (all 4 K panels) from its source rows, WITHOUT the
+// chain of k_outer_trsm -- T comes from k_outer_trsm<.., IDENT> once per panel.  One workgroup per tile; the "rows" are the
+// panel's NQ = K x 256 pivots (4 per lane), the "blocks" its K source blocks: per source block the 32 byte-field tables are
+// built from that block's 256 SOURCE rows by slot (read from the matrix before anything is written: outputs are stored at
+// the very end, into the rows of the same set), the lookups go by the T row's 32 bytes of that block -- the table and lookup
+// code of the bulk update, accumulating from zero.  ~5 us per source block and tile instead of a 0.3 ms chain per word group.
+__global__ void __launch_bounds__(512)
+k_outer_apply(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__restrict__ lists, const u64 *__restrict__ Tm, int tile_begin)
+{
+	constexpr int NT = 512, NW = 8, SEG = GF2_KMAX * GF2_GMAX * 64 / NT, NQ = GF2_KMAX * GF2_GMAX * 64;      // 4 pivots per lane
+	__shared__ __attribute__((aligned(256))) uint4 tab[2 * 256 * 16];      // 128 KiB at LDS address 0
+	__shared__ uint4 stage[GF2_GMAX * 64];
+	__shared__ int srcrow[NQ];
+	if ((unsigned)(size_t)tab != 0u) __builtin_trap();
+	const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+	for (int t = threadIdx.x; t < NQ; t += NT) srcrow[t] = lists[NQ + GF2_KMAX + t];
+	__syncthreads();
+	unsigned KC[6];
+	{
+		const int rq_lo = lane & 7, rq_hi = (lane >> 3) & 1;
+#pragma unroll
+		for (int v = 0; v < 6; v++) {
+			unsigned k = 1u << 24;
+#pragma unroll
+			for (int b = 0; b < 3; b++) {
+				const int s = 3 * v + b;
+				if (s < 16) k |= (unsigned)(16 * (8 * ((s >> 3) ^ rq_hi) + (((s & 7) + rq_lo) & 7))) << (8 * b);
+			}
+			asm volatile("" : "+v"(k));
+			KC[v] = k;
+		}
+	}
+	const i64 R64 = (rows + 63) & ~(i64)63;
+	uint4 *Mw = reinterpret_cast<uint4 *>(M) + ((i64)tile_begin + blockIdx.x) * srows;
+	uint4 d[SEG];
+#pragma unroll
+	for (int j = 0; j < SEG; j++) d[j] = make_uint4(0, 0, 0, 0);
+	uint4 staged = make_uint4(0, 0, 0, 0);
+	if (threadIdx.x < GF2_GMAX * 64) { const int sr = srcrow[threadIdx.x]; staged = sr >= 0 ? Mw[sr] : make_uint4(0, 0, 0, 0); }
+	const uint4 *tbase = reinterpret_cast<const uint4 *>(Tm);
+#pragma unroll 1
+	for (int k = 0; k < nblk; k++) {
+		__syncthreads();
+		if (threadIdx.x < GF2_GMAX * 64) stage[threadIdx.x] = staged;
+		__syncthreads();
+		for (int e = threadIdx.x; e < 2 * 31 * 16; e += NT) {
+			const int sub = e & 15, q = (e >> 4) % 31, grp = (e >> 4) / 31;
+			const int idx = q <= 15 ? q : (q - 15) << 4;
+			const uint4 *st = stage + (2 * grp + (sub >> 3)) * 64 + 8 * (sub & 7);
+			uint4 acc = make_uint4(0, 0, 0, 0);
+			int bits = idx;
+			while (bits) { const int l = __ffs(bits) - 1; bits &= bits - 1; acc = xor4(acc, st[l]); }
+			tab[grp * 4096 + idx * 16 + sub] = acc;
+		}
+		__syncthreads();
+		for (int e = threadIdx.x; e < 2 * 225 * 16; e += NT) {
+			const int sub = e & 15, q = (e >> 4) % 225, grp = (e >> 4) / 225;
+			const int lo = 1 + q % 15, hi = (1 + q / 15) << 4;
+			uint4 *tb = tab + grp * 4096 + sub;
+			tb[(lo | hi) * 16] = xor4(tb[lo * 16], tb[hi * 16]);
+		}
+		if (k + 1 < nblk && threadIdx.x < GF2_GMAX * 64) {
+			const int sr = srcrow[(k + 1) * 256 + threadIdx.x];
+			staged = sr >= 0 ? Mw[sr] : make_uint4(0, 0, 0, 0);
+		}
+		__syncthreads();
+		const uint4 *mq = tbase + (i64)k * (NQ * 2);           // T's multiplier set of source block k: 32 B per pivot
+#pragma unroll
+		for (int j = 0; j < SEG; j++) {
+			const int i = (j * NW + wv) * 64 + lane;           // pivot index 64 q + k'
+			const uint4 a0 = mq[i * 2], a1 = mq[i * 2 + 1];
+			const unsigned mw[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+#pragma unroll
+			for (int r = 0; r < 4; r++) {
+				const int grp = r >> 1, hf = r & 1;
+				u32x4 v[8];
+#pragma unroll
+				for (int q = 0; q < 8; q++) {
+					const int s = 8 * hf + q;
+					const unsigned sel = (unsigned)(s % 3) | ((4u + (unsigned)(q & 3)) << 8) | ((grp ? 3u : 12u) << 16) | (12u << 24);
+					const unsigned at = __builtin_amdgcn_perm(mw[2 * (2 * grp + hf) + (q >> 2)], KC[s / 3], sel);
+					v[q] = *(lds_u4_ptr)(size_t)at;
+				}
+#pragma unroll
+				for (int h = 0; h < 4; h++) {
+					d[j].x = __builtin_amdgcn_bitop3_b32(d[j].x, v[2 * h].x, v[2 * h + 1].x, 0x96);
+					d[j].y = __builtin_amdgcn_bitop3_b32(d[j].y, v[2 * h].y, v[2 * h + 1].y, 0x96);
+					d[j].z = __builtin_amdgcn_bitop3_b32(d[j].z, v[2 * h].z, v[2 * h + 1].z, 0x96);
+					d[j].w = __builtin_amdgcn_bitop3_b32(d[j].w, v[2 * h].w, v[2 * h + 1].w, 0x96);
+				}
+			}
+		}
+	}
+	// every source row has been read (the last block's were staged above): the pivot rows go into their rows; lanes whose
+	// pivot does not exist store into the slab's padding row
+#pragma unroll
+	for (int j = 0; j < SEG; j++) {
+		const int i = (j * NW + wv) * 64 + lane;
+		const int pr = srcrow[i];
+		Mw[pr >= 0 ? (i64)pr : R64] = d[j];
 	}
 }
 

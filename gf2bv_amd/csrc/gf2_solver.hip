@@ -64,6 +64,9 @@ int guarded(F &&body)
 	} while (0)
 
 inline i64 round_up(i64 v, i64 m) { return (v + m - 1) / m * m; }
+// k_update16k does not clamp its row indices: a tile's last chunk of GF2_KSEG x 512 rows may read that far past the tile
+// (never stored); the working matrix and the multiplier sets get this much slack behind them
+constexpr size_t kOuterSlackBytes = (size_t)GF2_KSEG * 512 * 32;
 
 struct Trace {
 	bool on = getenv("GF2BV_TRACE") != nullptr;
@@ -333,10 +336,15 @@ struct Solver {
 	// two-level elimination (large systems; see k_update16k): blocks [0, tl_bend) go in outer panels of tl_K blocks
 	int tl_K = 0, tl_bend = 0;
 	i64 tile_hi = 0;              // bulk kernels touch tiles < tile_hi (= ntiles; the outer panel's end while it is eliminated)
-	hipEvent_t evOuter = nullptr;
+	hipStream_t sC = nullptr;     // outer passes: panel p's runs BESIDE the inner elimination of panel p + 1 (sA + sB)
+	hipEvent_t evOuter = nullptr, evPri = nullptr, evPanelDone = nullptr;
+	bool bulk_waits_outer = false;     // the next bulk launch of the one-level schedule has to wait for the last outer pass
 	bool ends_outer_panel(int b) const { return tl_K > 0 && b < tl_bend && (b + 1) % tl_K == 0; }
 	u64 *Wb = nullptr;            // 2 x rows x GMAX window words (the panel steps ping-pong between the halves)
 	u64 *Uwin = nullptr;          // rank x GMAX: pivot rows' words of the following window (k_prio_window -> k_unwind)
+	int *oprow = nullptr;         // k_outer_prow -> k_outer_apply / k_update16k: row lists of the outer panel being applied
+	u64 *Tm = nullptr;            // k_outer_trsm<IDENT> -> k_outer_apply: the panel's pivot rows as combinations of its source rows
+	bool outer_chain = false;     // GF2BV_OUTER_CHAIN=1: the chain itself on every word group instead (the first form; tests)
 	u64 *Pfast = nullptr;         // scratch of k_block_fast: the pivot rows' window words of a block, [panel][word][column]
 	SyncFlags *sf = nullptr;      // progress counters of the two streams (k_gate)
 	bool flag_sync = true;        // per-block hand-overs between the streams through sf + k_gate instead of events (GF2BV_FLAG_SYNC=0)
@@ -389,6 +397,7 @@ struct Solver {
 			return;
 		}
 		// nothing goes back to the pool while work may still be in flight (error paths return early)
+		if (sC) (void)hipStreamSynchronize(sC);
 		if (sB) (void)hipStreamSynchronize(sB);
 		if (arena || M) (void)hipStreamSynchronize(sA);
 		Pool &P = pool();
@@ -397,7 +406,9 @@ struct Solver {
 		st = nullptr; panels = nullptr; aux = nullptr; fu = nullptr; died = nullptr; pivcol = nullptr;
 		urow = nullptr; blk_first = nullptr; mult = nullptr; Wb = nullptr;
 		for (hipEvent_t *e : { &ev0, &ev1, &ev2, &ev3, &evx }) { P.release_event(*e, true); *e = nullptr; }
-		P.release_event(evOuter, false); evOuter = nullptr;
+		for (hipEvent_t *e : { &evOuter, &evPri, &evPanelDone }) { P.release_event(*e, false); *e = nullptr; }
+		if (sC) P.release_stream(sC, device, true);
+		sC = nullptr;
 		for (hipEvent_t e : kev) P.release_event(e, true);
 		for (hipEvent_t e : evA) P.release_event(e, false);
 		for (hipEvent_t e : evPrio) P.release_event(e, false);
@@ -458,17 +469,19 @@ int check_device(int device)
 }
 
 // Two-level elimination (k_outer_trsm + k_update16k): which blocks go in outer panels, and of how many blocks.
-// An outer panel costs its inner elimination (K panel paths of ~90 us with nothing to hide behind: the outer pass has no
-// look-ahead yet) and saves (1 - ~0.73) of K bulk passes over what lies right of it, so it pays while that remainder is
-// large: default K = 4 while more than 1.5 GiB remain (nothing at 65536^2, the first 57 % of the pivots = 92 % of the bulk
-// work at 262144^2).  GF2BV_TWO_LEVEL=0 turns it off, =K (2..8) forces K from the first block on for every full panel
-// whatever the size (tests).  Single systems on one GPU only: gangs and column-slab solves keep the one-level schedule.
+// An outer panel of K blocks saves HBM round trips -- the rows right of it make one trip per K blocks, and the outer pass runs
+// 4.3-4.8 TB/s of sweep-words inside a solve (K = 8) where k_update16 runs 3.6-4.0 -- and costs k_outer_trsm, a latency chain
+// of 4 K steps per word group that does not shrink with the matrix (~0.9 ms per panel of 8 blocks at 131072 rows).  Measured
+// (forced K = 8 from the first block on): 262144^2 1.517 -> 1.395 s, 131072^2 203 -> 218 ms, 65536^2 34 -> 48 ms.  So: K = 8 while
+// more than 3 GiB remain right of the panel (262144^2: the first 39 % of the pivots = 77 % of the bulk work; nothing below
+// ~160000^2).  GF2BV_TWO_LEVEL=0 turns it off, =K (2..8) forces K from the first block on for every full panel whatever the
+// size (tests).  Single systems on one GPU only: gangs and column-slab solves keep the one-level schedule.
 void plan_two_level(Solver &S)
 {
 	S.tl_K = 0; S.tl_bend = 0; S.nsets = 2;
 	if (S.world != 1 || S.nsys != 1 || S.impl->G != GF2_GMAX) return;
-	int K = 4;
-	double min_bytes = 1.5 * 1073741824.0;
+	int K = GF2_KMAX;
+	double min_bytes = 3.0 * 1073741824.0;
 	if (const char *e = getenv("GF2BV_TWO_LEVEL"); e && *e) {
 		const int v = atoi(e);
 		if (v <= 0) return;
@@ -484,7 +497,9 @@ void plan_two_level(Solver &S)
 		bend = b0 + K;
 	}
 	if (!bend) return;
-	S.tl_K = K; S.tl_bend = bend; S.nsets = K;
+	S.tl_K = K; S.tl_bend = bend;
+	if (const char *e = getenv("GF2BV_OUTER_CHAIN"); e && *e) S.outer_chain = atoi(e) != 0;
+	S.nsets = 2 * K;              // the outer pass of panel p reads its K sets while the blocks of panel p + 1 write theirs
 }
 
 int solver_alloc(Solver &S)
@@ -497,7 +512,7 @@ int solver_alloc(Solver &S)
 	S.ntiles = tiles_for(S.wt);
 	S.srows = slab_rows(S.rows);
 	S.m_stride = S.ntiles * TW * S.srows;
-	if (!S.M) HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * S.m_stride * S.nsys, S.device));
+	if (!S.M) HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * S.m_stride * S.nsys + kOuterSlackBytes, S.device));
 	if (S.src && S.rows > 0) {
 		const i64 threads = S.rows * GF2_LPR;
 		k_to_tiled<<<dim3((unsigned)((threads + 255) / 256), (unsigned)S.ntiles, S.nsys), dim3(256), 0, S.sA>>>(
@@ -540,9 +555,10 @@ int solver_alloc(Solver &S)
 		const size_t o_st = carve(sizeof(SolveState)), o_sf = carve(sizeof(SyncFlags)), o_pan = carve(sizeof(PanelRec) * NP), o_aux = carve(sizeof(PanelAux) * NP),
 		             o_fu = carve(sizeof(FindUnit) * (S.units + 1 + GF2_MAXGROUPS)), o_alive = carve(sizeof(int) * (size_t)R),
 		             o_piv = carve(sizeof(int) * (S.maxr + 64)), o_urow = carve(sizeof(int) * (S.maxr + 64)),
-		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * S.nsets * G * mult_rows(R)),
+		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * S.nsets * G * mult_rows(R) + (S.tl_K ? kOuterSlackBytes : 0)),
 		             o_wb = carve(sizeof(u64) * 2 * GF2_GMAX * R), o_uw = carve(sizeof(u64) * GF2_GMAX * (S.maxr + 64)),
-		             o_pf = carve(sizeof(u64) * GF2_GMAX * GF2_GMAX * 64);
+		             o_pf = carve(sizeof(u64) * GF2_GMAX * GF2_GMAX * 64), o_opr = carve(sizeof(int) * GF2_OUTER_LISTS * 2),
+		             o_tm = carve(S.tl_K ? sizeof(u64) * GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX : 0);
 		S.arena_stride = off;
 		S.sync_base = 0;
 		HIPCHK(pool().alloc(&S.arena, off * S.nsys, S.device));
@@ -550,7 +566,7 @@ int solver_alloc(Solver &S)
 		S.st = (SolveState *)(base + o_st); S.sf = (SyncFlags *)(base + o_sf); S.panels = (PanelRec *)(base + o_pan); S.aux = (PanelAux *)(base + o_aux);
 		S.fu = (FindUnit *)(base + o_fu); S.died = (int *)(base + o_alive); S.pivcol = (int *)(base + o_piv);
 		S.urow = (int *)(base + o_urow); S.blk_first = (int *)(base + o_blk); S.mult = (u64 *)(base + o_mult);
-		S.Wb = (u64 *)(base + o_wb); S.Uwin = (u64 *)(base + o_uw); S.Pfast = (u64 *)(base + o_pf);
+		S.Wb = (u64 *)(base + o_wb); S.Uwin = (u64 *)(base + o_uw); S.Pfast = (u64 *)(base + o_pf); S.oprow = (int *)(base + o_opr); S.Tm = (u64 *)(base + o_tm);
 		// zero everything that is read before it is written: state, panel records, unit scratch, block bounds, multipliers
 		for (int s = 0; s < S.nsys; s++) {
 			char *b = base + (size_t)s * off;
@@ -563,7 +579,10 @@ int solver_alloc(Solver &S)
 	HIPCHK(pool().event(&S.ev1, true));
 	HIPCHK(pool().event(&S.ev2, true));
 	HIPCHK(pool().event(&S.ev3, true));
-	if (S.tl_K) HIPCHK(pool().event(&S.evOuter, false));
+	if (S.tl_K) {
+		for (hipEvent_t *e : { &S.evOuter, &S.evPri, &S.evPanelDone }) HIPCHK(pool().event(e, false));
+		if (S.sB != S.sA) HIPCHK(pool().stream(&S.sC, S.device, true));       // (GF2BV_SERIAL: everything on one stream)
+	}
 	S.evA.resize(S.nblocks); S.evPrio.resize(S.nblocks); S.waitPrio.assign(S.nblocks, nullptr);
 	for (int b = 0; b < S.nblocks; b++) {
 		HIPCHK(pool().event(&S.evA[b], false));
@@ -766,6 +785,7 @@ int enqueue_block_panel(Solver &S, int b, bool fast_only = false)
 int enqueue_block_bulk(Solver &S, int b)
 {
 	const BlockGeom g = block_geom(S, b);
+	if (S.bulk_waits_outer) { HIPCHK(hipStreamWaitEvent(S.sB, S.evOuter, 0)); S.bulk_waits_outer = false; }
 	if (S.flag_sync) {       // "bulk updates of the blocks before b complete"; wait for block b's multipliers
 		// (submitted AFTER the launch that announces narrow_done and BEFORE the panel stream's gate that waits for bulk_done:
 		// every wait targets earlier-submitted work.  A gate, not hipStreamWaitValue32: that is a polling kernel as well on this
@@ -853,32 +873,48 @@ int enqueue_check_rhs(Solver &S)
 	return GF2BV_OK;
 }
 
-// Two-level elimination, the outer step of the panel of blocks [b0, b1): pivot rows brought up to date on every tile right
-// of the panel (k_outer_trsm), then all its blocks applied there in one pass (k_update16k).  Bulk stream; evOuter = done.
-int enqueue_outer_apply(Solver &S, int b0, int b1)
+// Two-level elimination, the outer step of the panel of blocks [b0, b1) on the column tiles [t_begin, t_end): pivot rows
+// brought up to date there (k_outer_trsm), then all the panel's blocks applied in one pass (k_update16k).  One workgroup per
+// ITEM (tile, chunk of rows) -- not persistent ones: CUs come free all the time, and the next panel's elimination, whose
+// streams rank above this one, slips its kernels in between (a persistent launch filled every CU until its very end: the
+// look-ahead had nowhere to run; reserving CUs for it cost the pass more than the overlap gave back).
+int enqueue_outer_apply(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, i64 t_end, bool first_part)
 {
 	const int G = S.impl->G;
-	const i64 w_begin = (i64)b1 * G;
-	const i64 t_begin = w_begin / TW, nt = S.ntiles - t_begin;
-	if (nt > 0) {
-		const i64 set_words = (i64)G * mult_rows(S.rows);
-		const i64 g_begin = w_begin / 4, ng = S.ntiles * TW / 4 - g_begin;
-		k_outer_trsm<4><<<dim3((unsigned)ng), dim3(256), 0, S.sB>>>(S.M, S.rows, S.srows, b0 * G, (b1 - b0) * G, (int)g_begin, S.panels, S.aux,
-		                                                             S.mult, set_words, b0 % S.nsets, S.nsets, S.impl->T);
-		HIPCHK(hipGetLastError());
-		hipEvent_t ka = nullptr, kb = nullptr;
-		if (S.time_kernels) {
-			HIPCHK(pool().event(&ka, true)); HIPCHK(pool().event(&kb, true));
-			S.kev.push_back(ka); S.kev.push_back(kb);
-			if (!S.ext_events) HIPCHK(hipEventRecord(ka, S.sB));
-		}
-		hipExtLaunchKernelGGL((k_update16k<GF2_KSEG>), dim3(256), dim3(512), 0, S.sB, S.ext_events ? ka : nullptr, S.ext_events ? kb : nullptr, 0,
-		                      S.M, S.rows, S.srows, b0 * G, b1 - b0, (const PanelRec *)S.panels, (const PanelAux *)S.aux, (const u64 *)S.mult,
-		                      set_words, b0 % S.nsets, S.nsets, (const int *)(S.blk_first + b0), (const int *)S.died, (int)t_begin, (int)nt);
-		HIPCHK(hipGetLastError());
-		if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, S.sB));
+	const i64 nt = t_end - t_begin;
+	if (nt <= 0) return GF2BV_OK;
+	const i64 set_words = (i64)G * mult_rows(S.rows);
+	int *gprow = S.oprow + (size_t)((b0 / S.tl_K) & 1) * GF2_OUTER_LISTS;
+	const int npan = (b1 - b0) * G;
+	if (first_part) {
+		k_outer_prow<<<dim3(1), dim3(256), 0, st>>>(b0 * G, b1 - b0, S.panels, S.aux, gprow);
+		// T with P = T x S: the chain of panel steps run ONCE, on the identity (one workgroup per source block)
+		if (!S.outer_chain)
+			k_outer_trsm<4, true><<<dim3((unsigned)(npan / 4)), dim3(256), 0, st>>>(S.M, S.rows, S.srows, b0 * G, npan, 0, S.panels, S.aux, S.mult,
+			                                                                       set_words, b0 % S.nsets, S.nsets, S.impl->T, S.Tm);
 	}
-	HIPCHK(hipEventRecord(S.evOuter, S.sB));
+	if (S.outer_chain) {
+		const i64 g_begin = t_begin * TW / 4, ng = t_end * TW / 4 - g_begin;
+		k_outer_trsm<4, false><<<dim3((unsigned)ng), dim3(256), 0, st>>>(S.M, S.rows, S.srows, b0 * G, npan, (int)g_begin, S.panels, S.aux,
+		                                                                  S.mult, set_words, b0 % S.nsets, S.nsets, S.impl->T, (u64 *)nullptr);
+	} else
+		k_outer_apply<<<dim3((unsigned)nt), dim3(512), 0, st>>>(S.M, S.rows, S.srows, b1 - b0, (const int *)gprow, (const u64 *)S.Tm, (int)t_begin);
+	HIPCHK(hipGetLastError());
+	hipEvent_t ka = nullptr, kb = nullptr;
+	if (S.time_kernels) {
+		HIPCHK(pool().event(&ka, true)); HIPCHK(pool().event(&kb, true));
+		S.kev.push_back(ka); S.kev.push_back(kb);
+		if (!S.ext_events) HIPCHK(hipEventRecord(ka, st));
+	}
+	// items of a dense system: the kernel derives the true count from the alive bound and loops if there are more
+	const i64 est_lo = std::min<i64>(S.rows, (i64)b0 * 64 * G) & ~(i64)63, R64 = round_up(S.rows, 64);
+	const i64 nch = std::max<i64>(1, (R64 - est_lo + (i64)GF2_KSEG * 512 - 1) / ((i64)GF2_KSEG * 512));
+	const i64 wgs = std::min<i64>(nch * nt, (i64)1 << 30);
+	hipExtLaunchKernelGGL((k_update16k<GF2_KSEG>), dim3((unsigned)wgs), dim3(512), 0, st, S.ext_events ? ka : nullptr, S.ext_events ? kb : nullptr, 0,
+	                      S.M, S.rows, S.srows, b1 - b0, (const int *)gprow, (const u64 *)S.mult,
+	                      set_words, b0 % S.nsets, S.nsets, (const int *)(S.blk_first + b0), (const int *)S.died, b1 * G, (int)t_begin, (int)nt);
+	HIPCHK(hipGetLastError());
+	if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, st));
 	if (S.dbg_sync & 2) HIPCHK(hipDeviceSynchronize());
 	return GF2BV_OK;
 }
@@ -899,15 +935,20 @@ int enqueue_forward(Solver &S)
 	if (rc) return rc;
 	int b = 0;
 	// Two-level part (large single systems, plan_two_level): outer panels of tl_K blocks.  Inside a panel the blocks run
-	// exactly as below -- both streams, look-ahead from block to block -- with the bulk kernels confined to the panel's own
-	// tiles (tile_hi); then the outer step; the next panel's first window is gathered behind it.  Both panel paths stay
-	// enqueued per block (no optimistic enqueue here: these blocks are far from panel-bound).
+	// exactly as below -- panel and bulk stream, look-ahead from block to block -- with the bulk kernels confined to the
+	// panel's own tiles (tile_hi).  The outer step of panel p goes to a THIRD stream in two parts: first the tiles of panel
+	// p + 1 (a small launch), behind which that panel's first window is gathered and its elimination starts, then everything
+	// right of them, one workgroup per item so that the next panel's kernels find CUs while it runs.  What
+	// the two meet in: the multiplier sets (2 K of them: panel parity), the pivot marks (k_update16k takes "alive behind
+	// panel p", not "alive now") and disjoint tiles.  Both panel paths stay enqueued per block (no optimistic enqueue here).
+	bool after_two_level = true;
 	if (S.tl_K) {
 		const int G = S.impl->G;
+		hipStream_t so = S.sC ? S.sC : S.sB;           // (GF2BV_SERIAL: one stream, everything in order)
 		for (int p0 = 0; p0 < S.tl_bend; p0 += S.tl_K) {
 			const int p1 = p0 + S.tl_K;
 			if (p0 > 0) {
-				HIPCHK(hipStreamWaitEvent(S.sA, S.evOuter, 0));
+				HIPCHK(hipStreamWaitEvent(S.sA, S.evPri, 0));
 				if ((rc = enqueue_window_gather(S, p0))) return rc;
 			}
 			S.tile_hi = (i64)p1 * G / TW;
@@ -917,11 +958,20 @@ int enqueue_forward(Solver &S)
 				if ((rc = enqueue_block_prio(S, b))) return rc;
 			}
 			S.tile_hi = S.ntiles;
-			if ((rc = enqueue_outer_apply(S, p0, p1))) return rc;
+			// the outer step needs the panel's records and multipliers (panel stream), not its bulk updates (other tiles)
+			HIPCHK(hipEventRecord(S.evPanelDone, S.sA));
+			HIPCHK(hipStreamWaitEvent(so, S.evPanelDone, 0));
+			const i64 t0 = (i64)p1 * G / TW, t1 = std::min<i64>(S.ntiles, t0 + (i64)S.tl_K * G / TW);
+			if ((rc = enqueue_outer_apply(S, so, p0, p1, t0, t1, true))) return rc;
+			HIPCHK(hipEventRecord(S.evPri, so));
+			if ((rc = enqueue_outer_apply(S, so, p0, p1, t1, S.ntiles, false))) return rc;
 		}
+		HIPCHK(hipEventRecord(S.evOuter, so));
 		b = S.tl_bend;
-		HIPCHK(hipStreamWaitEvent(S.sA, S.evOuter, 0));
+		HIPCHK(hipStreamWaitEvent(S.sA, S.evPri, 0));
 		if (b < S.nblocks && (rc = enqueue_window_gather(S, b))) return rc;
+		S.bulk_waits_outer = S.sC != nullptr;          // the one-level bulk updates behind it touch every trailing tile
+		(void)after_two_level;
 	}
 	// Optimistic enqueue for dense systems.  k_block_fast decides ON THE DEVICE whether a block goes the fast way, so the
 	// general panel steps have to be enqueued behind it all the same, and on a fast block they are G + 1 empty launches
@@ -1165,6 +1215,14 @@ int finish_end(Solver &S, gf2bv_result **out)
 			st.n_sweeps++;
 			st.sweep_words += rows_swept * (double)(S.wt - wlo);
 			st.row_xors += rows_swept * (double)(S.impl->T * gb);
+			// what the launches moved: a block inside an outer panel is applied by k_update16 up to the panel's end only, the
+			// rest of the row takes the whole panel in one outer pass (counted at the panel's last block, two launches)
+			if (S.tl_K && b < S.tl_bend) {
+				const int pend_w = (b / S.tl_K + 1) * S.tl_K * G;
+				st.outer_blocks++;
+				if (pend_w > wlo) { st.hbm_words += rows_swept * (double)(std::min<i64>(pend_w, S.wt) - wlo); st.bulk_launches++; }
+				if ((b + 1) % S.tl_K == 0 && S.wt > pend_w) { st.hbm_words += rows_swept * (double)(S.wt - pend_w); st.bulk_launches += 2; }
+			} else { st.hbm_words += rows_swept * (double)(S.wt - wlo); st.bulk_launches++; }
 		}
 	}
 	st.ms_pack = S.ms_pack;
@@ -1493,7 +1551,7 @@ static int batch_digits_on(const uint32_t *digits, const int64_t *digit_off, int
 		S.nsys = (int)std::min<i64>(gang, nsys - s0);
 		S.rows = rows; S.cols = cols; S.mode = mode;
 		S.stride = ntiles * TW;
-		HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * m_stride * S.nsys, device));
+		HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * m_stride * S.nsys + kOuterSlackBytes, device));
 		const i64 total = rows * ntiles * TW;
 		if (total > 0)
 			k_pack_digits<<<dim3((unsigned)((ntiles * TW + 255) / 256), (unsigned)std::min<i64>(rows, 65535), S.nsys), dim3(256), 0, S.sA>>>(
@@ -1567,7 +1625,7 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 	const i64 wt = (cols + 1 + 63) / 64;
 	const i64 ntiles = tiles_for(wt);
 	S.stride = ntiles * TW;
-	HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * ntiles * TW * slab_rows(rows), device));     // packed straight into tiles
+	HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * ntiles * TW * slab_rows(rows) + kOuterSlackBytes, device));     // packed straight into tiles
 	const i64 ndig = digit_off[rows];
 	Scratch scratch;                  // digits, offsets and the pack events go back to the pool on every path
 	scratch.sync_first = S.sA;

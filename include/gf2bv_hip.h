@@ -65,6 +65,12 @@ typedef struct gf2bv_stats {
 	int32_t search_handovers;  /* panels whose first search unit stopped waiting for the rest of its launch and
 	                              left publishing to the last arriver (co-residency is not assumed)           */
 	int32_t fast_blocks;       /* blocks of 4 panels factorised by the one-launch dense block search (k_block_fast)     */
+	/* round 3 (two-level elimination): sweep_words above counts one word per word and BLOCK applied (the unit of the
+	 * roofline, whatever kernel applied it); an outer pass applies K blocks per trip through HBM, so what the bulk kernels
+	 * actually read + wrote is less: */
+	double  hbm_words;         /* 64-bit words the bulk-update launches moved (each read once and written once)       */
+	int32_t bulk_launches;     /* k_update16 + k_update16k launches that had pivots to apply                          */
+	int32_t outer_blocks;      /* blocks applied through outer passes (0: one-level schedule)                         */
 } gf2bv_stats;
 
 /* ---- library / device ------------------------------------------------------------------ */

@@ -57,12 +57,14 @@ def test_mode1_gang_of_mixed_ranks_at_8192(monkeypatch):
         _same(g, O.solve_words(a, n, n, 1), 1)
 
 
-@pytest.mark.parametrize("K", [2, 3, 4, 8])
-def test_two_level_elimination_forced_on_small_systems(monkeypatch, K):
-    """GF2BV_TWO_LEVEL=K: outer panels of K blocks from the first block on (k_outer_trsm + k_update16k) at sizes the oracle
+@pytest.mark.parametrize("K,chain", [(2, 0), (3, 0), (4, 0), (8, 0), (4, 1), (8, 1)])
+def test_two_level_elimination_forced_on_small_systems(monkeypatch, K, chain):
+    """GF2BV_TWO_LEVEL=K: outer panels of K blocks from the first block on (k_outer_trsm<IDENT> + k_outer_apply + k_update16k; chain:
+    GF2BV_OUTER_CHAIN=1, the pivot rows by the chain of panel steps on every word group instead of P = T x S) at sizes the oracle
     solves in seconds -- full rank, rank caps inside / at the edge of an outer panel, zero and duplicate-heavy rows, rows >> cols,
     inconsistent systems, both modes, events and flags."""
     monkeypatch.setenv("GF2BV_TWO_LEVEL", str(K))
+    monkeypatch.setenv("GF2BV_OUTER_CHAIN", str(chain))
     rng = random.Random(40 + K)
     shapes = [(3000, 2500, .5, None, True, 0), (3000, 2500, .5, 1000, True, 0), (3000, 2500, .5, 256 * K, True, 0),
               (3000, 2500, .5, 256 * K + 1, False, 0), (5000, 4097, .5, 4000, True, 300), (9000, 2049, .003, None, True, 0),

@@ -33,7 +33,7 @@ __device__ __forceinline__ uint4 xor4(uint4 a, uint4 b) { return make_uint4(a.x 
 // mult: [block][row][2] uint4 in the product's stored form (slot g ^ rq_hi, bytes rotated by rq_lo).
 template <int S, int K>
 __global__ void __launch_bounds__(512)
-k_kloop(uint4 *__restrict__ M, i64 rows, int ntiles, const uint4 *__restrict__ piv, const uint4 *__restrict__ mult)
+k_kloop(uint4 *__restrict__ M, i64 rows, int ntiles, const uint4 *__restrict__ piv, const uint4 *__restrict__ mult, int order)
 {
 	constexpr int NT = 512, NW = 8;
 	__shared__ __attribute__((aligned(256))) uint4 tab[2 * 256 * 16];      // 128 KiB at LDS address 0
@@ -56,8 +56,10 @@ k_kloop(uint4 *__restrict__ M, i64 rows, int ntiles, const uint4 *__restrict__ p
 	const i64 nch = rows / CH;                          // (rows is a multiple of CH in this benchmark)
 	const i64 items = (i64)ntiles * nch;
 	for (i64 it = blockIdx.x; it < items; it += gridDim.x) {
-		const int tile = (int)(it / nch);
-		const i64 r0 = (it % nch) * CH;
+		// order 0: tile-major (neighbouring workgroups: neighbouring row chunks of one tile); 1: chunk-major (the same rows of
+		// neighbouring tiles: the workgroups share their multipliers, but sit rows x 16 B apart in HBM)
+		const int tile = order ? (int)(it % ntiles) : (int)(it / nch);
+		const i64 r0 = (order ? it / ntiles : it % nch) * CH;
 		uint4 *Mw = M + (i64)tile * rows;
 		uint4 d[S];
 #pragma unroll
@@ -148,7 +150,7 @@ void run(uint4 *M, i64 rows, int ntiles, uint4 *piv, uint4 *mult, bool check, co
 		for (auto &v : h0) v = rnd();
 		CK(hipMemcpy(M, h0.data(), h0.size() * 8, hipMemcpyHostToDevice));
 		// (piv is indexed with the launch's ntiles: the check launches with the full tile count but only compares ct tiles)
-		k_kloop<S, K><<<dim3(97), dim3(512)>>>(M, rr, ntiles, piv, mult);
+		k_kloop<S, K><<<dim3(97), dim3(512)>>>(M, rr, ntiles, piv, mult, 0);
 		CK(hipDeviceSynchronize());
 		// the launch above walked every tile with row stride rr: compare the first ct tiles
 		CK(hipMemcpy(h1.data(), M, h1.size() * 8, hipMemcpyDeviceToHost));
@@ -164,7 +166,8 @@ void run(uint4 *M, i64 rows, int ntiles, uint4 *piv, uint4 *mult, bool check, co
 		printf("S=%2d K=%d correctness: %lld words checked, %lld wrong\n", S, K, (long long)checked, (long long)bad);
 	}
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-	auto launch = [&] { k_kloop<S, K><<<dim3(256), dim3(512)>>>(M, rr, ntiles, piv, mult); };
+	const int order = getenv("MB_ORDER") ? atoi(getenv("MB_ORDER")) : 0;
+	auto launch = [&] { k_kloop<S, K><<<dim3(256), dim3(512)>>>(M, rr, ntiles, piv, mult, order); };
 	CK(hipMemset(M, 0x5a, (size_t)rr * ntiles * 16));          // the same contents for every variant
 	launch(); launch(); CK(hipDeviceSynchronize());
 	const int reps = getenv("MB_REPS") ? atoi(getenv("MB_REPS")) : 10;
@@ -195,6 +198,11 @@ int main(int argc, char **argv)
 	printf("# K-loop bulk update: %lld rows x %d tiles of 16 B = %.2f GiB; multipliers %.1f MiB per block\n", (long long)rows, ntiles,
 	       (double)rows * ntiles * 16 / 1073741824.0, (double)rows * 32 / 1048576.0);
 	const bool chk = !getenv("MB_NOCHECK");
+	if (getenv("MB_QUICK")) {                                  // one configuration (size / order sweeps)
+		run<16, 4>(M, rows, ntiles, piv, mult, false, hp, plain);
+		run<16, 8>(M, rows, ntiles, piv, mult, false, hp, plain);
+		return 0;
+	}
 	for (int round = 0; round < 2; round++) {                  // twice: the second round shows what order / clocks do to the figures
 		run<8, 1>(M, rows, ntiles, piv, mult, chk && !round, hp, plain);
 		run<8, 2>(M, rows, ntiles, piv, mult, false, hp, plain);
