@@ -468,26 +468,30 @@ int check_device(int device)
 	return GF2BV_OK;
 }
 
-// Two-level elimination (k_outer_trsm + k_update16k): which blocks go in outer panels, and of how many blocks.
+// Two-level elimination: which blocks go in outer panels, and of how many blocks.
 // An outer panel of K blocks saves HBM round trips -- the rows right of it make one trip per K blocks, and the outer pass runs
-// 4.3-4.8 TB/s of sweep-words inside a solve (K = 8) where k_update16 runs 3.6-4.0 -- and costs k_outer_trsm, a latency chain
-// of 4 K steps per word group that does not shrink with the matrix (~0.9 ms per panel of 8 blocks at 131072 rows).  Measured
-// (forced K = 8 from the first block on): 262144^2 1.517 -> 1.395 s, 131072^2 203 -> 218 ms, 65536^2 34 -> 48 ms.  So: K = 8 while
-// more than 3 GiB remain right of the panel (262144^2: the first 39 % of the pivots = 77 % of the bulk work; nothing below
-// ~160000^2).  GF2BV_TWO_LEVEL=0 turns it off, =K (2..8) forces K from the first block on for every full panel whatever the
-// size (tests).  Single systems on one GPU only: gangs and column-slab solves keep the one-level schedule.
+// 4.5-4.9 TB/s of sweep-words inside a solve (K = 8) where k_update16 runs 3.6-4.0 -- and costs ~0.4 ms of small launches per
+// panel (k_outer_apply on two tile ranges, the priority part of the pass) plus a slower inner elimination beside the pass.
+// Measured (K = 8 from the first block to the last full panel): 262144^2 1.517 -> 1.277 s, 131072^2 203 -> 195 ms, 98304^2 89 ->
+// 100 ms, 65536^2 34 -> 47 ms; with a threshold on what remains right of the panel (profiles/r03_two_level.txt): 131072^2 best at
+// 384-512 MiB (182 ms), 98304^2 at 512 MiB (87.3 against 92.8), 65536^2 never.  So: K = 8 while more than 512 MiB remain
+// (262144^2: the first 75 % of the pivots; 131072^2: the first half; 98304^2: the first third; nothing below ~70000^2).
+// GF2BV_TWO_LEVEL=0 turns it off, =K (2..8)
+// forces K from the first block on for every full panel whatever the size (tests).  Single systems on one GPU only: gangs
+// and column-slab solves keep the one-level schedule.
 void plan_two_level(Solver &S)
 {
 	S.tl_K = 0; S.tl_bend = 0; S.nsets = 2;
 	if (S.world != 1 || S.nsys != 1 || S.impl->G != GF2_GMAX) return;
 	int K = GF2_KMAX;
-	double min_bytes = 3.0 * 1073741824.0;
+	double min_bytes = 0.5 * 1073741824.0;
 	if (const char *e = getenv("GF2BV_TWO_LEVEL"); e && *e) {
 		const int v = atoi(e);
 		if (v <= 0) return;
 		K = std::min(GF2_KMAX, std::max(2, v));
 		min_bytes = 0;
 	}
+	if (const char *e = getenv("GF2BV_TWO_LEVEL_MIN_MIB"); e && *e) min_bytes = 1048576.0 * atof(e);      // (threshold scans)
 	const int G = S.impl->G;
 	int bend = 0;
 	for (int b0 = 0; b0 + K < S.nblocks; b0 += K) {            // (the last block never ends an outer panel: it may be short)
@@ -558,7 +562,7 @@ int solver_alloc(Solver &S)
 		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * S.nsets * G * mult_rows(R) + (S.tl_K ? kOuterSlackBytes : 0)),
 		             o_wb = carve(sizeof(u64) * 2 * GF2_GMAX * R), o_uw = carve(sizeof(u64) * GF2_GMAX * (S.maxr + 64)),
 		             o_pf = carve(sizeof(u64) * GF2_GMAX * GF2_GMAX * 64), o_opr = carve(sizeof(int) * GF2_OUTER_LISTS * 2),
-		             o_tm = carve(S.tl_K ? sizeof(u64) * GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX : 0);
+		             o_tm = carve(S.tl_K ? 2 * sizeof(u64) * GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX : 0);
 		S.arena_stride = off;
 		S.sync_base = 0;
 		HIPCHK(pool().alloc(&S.arena, off * S.nsys, S.device));
@@ -847,7 +851,7 @@ int enqueue_forward_begin(Solver &S, bool gather_first_window)
 	HIPCHK(hipStreamWaitEvent(S.sB, S.ev0, 0));     // sB starts after the setup memsets on sA
 	if (S.npanels > 0 && gather_first_window) {
 		const int g0 = std::min(S.impl->G, S.npanels);
-		k_win_gather<<<dim3((unsigned)((S.rows * g0 + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, 0, g0, S.Wb, S.ss());
+		k_win_gather<<<dim3((unsigned)((S.rows * g0 + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, 0, g0, S.Wb, S.st, S.ss());
 	}
 	return GF2BV_OK;
 }
@@ -878,7 +882,26 @@ int enqueue_check_rhs(Solver &S)
 // ITEM (tile, chunk of rows) -- not persistent ones: CUs come free all the time, and the next panel's elimination, whose
 // streams rank above this one, slips its kernels in between (a persistent launch filled every CU until its very end: the
 // look-ahead had nowhere to run; reserving CUs for it cost the pass more than the overlap gave back).
-int enqueue_outer_apply(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, i64 t_end, bool first_part)
+// What the outer step of the panel of blocks [b0, b1) needs from its records alone: the row lists and T (P = T x S: the chain
+// of panel steps run ONCE, on the identity, one workgroup per source block).  Enqueued on the PANEL stream right behind the
+// panel's last block: it runs while the outer stream is still busy with the previous panel's pass (0.26 ms off its path).
+int enqueue_outer_prepare(Solver &S, hipStream_t st, int b0, int b1)
+{
+	const int G = S.impl->G;
+	const i64 set_words = (i64)G * mult_rows(S.rows);
+	const int npan = (b1 - b0) * G;
+	// (lists: two buffers by panel parity, T: two as well -- the previous panel's outer pass may still be reading its own)
+	int *gprow = S.oprow + (size_t)((b0 / S.tl_K) & 1) * GF2_OUTER_LISTS;
+	u64 *Tm = S.Tm + (size_t)((b0 / S.tl_K) & 1) * ((size_t)GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX);
+	k_outer_prow<<<dim3(1), dim3(256), 0, st>>>(b0 * G, b1 - b0, S.panels, S.aux, gprow);
+	if (!S.outer_chain)
+		k_outer_trsm<4, true><<<dim3((unsigned)(npan / 4)), dim3(256), 0, st>>>(S.M, S.rows, S.srows, b0 * G, npan, 0, S.panels, S.aux, S.mult,
+		                                                                       set_words, b0 % S.nsets, S.nsets, S.impl->T, Tm);
+	HIPCHK(hipGetLastError());
+	return GF2BV_OK;
+}
+
+int enqueue_outer_apply(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, i64 t_end)
 {
 	const int G = S.impl->G;
 	const i64 nt = t_end - t_begin;
@@ -886,19 +909,13 @@ int enqueue_outer_apply(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, 
 	const i64 set_words = (i64)G * mult_rows(S.rows);
 	int *gprow = S.oprow + (size_t)((b0 / S.tl_K) & 1) * GF2_OUTER_LISTS;
 	const int npan = (b1 - b0) * G;
-	if (first_part) {
-		k_outer_prow<<<dim3(1), dim3(256), 0, st>>>(b0 * G, b1 - b0, S.panels, S.aux, gprow);
-		// T with P = T x S: the chain of panel steps run ONCE, on the identity (one workgroup per source block)
-		if (!S.outer_chain)
-			k_outer_trsm<4, true><<<dim3((unsigned)(npan / 4)), dim3(256), 0, st>>>(S.M, S.rows, S.srows, b0 * G, npan, 0, S.panels, S.aux, S.mult,
-			                                                                       set_words, b0 % S.nsets, S.nsets, S.impl->T, S.Tm);
-	}
 	if (S.outer_chain) {
 		const i64 g_begin = t_begin * TW / 4, ng = t_end * TW / 4 - g_begin;
 		k_outer_trsm<4, false><<<dim3((unsigned)ng), dim3(256), 0, st>>>(S.M, S.rows, S.srows, b0 * G, npan, (int)g_begin, S.panels, S.aux,
 		                                                                  S.mult, set_words, b0 % S.nsets, S.nsets, S.impl->T, (u64 *)nullptr);
 	} else
-		k_outer_apply<<<dim3((unsigned)nt), dim3(512), 0, st>>>(S.M, S.rows, S.srows, b1 - b0, (const int *)gprow, (const u64 *)S.Tm, (int)t_begin);
+		k_outer_apply<<<dim3((unsigned)nt), dim3(512), 0, st>>>(S.M, S.rows, S.srows, b1 - b0, (const int *)gprow,
+		                                                        (const u64 *)(S.Tm + (size_t)((b0 / S.tl_K) & 1) * ((size_t)GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX)), (int)t_begin);
 	HIPCHK(hipGetLastError());
 	hipEvent_t ka = nullptr, kb = nullptr;
 	if (S.time_kernels) {
@@ -924,24 +941,52 @@ int enqueue_outer_apply(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, 
 int enqueue_window_gather(Solver &S, int b)
 {
 	const BlockGeom g = block_geom(S, b);
-	k_win_gather<<<dim3((unsigned)((S.rows * g.gb + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, S.Wb, S.ss());
+	k_win_gather<<<dim3((unsigned)((S.rows * g.gb + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, S.Wb, S.st, S.ss());
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
 
 int enqueue_forward(Solver &S)
 {
+	Trace tr;
 	int rc = enqueue_forward_begin(S, true);
 	if (rc) return rc;
+	// Optimistic enqueue for dense systems.  k_block_fast decides ON THE DEVICE whether a block goes the fast way, so the
+	// general panel steps have to be enqueued behind it all the same, and on a fast block they are G + 1 empty launches
+	// of ~4.5 us each on the critical path (and, beside an outer pass, ~500 workgroups each that take CUs from it).  One look
+	// at the device settles it for the usual case: block 0 is enqueued both ways and the host waits for its panel path (a
+	// ~50 us stall, once per solve); if the fast search took it, the blocks that can take it at all (full blocks with enough
+	// rows left) get k_block_fast + k_narrow_all only.  Should the search give up on one of them after all, it poisons the
+	// panel path from there on (SolveState::poison): every later panel-path kernel returns at once, the bulk and outer kernels
+	// find no pivots for the unpublished blocks and do nothing, and the host resumes from that block with both paths and the
+	// one-level schedule -- the matrix and the window buffer are exactly as that block needs.
+	bool optimistic = false;
+	SolveState hst{};
+	const bool may_probe = S.fast_blocks && S.optimistic && S.nsys == 1 && S.world == 1 && S.nblocks >= 8 && fast_block_possible(S, block_geom(S, 0));
+	auto fast_only_ok = [&](int blk) {
+		// rows left when the block starts: at most 64 leftover candidates sit below the bound besides the pivots found
+		return fast_block_possible(S, block_geom(S, blk)) && S.rows - (i64)blk * 64 * S.impl->G >= GF2_FAST_NC + 128;
+	};
+	auto one_block = [&](int blk) -> int {
+		int r;
+		if ((r = enqueue_block_panel(S, blk, optimistic && fast_only_ok(blk)))) return r;
+		if ((r = enqueue_block_bulk(S, blk))) return r;
+		if ((r = enqueue_block_prio(S, blk))) return r;
+		if (blk == 0 && may_probe) {
+			HIPCHK(hipMemcpyAsync(&hst, S.st, sizeof hst, hipMemcpyDeviceToHost, S.sA));
+			HIPCHK(hipStreamSynchronize(S.sA));
+			optimistic = hst.fast_done == 1;
+		}
+		return GF2BV_OK;
+	};
 	int b = 0;
 	// Two-level part (large single systems, plan_two_level): outer panels of tl_K blocks.  Inside a panel the blocks run
-	// exactly as below -- panel and bulk stream, look-ahead from block to block -- with the bulk kernels confined to the
-	// panel's own tiles (tile_hi).  The outer step of panel p goes to a THIRD stream in two parts: first the tiles of panel
-	// p + 1 (a small launch), behind which that panel's first window is gathered and its elimination starts, then everything
-	// right of them, one workgroup per item so that the next panel's kernels find CUs while it runs.  What
+	// exactly as in the one-level loop below -- panel and bulk stream, look-ahead from block to block -- with the bulk kernels
+	// confined to the panel's own tiles (tile_hi).  The outer step of panel p goes to a THIRD stream in two parts: first the
+	// tiles of panel p + 1 (a small launch), behind which that panel's first window is gathered and its elimination starts,
+	// then everything right of them, one workgroup per item so that the next panel's kernels find CUs while it runs.  What
 	// the two meet in: the multiplier sets (2 K of them: panel parity), the pivot marks (k_update16k takes "alive behind
-	// panel p", not "alive now") and disjoint tiles.  Both panel paths stay enqueued per block (no optimistic enqueue here).
-	bool after_two_level = true;
+	// panel p", not "alive now") and disjoint tiles.
 	if (S.tl_K) {
 		const int G = S.impl->G;
 		hipStream_t so = S.sC ? S.sC : S.sB;           // (GF2BV_SERIAL: one stream, everything in order)
@@ -952,67 +997,45 @@ int enqueue_forward(Solver &S)
 				if ((rc = enqueue_window_gather(S, p0))) return rc;
 			}
 			S.tile_hi = (i64)p1 * G / TW;
-			for (b = p0; b < p1; b++) {
-				if ((rc = enqueue_block_panel(S, b))) return rc;
-				if ((rc = enqueue_block_bulk(S, b))) return rc;
-				if ((rc = enqueue_block_prio(S, b))) return rc;
-			}
+			for (b = p0; b < p1; b++)
+				if ((rc = one_block(b))) return rc;
 			S.tile_hi = S.ntiles;
 			// the outer step needs the panel's records and multipliers (panel stream), not its bulk updates (other tiles)
+			if ((rc = enqueue_outer_prepare(S, S.sA, p0, p1))) return rc;
 			HIPCHK(hipEventRecord(S.evPanelDone, S.sA));
 			HIPCHK(hipStreamWaitEvent(so, S.evPanelDone, 0));
 			const i64 t0 = (i64)p1 * G / TW, t1 = std::min<i64>(S.ntiles, t0 + (i64)S.tl_K * G / TW);
-			if ((rc = enqueue_outer_apply(S, so, p0, p1, t0, t1, true))) return rc;
+			if ((rc = enqueue_outer_apply(S, so, p0, p1, t0, t1))) return rc;
 			HIPCHK(hipEventRecord(S.evPri, so));
-			if ((rc = enqueue_outer_apply(S, so, p0, p1, t1, S.ntiles, false))) return rc;
+			if ((rc = enqueue_outer_apply(S, so, p0, p1, t1, S.ntiles))) return rc;
 		}
 		HIPCHK(hipEventRecord(S.evOuter, so));
 		b = S.tl_bend;
 		HIPCHK(hipStreamWaitEvent(S.sA, S.evPri, 0));
 		if (b < S.nblocks && (rc = enqueue_window_gather(S, b))) return rc;
 		S.bulk_waits_outer = S.sC != nullptr;          // the one-level bulk updates behind it touch every trailing tile
-		(void)after_two_level;
 	}
-	// Optimistic enqueue for dense systems.  k_block_fast decides ON THE DEVICE whether a block goes the fast way, so the
-	// general panel steps have to be enqueued behind it all the same, and on a fast block they are G + 1 empty launches
-	// of ~4.5 us each on the critical path.  One look at the device settles it for the usual case: the first block is enqueued
-	// both ways and the host waits for its panel path (a ~50 us stall, once per solve); if the fast search took it, the
-	// blocks that can take it at all (full blocks with enough rows left) get k_block_fast + k_narrow_all only.  Should the
-	// search give up on one of them after all, it poisons the panel path from there on (SolveState::poison) and the
-	// host resumes from that block with both paths -- the matrix and the window buffer are exactly as that block needs.
-	bool optimistic = false;
-	SolveState hst{};
-	if (S.fast_blocks && S.optimistic && S.nsys == 1 && S.world == 1 && S.nblocks - b >= 8 && fast_block_possible(S, block_geom(S, b))) {
-		if ((rc = enqueue_block_panel(S, b))) return rc;
-		if ((rc = enqueue_block_bulk(S, b))) return rc;
-		if ((rc = enqueue_block_prio(S, b))) return rc;
-		HIPCHK(hipMemcpyAsync(&hst, S.st, sizeof hst, hipMemcpyDeviceToHost, S.sA));
-		HIPCHK(hipStreamSynchronize(S.sA));
-		optimistic = hst.fast_done == b + 1;
-		b++;
-	}
-	auto fast_only_ok = [&](int blk) {
-		// rows left when the block starts: at most 64 leftover candidates sit below the bound besides the pivots found
-		return fast_block_possible(S, block_geom(S, blk)) && S.rows - (i64)blk * 64 * S.impl->G >= GF2_FAST_NC + 128;
-	};
-	for (; b < S.nblocks; b++) {
-		if ((rc = enqueue_block_panel(S, b, optimistic && fast_only_ok(b)))) return rc;
-		if ((rc = enqueue_block_bulk(S, b))) return rc;
-		if ((rc = enqueue_block_prio(S, b))) return rc;
-	}
+	for (; b < S.nblocks; b++)
+		if ((rc = one_block(b))) return rc;
 	if ((rc = enqueue_forward_join(S))) return rc;
+	tr.mark("forward: all blocks submitted");          // (host side only: the device is still working; what follows waits for it)
 	if (optimistic) {
 		HIPCHK(hipMemcpyAsync(&hst, S.st, sizeof hst, hipMemcpyDeviceToHost, S.sA));
 		HIPCHK(hipStreamSynchronize(S.sA));
 		if (hst.poison) {                               // a block the fast search could not take: resume there, both paths
 			const int pb = hst.poison - 1;
+			if (S.sC) HIPCHK(hipStreamSynchronize(S.sC));
+			HIPCHK(hipStreamSynchronize(S.sB));
+			// (two-level: the outer panels before the poisoned one are complete; the published blocks of the poisoned panel have been
+			// applied to its own tiles by the bulk kernels and to everything right of it by its outer pass -- every tile has seen
+			// exactly the blocks before pb -- so the rest runs as a one-level schedule)
+			if (S.tl_K && pb < S.tl_bend) S.tl_bend = pb / S.tl_K * S.tl_K;
+			S.bulk_waits_outer = false;
 			HIPCHK(hipMemsetAsync(&S.st->poison, 0, sizeof(int), S.sA));
 			S.sync_base += S.nblocks + 1;
-			for (b = pb; b < S.nblocks; b++) {
-				if ((rc = enqueue_block_panel(S, b))) return rc;
-				if ((rc = enqueue_block_bulk(S, b))) return rc;
-				if ((rc = enqueue_block_prio(S, b))) return rc;
-			}
+			optimistic = false;
+			for (b = pb; b < S.nblocks; b++)
+				if ((rc = one_block(b))) return rc;
 			if ((rc = enqueue_forward_join(S))) return rc;
 		}
 	}
@@ -1240,6 +1263,78 @@ int finish_end(Solver &S, gf2bv_result **out)
 	return GF2BV_OK;
 }
 
+// Systems whose augmented matrix fits the LDS: the whole solve in ONE launch (k_small_solve) -- the reference's own examples
+// (README 4 x 4, examples/simple.py 128 x 128, examples/xoshiro.py 640 x 256) paid 0.4-1.0 ms of launch latency on the blocked
+// path.  Still the GPU (there is no host elimination anywhere in this library); GF2BV_SMALL=0 sends them the long way (tests
+// diff both against the CPU restatement).
+bool small_system(const Solver &S)
+{
+	const char *e = getenv("GF2BV_SMALL");
+	const bool on = !(e && *e && atoi(e) == 0);
+	const i64 wt = (S.cols + 1 + 63) / 64;
+	return on && S.nsys == 1 && S.world == 1 && !S.view && S.rows >= 1 && S.rows <= GF2_SMALL_MAXROWS && wt <= GF2_SMALL_MAXW &&
+	       S.rows * wt <= GF2_SMALL_WORDS;
+}
+
+int small_solve(Solver &S, gf2bv_result **out)
+{
+	const i64 cw = (S.cols + 63) / 64;
+	const size_t hdr_ints = 2 + GF2_SMALL_MAXW * 64, vec_words = (size_t)(S.cols + 1) * cw;
+	Scratch scratch;
+	scratch.sync_first = S.sA;
+	int *d_hdr = nullptr; u64 *d_vec = nullptr;
+	HIPCHK(scratch.alloc((void **)&d_hdr, sizeof(int) * hdr_ints, S.device));
+	HIPCHK(scratch.alloc((void **)&d_vec, sizeof(u64) * vec_words, S.device));
+	hipEvent_t e0, e1;
+	HIPCHK(scratch.event(&e0)); HIPCHK(scratch.event(&e1));
+	HIPCHK(hipEventRecord(e0, S.sA));
+	k_small_solve<<<dim3(1), dim3(64), 0, S.sA>>>(S.M ? nullptr : S.src, S.stride, S.M, S.M ? slab_rows(S.rows) : 0, (int)S.rows, (int)S.cols, S.mode,
+	                                              d_hdr, d_vec);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(e1, S.sA));
+	std::vector<int> hdr(hdr_ints);
+	std::vector<u64> vec(vec_words);
+	HIPCHK(hipMemcpyAsync(hdr.data(), d_hdr, sizeof(int) * hdr_ints, hipMemcpyDeviceToHost, S.sA));
+	HIPCHK(hipMemcpyAsync(vec.data(), d_vec, sizeof(u64) * vec_words, hipMemcpyDeviceToHost, S.sA));
+	HIPCHK(hipStreamSynchronize(S.sA));
+	gf2bv_result *R = new gf2bv_result();
+	R->status = hdr[0] ? GF2BV_STATUS_INCONSISTENT : GF2BV_STATUS_SOLVED;
+	R->rank = hdr[1];
+	R->cw = cw;
+	R->dim = S.cols - R->rank;
+	R->pivots.assign(hdr.begin() + 2, hdr.begin() + 2 + R->rank);
+	R->origin.assign(std::max<i64>(1, cw), 0);
+	if (R->status == GF2BV_STATUS_SOLVED) {
+		std::copy(vec.begin(), vec.begin() + cw, R->origin.begin());
+		if (S.mode == GF2BV_MODE_AFFINE_SPACE) {
+			// the kernel numbers its vectors by free column in increasing order; M4RI's order (contract S4): swap order[i] <-> order[c_i]
+			std::vector<int> order(S.cols), slot(S.cols, -1);
+			for (i64 i = 0; i < S.cols; i++) order[i] = (int)i;
+			for (i64 i = 0; i < R->rank; i++) std::swap(order[i], order[R->pivots[i]]);
+			std::vector<char> is_piv(S.cols, 0);
+			for (int c : R->pivots) is_piv[c] = 1;
+			int nf = 0;
+			for (i64 c = 0; c < S.cols; c++) if (!is_piv[c]) slot[c] = nf++;
+			R->basis.assign((size_t)R->dim * std::max<i64>(1, cw), 0);
+			for (i64 t = 0; t < R->dim; t++) {
+				const int f = order[R->rank + t];
+				std::copy(vec.begin() + (size_t)(1 + slot[f]) * cw, vec.begin() + (size_t)(2 + slot[f]) * cw, R->basis.begin() + (size_t)t * cw);
+			}
+		}
+	}
+	gf2bv_stats &st = R->stats;
+	st.rows = S.rows; st.cols = S.cols; st.stride_words = S.stride;
+	st.rank = R->rank; st.dimension = R->dim; st.status = R->status;
+	st.n_panels = (int)((S.cols + 63) / 64);
+	st.panels_per_sweep = GF2_GMAX; st.tables_per_sweep = GF2_GMAX * 8; st.table_bits = 8; st.tile_words = TW;
+	st.gang_systems = 1;
+	st.ms_pack = S.ms_pack;
+	(void)hipEventElapsedTime(&st.ms_eliminate, e0, e1);
+	st.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - S.t_begin).count();
+	*out = R;
+	return GF2BV_OK;
+}
+
 int solver_finish(Solver &S, gf2bv_result **out)
 {
 	int rc = finish_begin(S);
@@ -1380,6 +1475,7 @@ int gf2bv_solve_device(void *d_aug, int64_t rows, int64_t cols, int64_t stride_w
 	S.src = (const u64 *)d_aug;
 	S.rows = rows; S.cols = cols; S.stride = stride_words; S.mode = mode;
 	S.time_kernels = time_kernels != 0;
+	if (small_system(S)) return small_solve(S, out);
 	rc = solver_enqueue(S);
 	if (rc) return rc;
 	return solver_finish(S, out);
@@ -1494,6 +1590,7 @@ int gf2bv_solve_words(const uint64_t *aug, int64_t rows, int64_t cols, int64_t s
 	// bits above column `cols` are ignored by the reference (_internal.c:414): they are never
 	// pivot candidates (colmask), never exported, and the RHS is read at exactly column `cols`.
 	HIPCHK(hipEventRecord(p1, S.sA));
+	if (small_system(S)) return small_solve(S, out);
 	rc = solver_enqueue(S);
 	if (rc == GF2BV_OK) {
 		(void)hipEventSynchronize(p1);
@@ -1647,6 +1744,7 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(p1, S.sA));
+	if (small_system(S)) return small_solve(S, out);
 	rc = solver_enqueue(S);
 	if (rc == GF2BV_OK) {
 		(void)hipEventSynchronize(p1);
