@@ -2478,105 +2478,6 @@ k_outer_apply(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__r
 }
 
 // ==========================================================================================
-// SMALL SYSTEMS: the whole solve in one launch (round 3)
-// ==========================================================================================
-// The reference's own examples are tiny (README: 4 x 4, examples/simple.py: 128 x 128, examples/xoshiro.py: 640 x 256) and the
-// blocked elimination above costs them 0.4-1.0 ms of launch latency: ~20 dependent launches for one block of panels.  A system
-// whose augmented matrix fits the LDS (rows x words <= 16384 words = 128 KiB, <= 8 words = 511 columns per row, <= 2048 rows)
-// takes this kernel instead: ONE wavefront, the matrix in LDS, Gauss-Jordan column by column -- lane l owns rows l, l + 64, ...;
-// per column: every lane's first unused row that has the bit, a wave-wide minimum (the pivot row: any choice gives the same
-// column rank profile and the same reduced rows), the pivot row broadcast from LDS, every other row that has the bit takes
-// it.  The reduced system IS the result contract: pivots = the pivot columns, consistency = no unused row keeps
-// its right-hand side, origin = the pivot rows' right-hand sides, kernel vector of free column f = bit f of every pivot row.
-// No wave ever waits for another one; ~50 us for 640 x 256.  Same bits as the blocked path (tests diff both against the CPU restatement).
-#define GF2_SMALL_WORDS 16384
-#define GF2_SMALL_MAXW 8
-#define GF2_SMALL_MAXROWS 2048
-// out_hdr: [status (0 solved, 1 inconsistent), rank, pivot columns ...]; out_vec: origin (cw words), then (mode 1, consistent)
-// one kernel vector per free column in INCREASING column order (the host lays them out in M4RI's order, contract S4)
-__global__ void __launch_bounds__(64)
-k_small_solve(const u64 *__restrict__ src, i64 stride, const u64 *__restrict__ Mt, i64 srows, int rows, int cols, int mode,
-              int *__restrict__ out_hdr, u64 *__restrict__ out_vec)
-{
-	__shared__ u64 L[GF2_SMALL_WORDS];
-	__shared__ short pivrow[GF2_SMALL_MAXW * 64];      // column -> its pivot row, -1: free
-	__shared__ short pivcol[GF2_SMALL_MAXW * 64];      // pivot k -> column
-	__shared__ u64 vec[GF2_SMALL_MAXW];
-	const int lane = threadIdx.x;
-	const int wt = (cols + 1 + 63) >> 6, cw = (cols + 63) >> 6;
-	const int nslots = (rows + 63) >> 6;
-	for (int idx = lane; idx < rows * wt; idx += 64) {
-		const int r = idx / wt, w = idx - r * wt;
-		u64 v = src ? src[(i64)r * stride + w] : Mt[tidx(r, w, srows)];
-		if (w == wt - 1 && ((cols + 1) & 63)) v &= (1ull << ((cols + 1) & 63)) - 1;      // bits above the RHS column are not part of the system
-		L[idx] = v;
-	}
-	__syncthreads();
-	unsigned usedm = 0;                                // slot s of this lane = row lane + 64 s
-	int rank = 0;
-	for (int c = 0; c < cols; c++) {
-		const int wc = c >> 6;
-		const u64 bit = 1ull << (c & 63);
-		int mine = 0x7fffffff;
-		for (int sl = 0; sl < nslots; sl++) {
-			const int r = lane + 64 * sl;
-			if (r < rows && !((usedm >> sl) & 1) && (L[r * wt + wc] & bit)) { mine = r; break; }
-		}
-		int p = mine;
-#pragma unroll
-		for (int o = 32; o >= 1; o >>= 1) { const int q = __shfl_xor(p, o); p = q < p ? q : p; }
-		if (p == 0x7fffffff) { if (lane == 0) pivrow[c] = -1; continue; }          // (uniform)
-		if (lane == 0) { pivrow[c] = (short)p; pivcol[rank] = (short)c; }
-		rank++;
-		if ((p & 63) == lane) usedm |= 1u << (p >> 6);
-		for (int sl = 0; sl < nslots; sl++) {
-			const int r = lane + 64 * sl;
-			if (r < rows && r != p && (L[r * wt + wc] & bit))
-				for (int w = wc; w < wt; w++) L[r * wt + w] ^= L[p * wt + w];
-		}
-		__syncthreads();                               // (one wavefront: orders the LDS traffic of the step, costs a wait)
-	}
-	// consistency: an unused row is all zero left of the RHS column by now
-	const int wr = cols >> 6;
-	const u64 rbit = 1ull << (cols & 63);
-	int bad = 0;
-	for (int sl = 0; sl < nslots; sl++) {
-		const int r = lane + 64 * sl;
-		if (r < rows && !((usedm >> sl) & 1) && (L[r * wt + wr] & rbit)) bad = 1;
-	}
-	bad = __any(bad);
-	if (lane == 0) { out_hdr[0] = bad ? 1 : 0; out_hdr[1] = rank; }
-	for (int k = lane; k < rank; k += 64) out_hdr[2 + k] = pivcol[k];
-	if (bad) return;
-	// origin: free variables 0, pivot variable c_k = the RHS of its row
-	if (lane < GF2_SMALL_MAXW) vec[lane] = 0;
-	__syncthreads();
-	for (int k = lane; k < rank; k += 64) {
-		const int c = pivcol[k];
-		if (L[pivrow[c] * wt + wr] & rbit) atomicOr(&vec[c >> 6], 1ull << (c & 63));
-	}
-	__syncthreads();
-	if (lane < cw) out_vec[lane] = vec[lane];
-	if (mode != 1) return;
-	int nf = 0;
-	for (int f = 0; f < cols; f++) {
-		if (pivrow[f] >= 0) continue;                  // (uniform)
-		__syncthreads();
-		if (lane < GF2_SMALL_MAXW) vec[lane] = (lane == (f >> 6)) ? (1ull << (f & 63)) : 0ull;
-		__syncthreads();
-		const int wf = f >> 6;
-		const u64 fbit = 1ull << (f & 63);
-		for (int k = lane; k < rank; k += 64) {
-			const int c = pivcol[k];
-			if (L[pivrow[c] * wt + wf] & fbit) atomicOr(&vec[c >> 6], 1ull << (c & 63));
-		}
-		__syncthreads();
-		nf++;
-		if (lane < cw) out_vec[(i64)nf * cw + lane] = vec[lane];
-	}
-}
-
-// ==========================================================================================
 // BACK-SUBSTITUTION
 // ==========================================================================================
 

@@ -1263,78 +1263,6 @@ int finish_end(Solver &S, gf2bv_result **out)
 	return GF2BV_OK;
 }
 
-// Systems whose augmented matrix fits the LDS: the whole solve in ONE launch (k_small_solve) -- the reference's own examples
-// (README 4 x 4, examples/simple.py 128 x 128, examples/xoshiro.py 640 x 256) paid 0.4-1.0 ms of launch latency on the blocked
-// path.  Still the GPU (there is no host elimination anywhere in this library); GF2BV_SMALL=0 sends them the long way (tests
-// diff both against the CPU restatement).
-bool small_system(const Solver &S)
-{
-	const char *e = getenv("GF2BV_SMALL");
-	const bool on = !(e && *e && atoi(e) == 0);
-	const i64 wt = (S.cols + 1 + 63) / 64;
-	return on && S.nsys == 1 && S.world == 1 && !S.view && S.rows >= 1 && S.rows <= GF2_SMALL_MAXROWS && wt <= GF2_SMALL_MAXW &&
-	       S.rows * wt <= GF2_SMALL_WORDS;
-}
-
-int small_solve(Solver &S, gf2bv_result **out)
-{
-	const i64 cw = (S.cols + 63) / 64;
-	const size_t hdr_ints = 2 + GF2_SMALL_MAXW * 64, vec_words = (size_t)(S.cols + 1) * cw;
-	Scratch scratch;
-	scratch.sync_first = S.sA;
-	int *d_hdr = nullptr; u64 *d_vec = nullptr;
-	HIPCHK(scratch.alloc((void **)&d_hdr, sizeof(int) * hdr_ints, S.device));
-	HIPCHK(scratch.alloc((void **)&d_vec, sizeof(u64) * vec_words, S.device));
-	hipEvent_t e0, e1;
-	HIPCHK(scratch.event(&e0)); HIPCHK(scratch.event(&e1));
-	HIPCHK(hipEventRecord(e0, S.sA));
-	k_small_solve<<<dim3(1), dim3(64), 0, S.sA>>>(S.M ? nullptr : S.src, S.stride, S.M, S.M ? slab_rows(S.rows) : 0, (int)S.rows, (int)S.cols, S.mode,
-	                                              d_hdr, d_vec);
-	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(e1, S.sA));
-	std::vector<int> hdr(hdr_ints);
-	std::vector<u64> vec(vec_words);
-	HIPCHK(hipMemcpyAsync(hdr.data(), d_hdr, sizeof(int) * hdr_ints, hipMemcpyDeviceToHost, S.sA));
-	HIPCHK(hipMemcpyAsync(vec.data(), d_vec, sizeof(u64) * vec_words, hipMemcpyDeviceToHost, S.sA));
-	HIPCHK(hipStreamSynchronize(S.sA));
-	gf2bv_result *R = new gf2bv_result();
-	R->status = hdr[0] ? GF2BV_STATUS_INCONSISTENT : GF2BV_STATUS_SOLVED;
-	R->rank = hdr[1];
-	R->cw = cw;
-	R->dim = S.cols - R->rank;
-	R->pivots.assign(hdr.begin() + 2, hdr.begin() + 2 + R->rank);
-	R->origin.assign(std::max<i64>(1, cw), 0);
-	if (R->status == GF2BV_STATUS_SOLVED) {
-		std::copy(vec.begin(), vec.begin() + cw, R->origin.begin());
-		if (S.mode == GF2BV_MODE_AFFINE_SPACE) {
-			// the kernel numbers its vectors by free column in increasing order; M4RI's order (contract S4): swap order[i] <-> order[c_i]
-			std::vector<int> order(S.cols), slot(S.cols, -1);
-			for (i64 i = 0; i < S.cols; i++) order[i] = (int)i;
-			for (i64 i = 0; i < R->rank; i++) std::swap(order[i], order[R->pivots[i]]);
-			std::vector<char> is_piv(S.cols, 0);
-			for (int c : R->pivots) is_piv[c] = 1;
-			int nf = 0;
-			for (i64 c = 0; c < S.cols; c++) if (!is_piv[c]) slot[c] = nf++;
-			R->basis.assign((size_t)R->dim * std::max<i64>(1, cw), 0);
-			for (i64 t = 0; t < R->dim; t++) {
-				const int f = order[R->rank + t];
-				std::copy(vec.begin() + (size_t)(1 + slot[f]) * cw, vec.begin() + (size_t)(2 + slot[f]) * cw, R->basis.begin() + (size_t)t * cw);
-			}
-		}
-	}
-	gf2bv_stats &st = R->stats;
-	st.rows = S.rows; st.cols = S.cols; st.stride_words = S.stride;
-	st.rank = R->rank; st.dimension = R->dim; st.status = R->status;
-	st.n_panels = (int)((S.cols + 63) / 64);
-	st.panels_per_sweep = GF2_GMAX; st.tables_per_sweep = GF2_GMAX * 8; st.table_bits = 8; st.tile_words = TW;
-	st.gang_systems = 1;
-	st.ms_pack = S.ms_pack;
-	(void)hipEventElapsedTime(&st.ms_eliminate, e0, e1);
-	st.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - S.t_begin).count();
-	*out = R;
-	return GF2BV_OK;
-}
-
 int solver_finish(Solver &S, gf2bv_result **out)
 {
 	int rc = finish_begin(S);
@@ -1475,7 +1403,6 @@ int gf2bv_solve_device(void *d_aug, int64_t rows, int64_t cols, int64_t stride_w
 	S.src = (const u64 *)d_aug;
 	S.rows = rows; S.cols = cols; S.stride = stride_words; S.mode = mode;
 	S.time_kernels = time_kernels != 0;
-	if (small_system(S)) return small_solve(S, out);
 	rc = solver_enqueue(S);
 	if (rc) return rc;
 	return solver_finish(S, out);
@@ -1590,7 +1517,6 @@ int gf2bv_solve_words(const uint64_t *aug, int64_t rows, int64_t cols, int64_t s
 	// bits above column `cols` are ignored by the reference (_internal.c:414): they are never
 	// pivot candidates (colmask), never exported, and the RHS is read at exactly column `cols`.
 	HIPCHK(hipEventRecord(p1, S.sA));
-	if (small_system(S)) return small_solve(S, out);
 	rc = solver_enqueue(S);
 	if (rc == GF2BV_OK) {
 		(void)hipEventSynchronize(p1);
@@ -1744,7 +1670,6 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(p1, S.sA));
-	if (small_system(S)) return small_solve(S, out);
 	rc = solver_enqueue(S);
 	if (rc == GF2BV_OK) {
 		(void)hipEventSynchronize(p1);

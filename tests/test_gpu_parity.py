@@ -19,14 +19,6 @@ def _need_gpu():
     assert hip.device_count() >= 1, "gpu tests need an MI355X; the product path has no CPU fallback"
 
 
-@pytest.fixture(autouse=True)
-def _blocked_path_by_default(monkeypatch):
-    """This file is about the blocked elimination: its small corner cases (1 x 1, 63 / 64 / 65 columns, structured hard panels)
-    must keep going through it, so the one-launch path for systems that fit the LDS (k_small_solve, round 3) is switched off
-    here unless a test turns it on (`small` parameter); tests/test_gpu_small.py holds that path to the oracle."""
-    monkeypatch.setenv("GF2BV_SMALL", "0")
-
-
 def assert_same(got: hip.Solution, want: dict, mode: int):
     assert got.status == want["status"]
     assert got.rank == want["rank"]
@@ -51,11 +43,7 @@ SHAPES = [
 
 @pytest.mark.parametrize("shape", SHAPES, ids=lambda s: f"{s[0]}x{s[1]}")
 @pytest.mark.parametrize("mode", [0, 1])
-@pytest.mark.parametrize("small", ["1", "0"], ids=["one-launch-if-small", "blocked"])
-def test_words_path_matches_oracle(shape, mode, small, monkeypatch):
-    # systems that fit the LDS take ONE launch (k_small_solve, round 3); GF2BV_SMALL=0 sends them through the blocked
-    # elimination like everything else, so its 1 x 1 / 63-64-65 column / rows >> cols corner cases stay under test
-    monkeypatch.setenv("GF2BV_SMALL", small)
+def test_words_path_matches_oracle(shape, mode):
     rows, cols, dens, cap, cons, zr = shape
     rng = random.Random(hash(shape) & 0xFFFF)
     eqs = random_system(rng, rows, cols, dens, cap, cons, zr)
