@@ -129,14 +129,15 @@ def gpu_equals_oracle(cb: dict, m: int, seed: int, device: int) -> bool:
     return bool(g.rank == cb["rank"] and g.status == o_status and np.array_equal(g.origin, o_origin))
 
 
-def pmc_traffic(n: int, g: int, t: int):
-    """HBM bytes per bulk-update pass from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
+def pmc_traffic(n: int, g: int, t: int, kernel: str = "k_update16"):
+    """HBM bytes per launch of the dominant bulk kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
     gfx950 note in MI355X_MICROARCH.md, WRITE_SIZE as is); None when no profile of this config is committed."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
     for rec in json.load(open(path)):
-        if rec["n"] == n and rec["G"] == g and rec["T"] == t and rec.get("current", True):
+        if (rec["n"] == n and rec["G"] == g and rec["T"] == t and rec.get("current", True)
+                and rec.get("kernel", "k_update16") == kernel):
             return rec["hbm_bytes_per_pass"]
     return None
 
@@ -153,7 +154,9 @@ def roofline_block(stats_list, sweep_ms_total: float, n: int, device: int, ceil:
     t = s0["tables_per_sweep"] // g
     out = {
         "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(n, g, t),
+        "frac": achieved / HBM_PEAK_GBS,
+        # PMC bytes per launch of the kernel that dominates this solve (k_update16k where outer passes cover most blocks)
+        "traffic": pmc_traffic(n, g, t, "k_update16k" if 2 * s0.get("outer_blocks", 0) > s0["n_sweeps"] else "k_update16"),
         "kernel": (f"k_update16 (bulk update on 16-byte tiles, {g} panels = {64 * g} pivots = {g * t} byte-field tables per pass)"
                    + (f" + k_update16k (outer passes of the two-level elimination: {s0['outer_blocks']} of the {s0['n_sweeps']} blocks, "
                       f"several blocks per trip through HBM)" if s0.get("outer_blocks") else "")),
@@ -185,6 +188,9 @@ def finish_roofline(roofline: dict, s0: dict, blocks: int):
     roofline["alg_bytes_per_launch"] = roofline["alg_bytes_total"] / nl
     roofline["hbm_bytes_per_launch"] = roofline["hbm_bytes_total"] / nl
     roofline["avg_launch_ms"] = roofline["kernel_ms_total"] / nl
+    # (the bulk kernels of an outer panel -- inner updates on its own tiles -- overlap the previous panel's outer pass on another
+    # stream since round 3: kernel_ms_total is the SUM of launch durations and can exceed the elimination's wall time; `achieved`
+    # is therefore a lower bound there, and elimination_* below is the whole forward elimination, panel path included)
 
 
 def timed_single(mat: torch.Tensor, n: int, stride: int, steps: int, warmup: int, device: int, dev, world: int,
@@ -262,6 +268,9 @@ def run_single(args, world, rank, local_rank, dev):
     if rl:
         roofline, launches = rl
         finish_roofline(roofline, s0, launches)
+        elim_ms = float(sum(s.stats["ms_eliminate"] for s in stats))
+        roofline["elimination_GBs"] = roofline["alg_bytes_total"] / (elim_ms * 1e-3) / 1e9
+        roofline["elimination_frac"] = roofline["elimination_GBs"] / HBM_PEAK_GBS
     out = {
         "metric": "GF(2) row-XORs/s (solve_one, dense NxN)", "value": float(agg.item()) / elapsed,
         "unit": "row-XORs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -316,6 +325,9 @@ def target_leg(n: int, device: int, dev, ceil: dict) -> dict:
     s0 = stats[-1].stats
     roofline, launches = roofline_block([s.stats for s in stats], float(sum(s.stats["ms_sweep"] for s in stats)), n, device, ceil)
     finish_roofline(roofline, s0, launches)
+    elim_ms = float(sum(s.stats["ms_eliminate"] for s in stats))
+    roofline["elimination_GBs"] = roofline["alg_bytes_total"] / (elim_ms * 1e-3) / 1e9
+    roofline["elimination_frac"] = roofline["elimination_GBs"] / HBM_PEAK_GBS
     return {"n": n, "seed": seed, "steps": steps, "warmup": 1, "ms_per_step": elapsed / steps * 1e3,
             "row_xors_per_s": float(sum(s.stats["row_xors"] for s in stats)) / elapsed,
             "rank": int(stats[-1].rank), "residual_rows": int(bad), "all_solved": all(s.solved for s in stats),
