@@ -2232,13 +2232,14 @@ k_update16k(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__res
 	static_assert(GF2_KMAX * GF2_GMAX * 64 % 512 == 0, "k_outer_apply: whole pivots per lane");
 	__shared__ __attribute__((aligned(256))) uint4 tab[2 * 256 * 16];      // 128 KiB, must sit at LDS address 0 (checked below)
 	__shared__ uint4 stage[GF2_GMAX * 64];
-	__shared__ int prow[GF2_KMAX * GF2_GMAX * 64];                        // [block][panel][pivot bit] -> physical row, -1 if none
 	__shared__ int anyb[GF2_KMAX];
 	if ((unsigned)(size_t)tab != 0u) __builtin_trap();
 	const int lane = threadIdx.x & 63;
 	const unsigned ulane = (unsigned)lane;
 	const int wvu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // wave-uniform by construction: keep it scalar
-	for (int t = threadIdx.x; t < nblk * GF2_GMAX * 64; t += NT) prow[t] = gprow[t];
+	// (gprow = [block][panel][pivot bit] -> physical row, -1 if none: read where needed, one coalesced KiB per block out of
+	// the L2 -- a copy in the LDS would be 8 KiB of the 20 a CU has left beside the tables, and k_block_fast / k_block_trsm of the
+	// next panel need 25 to start on this CU)
 	if (threadIdx.x < GF2_KMAX) anyb[threadIdx.x] = gprow[GF2_KMAX * GF2_GMAX * 64 + threadIdx.x];
 	__syncthreads();
 	int first_blk = -1, last_blk = -1;
@@ -2292,7 +2293,7 @@ k_update16k(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__res
 			if (rl < rows && dd >= j_end) alive |= 1u << j;
 		}
 		uint4 staged = make_uint4(0, 0, 0, 0);
-		if (threadIdx.x < GF2_GMAX * 64) { const int pr = prow[first_blk * 256 + threadIdx.x]; staged = pr >= 0 ? Mw[pr] : make_uint4(0, 0, 0, 0); }
+		if (threadIdx.x < GF2_GMAX * 64) { const int pr = gprow[first_blk * 256 + threadIdx.x]; staged = pr >= 0 ? Mw[pr] : make_uint4(0, 0, 0, 0); }
 #pragma unroll 1
 		for (int k = first_blk; k <= last_blk; k++) {
 			if (!anyb[k]) continue;          // (uniform.  A loop that steps from block to block through the LDS flags made the
@@ -2319,7 +2320,7 @@ k_update16k(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__res
 			{
 				const int kn = k + 1;                       // (a block without pivots stages zeros and is skipped)
 				if (kn <= last_blk && threadIdx.x < GF2_GMAX * 64) {
-					const int pr = prow[kn * 256 + threadIdx.x];
+					const int pr = gprow[kn * 256 + threadIdx.x];
 					staged = pr >= 0 ? Mw[pr] : make_uint4(0, 0, 0, 0);
 				}
 			}
