@@ -116,6 +116,9 @@ struct SolveState {
 	// (the bulk kernels of unpublished blocks find no pivots and do nothing) until the host resumes from that block.
 	int poison;
 	int gate_timeout;    // a hand-over gate (k_gate) gave up waiting: the solve's results are void (the host reports an error)
+	// k_block_fast_narrow: progress of the search workgroup for the narrowing workgroups of the same launch -- 8 blk + g + 1 once
+	// panel g's reduced pivot rows are in Pfast, 8 blk + 5 once the block is published (monotone over a solve)
+	int fast_pub;
 };
 
 // Hand-over between the panel stream and the bulk stream through memory instead of events.  An event wait costs a
@@ -1101,28 +1104,33 @@ __device__ __forceinline__ void narrow_all_panels(StepLds &L, const u64 *__restr
 	}
 }
 
-__global__ void __launch_bounds__(256)
-k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_only, int blk,
+// LDS of the one-launch block search (one workgroup); the fused launch's other workgroups lay NarrowLds over it
+struct FastLds {
+	StepLds L;
+	u64 cw[GF2_FAST_NC * GF2_GMAX];          // candidates' window words; word g becomes the multiplier once panel g is through
+	unsigned char used[GF2_FAST_NC];         // dead on entry, or a source of an earlier panel
+	int srcs[GF2_GMAX][64];                  // [panel][pivot column] -> candidate that is its source
+	u64 combs[GF2_GMAX][64];
+	int ok;
+	int crow[GF2_FAST_NC];                   // candidate -> row: the first GF2_FAST_NC ALIVE rows from the bound on
+	int wcnt[4];
+};
+// PUB (the fused launch k_block_fast_narrow): panel g's reduced pivot rows go to Pfast[g][word][pivot bit] with write-through
+// stores the moment they are formed, and st->fast_pub = 8 blk + g + 1 says so; 8 blk + 5 after everything is published.
+// Returns 1 if the block is factorised, 0 if it gave up (by all threads).
+template <bool PUB>
+__device__ __forceinline__ int block_fast_body(FastLds &F, u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_only, int blk,
              const u64 *__restrict__ Wb_in, SolveState *__restrict__ st, int *__restrict__ died,
              PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol, int *__restrict__ urow,
-             int *__restrict__ blk_first_out, u64 *__restrict__ Pfast, SysStride ss)
+             int *__restrict__ blk_first_out, u64 *__restrict__ Pfast)
 {
-	__builtin_amdgcn_s_setprio(3);
-	{
-		const i64 ao = blockIdx.y * ss.arena_bytes;
-		M += blockIdx.y * ss.m_words;
-		Wb_in = sys_at(Wb_in, ao); st = sys_at(st, ao); died = sys_at(died, ao); panels = sys_at(panels, ao);
-		aux = sys_at(aux, ao); pivcol = sys_at(pivcol, ao); urow = sys_at(urow, ao); blk_first_out = sys_at(blk_first_out, ao);
-		(void)Pfast;                                        // (scratch of an earlier version: the pivot rows' words stay in registers)
-	}
-	__shared__ StepLds L;
-	__shared__ u64 cw[GF2_FAST_NC * GF2_GMAX];          // candidates' window words; word g becomes the multiplier once panel g is through
-	__shared__ unsigned char used[GF2_FAST_NC];         // dead on entry, or a source of an earlier panel
-	__shared__ int srcs[GF2_GMAX][64];                  // [panel][pivot column] -> candidate that is its source
-	__shared__ u64 combs[GF2_GMAX][64];
-	__shared__ int ok;
-	__shared__ int crow[GF2_FAST_NC];                   // candidate -> row: the first GF2_FAST_NC ALIVE rows from the bound on
-	__shared__ int wcnt[4];
+	StepLds &L = F.L;
+	u64 *const cw = F.cw; unsigned char *const used = F.used; int (*const srcs)[64] = F.srcs; u64 (*const combs)[64] = F.combs;
+	int &ok = F.ok; int *const crow = F.crow; int *const wcnt = F.wcnt;
+	// PUB: everything this workgroup leaves for OTHER streams (the bulk path starts on narrow_done, which the fused launch
+	// announces through signal_light BEFORE the kernel ends) goes out with write-through stores -- a plain store may sit in
+	// this XCD's L2 until the end of the kernel, and the TRSM of another XCD would read the old panel records
+#define PST(ptr, val) do { auto *pst_p = (ptr); if (PUB) GF2_ST(pst_p, (__typeof__(*pst_p))(val)); else *pst_p = (val); } while (0)
 	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
 	const int first = st->first, r0 = st->rank;
 #ifdef GF2_STEP_PROBE
@@ -1132,12 +1140,17 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_
 #define GF2_PROBE_FAST(k) do { } while (0)
 #endif
 	GF2_PROBE_FAST(0);
-	if (st->poison) return;
+	if (st->poison) return 0;
 	// fast_only: no general steps are enqueued behind this launch -- giving up poisons the rest of the enqueued work
-	auto give_up = [&]() { if (t == 0) { st->fast_off = 1; if (fast_only) st->poison = blk + 1; } };
+	auto give_up = [&]() {
+		if (t == 0) {
+			if (PUB) { GF2_ST(&st->fast_off, 1); if (fast_only) GF2_ST(&st->poison, blk + 1); }      // (the fused launch's other workgroups poll these)
+			else { st->fast_off = 1; if (fast_only) st->poison = blk + 1; }
+		}
+	};
 	if (st->fast_off || gb != GF2_GMAX || rows - first < GF2_FAST_NC) {      // (uniform)
 		give_up();
-		return;
+		return 0;
 	}
 	// the alive rows are not contiguous (the leftovers of the previous blocks' candidate sets sit between their
 	// sources): compact them, 256 rows per round, at most 8 rounds.  A round fetches the rows' alive marks AND their
@@ -1178,7 +1191,7 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_
 	}
 	if (have_c < GF2_FAST_NC) {                             // (uniform)
 		give_up();
-		return;
+		return 0;
 	}
 	if (t == 0) ok = 1;
 	__syncthreads();
@@ -1211,7 +1224,7 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_
 		__syncthreads();
 		if (!ok) {                                          // (uniform) leave everything to the general steps
 			give_up();
-			return;
+			return 0;
 		}
 		GF2_PROBE_FAST(2 + 3 * g);
 		// the pivot rows' window words right of the panel = comb x source words: the 64 source rows are folded into nibble
@@ -1223,14 +1236,19 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_
 		__syncthreads();
 		const u64 acc = use ? nibble_word(L.Tn, L.Cm[sl], e_) : 0ull;
 		Pk[g] = acc;
+		if (PUB && g + 1 < GF2_GMAX) {                      // (the last panel's rows have no window word left to take)
+			GF2_ST(&Pfast[(g * GF2_GMAX + e_) * 64 + sl], (e_ > g) ? acc : 0ull);
+			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		}
 		__syncthreads();                                    // (the tables are read by every thread before Pb changes under them)
+		if (PUB && g + 1 < GF2_GMAX && t == 0) GF2_ST(&st->fast_pub, 8 * blk + g + 1);
 		L.Pb[e_][sl] = (e_ > g) ? acc : 0ull;               // (word g of pivot b is the single bit b: nothing to look up there)
 		if (t < 64) {
 			PanelAux *A = aux + j0 + g;
-			A->slot_row[t] = crow[srcs[g][t]];
-			A->comb[t] = combs[g][t];
+			PST(&A->slot_row[t], crow[srcs[g][t]]);
+			PST(&A->comb[t], combs[g][t]);
 #pragma unroll
-			for (int e = 0; e < GF2_GMAX; e++) A->src_mult[t][e] = (e < g) ? cw[srcs[g][t] * 4 + e] : 0ull;
+			for (int e = 0; e < GF2_GMAX; e++) PST(&A->src_mult[t][e], (e < g) ? cw[srcs[g][t] * 4 + e] : 0ull);
 		}
 		__syncthreads();
 		GF2_PROBE_FAST(3 + 3 * g);
@@ -1260,32 +1278,56 @@ k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_
 	}
 #pragma unroll
 	for (int g = 0; g < GF2_GMAX; g++)
-		if (e_ >= g) M[tidx(crow[srcs[g][sl]], j0 + e_, srows)] = Pk[g];
+		if (e_ >= g) PST(&M[tidx(crow[srcs[g][sl]], j0 + e_, srows)], Pk[g]);
 	if (t < 64) {
 #pragma unroll
 		for (int g = 0; g < GF2_GMAX; g++) {
 			const int row = crow[srcs[g][t]];
-			died[row] = j0 + g;
-			urow[r0 + 64 * g + t] = row;
-			pivcol[r0 + 64 * g + t] = 64 * (j0 + g) + t;
+			PST(&died[row], j0 + g);                        // (PUB: the narrowing workgroups look again after the last flag)
+			PST(&urow[r0 + 64 * g + t], row);
+			PST(&pivcol[r0 + 64 * g + t], 64 * (j0 + g) + t);
 		}
 	}
 	if (t == 0) {
 		const int new_first = crow[nf];                    // (at least GF2_FAST_NC - 64 * GF2_GMAX candidates are left over)
 #pragma unroll
 		for (int g = 0; g < GF2_GMAX; g++) {
-			panels[j0 + g].start = r0 + 64 * g; panels[j0 + g].p = 64; panels[j0 + g].mask = ~0ull;
-			aux[j0 + g].first_after = (g == GF2_GMAX - 1) ? new_first : first;
+			PST(&panels[j0 + g].start, r0 + 64 * g); PST(&panels[j0 + g].p, 64); PST(&panels[j0 + g].mask, ~0ull);
+			PST(&aux[j0 + g].first_after, (g == GF2_GMAX - 1) ? new_first : first);
 		}
-		st->rank = r0 + 64 * GF2_GMAX;
-		st->first = new_first;
-		st->wide = 0;
-		*blk_first_out = new_first;
-		st->fast_off = 0;
-		st->fast_done = blk + 1;
-		st->fast_blocks++;
+		PST(&st->rank, r0 + 64 * GF2_GMAX);
+		PST(&st->first, new_first);
+		PST(&st->wide, 0);
+		PST(blk_first_out, new_first);
+		PST(&st->fast_off, 0);
+		PST(&st->fast_done, blk + 1);
+		PST(&st->fast_blocks, st->fast_blocks + 1);
+	}
+	if (PUB) {
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
+		if (t == 0) GF2_ST(&st->fast_pub, 8 * blk + 5);
 	}
 	GF2_PROBE_FAST(14);
+	return 1;
+}
+#undef PST
+
+__global__ void __launch_bounds__(256)
+k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_only, int blk,
+             const u64 *__restrict__ Wb_in, SolveState *__restrict__ st, int *__restrict__ died,
+             PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol, int *__restrict__ urow,
+             int *__restrict__ blk_first_out, u64 *__restrict__ Pfast, SysStride ss)
+{
+	__builtin_amdgcn_s_setprio(3);
+	{
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		M += blockIdx.y * ss.m_words;
+		Wb_in = sys_at(Wb_in, ao); st = sys_at(st, ao); died = sys_at(died, ao); panels = sys_at(panels, ao);
+		aux = sys_at(aux, ao); pivcol = sys_at(pivcol, ao); urow = sys_at(urow, ao); blk_first_out = sys_at(blk_first_out, ao);
+	}
+	__shared__ FastLds F;
+	block_fast_body<false>(F, M, rows, srows, j0, gb, fast_only, blk, Wb_in, st, died, panels, aux, pivcol, urow, blk_first_out, Pfast);
 }
 
 // The narrow halves of a block that k_block_fast has factorised, as a launch of its own (optimistic enqueue: no
@@ -1305,6 +1347,105 @@ k_narrow_all(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int blk, co
 	if (!(st->poison || st->fast_done != blk + 1))
 		narrow_all_panels(L, M, rows, srows, j0, Wb_in, died, aux, multset, upd_T, (i64)blockIdx.x, rpt, sig.count != nullptr);
 	signal_light(sig, blockIdx.y * ss.arena_bytes, gridDim.x);      // (narrow_done: the bulk stream's gate waits for it)
+}
+
+// Search and narrow step of a dense block in ONE launch (optimistic enqueue): workgroup 0 is k_block_fast, the others are
+// k_narrow_all -- but they start with it and take each panel the moment its pivot rows are formed (Pfast + the fast_pub
+// counter in SolveState) instead of after the whole search: when the search ends, three of the four narrow steps are done.
+// Workgroup 0 is dispatched first, so whoever spins has its producer resident; a spinner gives up after GF2_GATE_TICKS
+// like a hand-over gate (gate_timeout: the solve is void).  Pivot rows of this very block get zero multipliers as in
+// k_narrow_all: the rows look at died[] again after the last flag.
+struct NarrowLds { StepLds L; u64 Pall[GF2_GMAX - 1][GF2_GMAX][64]; int go; };
+__global__ void __launch_bounds__(256)
+k_block_fast_narrow(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int blk,
+                    const u64 *__restrict__ Wb_in, SolveState *__restrict__ st, int *__restrict__ died,
+                    PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol, int *__restrict__ urow,
+                    int *__restrict__ blk_first_out, u64 *__restrict__ Pfast, u64 *__restrict__ multset, int upd_T, int rpt,
+                    DoneSignal sig, SysStride ss)
+{
+	__builtin_amdgcn_s_setprio(3);
+	{
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		M += blockIdx.y * ss.m_words;
+		Wb_in = sys_at(Wb_in, ao); st = sys_at(st, ao); died = sys_at(died, ao); panels = sys_at(panels, ao);
+		aux = sys_at(aux, ao); pivcol = sys_at(pivcol, ao); urow = sys_at(urow, ao); blk_first_out = sys_at(blk_first_out, ao);
+		Pfast = sys_at(Pfast, ao); multset = sys_at(multset, ao);
+	}
+	constexpr size_t LB = sizeof(FastLds) > sizeof(NarrowLds) ? sizeof(FastLds) : sizeof(NarrowLds);
+	__shared__ __attribute__((aligned(16))) unsigned char lds[LB];
+	if (blockIdx.x == 0) {
+		block_fast_body<true>(*reinterpret_cast<FastLds *>(lds), M, rows, srows, j0, gb, 1, blk, Wb_in, st, died, panels, aux, pivcol, urow,
+		                      blk_first_out, Pfast);
+		signal_light(sig, blockIdx.y * ss.arena_bytes, gridDim.x);
+		return;
+	}
+	NarrowLds &N = *reinterpret_cast<NarrowLds *>(lds);
+	StepLds &L = N.L;
+	const int t = threadIdx.x, e_ = t >> 6, sl = t & 63;
+	// wait until the search workgroup has got as far as `stage` (1..3: panel stage - 1 formed; 5: published); 0 = it gave up
+	// (or a spinner timed out): nothing to narrow.  By all threads.
+	auto wait_for = [&](int stage) -> bool {
+		if (t == 0) {
+			int go = 1;
+			const unsigned long long t0 = wall_clock64();
+			while (GF2_LD(&st->fast_pub) < 8 * blk + stage) {
+				if (GF2_LD(&st->poison) || GF2_LD(&st->fast_off) || GF2_LD(&st->gate_timeout)) { go = 0; break; }
+				if (wall_clock64() - t0 > GF2_GATE_TICKS) { GF2_ST(&st->gate_timeout, 1); go = 0; break; }
+				__builtin_amdgcn_s_sleep(4);
+			}
+			N.go = go;
+		}
+		__syncthreads();
+		const bool go = N.go != 0;
+		__syncthreads();
+		return go;
+	};
+	bool live = !GF2_LD(&st->poison);
+	const i64 rb = (i64)blockIdx.x - 1;
+	int have = 0;                                           // panels whose pivot rows are in N.Pall
+	for (int r = 0; live && r < rpt; r++) {
+		const i64 i = (rb * rpt + r) * 256 + t;
+		if (i - t >= rows) break;                           // (uniform)
+		const i64 ic = i < rows ? i : rows - 1;
+		const bool alive = i < rows && died[ic] == GF2_NEVER;      // (before this block's pivots are marked: looked at again below)
+		const uint4 *src = reinterpret_cast<const uint4 *>(Wb_in + ic * GF2_GMAX);
+		const uint4 lo = src[0], hi = src[1];
+		u64 w[GF2_GMAX] = { ((u64)lo.y << 32) | lo.x, ((u64)lo.w << 32) | lo.z, ((u64)hi.y << 32) | hi.x, ((u64)hi.w << 32) | hi.z };
+		u64 m[GF2_GMAX];
+#pragma unroll
+		for (int g = 0; g < GF2_GMAX; g++) {
+			m[g] = alive ? w[g] : 0ull;
+			if (g == GF2_GMAX - 1) break;
+			if (have <= g) {                                // (uniform) first row batch: fetch the panel when it is there
+				if (!wait_for(g + 1)) { live = false; break; }
+				N.Pall[g][e_][sl] = GF2_LD(&Pfast[(g * GF2_GMAX + e_) * 64 + sl]);
+				have = g + 1;
+			}
+			__syncthreads();                                // the previous tables are done with (and Pall[g] is complete)
+			L.Pb[e_][sl] = N.Pall[g][e_][sl];
+			__syncthreads();
+			build_nibble_tables(L, t);
+			__syncthreads();
+			if (m[g]) {
+				u64 acc[GF2_GMAX];
+				nibble_rows(L.Tn, m[g], acc);
+#pragma unroll
+				for (int e = 0; e < GF2_GMAX; e++) if (e > g) w[e] ^= acc[e];
+			}
+		}
+		if (!live) break;
+		if (r == 0 && !wait_for(5)) { live = false; break; }
+		if (i < rows) {
+			const bool still = GF2_LD(&died[ic]) == GF2_NEVER;      // a pivot row of this block: no multipliers (as k_narrow_all sees it)
+#pragma unroll
+			for (int g = 0; g < GF2_GMAX; g++) {
+				const u64 v = mult_stored(upd_T, still ? m[g] : 0ull, i);
+				if (sig.count) GF2_ST(&multset[midx(g, i, rows)], v);      // (the launch announces its own end: signal_light)
+				else multset[midx(g, i, rows)] = v;
+			}
+		}
+	}
+	signal_light(sig, blockIdx.y * ss.arena_bytes, gridDim.x);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1507,7 +1648,7 @@ __global__ void __launch_bounds__(256)
 k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo, int gnext,
               const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
               const u64 *__restrict__ multset, const int *__restrict__ blk_first, u64 *__restrict__ Wb_out,
-              u64 *__restrict__ Uwin, int upd_T, const SolveState *__restrict__ st, SysStride ss)
+              u64 *__restrict__ Uwin, int upd_T, SolveState *__restrict__ st, SyncFlags *__restrict__ sf, int need_bulk, SysStride ss)
 {
 	__builtin_amdgcn_s_setprio(3);
 	if (sys_at(st, blockIdx.y * ss.arena_bytes)->poison) return;     // (the window buffer must stay what the resumed block needs)
@@ -1515,8 +1656,16 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 		const i64 ao = blockIdx.y * ss.arena_bytes;
 		M += blockIdx.y * ss.m_words;
 		panels = sys_at(panels, ao); aux = sys_at(aux, ao); multset = sys_at(multset, ao); blk_first = sys_at(blk_first, ao);
-		Wb_out = sys_at(Wb_out, ao); Uwin = sys_at(Uwin, ao);
+		Wb_out = sys_at(Wb_out, ao); Uwin = sys_at(Uwin, ao); st = sys_at(st, ao);
+		if (sf) sf = sys_at(sf, ao);
 	}
+	// sf (flag hand-over): this launch is its own gate -- every workgroup waits for "bulk update of block b - 1 complete"
+	// (bulk_done >= need_bulk, announced by the bulk stream's gate of block b, submitted before this launch) AFTER it has
+	// requested its parameters and multipliers, which do not depend on it: no k_gate launch in between (2-3 us + a launch
+	// gap per block).  The matrix words are then read with agent-scope loads: the bulk update may have written them on
+	// another XCD after this kernel began, i.e. after the invalidate at its start.
+	const bool own_gate = sf != nullptr && need_bulk > 0;
+	auto ldM = [&](const u64 *q) -> u64 { return own_gate ? GF2_LD(q) : *q; };
 	constexpr int W = GF2_GMAX;
 	static_assert(W == 4, "thread <-> table entry mapping below");
 	// [panel][slot][word] source rows; once panel g's tables are built its slice is dead and takes the pivot rows
@@ -1547,9 +1696,23 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 		mrow[g] = multset[midx(gc, ic, rows)];
 		if (g >= gb) { rec[g].p = 0; rec[g].mask = 0; mrow[g] = 0; }
 	}
+	if (own_gate) {
+		__shared__ int gate_ok;
+		if (t == 0) {
+			int okv = 1, polls = 0;
+			const unsigned long long t0 = wall_clock64();
+			while (GF2_LD(&sf->bulk_done) < need_bulk) {
+				if (++polls < 512) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(64);
+				if (wall_clock64() - t0 > GF2_GATE_TICKS || GF2_LD(&st->gate_timeout)) { GF2_ST(&st->gate_timeout, 1); okv = 0; break; }
+			}
+			gate_ok = okv;
+		}
+		__syncthreads();
+		if (!gate_ok) return;                               // (the solve is void: the host reports it)
+	}
 	u64 wv[W];
 #pragma unroll
-	for (int e = 0; e < W; e++) wv[e] = M[tidx(ic, wlo + (e < gnext ? e : 0), srows)];
+	for (int e = 0; e < W; e++) wv[e] = ldM(&M[tidx(ic, wlo + (e < gnext ? e : 0), srows)]);
 	// every row of this workgroup is dead (uniform); workgroup 0 still runs: it records the pivot rows' window words
 	if (blockIdx.x != 0 && (i64)(blockIdx.x + 1) * 256 <= first) return;
 	int anyp = 0;
@@ -1558,7 +1721,7 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 	if (anyp) {
 #pragma unroll
 		for (int g = 0; g < GF2_GMAX; g++) {
-			const u64 v = M[tidx(r < rec[g].p ? srow[g] : 0, wlo + (live ? w : 0), srows)];
+			const u64 v = ldM(&M[tidx(r < rec[g].p ? srow[g] : 0, wlo + (live ? w : 0), srows)]);
 			S[(g * 64 + r) * W + w] = (r < rec[g].p && live) ? v : 0ull;
 			if (w == 0 && ((rec[g].mask >> r) & 1)) Bk[g * 64 + __popcll(rec[g].mask & lanemask_lt(r))] = r;
 		}

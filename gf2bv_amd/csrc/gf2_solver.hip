@@ -355,6 +355,8 @@ struct Solver {
 	bool ext_events = true;       // hand-off and timing events ride on kernel start / completion signals (hipExtLaunchKernel)
 	                              // instead of marker packets: ~1 % at every size; GF2BV_EXT_EVENTS=0 restores hipEventRecord
 	int sparse_mode = 2;          // search skips absent columns: 0 never, 1 always, 2 per chunk by density (GF2BV_SPARSE)
+	bool prio_gate = false;       // GF2BV_PRIO_GATE=1: k_prio_window behind a k_gate launch instead of waiting for the bulk update itself
+	bool fused_narrow = true;     // optimistic blocks: search and narrow step in ONE launch (k_block_fast_narrow); GF2BV_FUSED_NARROW=0: two
 	int narrow_rpt = 1;           // row blocks of 256 per narrow workgroup of a panel step (set in solver_alloc; GF2BV_NARROW_RPT)
 	int self_wait = 5000;         // ticks (100 MHz) unit 0 of a panel search waits for the other units before it leaves
 	                              // publishing to the last arriver: 50 us (GF2BV_SELF_WAIT_US; 0 = never wait)
@@ -533,6 +535,8 @@ int solver_alloc(Solver &S)
 	if (const char *e = getenv("GF2BV_FLAG_SYNC")) S.flag_sync = S.flag_sync && atoi(e) != 0;
 	if (getenv("GF2BV_SERIAL")) S.flag_sync = false;      // (one stream: the panel gate would wait for a gate queued behind it)
 	if (const char *e = getenv("GF2BV_OPTIMISTIC")) S.optimistic = atoi(e) != 0;
+	if (const char *e = getenv("GF2BV_FUSED_NARROW")) S.fused_narrow = atoi(e) != 0;
+	if (const char *e = getenv("GF2BV_PRIO_GATE")) S.prio_gate = atoi(e) != 0;
 	// narrow workgroups: as many rows each as keeps ~256 of them (all systems of a gang together) busy, at most 8 blocks
 	{
 		const i64 blocks = (S.rows + 255) / 256 * std::max(1, S.nsys);
@@ -744,6 +748,17 @@ int enqueue_block_panel(Solver &S, int b, bool fast_only = false)
 	const BlockGeom g = block_geom(S, b);
 	const unsigned row_blocks = (unsigned)((S.rows + 255) / 256);
 	u64 *const half[2] = { S.Wb, S.Wb + (i64)GF2_GMAX * S.rows };
+	if (fast_only && S.fused_narrow) {
+		// search + narrow step in one launch: workgroup 0 searches, the others narrow each panel as soon as it is formed
+		hipExtLaunchKernelGGL(k_block_fast_narrow, dim3(1 + (row_blocks + S.narrow_rpt - 1) / S.narrow_rpt, S.nsys), dim3(256), 0, S.sA, nullptr,
+		                      S.ext_events && !S.flag_sync ? S.evA[b] : nullptr, 0, S.M, S.rows, S.srows, g.j0, g.gb, b, (const u64 *)half[0],
+		                      S.st, S.died, S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, S.Pfast, g.mset, S.impl->T, S.narrow_rpt,
+		                      S.flag_sync ? DoneSignal{ &S.sf->cnt_narrow, &S.sf->narrow_done, S.sync_base + b + 1 } : DoneSignal{}, S.ss());
+		HIPCHK(hipGetLastError());
+		if (S.flag_sync) return GF2BV_OK;       // (the launch announces narrow_done itself)
+		if (!S.ext_events) HIPCHK(hipEventRecord(S.evA[b], S.sA));
+		return GF2BV_OK;
+	}
 	if (fast_only) {
 		k_block_fast<<<dim3(1, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, 1, b, (const u64 *)half[0], S.st, S.died,
 		                                                      S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, S.Pfast, S.ss());
@@ -834,13 +849,17 @@ int enqueue_block_prio(Solver &S, int b)
 	const BlockGeom g = block_geom(S, b);
 	const unsigned row_blocks = (unsigned)((S.rows + 255) / 256);
 	if (b > 0 && !S.flag_sync) HIPCHK(hipStreamWaitEvent(S.sA, S.waitPrio[b - 1], 0));
-	if (b > 0 && S.flag_sync) {      // the bulk update of block b - 1: announced by the bulk stream's gate of block b (submitted before this one)
+	// flag hand-over: the bulk update of block b - 1 is announced by the bulk stream's gate of block b (submitted before this
+	// launch), and the launch waits for it itself (GF2BV_PRIO_GATE=1: a k_gate launch in front of it, as before round 3)
+	const bool own_gate = b > 0 && S.flag_sync && !S.prio_gate;
+	if (b > 0 && S.flag_sync && !own_gate) {
 		k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sA>>>(S.sf, S.st, 0, 0, 0, S.sync_base + b, S.ss());
 		HIPCHK(hipGetLastError());
 	}
 	k_prio_window<<<dim3(row_blocks, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, g.wlo, std::max(g.gnext, 1),
 	                                                             S.panels, S.aux, g.mset, S.blk_first + b, S.Wb, S.Uwin,
-	                                                             S.impl->T, S.st, S.ss());
+	                                                             S.impl->T, S.st, own_gate ? S.sf : (SyncFlags *)nullptr,
+	                                                             own_gate ? S.sync_base + b : 0, S.ss());
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
@@ -2086,6 +2105,11 @@ int gf2bv_kernel_resources(int device, int32_t *out, int n)
 		hipFuncAttributes a{};
 		HIPCHK(hipFuncGetAttributes(&a, (const void *)k_update16k<GF2_KSEG>));
 		out[10] = a.numRegs; out[11] = (int32_t)a.sharedSizeBytes; out[12] = (int32_t)a.localSizeBytes;
+	}
+	if (n >= 15) {                 // search + narrow step in one launch (runs beside the bulk update like the two it replaces)
+		hipFuncAttributes a{};
+		HIPCHK(hipFuncGetAttributes(&a, (const void *)k_block_fast_narrow));
+		out[13] = a.numRegs; out[14] = (int32_t)a.sharedSizeBytes;
 	}
 	return GF2BV_OK;
 	});

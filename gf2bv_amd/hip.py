@@ -300,11 +300,12 @@ def stream_ceiling(nbytes: int = 2 << 30, device: int = 0) -> dict:
 
 def kernel_resources(device: int = 0) -> dict:
     """VGPRs per lane and static LDS bytes of the bulk-update kernel and of the panel kernels that run beside it."""
-    out = (ctypes.c_int32 * 13)()
-    _check(lib().gf2bv_kernel_resources(device, out, 13))
+    out = (ctypes.c_int32 * 15)()
+    _check(lib().gf2bv_kernel_resources(device, out, 15))
     names = ("update", "block_fast", "narrow_all", "prio_window", "panel_step")
     res = {nm: {"vgprs": int(out[2 * k]), "lds": int(out[2 * k + 1])} for k, nm in enumerate(names)}
     res["update_outer"] = {"vgprs": int(out[10]), "lds": int(out[11]), "scratch": int(out[12])}      # k_update16k (two-level)
+    res["block_fast_narrow"] = {"vgprs": int(out[13]), "lds": int(out[14])}                          # search + narrow step in one launch
     return res
 
 

@@ -232,7 +232,7 @@ int gf2bv_stream_ceiling_device(int device, int64_t bytes, double *rmw_gbs, doub
  * instance, then k_block_fast, k_narrow_all, k_prio_window, k_panel_step (registers, LDS each; n >= 10).  A test holds the
  * budget: registers <= 512 - 2 x round_up(update's, 8), LDS <= 160 KiB - update's.  With n >= 13: out[10..12] = registers,
  * LDS and SCRATCH bytes per lane of k_update16k, the outer pass of the two-level elimination (it keeps 16 row segments per
- * lane in registers: scratch must be 0). */
+ * lane in registers: scratch must be 0).  With n >= 15: out[13..14] = registers, LDS of k_block_fast_narrow. */
 int gf2bv_kernel_resources(int device, int32_t *out, int n);
 
 /* plain device buffer helpers so a host language without a HIP binding can stage data */

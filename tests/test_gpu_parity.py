@@ -544,7 +544,7 @@ def test_panel_kernels_fit_beside_the_bulk_update():
     upd = res["update"]
     free_vgprs = 512 - 2 * ((upd["vgprs"] + 7) // 8 * 8)
     free_lds = 160 * 1024 - upd["lds"]
-    for name in ("block_fast", "narrow_all", "prio_window", "panel_step"):
+    for name in ("block_fast", "narrow_all", "prio_window", "panel_step", "block_fast_narrow"):
         assert res[name]["vgprs"] <= free_vgprs, (name, res)
         assert res[name]["lds"] <= free_lds, (name, res)
     # the outer pass of the two-level elimination keeps 16 row segments per lane in registers: it must not spill (a spilled

@@ -57,6 +57,38 @@ def test_mode1_gang_of_mixed_ranks_at_8192(monkeypatch):
         _same(g, O.solve_words(a, n, n, 1), 1)
 
 
+@pytest.mark.parametrize("fused,prio_gate", [(1, 0), (0, 0), (1, 1), (0, 1)])
+def test_fused_search_and_narrow_launch_and_the_look_ahead_as_its_own_gate(monkeypatch, fused, prio_gate):
+    """Round 3's panel path: k_block_fast_narrow (workgroup 0 searches, the others narrow every panel the moment its pivot
+    rows are formed -- progress counter in SolveState, write-through stores for everything the bulk stream reads) and
+    k_prio_window waiting for the bulk update itself, against the separate launches they replace (GF2BV_FUSED_NARROW=0,
+    GF2BV_PRIO_GATE=1) and the oracle: full rank, rank caps in the middle of a block (the search gives up after it has
+    published some panels: poison, resume with the general steps), rows >> cols, a gang, and 16 solves in flight at once."""
+    from concurrent.futures import ThreadPoolExecutor
+    monkeypatch.setenv("GF2BV_FUSED_NARROW", str(fused))
+    monkeypatch.setenv("GF2BV_PRIO_GATE", str(prio_gate))
+    rng = random.Random(77)
+    jobs = []
+    for rows, cols, density, cap, cons in ((2700, 2600, .5, None, True), (5000, 4097, .5, 2600, True), (2300, 2200, .5, 2193, True),
+                                           (9000, 1300, .5, 700, False), (3100, 3000, .5, 300, True)):
+        eqs = random_system(rng, rows, cols, density, cap, cons, 0)
+        aug = O.eqs_to_aug(eqs, cols)
+        want = O.solve_words(aug, rows, cols, 1)
+        got = hip.solve_words(aug, rows, cols, 1)
+        _same(got, want, 1)
+        jobs.append((aug, rows, cols, want))
+    assert got.stats["fast_blocks"] > 0
+    with ThreadPoolExecutor(16) as ex:
+        res = list(ex.map(lambda j: hip.solve_words(j[0], j[1], j[2], 1), jobs * 6))
+    for j, g in zip(jobs * 6, res):
+        _same(g, j[3], 1)
+    n = 2048
+    augs = np.stack([O.eqs_to_aug(random_system(rng, n, n, .5, cap, True, 0), n) for cap in (None, n - 1, 1500, None, 700)])
+    monkeypatch.setenv("GF2BV_GANG", "5")
+    for a, g in zip(augs, hip.solve_batch_words(augs, n, n, 1)):
+        _same(g, O.solve_words(a, n, n, 1), 1)
+
+
 @pytest.mark.parametrize("K,chain", [(2, 0), (3, 0), (4, 0), (8, 0), (4, 1), (8, 1)])
 def test_two_level_elimination_forced_on_small_systems(monkeypatch, K, chain):
     """GF2BV_TWO_LEVEL=K: outer panels of K blocks from the first block on (k_outer_trsm<IDENT> + k_outer_apply + k_update16k; chain:
