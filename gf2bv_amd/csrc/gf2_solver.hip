@@ -79,8 +79,14 @@ struct Trace {
 		t0 = t;
 	}
 };
-// rows of one tile slab: slab bytes = 256 (mod 8192), so neighbouring tiles are skewed across channels
-inline i64 slab_rows(i64 rows) { return round_up(std::max<i64>(rows, 1), 64) + 2; }
+// rows of one tile slab: the rows padded to a wavefront's 64, plus 64 more (>= 1 is needed: rows nobody owns take the outer
+// pass's dummy stores).  A slab is then a whole number of KiB, and a wavefront's batch -- 64 consecutive rows of a 16-byte tile
+// -- is eight whole 128-byte lines.  Rounds 1-2 padded by 2 rows ("skew neighbouring tiles across the channels": 32 bytes per
+// tile with 16-byte tiles): every batch of every tile but the first then straddled NINE lines.  65536^2: 33.7 -> 32.5 ms with
+// any multiple of 64 (64 ... 1024 alike: the channel hash does not care about the stride); other sizes 0-1 %
+// (profiles/r03_slab_pad.txt; GF2BV_SLAB_PAD=2 restores the old layout).
+inline i64 slab_pad() { static const i64 pad = getenv("GF2BV_SLAB_PAD") ? std::max<i64>(1, atol(getenv("GF2BV_SLAB_PAD"))) : 64; return pad; }
+inline i64 slab_rows(i64 rows) { return round_up(std::max<i64>(rows, 1), 64) + slab_pad(); }
 // column tiles of a row of wt words: whole ownership units of 8 words (one 64-byte tile / four 16-byte tiles)
 inline i64 tiles_for(i64 wt) { return round_up(std::max<i64>(wt, 1), (i64)1 << GF2_OWN_LOG) / GF2_TW; }
 

@@ -32,7 +32,7 @@ int main(int argc, char **argv)
 	const i64 rows = argc > 1 ? atol(argv[1]) : 131072;
 	const int ntiles = argc > 2 ? atoi(argv[2]) : 512;               // 8 KiB of row width by default: 1 GiB
 	const int wgs = argc > 3 ? atoi(argv[3]) : 256;
-	const i64 srows = (rows + 63) / 64 * 64 + 2;
+	const i64 srows = (rows + 63) / 64 * 64 + (getenv("MB_PAD") ? atol(getenv("MB_PAD")) : 64);      // MB_PAD: rows of padding behind a tile (x 16 B): does the tile stride matter to the HBM channels?
 	const i64 R64 = (rows + 63) / 64 * 64;
 	u64 *M, *mult4; PanelRec *panels; PanelAux *aux; int *blkf;
 	const size_t mwords = (size_t)ntiles * srows * 2;
