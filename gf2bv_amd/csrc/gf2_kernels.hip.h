@@ -2122,6 +2122,8 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 			const i64 ic = i < nb ? i : nb - 1;         // (a prefetch past the end re-reads the last batch: no control flow around loads)
 			const i64 row = rbeg + (ic * NW + wv) * 64 + lane;
 			H.row = row;
+			// (the two 16-byte halves of a row's multipliers side by side: as two contiguous planes -- every load then whole
+			// lines of its own -- the kernel is 5-7 % SLOWER, 4.08 against 4.31 TB/s at 65536 x 512 tiles: a third stream per wave)
 			H.m0 = mq[row * 2]; H.m1 = mq[row * 2 + 1];
 #ifdef GF2_MB_L2               /* tools/microbench_update16.hip: keep the row data L2-resident to time the table work alone */
 			H.d = Mw[row & 4095];
