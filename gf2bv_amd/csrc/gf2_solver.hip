@@ -361,6 +361,7 @@ struct Solver {
 	bool ext_events = true;       // hand-off and timing events ride on kernel start / completion signals (hipExtLaunchKernel)
 	                              // instead of marker packets: ~1 % at every size; GF2BV_EXT_EVENTS=0 restores hipEventRecord
 	int sparse_mode = 2;          // search skips absent columns: 0 never, 1 always, 2 per chunk by density (GF2BV_SPARSE)
+	int fused_rpt = 0;            // GF2BV_FUSED_RPT: row blocks of 256 per narrowing workgroup of k_block_fast_narrow (0 = by size)
 	bool prio_gate = false;       // GF2BV_PRIO_GATE=1: k_prio_window behind a k_gate launch instead of waiting for the bulk update itself
 	bool fused_narrow = true;     // optimistic blocks: search and narrow step in ONE launch (k_block_fast_narrow); GF2BV_FUSED_NARROW=0: two
 	int narrow_rpt = 1;           // row blocks of 256 per narrow workgroup of a panel step (set in solver_alloc; GF2BV_NARROW_RPT)
@@ -543,6 +544,7 @@ int solver_alloc(Solver &S)
 	if (const char *e = getenv("GF2BV_OPTIMISTIC")) S.optimistic = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_FUSED_NARROW")) S.fused_narrow = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_PRIO_GATE")) S.prio_gate = atoi(e) != 0;
+	if (const char *e = getenv("GF2BV_FUSED_RPT")) S.fused_rpt = atoi(e);
 	// narrow workgroups: as many rows each as keeps ~256 of them (all systems of a gang together) busy, at most 8 blocks
 	{
 		const i64 blocks = (S.rows + 255) / 256 * std::max(1, S.nsys);
@@ -756,9 +758,14 @@ int enqueue_block_panel(Solver &S, int b, bool fast_only = false)
 	u64 *const half[2] = { S.Wb, S.Wb + (i64)GF2_GMAX * S.rows };
 	if (fast_only && S.fused_narrow) {
 		// search + narrow step in one launch: workgroup 0 searches, the others narrow each panel as soon as it is formed
-		hipExtLaunchKernelGGL(k_block_fast_narrow, dim3(1 + (row_blocks + S.narrow_rpt - 1) / S.narrow_rpt, S.nsys), dim3(256), 0, S.sA, nullptr,
+		// at most ~128 narrowing workgroups: they stay resident for the whole search, and a CU that holds TWO of them (2 x 26 KiB
+		// of LDS) cannot take a bulk-update workgroup (133 of 160 KiB) until they end -- with 257 workgroups on 256 CUs there is
+		// always such a CU, and the pass whose launch lands just behind the search waits ~20 us for its last workgroup
+		// (tools/pass_rates.py: every fourth pass of the mid-range of a 65536^2 solve)
+		const int rpt = S.fused_rpt > 0 ? S.fused_rpt : (int)std::min<i64>(8, std::max<i64>(S.narrow_rpt, (row_blocks + 127) / 128));
+		hipExtLaunchKernelGGL(k_block_fast_narrow, dim3(1 + (row_blocks + rpt - 1) / rpt, S.nsys), dim3(256), 0, S.sA, nullptr,
 		                      S.ext_events && !S.flag_sync ? S.evA[b] : nullptr, 0, S.M, S.rows, S.srows, g.j0, g.gb, b, (const u64 *)half[0],
-		                      S.st, S.died, S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, S.Pfast, g.mset, S.impl->T, S.narrow_rpt,
+		                      S.st, S.died, S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, S.Pfast, g.mset, S.impl->T, rpt,
 		                      S.flag_sync ? DoneSignal{ &S.sf->cnt_narrow, &S.sf->narrow_done, S.sync_base + b + 1 } : DoneSignal{}, S.ss());
 		HIPCHK(hipGetLastError());
 		if (S.flag_sync) return GF2BV_OK;       // (the launch announces narrow_done itself)
