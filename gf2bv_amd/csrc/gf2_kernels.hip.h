@@ -1648,7 +1648,7 @@ __global__ void __launch_bounds__(256)
 k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo, int gnext,
               const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
               const u64 *__restrict__ multset, const int *__restrict__ blk_first, u64 *__restrict__ Wb_out,
-              u64 *__restrict__ Uwin, int upd_T, SolveState *__restrict__ st, SyncFlags *__restrict__ sf, int need_bulk, SysStride ss)
+              u64 *__restrict__ Uwin, int upd_T, const SolveState *__restrict__ st, SysStride ss)
 {
 	__builtin_amdgcn_s_setprio(3);
 	if (sys_at(st, blockIdx.y * ss.arena_bytes)->poison) return;     // (the window buffer must stay what the resumed block needs)
@@ -1656,16 +1656,8 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 		const i64 ao = blockIdx.y * ss.arena_bytes;
 		M += blockIdx.y * ss.m_words;
 		panels = sys_at(panels, ao); aux = sys_at(aux, ao); multset = sys_at(multset, ao); blk_first = sys_at(blk_first, ao);
-		Wb_out = sys_at(Wb_out, ao); Uwin = sys_at(Uwin, ao); st = sys_at(st, ao);
-		if (sf) sf = sys_at(sf, ao);
+		Wb_out = sys_at(Wb_out, ao); Uwin = sys_at(Uwin, ao);
 	}
-	// sf (flag hand-over): this launch is its own gate -- every workgroup waits for "bulk update of block b - 1 complete"
-	// (bulk_done >= need_bulk, announced by the bulk stream's gate of block b, submitted before this launch) AFTER it has
-	// requested its parameters and multipliers, which do not depend on it: no k_gate launch in between (2-3 us + a launch
-	// gap per block).  The matrix words are then read with agent-scope loads: the bulk update may have written them on
-	// another XCD after this kernel began, i.e. after the invalidate at its start.
-	const bool own_gate = sf != nullptr && need_bulk > 0;
-	auto ldM = [&](const u64 *q) -> u64 { return own_gate ? GF2_LD(q) : *q; };
 	constexpr int W = GF2_GMAX;
 	static_assert(W == 4, "thread <-> table entry mapping below");
 	// [panel][slot][word] source rows; once panel g's tables are built its slice is dead and takes the pivot rows
@@ -1696,23 +1688,9 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 		mrow[g] = multset[midx(gc, ic, rows)];
 		if (g >= gb) { rec[g].p = 0; rec[g].mask = 0; mrow[g] = 0; }
 	}
-	if (own_gate) {
-		__shared__ int gate_ok;
-		if (t == 0) {
-			int okv = 1, polls = 0;
-			const unsigned long long t0 = wall_clock64();
-			while (GF2_LD(&sf->bulk_done) < need_bulk) {
-				if (++polls < 512) __builtin_amdgcn_s_sleep(2); else __builtin_amdgcn_s_sleep(64);
-				if (wall_clock64() - t0 > GF2_GATE_TICKS || GF2_LD(&st->gate_timeout)) { GF2_ST(&st->gate_timeout, 1); okv = 0; break; }
-			}
-			gate_ok = okv;
-		}
-		__syncthreads();
-		if (!gate_ok) return;                               // (the solve is void: the host reports it)
-	}
 	u64 wv[W];
 #pragma unroll
-	for (int e = 0; e < W; e++) wv[e] = ldM(&M[tidx(ic, wlo + (e < gnext ? e : 0), srows)]);
+	for (int e = 0; e < W; e++) wv[e] = M[tidx(ic, wlo + (e < gnext ? e : 0), srows)];
 	// every row of this workgroup is dead (uniform); workgroup 0 still runs: it records the pivot rows' window words
 	if (blockIdx.x != 0 && (i64)(blockIdx.x + 1) * 256 <= first) return;
 	int anyp = 0;
@@ -1721,7 +1699,7 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 	if (anyp) {
 #pragma unroll
 		for (int g = 0; g < GF2_GMAX; g++) {
-			const u64 v = ldM(&M[tidx(r < rec[g].p ? srow[g] : 0, wlo + (live ? w : 0), srows)]);
+			const u64 v = M[tidx(r < rec[g].p ? srow[g] : 0, wlo + (live ? w : 0), srows)];
 			S[(g * 64 + r) * W + w] = (r < rec[g].p && live) ? v : 0ull;
 			if (w == 0 && ((rec[g].mask >> r) & 1)) Bk[g * 64 + __popcll(rec[g].mask & lanemask_lt(r))] = r;
 		}

@@ -43,10 +43,12 @@ int fail(int code, const char *what, hipError_t e = hipSuccess)
 // has been marked accordingly (streams_run_concurrently) and the solve is repeated once, with the event hand-over: the
 // input is never modified.
 #define GF2BV_RETRY_EVENTS (-77)
+thread_local int g_attempt = 0;      // attempt of the running C-ABI call (gf2bv_stats::handover_retries)
 template <class F>
 int guarded(F &&body)
 {
 	for (int attempt = 0;; attempt++) {
+		g_attempt = attempt;
 		try {
 			const int rc = body();
 			if (rc != GF2BV_RETRY_EVENTS) return rc;
@@ -362,7 +364,6 @@ struct Solver {
 	                              // instead of marker packets: ~1 % at every size; GF2BV_EXT_EVENTS=0 restores hipEventRecord
 	int sparse_mode = 2;          // search skips absent columns: 0 never, 1 always, 2 per chunk by density (GF2BV_SPARSE)
 	int fused_rpt = 0;            // GF2BV_FUSED_RPT: row blocks of 256 per narrowing workgroup of k_block_fast_narrow (0 = by size)
-	bool prio_gate = false;       // GF2BV_PRIO_GATE=1: k_prio_window behind a k_gate launch instead of waiting for the bulk update itself
 	bool fused_narrow = true;     // optimistic blocks: search and narrow step in ONE launch (k_block_fast_narrow); GF2BV_FUSED_NARROW=0: two
 	int narrow_rpt = 1;           // row blocks of 256 per narrow workgroup of a panel step (set in solver_alloc; GF2BV_NARROW_RPT)
 	int self_wait = 5000;         // ticks (100 MHz) unit 0 of a panel search waits for the other units before it leaves
@@ -543,7 +544,6 @@ int solver_alloc(Solver &S)
 	if (getenv("GF2BV_SERIAL")) S.flag_sync = false;      // (one stream: the panel gate would wait for a gate queued behind it)
 	if (const char *e = getenv("GF2BV_OPTIMISTIC")) S.optimistic = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_FUSED_NARROW")) S.fused_narrow = atoi(e) != 0;
-	if (const char *e = getenv("GF2BV_PRIO_GATE")) S.prio_gate = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_FUSED_RPT")) S.fused_rpt = atoi(e);
 	// narrow workgroups: as many rows each as keeps ~256 of them (all systems of a gang together) busy, at most 8 blocks
 	{
@@ -862,17 +862,17 @@ int enqueue_block_prio(Solver &S, int b)
 	const BlockGeom g = block_geom(S, b);
 	const unsigned row_blocks = (unsigned)((S.rows + 255) / 256);
 	if (b > 0 && !S.flag_sync) HIPCHK(hipStreamWaitEvent(S.sA, S.waitPrio[b - 1], 0));
-	// flag hand-over: the bulk update of block b - 1 is announced by the bulk stream's gate of block b (submitted before this
-	// launch), and the launch waits for it itself (GF2BV_PRIO_GATE=1: a k_gate launch in front of it, as before round 3)
-	const bool own_gate = b > 0 && S.flag_sync && !S.prio_gate;
-	if (b > 0 && S.flag_sync && !own_gate) {
+	// the bulk update of block b - 1: announced by the bulk stream's gate of block b (submitted before this one).  A k_gate
+	// launch -- ONE spinning wavefront -- and not a wait inside k_prio_window (built in round 3: 32768^2 8.85 -> 8.7 ms): up
+	// to thousands of workgroups spinning with 17 KiB of LDS each can sit on every CU before the bulk update they wait for
+	// has been placed, which needs 133 KiB of a CU -- a deadlock until the time-out; seen at 327680^2 and beyond.
+	if (b > 0 && S.flag_sync) {
 		k_gate<<<dim3(1, S.nsys), dim3(64), 0, S.sA>>>(S.sf, S.st, 0, 0, 0, S.sync_base + b, S.ss());
 		HIPCHK(hipGetLastError());
 	}
 	k_prio_window<<<dim3(row_blocks, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, g.wlo, std::max(g.gnext, 1),
 	                                                             S.panels, S.aux, g.mset, S.blk_first + b, S.Wb, S.Uwin,
-	                                                             S.impl->T, S.st, own_gate ? S.sf : (SyncFlags *)nullptr,
-	                                                             own_gate ? S.sync_base + b : 0, S.ss());
+	                                                             S.impl->T, S.st, S.ss());
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
@@ -1281,6 +1281,7 @@ int finish_end(Solver &S, gf2bv_result **out)
 		}
 	}
 	st.ms_pack = S.ms_pack;
+	st.handover_retries = g_attempt;
 	(void)hipEventElapsedTime(&st.ms_eliminate, S.ev0, S.ev1);
 	(void)hipEventElapsedTime(&st.ms_backsub, S.ev1, S.ev2);
 	(void)hipEventElapsedTime(&st.ms_export, S.ev2, evx);
@@ -1489,6 +1490,7 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 				// an expired hand-over gate voids THIS gang only: its results (if any were built) are dropped and the
 				// gang runs once more with events -- the device is marked by then; other gangs' results stay
 				for (int attempt = 0; attempt < 2; attempt++) {
+					g_attempt = attempt;                        // (this worker thread's: gf2bv_stats::handover_retries of the gang)
 					Solver S;
 					S.t_begin = std::chrono::steady_clock::now();
 					S.device = device;

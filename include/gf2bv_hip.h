@@ -71,6 +71,9 @@ typedef struct gf2bv_stats {
 	double  hbm_words;         /* 64-bit words the bulk-update launches moved (each read once and written once)       */
 	int32_t bulk_launches;     /* k_update16 + k_update16k launches that had pivots to apply                          */
 	int32_t outer_blocks;      /* blocks applied through outer passes (0: one-level schedule)                         */
+	int32_t handover_retries;  /* 1: a stream hand-over gate expired on the device and this is the result of the SECOND attempt,
+	                              made with events (the device stays on events for this process); 0 normally        */
+	int32_t reserved0;
 } gf2bv_stats;
 
 /* ---- library / device ------------------------------------------------------------------ */

@@ -579,13 +579,40 @@ def test_target_262144_properties():
     _dense_properties(262144, 1234)
 
 
-def _dense_properties(n, seed):
+@pytest.mark.timeout(300)
+def test_two_level_beyond_the_target_size_hands_over_without_retry():
+    """327680 x 327680 (12.5 GiB + the working copy; ~2.5 s): the two-level schedule with 1280 row blocks per all-rows launch.
+    Round 3 built a look-ahead that waited for the bulk update INSIDE k_prio_window: its workgroups, spinning with 17 KiB of LDS
+    each, sat on every CU before the bulk update they were waiting for had been placed (133 KiB of a CU) -- a deadlock until the
+    gate time-out; every solve of this size ran twice (9.9 s instead of 2.5 s) and was still bit-exact, so only the retry
+    counter shows it."""
+    _dense_properties(327680, 1234, repeat=False)
+
+
+@pytest.mark.timeout(120)
+def test_tall_system_hands_over_without_retry():
+    """400000 x 3000: 1563 row blocks per all-rows launch on a one-level schedule; the result against the residual check."""
+    rows, cols = 400000, 3000
+    stride = hip.padded_stride(cols)
+    buf = hip.DeviceBuffer(rows * stride * 8)
+    hip.synth_device(buf.ptr, rows, cols, stride, 77)
+    sol = hip.solve_device(buf.ptr, rows, cols, stride, 0)
+    hip.synth_device(buf.ptr, rows, cols, stride, 77)
+    assert sol.status == 0 and sol.rank == cols and sol.stats["handover_retries"] == 0
+    assert hip.residual_device(buf.ptr, rows, cols, stride, sol.origin) == 0
+    buf.free()
+
+
+def _dense_properties(n, seed, repeat=True):
     stride = hip.padded_stride(n)
     buf = hip.DeviceBuffer(n * stride * 8)
     hip.synth_device(buf.ptr, n, n, stride, seed)
     sol = hip.solve_device(buf.ptr, n, n, stride, 0)
     hip.synth_device(buf.ptr, n, n, stride, seed)
     assert sol.status == 0 and hip.residual_device(buf.ptr, n, n, stride, sol.origin) == 0
+    # no hand-over gate expired on the way (the call would have repeated the solve with events and still be right --
+    # at several times the run time, and the device would stay on events for the rest of the process)
+    assert sol.stats["handover_retries"] == 0
     piv = sol.pivots
     assert len(piv) == sol.rank and (np.diff(piv) > 0).all() and sol.rank >= n - 8
     free = np.setdiff1d(np.arange(n), piv)
@@ -595,7 +622,8 @@ def _dense_properties(n, seed):
         assert np.array_equal(x, O.planted_solution(n, seed))
     # linearity: the solution of the system with RHS flipped on a pivot-consistent way is covered by
     # mode 1 at a smaller size (test_words_path_matches_oracle); here: solving twice is deterministic
-    hip.synth_device(buf.ptr, n, n, stride, seed)
-    again = hip.solve_device(buf.ptr, n, n, stride, 0)
-    assert np.array_equal(again.origin, sol.origin) and again.rank == sol.rank
+    if repeat:
+        hip.synth_device(buf.ptr, n, n, stride, seed)
+        again = hip.solve_device(buf.ptr, n, n, stride, 0)
+        assert np.array_equal(again.origin, sol.origin) and again.rank == sol.rank
     buf.free()

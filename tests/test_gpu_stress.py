@@ -57,16 +57,14 @@ def test_mode1_gang_of_mixed_ranks_at_8192(monkeypatch):
         _same(g, O.solve_words(a, n, n, 1), 1)
 
 
-@pytest.mark.parametrize("fused,prio_gate", [(1, 0), (0, 0), (1, 1), (0, 1)])
-def test_fused_search_and_narrow_launch_and_the_look_ahead_as_its_own_gate(monkeypatch, fused, prio_gate):
+@pytest.mark.parametrize("fused", [1, 0])
+def test_fused_search_and_narrow_launch(monkeypatch, fused):
     """Round 3's panel path: k_block_fast_narrow (workgroup 0 searches, the others narrow every panel the moment its pivot
-    rows are formed -- progress counter in SolveState, write-through stores for everything the bulk stream reads) and
-    k_prio_window waiting for the bulk update itself, against the separate launches they replace (GF2BV_FUSED_NARROW=0,
-    GF2BV_PRIO_GATE=1) and the oracle: full rank, rank caps in the middle of a block (the search gives up after it has
+    rows are formed -- progress counter in SolveState, write-through stores for everything the bulk stream reads) against the
+    two launches it replaces (GF2BV_FUSED_NARROW=0) and the oracle: full rank, rank caps in the middle of a block (the search gives up after it has
     published some panels: poison, resume with the general steps), rows >> cols, a gang, and 16 solves in flight at once."""
     from concurrent.futures import ThreadPoolExecutor
     monkeypatch.setenv("GF2BV_FUSED_NARROW", str(fused))
-    monkeypatch.setenv("GF2BV_PRIO_GATE", str(prio_gate))
     rng = random.Random(77)
     jobs = []
     for rows, cols, density, cap, cons in ((2700, 2600, .5, None, True), (5000, 4097, .5, 2600, True), (2300, 2200, .5, 2193, True),
@@ -77,7 +75,7 @@ def test_fused_search_and_narrow_launch_and_the_look_ahead_as_its_own_gate(monke
         got = hip.solve_words(aug, rows, cols, 1)
         _same(got, want, 1)
         jobs.append((aug, rows, cols, want))
-    assert got.stats["fast_blocks"] > 0
+    assert got.stats["fast_blocks"] > 0 and got.stats["handover_retries"] == 0
     with ThreadPoolExecutor(16) as ex:
         res = list(ex.map(lambda j: hip.solve_words(j[0], j[1], j[2], 1), jobs * 6))
     for j, g in zip(jobs * 6, res):
