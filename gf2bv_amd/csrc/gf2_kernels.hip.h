@@ -1403,20 +1403,32 @@ k_block_fast_narrow(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 	bool live = !GF2_LD(&st->poison);
 	const i64 rb = (i64)blockIdx.x - 1;
 	int have = 0;                                           // panels whose pivot rows are in N.Pall
-	for (int r = 0; live && r < rpt; r++) {
-		const i64 i = (rb * rpt + r) * 256 + t;
-		if (i - t >= rows) break;                           // (uniform)
-		const i64 ic = i < rows ? i : rows - 1;
-		const bool alive = i < rows && died[ic] == GF2_NEVER;      // (before this block's pivots are marked: looked at again below)
-		const uint4 *src = reinterpret_cast<const uint4 *>(Wb_in + ic * GF2_GMAX);
-		const uint4 lo = src[0], hi = src[1];
-		u64 w[GF2_GMAX] = { ((u64)lo.y << 32) | lo.x, ((u64)lo.w << 32) | lo.z, ((u64)hi.y << 32) | hi.x, ((u64)hi.w << 32) | hi.z };
-		u64 m[GF2_GMAX];
+	// row batches in PAIRS: both rows of a thread go through a panel's tables together, so that with two batches per
+	// workgroup (65536 rows) everything but the last panel's step is done when the search ends; further pairs (taller systems)
+	// follow behind it
+	for (int r = 0; live && r < rpt; r += 2) {
+		i64 i[2], ic[2];
+		bool alive[2];
+		u64 w[2][GF2_GMAX], m[2][GF2_GMAX];
+#pragma unroll
+		for (int q = 0; q < 2; q++) {
+			i[q] = (rb * rpt + r + q) * 256 + t;
+			const bool in = r + q < rpt && i[q] < rows;
+			ic[q] = in ? i[q] : rows - 1;
+			if (!in) i[q] = rows;                               // (never stored)
+			alive[q] = in && died[ic[q]] == GF2_NEVER;      // (before this block's pivots are marked: looked at again below)
+			const uint4 *src = reinterpret_cast<const uint4 *>(Wb_in + ic[q] * GF2_GMAX);
+			const uint4 lo = src[0], hi = src[1];
+			w[q][0] = ((u64)lo.y << 32) | lo.x; w[q][1] = ((u64)lo.w << 32) | lo.z;
+			w[q][2] = ((u64)hi.y << 32) | hi.x; w[q][3] = ((u64)hi.w << 32) | hi.z;
+		}
+		if ((rb * rpt + r) * 256 >= rows) break;            // (uniform: nothing left for this workgroup)
 #pragma unroll
 		for (int g = 0; g < GF2_GMAX; g++) {
-			m[g] = alive ? w[g] : 0ull;
+#pragma unroll
+			for (int q = 0; q < 2; q++) m[q][g] = alive[q] ? w[q][g] : 0ull;
 			if (g == GF2_GMAX - 1) break;
-			if (have <= g) {                                // (uniform) first row batch: fetch the panel when it is there
+			if (have <= g) {                                // (uniform) first pair: fetch the panel when it is there
 				if (!wait_for(g + 1)) { live = false; break; }
 				N.Pall[g][e_][sl] = GF2_LD(&Pfast[(g * GF2_GMAX + e_) * 64 + sl]);
 				have = g + 1;
@@ -1426,24 +1438,28 @@ k_block_fast_narrow(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 			__syncthreads();
 			build_nibble_tables(L, t);
 			__syncthreads();
-			if (m[g]) {
-				u64 acc[GF2_GMAX];
-				nibble_rows(L.Tn, m[g], acc);
 #pragma unroll
-				for (int e = 0; e < GF2_GMAX; e++) if (e > g) w[e] ^= acc[e];
-			}
+			for (int q = 0; q < 2; q++)
+				if (m[q][g]) {
+					u64 acc[GF2_GMAX];
+					nibble_rows(L.Tn, m[q][g], acc);
+#pragma unroll
+					for (int e = 0; e < GF2_GMAX; e++) if (e > g) w[q][e] ^= acc[e];
+				}
 		}
 		if (!live) break;
 		if (r == 0 && !wait_for(5)) { live = false; break; }
-		if (i < rows) {
-			const bool still = GF2_LD(&died[ic]) == GF2_NEVER;      // a pivot row of this block: no multipliers (as k_narrow_all sees it)
 #pragma unroll
-			for (int g = 0; g < GF2_GMAX; g++) {
-				const u64 v = mult_stored(upd_T, still ? m[g] : 0ull, i);
-				if (sig.count) GF2_ST(&multset[midx(g, i, rows)], v);      // (the launch announces its own end: signal_light)
-				else multset[midx(g, i, rows)] = v;
+		for (int q = 0; q < 2; q++)
+			if (i[q] < rows) {
+				const bool still = GF2_LD(&died[ic[q]]) == GF2_NEVER;      // a pivot row of this block: no multipliers (as k_narrow_all sees it)
+#pragma unroll
+				for (int g = 0; g < GF2_GMAX; g++) {
+					const u64 v = mult_stored(upd_T, still ? m[q][g] : 0ull, i[q]);
+					if (sig.count) GF2_ST(&multset[midx(g, i[q], rows)], v);      // (the launch announces its own end: signal_light)
+					else multset[midx(g, i[q], rows)] = v;
+				}
 			}
-		}
 	}
 	signal_light(sig, blockIdx.y * ss.arena_bytes, gridDim.x);
 }
