@@ -756,8 +756,10 @@ int enqueue_block_panel(Solver &S, int b, bool fast_only = false)
 	const BlockGeom g = block_geom(S, b);
 	const unsigned row_blocks = (unsigned)((S.rows + 255) / 256);
 	u64 *const half[2] = { S.Wb, S.Wb + (i64)GF2_GMAX * S.rows };
-	if (fast_only && S.fused_narrow) {
+	if (fast_only && S.fused_narrow && S.nsys == 1) {
 		// search + narrow step in one launch: workgroup 0 searches, the others narrow each panel as soon as it is formed
+		// (single systems: a gang is throughput-bound, and its ~130 x nsys narrowing workgroups would hold their LDS for the whole
+		// search -- measured equal either way, 243 against 242 systems/s of 32768^2: gangs keep the two launches)
 		// at most ~128 narrowing workgroups: they stay resident for the whole search, and a CU that holds TWO of them (2 x 26 KiB
 		// of LDS) cannot take a bulk-update workgroup (133 of 160 KiB) until they end -- with 257 workgroups on 256 CUs there is
 		// always such a CU, and the pass whose launch lands just behind the search waits ~20 us for its last workgroup
