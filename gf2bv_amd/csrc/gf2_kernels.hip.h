@@ -1845,12 +1845,14 @@ k_import_marks(int j0, int gb, const PanelRec *__restrict__ panels, const PanelA
 template <int TW, int WPW>
 __global__ void __launch_bounds__(64 * WPW)
 k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int group_begin, int world, int wrank,
-             const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux, int nw_lo, int nw_hi, SysStride ss)
+             const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux, int nw_lo, int nw_hi, u64 *__restrict__ Pc,
+             SysStride ss)
 {
 	__builtin_amdgcn_s_setprio(2);
 	M += blockIdx.y * ss.m_words;
 	panels = sys_at(panels, blockIdx.y * ss.arena_bytes);
 	aux = sys_at(aux, blockIdx.y * ss.arena_bytes);
+	if (Pc) Pc = sys_at(Pc, blockIdx.y * ss.arena_bytes);
 	constexpr int NT = 64 * WPW;
 	static_assert(WPW == 4 && NT == 256, "thread <-> table entry mapping below");
 	__shared__ u64 S[GF2_GMAX * 64 * WPW];     // [panel][slot][word]
@@ -1931,6 +1933,16 @@ k_block_trsm(u64 *__restrict__ M, i64 srows, int j0, int gb, int wlo, int group_
 			if (h < gb && r < rec[h].p) S[(h * 64 + r) * WPW + w] ^= lookup(smul[h][g]);
 		__syncthreads();
 	}
+	// The final pivot rows once more, COMPACT and by pivot bit: Pc[tile][panel][pivot bit] = the row's 16-byte segment of that
+	// tile (zero where a panel has no pivot at that bit) -- exactly what a table build of the bulk update stages.  The update
+	// then starts with ONE coalesced load per tile instead of the chain panel records -> source rows -> matrix rows.
+	if (Pc) {
+		__syncthreads();
+		const i64 wabs = w0 + w;
+#pragma unroll
+		for (int g = 0; g < GF2_GMAX; g++)
+			Pc[(((wabs >> 1) * GF2_GMAX + g) * 64 + r) * 2 + (wabs & 1)] = Pbit[(g * 64 + r) * WPW + w];
+	}
 	(void)NT;
 }
 
@@ -1985,12 +1997,13 @@ __global__ void __launch_bounds__(LB)
 k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
            const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
            const u64 *__restrict__ mult4, const int *__restrict__ blk_first,
-           int tile_begin, int ntiles, int world, int wrank, SysStride ss)
+           int tile_begin, int ntiles, int world, int wrank, const uint4 *__restrict__ Pc, SysStride ss)
 {
 	{
 		const i64 ao = blockIdx.y * ss.arena_bytes;
 		M += blockIdx.y * ss.m_words;
 		panels = sys_at(panels, ao); aux = sys_at(aux, ao); mult4 = sys_at(mult4, ao); blk_first = sys_at(blk_first, ao);
+		if (Pc) Pc = sys_at(Pc, ao);
 	}
 	constexpr int NW = NT / 64;
 	__shared__ __attribute__((aligned(256))) uint4 tab[2 * 256 * 16];      // 128 KiB, must sit at LDS address 0 (checked below)
@@ -2044,7 +2057,7 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		const i64 rend = (rbeg + span < R64) ? rbeg + span : R64;
 		if (!first_span) __syncthreads();           // the previous span's rows are done with the tables
 		// ---- tables ----
-		if (first_span) {
+		if (first_span && !Pc) {                    // (Pc: the pivot rows' segments come compact from k_block_trsm, no row list needed)
 			for (int t = threadIdx.x; t < GF2_GMAX * 64; t += NT) {
 				const int g = t >> 6, b = t & 63;
 				int pr = -1;
@@ -2058,8 +2071,8 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		}
 		const uint4 *Mq = reinterpret_cast<const uint4 *>(M) + tile * srows;       // this tile's slab, one uint4 per row
 		if (threadIdx.x < GF2_GMAX * 64) {
-			const int pr = prow[threadIdx.x];
-			uint4 v = have_staged ? staged : Mq[pr >= 0 ? pr : 0];
+			const int pr = Pc ? 0 : prow[threadIdx.x];      // (Pc holds zeros where a panel has no pivot)
+			uint4 v = have_staged ? staged : Pc ? Pc[tile * (GF2_GMAX * 64) + threadIdx.x] : Mq[pr >= 0 ? pr : 0];
 			// words left of wlo belong to windows the panel path owns: their table bits stay zero
 			const bool k0 = pr >= 0 && 2 * tile >= wlo, k1 = pr >= 0 && 2 * tile + 1 >= wlo;
 			if (!k0) { v.x = 0; v.y = 0; }
@@ -2095,8 +2108,11 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		if (pos < pend) {
 			const i64 ntile = owned_item((int)(pos / R), tile_begin, GF2_OWN_LOG - 1, world, wrank);
 			if (threadIdx.x < GF2_GMAX * 64) {
-				const int pr = prow[threadIdx.x];
-				staged = (reinterpret_cast<const uint4 *>(M) + ntile * srows)[pr >= 0 ? pr : 0];
+				if (Pc) staged = Pc[ntile * (GF2_GMAX * 64) + threadIdx.x];
+				else {
+					const int pr = prow[threadIdx.x];
+					staged = (reinterpret_cast<const uint4 *>(M) + ntile * srows)[pr >= 0 ? pr : 0];
+				}
 			}
 			have_staged = true;
 		}

@@ -232,7 +232,7 @@ void forget_concurrency(int device);
 struct UpdateImpl {
 	int G, T, lds_bytes, threads;
 	hipError_t (*update)(dim3, hipStream_t, u64 *, i64, i64, int, int, int, const PanelRec *, const PanelAux *,
-	                     const u64 *, const int *, int, int, int, int, int, int, SysStride, hipEvent_t, hipEvent_t);
+	                     const u64 *, const int *, int, int, int, int, int, int, const uint4 *, SysStride, hipEvent_t, hipEvent_t);
 };
 
 // 16-byte tiles: G = 4 panels, T = 8 byte fields per panel.  nw_lo < 0 selects the HALF instance (only the tile's second
@@ -240,16 +240,16 @@ struct UpdateImpl {
 template <int NT, int DEPTH, bool PIPE, int LB>
 hipError_t launch_update16(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows, int j0, int gb, int wlo,
                            const PanelRec *panels, const PanelAux *aux, const u64 *multset, const int *blk_first,
-                           int tile_begin, int ntiles, int world, int wrank, int nw_lo, int nw_hi, SysStride ss, hipEvent_t begun,
-                           hipEvent_t done)
+                           int tile_begin, int ntiles, int world, int wrank, int nw_lo, int nw_hi, const uint4 *Pc, SysStride ss,
+                           hipEvent_t begun, hipEvent_t done)
 {
 	(void)nw_hi;
 	if (nw_lo < 0)
 		hipExtLaunchKernelGGL((k_update16<NT, true, DEPTH, PIPE, LB>), grid, dim3(NT), 0, s, begun, done, 0, M, rows, srows, j0, gb, wlo,
-		                      panels, aux, multset, blk_first, tile_begin, ntiles, world, wrank, ss);
+		                      panels, aux, multset, blk_first, tile_begin, ntiles, world, wrank, Pc, ss);
 	else
 		hipExtLaunchKernelGGL((k_update16<NT, false, DEPTH, PIPE, LB>), grid, dim3(NT), 0, s, begun, done, 0, M, rows, srows, j0, gb, wlo,
-		                      panels, aux, multset, blk_first, tile_begin, ntiles, world, wrank, ss);
+		                      panels, aux, multset, blk_first, tile_begin, ntiles, world, wrank, Pc, ss);
 	return hipGetLastError();
 }
 #define UPDATE16_IMPL(NT, D, P, LB) { 4, 8, 2 * 256 * 256 + GF2_GMAX * 64 * 20, NT, launch_update16<NT, D, P, LB> }
@@ -353,6 +353,7 @@ struct Solver {
 	int *oprow = nullptr;         // k_outer_prow -> k_outer_apply / k_update16k: row lists of the outer panel being applied
 	u64 *Tm = nullptr;            // k_outer_trsm<IDENT> -> k_outer_apply: the panel's pivot rows as combinations of its source rows
 	bool outer_chain = false;     // GF2BV_OUTER_CHAIN=1: the chain itself on every word group instead (the first form; tests)
+	u64 *Pc = nullptr;            // final pivot rows of the current block, compact: [tile][panel][pivot bit] x 16 B (k_block_trsm -> k_update16)
 	u64 *Pfast = nullptr;         // scratch of k_block_fast: the pivot rows' window words of a block, [panel][word][column]
 	SyncFlags *sf = nullptr;      // progress counters of the two streams (k_gate)
 	bool flag_sync = true;        // per-block hand-overs between the streams through sf + k_gate instead of events (GF2BV_FLAG_SYNC=0)
@@ -364,6 +365,7 @@ struct Solver {
 	                              // instead of marker packets: ~1 % at every size; GF2BV_EXT_EVENTS=0 restores hipEventRecord
 	int sparse_mode = 2;          // search skips absent columns: 0 never, 1 always, 2 per chunk by density (GF2BV_SPARSE)
 	int fused_rpt = 0;            // GF2BV_FUSED_RPT: row blocks of 256 per narrowing workgroup of k_block_fast_narrow (0 = by size)
+	bool use_pc = true;           // GF2BV_PC=0: the bulk update fetches the pivot rows through the panel records, as before round 3
 	bool fused_narrow = true;     // optimistic blocks: search and narrow step in ONE launch (k_block_fast_narrow); GF2BV_FUSED_NARROW=0: two
 	int narrow_rpt = 1;           // row blocks of 256 per narrow workgroup of a panel step (set in solver_alloc; GF2BV_NARROW_RPT)
 	int self_wait = 5000;         // ticks (100 MHz) unit 0 of a panel search waits for the other units before it leaves
@@ -544,6 +546,7 @@ int solver_alloc(Solver &S)
 	if (getenv("GF2BV_SERIAL")) S.flag_sync = false;      // (one stream: the panel gate would wait for a gate queued behind it)
 	if (const char *e = getenv("GF2BV_OPTIMISTIC")) S.optimistic = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_FUSED_NARROW")) S.fused_narrow = atoi(e) != 0;
+	if (const char *e = getenv("GF2BV_PC")) S.use_pc = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_FUSED_RPT")) S.fused_rpt = atoi(e);
 	// narrow workgroups: as many rows each as keeps ~256 of them (all systems of a gang together) busy, at most 8 blocks
 	{
@@ -574,7 +577,8 @@ int solver_alloc(Solver &S)
 		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * S.nsets * G * mult_rows(R) + (S.tl_K ? kOuterSlackBytes : 0)),
 		             o_wb = carve(sizeof(u64) * 2 * GF2_GMAX * R), o_uw = carve(sizeof(u64) * GF2_GMAX * (S.maxr + 64)),
 		             o_pf = carve(sizeof(u64) * GF2_GMAX * GF2_GMAX * 64), o_opr = carve(sizeof(int) * GF2_OUTER_LISTS * 2),
-		             o_tm = carve(S.tl_K ? 2 * sizeof(u64) * GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX : 0);
+		             o_tm = carve(S.tl_K ? 2 * sizeof(u64) * GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX : 0),
+		             o_pc = carve(S.use_pc ? sizeof(u64) * 2 * GF2_GMAX * 64 * (size_t)S.ntiles : 0);
 		S.arena_stride = off;
 		S.sync_base = 0;
 		HIPCHK(pool().alloc(&S.arena, off * S.nsys, S.device));
@@ -583,6 +587,7 @@ int solver_alloc(Solver &S)
 		S.fu = (FindUnit *)(base + o_fu); S.died = (int *)(base + o_alive); S.pivcol = (int *)(base + o_piv);
 		S.urow = (int *)(base + o_urow); S.blk_first = (int *)(base + o_blk); S.mult = (u64 *)(base + o_mult);
 		S.Wb = (u64 *)(base + o_wb); S.Uwin = (u64 *)(base + o_uw); S.Pfast = (u64 *)(base + o_pf); S.oprow = (int *)(base + o_opr); S.Tm = (u64 *)(base + o_tm);
+		S.Pc = S.use_pc ? (u64 *)(base + o_pc) : nullptr;
 		// zero everything that is read before it is written: state, panel records, unit scratch, block bounds, multipliers
 		for (int s = 0; s < S.nsys; s++) {
 			char *b = base + (size_t)s * off;
@@ -678,7 +683,7 @@ int launch_trsm(Solver &S, hipStream_t st, int j0, int gb, int wlo, int nw_lo, i
 	const i64 ng = owned_count(g0, g1, GF2_OWN_LOG - 2, S.world, S.wrank);
 	if (ng <= 0) return GF2BV_OK;
 	k_block_trsm<TW, WPW><<<dim3((unsigned)ng, S.nsys), dim3(64 * WPW), 0, st>>>(S.M, S.srows, j0, gb, wlo, (int)g0, S.world, S.wrank,
-	                                                                           S.panels, S.aux, nw_lo, nw_hi, S.ss());
+	                                                                           S.panels, S.aux, nw_lo, nw_hi, S.Pc, S.ss());
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
@@ -699,7 +704,7 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 	hipEvent_t begun = nullptr, done = nullptr;
 	if (S.ext_events) { begun = ka; done = S.time_kernels ? kb : (last && !S.flag_sync ? S.evPrio[b] : nullptr); }
 	HIPCHK(S.impl->update(dim3((unsigned)wgs, S.nsys), st, S.M, S.rows, S.srows, j0, gb, wlo, S.panels, S.aux, mset,
-	                      S.blk_first + b, tile_begin, ntiles, S.world, S.wrank, nw_lo, nw_hi, S.ss(), begun, done));
+	                      S.blk_first + b, tile_begin, ntiles, S.world, S.wrank, nw_lo, nw_hi, (const uint4 *)S.Pc, S.ss(), begun, done));
 	if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, st));
 	if (!last || S.flag_sync) return GF2BV_OK;
 	if (S.ext_events) *handoff = done;
@@ -1320,7 +1325,7 @@ int make_view(const Solver &S, int s, Solver &V)
 	auto mv = [ao](auto *&p) { p = reinterpret_cast<decltype(+p)>(reinterpret_cast<char *>(p) + ao); };
 	V.M = S.M + S.m_stride * s;
 	V.arena = (char *)S.arena + ao;
-	mv(V.st); mv(V.panels); mv(V.aux); mv(V.fu); mv(V.died); mv(V.pivcol); mv(V.urow); mv(V.blk_first); mv(V.mult); mv(V.Wb); mv(V.Uwin); mv(V.Pfast);
+	mv(V.st); mv(V.panels); mv(V.aux); mv(V.fu); mv(V.died); mv(V.pivcol); mv(V.urow); mv(V.blk_first); mv(V.mult); mv(V.Wb); mv(V.Uwin); mv(V.Pfast); if (V.Pc) mv(V.Pc);
 	V.Y = nullptr; V.ycols = nullptr; V.out = nullptr;
 	V.ev2 = nullptr;
 	HIPCHK(pool().event(&V.ev2, true));
