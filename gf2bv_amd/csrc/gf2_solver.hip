@@ -1374,11 +1374,12 @@ int solve_gang(Solver &S, gf2bv_result **out)
 // Gang size for nsys same-shape systems.
 i64 pick_gang(i64 nsys, i64 rows, i64 cols)
 {
-	// gang size: ~2 GiB of working matrices per gang (32768^2: 16 systems, 4096^2: 64), at least four gangs
+	// gang size: ~3.5 GiB of working matrices per gang (32768^2: 24 systems, 4096^2: 64), at least four gangs (round 3, 144 x
+	// 32768^2 on one box: gangs of 4 / 8 / 12 / 18 / 24 / 36 -> 231 / 248 / 250 / 239-254 / 255-256 / 255 systems per second)
 	// when there are enough systems (measured on MI355X, 48 x 32768^2: gang 4/8/16 -> 7.6/6.3/6.0 ms per
 	// system, one system at a time 15-28; 64 x 4096^2: 0.22 ms per system against 1.8)
 	const double per_sys = 1.05 * 8.0 * (double)(rows + 64) * (double)((cols + 64) / 64 + TW + 4 * GF2_GMAX);
-	i64 gang = std::max<i64>(2, std::min<i64>(64, (i64)(2.5 * 1073741824.0 / per_sys)));
+	i64 gang = std::max<i64>(2, std::min<i64>(64, (i64)(3.5 * 1073741824.0 / per_sys)));
 	gang = std::min(gang, std::max<i64>(1, (nsys + 3) / 4));
 	// equal gangs, an even number of them (two host threads take alternate gangs): 64 systems of 32768^2 go as 4 x 16
 	// (3.90 ms per system) rather than 4 x 14 + 8 (4.10)
