@@ -2055,6 +2055,35 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		const i64 rbeg = rlo + r0;
 		if (rbeg >= R64) continue;
 		const i64 rend = (rbeg + span < R64) ? rbeg + span : R64;
+		uint4 *Mw = reinterpret_cast<uint4 *>(M) + tile * srows;
+		const uint4 *mq = reinterpret_cast<const uint4 *>(mult4);
+		const i64 nsteps = (rend - rbeg + ALIGN - 1) / ALIGN;
+		// batches of this wave: rows rbeg + (i * NW + wv) * 64 + lane, i < nb
+		i64 nb = nsteps;
+		if (rbeg + ((nsteps - 1) * NW + wv) * 64 >= rend) nb--;
+		struct Bt { uint4 d, m0, m1; i64 row; };
+		auto load = [&](Bt &H, i64 i) {
+			const i64 ic = i < nb ? i : nb - 1;         // (a prefetch past the end re-reads the last batch: no control flow around loads)
+			const i64 row = rbeg + (ic * NW + wv) * 64 + lane;
+			H.row = row;
+			// (the two 16-byte halves of a row's multipliers side by side: as two contiguous planes -- every load then whole
+			// lines of its own -- the kernel is 5-7 % SLOWER, 4.08 against 4.31 TB/s at 65536 x 512 tiles: a third stream per wave)
+			H.m0 = mq[row * 2]; H.m1 = mq[row * 2 + 1];
+#ifdef GF2_MB_L2               /* tools/microbench_update16.hip: keep the row data L2-resident to time the table work alone */
+			H.d = Mw[row & 4095];
+#elif defined(GF2_NT_LOAD)     /* cache-policy experiments (tools/microbench_update16.hip) */
+			{ const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Mw + row)); H.d = make_uint4(t.x, t.y, t.z, t.w); }
+#else
+			H.d = Mw[row];
+#endif
+		};
+		// the span's first batches are requested BEFORE its tables are built: the build (~1.5 us, LDS only) then runs under
+		// their memory latency instead of in front of it
+		Bt H[DEPTH] = {};
+		if (nb > 0) {
+#pragma unroll
+			for (int d = 0; d < DEPTH - 1; d++) load(H[d], d);
+		}
 		if (!first_span) __syncthreads();           // the previous span's rows are done with the tables
 		// ---- tables ----
 		if (first_span && !Pc) {                    // (Pc: the pivot rows' segments come compact from k_block_trsm, no row list needed)
@@ -2121,28 +2150,6 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		// batch i+1 are in flight while batch i does its 32 lookups.  No control flow around vector-memory
 		// instructions (the compiler then waits with vmcnt(N > 0), see k_update): a wave knows its batch count up
 		// front and its last prefetch re-reads its last batch.
-		uint4 *Mw = reinterpret_cast<uint4 *>(M) + tile * srows;
-		const uint4 *mq = reinterpret_cast<const uint4 *>(mult4);
-		const i64 nsteps = (rend - rbeg + ALIGN - 1) / ALIGN;
-		// batches of this wave: rows rbeg + (i * NW + wv) * 64 + lane, i < nb
-		i64 nb = nsteps;
-		if (rbeg + ((nsteps - 1) * NW + wv) * 64 >= rend) nb--;
-		struct Bt { uint4 d, m0, m1; i64 row; };
-		auto load = [&](Bt &H, i64 i) {
-			const i64 ic = i < nb ? i : nb - 1;         // (a prefetch past the end re-reads the last batch: no control flow around loads)
-			const i64 row = rbeg + (ic * NW + wv) * 64 + lane;
-			H.row = row;
-			// (the two 16-byte halves of a row's multipliers side by side: as two contiguous planes -- every load then whole
-			// lines of its own -- the kernel is 5-7 % SLOWER, 4.08 against 4.31 TB/s at 65536 x 512 tiles: a third stream per wave)
-			H.m0 = mq[row * 2]; H.m1 = mq[row * 2 + 1];
-#ifdef GF2_MB_L2               /* tools/microbench_update16.hip: keep the row data L2-resident to time the table work alone */
-			H.d = Mw[row & 4095];
-#elif defined(GF2_NT_LOAD)     /* cache-policy experiments (tools/microbench_update16.hip) */
-			{ const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Mw + row)); H.d = make_uint4(t.x, t.y, t.z, t.w); }
-#else
-			H.d = Mw[row];
-#endif
-		};
 		// round r = 0..3 of a batch: the 8 lookups of (group r >> 1, half r & 1)
 		auto issue = [&](u32x4 *v, const Bt &H, int r) {
 			const unsigned mw[8] = { H.m0.x, H.m0.y, H.m0.z, H.m0.w, H.m1.x, H.m1.y, H.m1.z, H.m1.w };
@@ -2183,9 +2190,6 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 			// DEPTH batches in flight per wave (loads DEPTH-1 batches ahead); PIPE: the lookups of round r+1 -- also
 			// across the batch boundary -- are issued before the XORs of round r, so the LDS always has this wave's
 			// next 8 reads queued
-			Bt H[DEPTH];
-#pragma unroll
-			for (int d = 0; d < DEPTH - 1; d++) load(H[d], d);
 			u32x4 va[8], vb[8];
 #ifndef GF2_MB_NOLOOKUP
 			if (PIPE) issue(va, H[0], 0);
