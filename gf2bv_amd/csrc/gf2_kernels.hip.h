@@ -1237,11 +1237,11 @@ __device__ __forceinline__ int block_fast_body(FastLds &F, u64 *__restrict__ M, 
 		const u64 acc = use ? nibble_word(L.Tn, L.Cm[sl], e_) : 0ull;
 		Pk[g] = acc;
 		if (PUB && g + 1 < GF2_GMAX) {                      // (the last panel's rows have no window word left to take)
+			// (the flag follows at the END of this panel's phase, when these stores have long landed: waiting for them here
+			// put a write-through round trip into the search chain, three per block)
 			GF2_ST(&Pfast[(g * GF2_GMAX + e_) * 64 + sl], (e_ > g) ? acc : 0ull);
-			asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 		}
 		__syncthreads();                                    // (the tables are read by every thread before Pb changes under them)
-		if (PUB && g + 1 < GF2_GMAX && t == 0) GF2_ST(&st->fast_pub, 8 * blk + g + 1);
 		L.Pb[e_][sl] = (e_ > g) ? acc : 0ull;               // (word g of pivot b is the single bit b: nothing to look up there)
 		if (t < 64) {
 			PanelAux *A = aux + j0 + g;
@@ -1264,7 +1264,9 @@ __device__ __forceinline__ int block_fast_body(FastLds &F, u64 *__restrict__ M, 
 					for (int e = 0; e < GF2_GMAX; e++) if (e > g) cw[c * 4 + e] ^= a4[e];
 				}
 			}
+			if (PUB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's share of Pfast[g] (and of PanelAux) is out
 			__syncthreads();
+			if (PUB && t == 0) GF2_ST(&st->fast_pub, 8 * blk + g + 1);
 		}
 		GF2_PROBE_FAST(4 + 3 * g);
 	}
