@@ -488,14 +488,17 @@ int check_device(int device)
 // 100 ms, 65536^2 34 -> 47 ms; with a threshold on what remains right of the panel (profiles/r03_two_level.txt): 131072^2 best at
 // 384-512 MiB (182 ms), 98304^2 at 512 MiB (87.3 against 92.8), 65536^2 never.  So: K = 8 while more than 512 MiB remain
 // (262144^2: the first 75 % of the pivots; 131072^2: the first half; 98304^2: the first third; nothing below ~70000^2).
-// GF2BV_TWO_LEVEL=0 turns it off, =K (2..8)
+// GF2BV_TWO_LEVEL=0 turns it off, =K (2..12)
 // forces K from the first block on for every full panel whatever the size (tests).  Single systems on one GPU only: gangs
 // and column-slab solves keep the one-level schedule.
 void plan_two_level(Solver &S)
 {
 	S.tl_K = 0; S.tl_bend = 0; S.nsets = 2;
 	if (S.world != 1 || S.nsys != 1 || S.impl->G != GF2_GMAX) return;
-	int K = GF2_KMAX;
+	// outer panels of 12 blocks from 3 GiB up, of 8 below: the outer pass gains with K (isolated 5.20 / 5.30 / 5.38 TB/s of
+	// sweep-words for K = 8 / 10 / 12), the inner elimination and the T chain grow with it -- 262144^2 1.303 -> 1.269 s,
+	// 196608^2 566 -> 557 ms, 393216^2 4.26 -> 4.13 s, but 131072^2 184.0 -> 185.3 ms (profiles/r03_two_level.txt)
+	int K = (double)S.rows * (double)S.wt * 8.0 >= 3.0 * 1073741824.0 ? GF2_KMAX : 8;
 	double min_bytes = 0.5 * 1073741824.0;
 	if (const char *e = getenv("GF2BV_TWO_LEVEL"); e && *e) {
 		const int v = atoi(e);
@@ -504,6 +507,7 @@ void plan_two_level(Solver &S)
 		min_bytes = 0;
 	}
 	if (const char *e = getenv("GF2BV_TWO_LEVEL_MIN_MIB"); e && *e) min_bytes = 1048576.0 * atof(e);      // (threshold scans)
+	if (const char *e = getenv("GF2BV_OUTER_K"); e && *e) K = std::min(GF2_KMAX, std::max(2, atoi(e)));  // (K scans under the default plan)
 	const int G = S.impl->G;
 	int bend = 0;
 	for (int b0 = 0; b0 + K < S.nblocks; b0 += K) {            // (the last block never ends an outer panel: it may be short)

@@ -87,9 +87,9 @@ def test_fused_search_and_narrow_launch(monkeypatch, fused):
         _same(g, O.solve_words(a, n, n, 1), 1)
 
 
-@pytest.mark.parametrize("K,chain", [(2, 0), (3, 0), (4, 0), (8, 0), (4, 1), (8, 1)])
+@pytest.mark.parametrize("K,chain", [(2, 0), (3, 0), (4, 0), (8, 0), (12, 0), (4, 1), (8, 1), (12, 1)])
 def test_two_level_elimination_forced_on_small_systems(monkeypatch, K, chain):
-    """GF2BV_TWO_LEVEL=K: outer panels of K blocks from the first block on (k_outer_trsm<IDENT> + k_outer_apply + k_update16k; chain:
+    """GF2BV_TWO_LEVEL=K: outer panels of K = 2 ... 12 blocks from the first block on (k_outer_trsm<IDENT> + k_outer_apply + k_update16k; chain:
     GF2BV_OUTER_CHAIN=1, the pivot rows by the chain of panel steps on every word group instead of P = T x S) at sizes the oracle
     solves in seconds -- full rank, rank caps inside / at the edge of an outer panel, zero and duplicate-heavy rows, rows >> cols,
     inconsistent systems, both modes, events and flags."""
