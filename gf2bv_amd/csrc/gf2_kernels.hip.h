@@ -2236,7 +2236,9 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 // keeps row segments in REGISTERS across the K blocks, rebuilding the tables per block.  Memory-side traffic per segment
 // update falls from 64 B to 32 + 32 / K; isolated: 4.7 / 5.4 / 5.7 TB/s of 256-pivot sweep-words for K = 2 / 4 / 8 against
 // 3.8 - 3.95 for k_update16 on the same box (profiles/r03_kloop.txt).
+#ifndef GF2_KMAX
 #define GF2_KMAX 12               /* blocks per outer panel at most */
+#endif
 #ifndef GF2_KSEG
 #define GF2_KSEG 16               /* row segments a lane of k_update16k keeps in registers (x 512 lanes = 8192 rows per table build):
                                      217 VGPRs, no scratch (a test holds that: gf2bv_kernel_resources).  Isolated, K = 8: 16 -> 5.33,
