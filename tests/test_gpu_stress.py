@@ -52,7 +52,7 @@ def test_mode1_gang_of_mixed_ranks_at_8192(monkeypatch):
     specs = [(.5, None, True), (.5, n - 1, True), (.5, n - 5, True), (.5, n - 70, True), (.5, n - 3, False), (.01, None, True)]
     augs = np.stack([O.eqs_to_aug(random_system(rng, n, n, d, cap, cons, 0), n) for d, cap, cons in specs])
     got = hip.solve_batch_words(augs, n, n, 1)
-    assert all(g.stats["gang_systems"] == 6 for g in got)
+    assert all(g.stats["gang_systems"] == 6 and g.stats["handover_retries"] == 0 for g in got)
     for a, g in zip(augs, got):
         _same(g, O.solve_words(a, n, n, 1), 1)
 
