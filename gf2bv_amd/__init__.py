@@ -6,7 +6,7 @@ Drop-in for the solve path of maple3142/gf2bv: ``LinearSystem`` / ``gens()`` /
 back-substitution / kernel basis run as HIP kernels on gfx950 (gf2bv_amd/csrc).
 There is no CPU fallback: importing works anywhere, solving needs the GPU.
 """
-from ._internal import AffineSpace, m4ri_solve, mul_bit_quad, to_bits, tuple_where, xor_tuple
+from ._internal import AffineSpace, eqs_to_sage_mat_helper, m4ri_solve, mul_bit_quad, to_bits, tuple_where, xor_tuple
 from .bitvec import BitVec
 from .linsys import DimensionTooLargeError, LinearSystem, QuadraticSystem, Zeros
 
@@ -24,5 +24,5 @@ def __getattr__(name):
 __all__ = [
     "AffineSpace", "BitVec", "DimensionTooLargeError", "LinearSystem", "PackedBitVec", "PackedLinearSystem",
     "QuadraticSystem", "Zeros",
-    "m4ri_solve", "mul_bit_quad", "to_bits", "tuple_where", "xor_tuple",
+    "eqs_to_sage_mat_helper", "m4ri_solve", "mul_bit_quad", "to_bits", "tuple_where", "xor_tuple",
 ]

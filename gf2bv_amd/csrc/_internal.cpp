@@ -329,17 +329,23 @@ bool parse_device(PyObject *obj, int *device)
 	*device = (int)d;
 	return true;
 }
-// devices: None = every visible device, an int, or a sequence of ints (repeats allowed)
+// devices: None = the module's default device (set_default_device / GF2BV_DEVICE -- what m4ri_solve and m4ri_solve_packed use:
+// a process pinned to one GPU stays on it), the string "all" = every visible device, an int, or a sequence of ints (repeats allowed)
 bool parse_devices(PyObject *obj, std::vector<int> *devs)
 {
 	devs->clear();
-	if (obj == Py_None) {
+	if (obj == Py_None) { devs->push_back(default_device()); return true; }
+	if (PyUnicode_Check(obj)) {
+		if (PyUnicode_CompareWithASCIIString(obj, "all") != 0) {
+			PyErr_SetString(PyExc_ValueError, "devices must be None, 'all', an int or a sequence of ints");
+			return false;
+		}
 		const int n = gf2bv_device_count();
 		for (int d = 0; d < (n > 0 ? n : 1); d++) devs->push_back(d);
 		return true;
 	}
 	if (PyLong_Check(obj)) { int d; if (!parse_device(obj, &d)) return false; devs->push_back(d); return true; }
-	PyObject *seq = PySequence_Fast(obj, "devices must be None, an int or a sequence of ints");
+	PyObject *seq = PySequence_Fast(obj, "devices must be None, 'all', an int or a sequence of ints");
 	if (!seq) return false;
 	const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
 	for (Py_ssize_t i = 0; i < n; i++) {
@@ -514,8 +520,8 @@ PyObject *py_m4ri_solve_packed(PyObject *, PyObject *const *args, Py_ssize_t nar
 // m4ri_solve_many(list_of_equation_lists, cols, mode[, devices]) -> list of (None | int | AffineSpace).
 // New entry (no counterpart in the reference): independent systems of one shape -- one per output
 // bit / per instance in the recovery examples -- are solved as lock-step gangs by one call; every
-// element of the result is what m4ri_solve would return for that system.  `devices`: None (default) = every
-// visible GPU, an int, or a sequence of device indices -- the systems are sharded in contiguous blocks over them,
+// element of the result is what m4ri_solve would return for that system.  `devices`: None (default) = the module's default
+// device, "all" = every visible GPU, an int, or a sequence of device indices -- the systems are sharded in contiguous blocks over them,
 // one host thread per entry inside the library (gf2bv_solve_batch_digits_multi), results in input order.
 PyObject *py_m4ri_solve_many(PyObject *, PyObject *const *args, Py_ssize_t nargs)
 {
@@ -701,12 +707,134 @@ PyObject *py_mul_bit_quad(PyObject *, PyObject *const *args, Py_ssize_t nargs)
 	return v;
 }
 
-// Sage / libgd export (_internal.c:678-765) is outside the solve path.
-PyObject *py_sage_helper(PyObject *, PyObject *const *, Py_ssize_t)
+// eqs_to_sage_mat_helper(eqs, cols) -> (png_bytes, affine_list)      (_internal.c:678-765)
+// The reference renders the coefficient matrix as an image -- pixel (x = column, y = row) BLACK where the bit is set -- through
+// libgd (dlopen at first use) and returns gdImagePngPtrEx(im, &size, 0): a palette PNG with colour 0 = black, 1 = white,
+// compression level 0, which Sage's unpickle_matrix_mod2_dense_v2 reads back as entry = 1 - palette index.  Here the PNG is
+// written directly (no libgd, no libpng, no zlib): signature, IHDR (bit depth 1, colour type 3 -- what libgd's writer picks
+// for a two-colour palette), PLTE {000000, FFFFFF}, the scanlines (filter byte 0, pixels MSB first, padding bits white) as
+// STORED deflate blocks (level 0) in IDAT chunks of at most 1 MiB, IEND.  Same pixels and palette as the reference's image;
+// byte-for-byte equality with a particular libgd/libpng build is not claimed (chunking and zlib framing are the encoder's).
+// affine[i] = bit 0 of eqs[i] as a bool; the reference leaves a NULL slot for an equation that is the int 0 (its bit loop
+// never runs, _internal.c:741-752) -- get_eqs never passes one -- here that entry is False.
+namespace png {
+uint32_t crc_table[256];
+bool crc_ready = false;
+uint32_t crc32(uint32_t c, const unsigned char *p, size_t n)
 {
-	PyErr_SetString(PyExc_NotImplementedError,
-	                "eqs_to_sage_mat_helper (Sage/libgd export) is out of scope of gf2bv_amd");
-	return nullptr;
+	if (!crc_ready) {
+		for (uint32_t i = 0; i < 256; i++) {
+			uint32_t v = i;
+			for (int k = 0; k < 8; k++) v = (v & 1) ? 0xEDB88320u ^ (v >> 1) : v >> 1;
+			crc_table[i] = v;
+		}
+		crc_ready = true;
+	}
+	c = ~c;
+	for (size_t i = 0; i < n; i++) c = crc_table[(c ^ p[i]) & 0xff] ^ (c >> 8);
+	return ~c;
+}
+void be32(std::vector<unsigned char> &o, uint32_t v) { for (int s = 24; s >= 0; s -= 8) o.push_back((unsigned char)(v >> s)); }
+void chunk(std::vector<unsigned char> &o, const char *type, const unsigned char *data, size_t n)
+{
+	be32(o, (uint32_t)n);
+	const size_t at = o.size();
+	o.insert(o.end(), type, type + 4);
+	o.insert(o.end(), data, data + n);
+	be32(o, crc32(0, o.data() + at, n + 4));
+}
+}  // namespace png
+
+PyObject *py_sage_helper(PyObject *, PyObject *const *args, Py_ssize_t nargs)
+{
+	if (nargs != 2) { PyErr_SetString(PyExc_TypeError, "eqs_to_sage_mat_helper requires 2 arguments"); return nullptr; }
+	PyObject *list = args[0];
+	if (!PyList_Check(list)) { PyErr_SetString(PyExc_TypeError, "The first argument equations must be a list"); return nullptr; }
+	const Py_ssize_t cols = PyLong_AsSsize_t(args[1]);
+	if (cols <= 0) {
+		if (cols == -1 && PyErr_Occurred()) return nullptr;
+		PyErr_SetString(PyExc_ValueError, "Number of columns must be positive");
+		return nullptr;
+	}
+	const Py_ssize_t rows = PyList_GET_SIZE(list);
+	if (cols > 0x7fffffff || rows > 0x7fffffff) { PyErr_SetString(PyExc_ValueError, "image dimensions exceed PNG's 2^31 - 1"); return nullptr; }
+	for (Py_ssize_t i = 0; i < rows; i++)
+		if (!PyLong_Check(PyList_GET_ITEM(list, i))) { PyErr_SetString(PyExc_TypeError, "All elements in the equations list must be integers"); return nullptr; }
+	PyObject *affine = PyList_New(rows);
+	if (!affine) return nullptr;
+	try {
+		const size_t rb = (size_t)(cols + 7) / 8, line = rb + 1;
+		const size_t words = (size_t)(cols + 63) / 64;
+		// the raw image (filter byte + packed pixels per row)
+		std::vector<unsigned char> raw(line * (size_t)rows);
+		std::vector<uint64_t> bits(words + 1);
+		static unsigned char rev[256];
+		static bool rev_ready = false;
+		if (!rev_ready) { for (int v = 0; v < 256; v++) { int r = 0; for (int k = 0; k < 8; k++) if (v >> k & 1) r |= 0x80 >> k; rev[v] = (unsigned char)r; } rev_ready = true; }
+		for (Py_ssize_t i = 0; i < rows; i++) {
+			PyLongObject *v = (PyLongObject *)PyList_GET_ITEM(list, i);
+			const Py_ssize_t nd = GF2_DIGIT_COUNT(v);
+			PyObject *aff = (nd > 0 && (GF2_DIGITS(v)[0] & 1)) ? Py_True : Py_False;
+			Py_INCREF(aff);
+			PyList_SET_ITEM(affine, i, aff);
+			// bits[c] = bit c + 1 of |v| for c < cols (the sign is ignored, bits above cols are ignored: _internal.c:41-59)
+			std::fill(bits.begin(), bits.end(), 0);
+			for (Py_ssize_t d = 0; d < nd; d++) {
+				uint64_t val = GF2_DIGITS(v)[d];
+				Py_ssize_t at = d * PyLong_SHIFT - 1;
+				if (d == 0) { val >>= 1; at = 0; }
+				if (at >= cols) break;
+				bits[(size_t)at >> 6] |= val << (at & 63);
+				if ((at & 63) + PyLong_SHIFT > 64) bits[((size_t)at >> 6) + 1] |= val >> (64 - (at & 63));
+			}
+			if (cols & 63) bits[words - 1] &= (~0ull >> (64 - (cols & 63)));
+			unsigned char *dst = raw.data() + line * (size_t)i;
+			dst[0] = 0;                                       // filter type None
+			for (size_t k = 0; k < rb; k++) dst[1 + k] = rev[(unsigned char)~(bits[k >> 3] >> (8 * (k & 7)))];      // set bit -> index 0 (black)
+		}
+		// zlib stream of stored blocks
+		std::vector<unsigned char> z;
+		z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+		z.push_back(0x78); z.push_back(0x01);
+		uint32_t a1 = 1, a2 = 0;
+		size_t pos = 0;
+		do {
+			const size_t n = std::min<size_t>(65535, raw.size() - pos);
+			z.push_back(pos + n == raw.size() ? 1 : 0);
+			z.push_back((unsigned char)(n & 0xff)); z.push_back((unsigned char)(n >> 8));
+			z.push_back((unsigned char)(~n & 0xff)); z.push_back((unsigned char)((~n >> 8) & 0xff));
+			z.insert(z.end(), raw.begin() + pos, raw.begin() + pos + n);
+			for (size_t k = 0; k < n;) {                      // adler32, reduced every 5552 bytes
+				const size_t m = std::min<size_t>(5552, n - k);
+				for (size_t e = 0; e < m; e++) { a1 += raw[pos + k + e]; a2 += a1; }
+				a1 %= 65521; a2 %= 65521; k += m;
+			}
+			pos += n;
+		} while (pos < raw.size());
+		png::be32(z, (a2 << 16) | a1);
+		std::vector<unsigned char>().swap(raw);
+		std::vector<unsigned char> out;
+		out.reserve(z.size() + z.size() / (1 << 20) * 12 + 128);
+		static const unsigned char sig[8] = { 0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a };
+		out.insert(out.end(), sig, sig + 8);
+		std::vector<unsigned char> ihdr;
+		png::be32(ihdr, (uint32_t)cols); png::be32(ihdr, (uint32_t)rows);
+		ihdr.push_back(1); ihdr.push_back(3); ihdr.push_back(0); ihdr.push_back(0); ihdr.push_back(0);
+		png::chunk(out, "IHDR", ihdr.data(), ihdr.size());
+		static const unsigned char plte[6] = { 0, 0, 0, 255, 255, 255 };
+		png::chunk(out, "PLTE", plte, 6);
+		for (size_t at = 0; at < z.size(); at += (size_t)1 << 20)
+			png::chunk(out, "IDAT", z.data() + at, std::min<size_t>((size_t)1 << 20, z.size() - at));
+		png::chunk(out, "IEND", nullptr, 0);
+		PyObject *bytes = PyBytes_FromStringAndSize((const char *)out.data(), (Py_ssize_t)out.size());
+		if (!bytes) { Py_DECREF(affine); return nullptr; }
+		PyObject *ret = PyTuple_Pack(2, bytes, affine);
+		Py_DECREF(bytes); Py_DECREF(affine);
+		return ret;
+	} catch (const std::bad_alloc &) {
+		Py_DECREF(affine);
+		return PyErr_NoMemory();
+	}
 }
 
 // _space_from_ints(cols, origin, basis): build an AffineSpace from host integers.  Not part of the
@@ -757,12 +885,13 @@ PyMethodDef module_methods[] = {
 	{"m4ri_solve_packed", FAST(py_m4ri_solve_packed), METH_FASTCALL,
 	 "m4ri_solve_packed(buffer, rows, words, cols, mode, device=None)\n--\n\nm4ri_solve on equations already packed as rows x words 64-bit words (equation-int bit order)."},
 	{"m4ri_solve_many", FAST(py_m4ri_solve_many), METH_FASTCALL,
-	 "m4ri_solve_many(systems, cols, mode, devices=None)\n--\n\nSolve a list of same-shape systems in one batched call, sharded over the given (default: all visible) GPUs; list of m4ri_solve results."},
+	 "m4ri_solve_many(systems, cols, mode, devices=None)\n--\n\nSolve a list of same-shape systems in one batched call, sharded over the given GPUs (None: the default device, \"all\": every visible one); list of m4ri_solve results."},
 	{"to_bits", FAST(py_to_bits), METH_FASTCALL, "to_bits(n, a)\n--\n\nLow n bits of a, LSB first."},
 	{"mul_bit_quad", FAST(py_mul_bit_quad), METH_FASTCALL, "mul_bit_quad(n, a, b, v, basis)\n--\n\n"},
 	{"xor_tuple", FAST(py_xor_tuple), METH_FASTCALL, "xor_tuple(a, b)\n--\n\nElement-wise xor."},
 	{"tuple_where", FAST(py_tuple_where), METH_FASTCALL, "tuple_where(cond, a, b)\n--\n\nIn-place select."},
-	{"eqs_to_sage_mat_helper", FAST(py_sage_helper), METH_FASTCALL, "not available in gf2bv_amd"},
+	{"eqs_to_sage_mat_helper", FAST(py_sage_helper), METH_FASTCALL,
+	 "eqs_to_sage_mat_helper(equations, cols)\n--\n\n(png_bytes, affine): the coefficient matrix as a two-colour PNG (black = 1) for Sage's unpickle_matrix_mod2_dense_v2, and the affine bits."},
 	{"_space_from_ints", FAST(py_space_from_ints), METH_FASTCALL, "test hook: AffineSpace from ints"},
 	{"device_count", py_device_count, METH_NOARGS, "number of visible HIP devices"},
 	{"get_default_device", py_get_default_device, METH_NOARGS, "the device solves run on when no `device` argument is given"},

@@ -230,8 +230,10 @@ __host__ __device__ __forceinline__ i64 owned_item(i64 ct, i64 first, int ulog, 
 // One thread per output word.  Row r's int occupies digits[off[r]..off[r+1]); bit 0 is the
 // affine term (-> column `cols`), bit k the coefficient of variable k-1 (-> column k-1).
 __global__ void k_pack_digits(const uint32_t *__restrict__ digits, const i64 *__restrict__ off,
-                              int bpd, i64 rows, i64 cols, i64 wtot, i64 srows, u64 *__restrict__ M, SysStride ss)
+                              int bpd, i64 rows, i64 cols, i64 wtot, i64 srows, u64 *__restrict__ M, SysStride ss, i64 dig_base)
 {
+	// dig_base: the offsets are absolute positions in the caller's digit array, `digits` holds its part from dig_base on
+	// (a device's share of a larger batch)
 	// grid: x = words of a row, y = rows (strided: a launch dimension holds at most 2^32 - 1 work-items and
 	// 65535 workgroups in y), z = system of a gang (its rows follow the previous system's in the offset table)
 	off += blockIdx.z * rows;
@@ -239,7 +241,7 @@ __global__ void k_pack_digits(const uint32_t *__restrict__ digits, const i64 *__
 	const i64 w = (i64)blockIdx.x * blockDim.x + threadIdx.x;
 	if (w >= wtot) return;
 	for (i64 r = blockIdx.y; r < rows; r += gridDim.y) {
-	const uint32_t *d = digits + off[r];
+	const uint32_t *d = digits + (off[r] - dig_base);
 	i64 nd = off[r + 1] - off[r];
 	u64 val = 0;
 	i64 c0 = w * 64;                         // first column of this word
@@ -2704,8 +2706,14 @@ k_check_rhs(const u64 *__restrict__ M, i64 rows, i64 srows, i64 cols,
 __global__ void __launch_bounds__(256)
 k_bs_far(const u64 *__restrict__ M, i64 srows, i64 cw, int qa, int qb, const PanelRec *__restrict__ panels,
          const int *__restrict__ urow, const int *__restrict__ pivcol, const int *__restrict__ ycols, int ny,
-         const u64 *__restrict__ X, unsigned char *__restrict__ accv, i64 nacc)
+         const u64 *__restrict__ X, unsigned char *__restrict__ accv, i64 nacc, SysStride ss, i64 x_sys_words)
 {
+	// gang (blockIdx.y = system): the records and accv live in the system's arena, X holds ny x cw words per system
+	{
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		M += blockIdx.y * ss.m_words; X += blockIdx.y * x_sys_words;
+		panels = sys_at(panels, ao); urow = sys_at(urow, ao); pivcol = sys_at(pivcol, ao); accv = sys_at(accv, ao);
+	}
 	const int lane = threadIdx.x & 63;
 	const i64 wv = ((i64)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 	const int kbeg = panels[qa].start;
@@ -2740,8 +2748,13 @@ k_bs_far(const u64 *__restrict__ M, i64 srows, i64 cw, int qa, int qb, const Pan
 // fetching them.
 __global__ void __launch_bounds__(256)
 k_bs_diag(const u64 *__restrict__ M, i64 srows, int npanels, const PanelRec *__restrict__ panels,
-          const int *__restrict__ urow, u64 *__restrict__ Dg)
+          const int *__restrict__ urow, u64 *__restrict__ Dg, SysStride ss, i64 dg_sys_words)
 {
+	{
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		M += blockIdx.y * ss.m_words; Dg += blockIdx.y * dg_sys_words;
+		panels = sys_at(panels, ao); urow = sys_at(urow, ao);
+	}
 	const int q = blockIdx.x, t = threadIdx.x;
 	const int r = t >> 2, q4 = t & 3;
 	const PanelRec rec = panels[q];
@@ -2763,8 +2776,13 @@ k_bs_diag(const u64 *__restrict__ M, i64 srows, int npanels, const PanelRec *__r
 __global__ void __launch_bounds__(256)
 k_bs_near(const u64 *__restrict__ Dg, i64 cw, int qa, int qb, const PanelRec *__restrict__ panels,
           const int *__restrict__ pivcol, int ny, u64 *__restrict__ X,
-          const unsigned char *__restrict__ accv, i64 nacc)
+          const unsigned char *__restrict__ accv, i64 nacc, SysStride ss, i64 dg_sys_words, i64 x_sys_words)
 {
+	{
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		Dg += blockIdx.y * dg_sys_words; X += blockIdx.y * x_sys_words;
+		panels = sys_at(panels, ao); pivcol = sys_at(pivcol, ao); accv = sys_at(accv, ao);
+	}
 	// 256 threads = 64 pivots x 4 lanes, a lane holding FOUR words of its row per panel.  The 16 panel steps are a
 	// serial chain (read the unknowns solved so far, 64 parities, publish 64 new bits): four wavefronts at the
 	// barrier, the row parity by two DPP quad swaps, one LDS atomic per wavefront (its 16 rows' bits ORed across

@@ -12,6 +12,7 @@
 #include "../../include/gf2bv_hip.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -325,6 +326,7 @@ struct Solver {
 	i64 m_stride = 0, src_sys_words = 0;
 	size_t arena_stride = 0;
 	bool view = false;            // a non-owning window on one system of a gang (back-substitution, export)
+	bool own_bs = true;           // (a view) Y / ycols / out are its own; false: `out` points into the gang's (enqueue_backward_gang)
 	SysStride ss() const { return SysStride{ m_stride, (i64)arena_stride }; }
 	int mode = 0;
 	bool time_kernels = false;
@@ -375,6 +377,7 @@ struct Solver {
 	u64 *out = nullptr;
 	i64 ys = 0;
 	int ny = 0;
+	int h_ycol = 0;               // (host copy of the gang's one right-hand-side column: lives as long as the copy may)
 	i64 maxr = 0;
 	int npanels = 0, nblocks = 0;
 	i64 wt = 0, cw = 0;
@@ -399,7 +402,7 @@ struct Solver {
 		if (view) {               // owns only what its own back-substitution allocated
 			if (sA && (Y || ycols || out)) (void)hipStreamSynchronize(sA);
 			Pool &P = pool();
-			for (void *p : { (void *)Y, (void *)ycols, (void *)out }) P.release(p);
+			if (own_bs) for (void *p : { (void *)Y, (void *)ycols, (void *)out }) P.release(p);
 			P.release_event(ev2, true);
 			P.release_event(evx, true); evx = nullptr;
 			Y = nullptr; ycols = nullptr; out = nullptr; ev2 = nullptr;
@@ -494,7 +497,9 @@ int check_device(int device)
 void plan_two_level(Solver &S)
 {
 	S.tl_K = 0; S.tl_bend = 0; S.nsets = 2;
-	if (S.world != 1 || S.nsys != 1 || S.impl->G != GF2_GMAX) return;
+	// (a column-slab handle -- ext_M, at world size 1 too -- is driven block by block through slab_factor_on / slab_apply_on, which
+	// know nothing of outer panels: with a plan it would skip the look-ahead at every panel end and never run an outer pass)
+	if (S.world != 1 || S.ext_M || S.nsys != 1 || S.impl->G != GF2_GMAX) return;
 	// outer panels of 12 blocks from 3 GiB up, of 8 below: the outer pass gains with K (isolated 5.20 / 5.30 / 5.38 TB/s of
 	// sweep-words for K = 8 / 10 / 12), the inner elimination and the T chain grow with it -- 262144^2 1.303 -> 1.269 s,
 	// 196608^2 566 -> 557 ms, 393216^2 4.26 -> 4.13 s, but 131072^2 184.0 -> 185.3 ms (profiles/r03_two_level.txt)
@@ -1142,7 +1147,7 @@ int enqueue_backward_parity(Solver &S, const std::vector<int> &ycols_host)
 	// the diagonal blocks of U, gathered by the whole chip into compact form for the serial walk of k_bs_near
 	HIPCHK(pool().alloc((void **)&S.Y, sizeof(u64) * 64 * 16 * std::max(1, S.npanels), S.device));
 	if (S.npanels > 0)
-		k_bs_diag<<<dim3(S.npanels), dim3(256), 0, S.sA>>>(S.M, S.srows, S.npanels, S.panels, S.urow, S.Y);
+		k_bs_diag<<<dim3(S.npanels), dim3(256), 0, S.sA>>>(S.M, S.srows, S.npanels, S.panels, S.urow, S.Y, SysStride{0, 0}, (i64)0);
 	// right-hand sides in groups of GF2_BSV (U is streamed once per group; the groups are independent)
 	for (int v0 = 0; v0 < S.ny; v0 += GF2_BSV) {
 		const int nv = std::min(GF2_BSV, S.ny - v0);
@@ -1150,9 +1155,41 @@ int enqueue_backward_parity(Solver &S, const std::vector<int> &ycols_host)
 			const int qa = std::max(0, qb - GF2_BSG);
 			const int waves = (qb - qa) * 64;
 			k_bs_far<<<dim3((waves + 3) / 4), dim3(256), 0, S.sA>>>(S.M, S.srows, cw, qa, qb, S.panels, S.urow, S.pivcol, S.ycols + v0, nv,
-			                                                        S.out + (i64)v0 * cw, accv, nacc);
-			k_bs_near<<<dim3(1), dim3(256), 0, S.sA>>>(S.Y, cw, qa, qb, S.panels, S.pivcol, nv, S.out + (i64)v0 * cw, accv, nacc);
+			                                                        S.out + (i64)v0 * cw, accv, nacc, SysStride{0, 0}, (i64)0);
+			k_bs_near<<<dim3(1), dim3(256), 0, S.sA>>>(S.Y, cw, qa, qb, S.panels, S.pivcol, nv, S.out + (i64)v0 * cw, accv, nacc,
+			                                           SysStride{0, 0}, (i64)0, (i64)0);
 		}
+	}
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(S.ev2, S.sA));
+	return GF2BV_OK;
+}
+
+// solve_one of a whole gang: the same three kernels with blockIdx.y = system -- one chain of 2 x ceil(npanels / 16) launches
+// for the gang instead of one per system (a 32768^2 system's chain is 64 launches of 6 + 13 us: 1.2 ms during which one
+// workgroup walks a diagonal block; 24 of them in a row were 15 % of a gang's wall time, profiles/r04_batch_budget.txt).
+// The gang owns ycols / out / Y; system s finds its solution at out + s * cw (the views point there, own_bs = false).
+int enqueue_backward_gang(Solver &S)
+{
+	S.ny = 1;
+	const i64 cw = std::max<i64>(1, S.cw);
+	S.h_ycol = (int)S.cols;
+	HIPCHK(pool().alloc((void **)&S.ycols, sizeof(int), S.device));
+	HIPCHK(hipMemcpyAsync(S.ycols, &S.h_ycol, sizeof(int), hipMemcpyHostToDevice, S.sA));
+	HIPCHK(pool().alloc((void **)&S.out, sizeof(u64) * cw * S.nsys, S.device));
+	HIPCHK(hipMemsetAsync(S.out, 0, sizeof(u64) * cw * S.nsys, S.sA));
+	unsigned char *accv = reinterpret_cast<unsigned char *>(S.mult);     // forward multipliers are dead by now
+	const i64 nacc = std::max<i64>(1, S.maxr);
+	const i64 dgw = (i64)64 * 16 * std::max(1, S.npanels);
+	HIPCHK(pool().alloc((void **)&S.Y, sizeof(u64) * dgw * S.nsys, S.device));
+	if (S.npanels > 0)
+		k_bs_diag<<<dim3(S.npanels, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.srows, S.npanels, S.panels, S.urow, S.Y, S.ss(), dgw);
+	for (int qb = S.npanels; qb > 0; qb -= GF2_BSG) {
+		const int qa = std::max(0, qb - GF2_BSG);
+		const int waves = (qb - qa) * 64;
+		k_bs_far<<<dim3((waves + 3) / 4, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.srows, cw, qa, qb, S.panels, S.urow, S.pivcol, S.ycols, 1,
+		                                                                S.out, accv, nacc, S.ss(), cw);
+		k_bs_near<<<dim3(1, S.nsys), dim3(256), 0, S.sA>>>(S.Y, cw, qa, qb, S.panels, S.pivcol, 1, S.out, accv, nacc, S.ss(), dgw, cw);
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(S.ev2, S.sA));
@@ -1350,11 +1387,22 @@ int solve_gang(Solver &S, gf2bv_result **out)
 		rc = make_view(S, s, V[s]);
 		if (rc) return rc;
 	}
-	if (S.mode == GF2BV_MODE_SINGLE)
-		for (int s = 0; s < S.nsys; s++) {
-			rc = enqueue_backward_single(V[s]);
+	if (S.mode == GF2BV_MODE_SINGLE) {
+		static const bool per_system = getenv("GF2BV_GANG_BS") && atoi(getenv("GF2BV_GANG_BS")) == 0;      // (A/B: one chain per system, as rounds 1-3)
+		if (per_system)
+			for (int s = 0; s < S.nsys; s++) {
+				rc = enqueue_backward_single(V[s]);
+				if (rc) return rc;
+			}
+		else {
+			rc = enqueue_backward_gang(S);
 			if (rc) return rc;
+			for (int s = 0; s < S.nsys; s++) {
+				V[s].out = S.out + (i64)s * std::max<i64>(1, S.cw); V[s].ny = 1; V[s].own_bs = false;
+				HIPCHK(hipEventRecord(V[s].ev2, S.sA));
+			}
 		}
+	}
 	for (int s = 0; s < S.nsys; s++) {
 		rc = finish_begin(V[s]);
 		if (rc) return rc;
@@ -1473,9 +1521,28 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 	// NS host threads each take every NS-th gang on their own stream pair (one gang's back-substitution
 	// and export then overlap the next gang's elimination).
 	const i64 gang = pick_gang(nsys, rows, cols);
-	const i64 ngangs = gang ? (nsys + gang - 1) / gang : 0;
-	int NS = (int)std::min<i64>(ngangs, 2);
-	if (const char *e = getenv("GF2BV_BATCH_THREADS")) { int v = atoi(e); if (v >= 1) NS = (int)std::min<i64>(ngangs, v); }
+	// Gangs in flight: NS host threads, each with its own stream pair, take the next gang off a shared list.  STAGGERED: a gang's
+	// elimination is bulk-bound (the chip is full) in its first half and a chain of small panel kernels in its second, and its
+	// back-substitution and export leave the chip nearly idle -- two threads that start together stay in phase for the whole
+	// job (round 3: both gangs in the tail at once, 14 % of the wall time with nothing to stream, profiles/r04_batch_budget.txt).
+	// The list therefore begins with part gangs, thread t's first gang being (t + 1) / NS of a full one: the threads then run
+	// 1 / NS of a period apart, one gang's tail beside another's head.  GF2BV_STAGGER=0: equal gangs, as before.
+	std::vector<std::pair<i64, int>> ranges;       // (first system, systems)
+	int NS = 2;
+	if (const char *e = getenv("GF2BV_BATCH_THREADS")) { int v = atoi(e); if (v >= 1) NS = std::min(v, 16); }
+	{
+		const bool stagger = !(getenv("GF2BV_STAGGER") && atoi(getenv("GF2BV_STAGGER")) == 0);
+		i64 s0 = 0;
+		if (stagger && gang >= 2 * NS && nsys > gang * NS)
+			for (int t = 0; t + 1 < NS && s0 < nsys; t++) {
+				const i64 ns = std::min<i64>(nsys - s0, std::max<i64>(1, gang * (t + 1) / NS));
+				ranges.emplace_back(s0, (int)ns); s0 += ns;
+			}
+		while (s0 < nsys) { const i64 ns = std::min<i64>(gang, nsys - s0); ranges.emplace_back(s0, (int)ns); s0 += ns; }
+	}
+	const i64 ngangs = (i64)ranges.size();
+	NS = (int)std::min<i64>(ngangs, NS);
+	std::atomic<i64> next_gang{0};
 	// Ordering contract: the matrices are whatever `stream` (the caller's stream, NULL = the null stream) has
 	// produced when this call is made.  The gangs run on the library's own non-blocking streams, which are not
 	// ordered against any other stream by themselves: each waits for an event recorded on `stream` here.
@@ -1494,10 +1561,10 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 			hipStream_t st = nullptr;
 			if (pool().stream(&st, device, false) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipStreamCreate"; return; }
 			if (hipStreamWaitEvent(st, ready.ev, 0) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipStreamWaitEvent"; }
-			for (i64 q = t; q < ngangs && rcs[t] == GF2BV_OK; q += NS) {
+			for (i64 q; (q = next_gang.fetch_add(1)) < ngangs && rcs[t] == GF2BV_OK;) {
 				try {
-				const i64 s0 = q * gang;
-				const int ns = (int)std::min<i64>(gang, nsys - s0);
+				const i64 s0 = ranges[(size_t)q].first;
+				const int ns = ranges[(size_t)q].second;
 				int rc = GF2BV_OK;
 				// an expired hand-over gate voids THIS gang only: its results (if any were built) are dropped and the
 				// gang runs once more with events -- the device is marked by then; other gangs' results stay
@@ -1595,6 +1662,8 @@ static int batch_digits_on(const uint32_t *digits, const int64_t *digit_off, int
 	const i64 m_stride = ntiles * TW * srows;
 	const i64 nrows_all = nsys * rows, dig0 = digit_off[0], ndig = digit_off[nrows_all] - dig0;
 	if (ndig < 0) return fail(GF2BV_ERR_ARG, "digit offsets must not decrease");
+	for (i64 r = 0; r < nrows_all; r++)          // (the pack kernel reads digits[off[r] .. off[r + 1]) of the uploaded share)
+		if (digit_off[r + 1] < digit_off[r]) return fail(GF2BV_ERR_ARG, "digit offsets must not decrease");
 	// all digits and offsets go up once; every gang packs its own systems straight into tile-major slabs
 	struct Staged {
 		uint32_t *dig = nullptr; i64 *off = nullptr; hipStream_t st = nullptr; int device = 0;
@@ -1624,7 +1693,7 @@ static int batch_digits_on(const uint32_t *digits, const int64_t *digit_off, int
 		const i64 total = rows * ntiles * TW;
 		if (total > 0)
 			k_pack_digits<<<dim3((unsigned)((ntiles * TW + 255) / 256), (unsigned)std::min<i64>(rows, 65535), S.nsys), dim3(256), 0, S.sA>>>(
-				G.dig - dig0, G.off + s0 * rows, bits_per_digit, (i64)rows, (i64)cols, ntiles * TW, srows, S.M, SysStride{m_stride, 0});
+				G.dig, G.off + s0 * rows, bits_per_digit, (i64)rows, (i64)cols, ntiles * TW, srows, S.M, SysStride{m_stride, 0}, dig0);
 		HIPCHK(hipGetLastError());
 		rc = solve_gang(S, &out[s0]);
 		if (rc) return rc;
@@ -1696,6 +1765,9 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 	S.stride = ntiles * TW;
 	HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * ntiles * TW * slab_rows(rows) + kOuterSlackBytes, device));     // packed straight into tiles
 	const i64 ndig = digit_off[rows];
+	if (digit_off[0] != 0) return fail(GF2BV_ERR_ARG, "digit offsets must start at 0");
+	for (i64 r = 0; r < rows; r++)
+		if (digit_off[r + 1] < digit_off[r]) return fail(GF2BV_ERR_ARG, "digit offsets must not decrease");
 	Scratch scratch;                  // digits, offsets and the pack events go back to the pool on every path
 	scratch.sync_first = S.sA;
 	uint32_t *d_dig = nullptr;
@@ -1712,7 +1784,7 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 		if (total > 0)
 			k_pack_digits<<<dim3((unsigned)((ntiles * TW + 255) / 256), (unsigned)std::min<i64>(rows, 65535)), dim3(256), 0, S.sA>>>(d_dig, d_off, bits_per_digit, (i64)rows,
 			                                                                            (i64)cols, ntiles * TW, slab_rows(rows), S.M,
-			                                                                            SysStride{0, 0});
+			                                                                            SysStride{0, 0}, (i64)0);
 	}
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(p1, S.sA));

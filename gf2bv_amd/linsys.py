@@ -9,7 +9,7 @@ from __future__ import annotations
 
 from typing import Iterable, Optional, Sequence, Union
 
-from ._internal import AffineSpace, m4ri_solve, m4ri_solve_many, mul_bit_quad
+from ._internal import AffineSpace, eqs_to_sage_mat_helper, m4ri_solve, m4ri_solve_many, mul_bit_quad
 from .bitvec import BitVec
 
 Zeros = Sequence[Union[BitVec, int]]
@@ -68,10 +68,19 @@ class LinearSystem:
         return A, b
 
     def get_sage_mat(self, zeros: Zeros):
-        """The reference's fast variant (reference :194-212) renders the matrix as a PNG through libgd for Sage's
-        unpickler (_internal.c:678-765); that helper is outside this package's scope (DESIGN.md
-        section 8), so this is the per-row variant above: same result, slower."""
-        return self.get_sage_mat_slow(zeros)
+        """(A, b) as Sage objects, the fast way (reference :194-212): the coefficient matrix travels as a two-colour PNG
+        (`eqs_to_sage_mat_helper`, _internal.c:678-765 -- written without libgd here) into Sage's own unpickler for
+        GF(2) matrices; the affine bits come back as a list of bools.  Needs Sage at call time."""
+        import struct                                     # noqa: PLC0415
+
+        from sage.all import GF, vector                   # noqa: PLC0415  (optional dependency, as in the reference)
+        from sage.matrix.matrix_mod2_dense import unpickle_matrix_mod2_dense_v2      # noqa: PLC0415
+
+        eqs = self.get_eqs(zeros)
+        buf, affine = eqs_to_sage_mat_helper(eqs, self._cols)
+        b = vector(GF(2), affine)
+        signed = struct.unpack(f">{len(buf)}b", buf)      # Sage wants the PNG as signed chars
+        return unpickle_matrix_mod2_dense_v2(len(eqs), self._cols, signed, len(signed), False), b
 
     # -- boundary call (reference :229-240) ------------------------------------------------------------
     def _solve_internal(self, zeros: Zeros, mode: int):
@@ -123,8 +132,9 @@ class LinearSystem:
     # Independent instances of the same LinearSystem (one zeros list per instance / per output bit) go to
     # the GPU as ONE call: _internal.m4ri_solve_many -> gf2bv_solve_batch_digits, lock-step gangs.
     # Element i of the result is exactly what the single-system method returns for zeros_list[i].
-    # `devices`: None = every visible GPU (the systems are sharded in contiguous blocks over them inside the library, one
-    # host thread per device, no collective -- gf2bv_solve_batch_digits_multi), an int, or a sequence of device indices.
+    # `devices`: None = the module's default device (set_default_device / GF2BV_DEVICE, like solve_one), "all" = every visible
+    # GPU, an int, or a sequence of device indices (the systems are sharded in contiguous blocks over them inside the library,
+    # one host thread per entry, no collective -- gf2bv_solve_batch_digits_multi).
     def _solve_internal_many(self, zeros_list: Sequence[Zeros], mode: int, devices=None) -> list:
         eqs_list = [self.get_eqs(z) for z in zeros_list]
         live = [i for i, eqs in enumerate(eqs_list) if 1 not in eqs]      # "1 = 0" is decided on the host

@@ -293,7 +293,7 @@ def test_batch_sharded_over_devices_from_the_python_boundary(monkeypatch):
     assert _internal.device_count() >= 1 and _internal.get_default_device() == 0
     for mode in (0, 1):
         one = _internal.m4ri_solve_many(systems, cols, mode, 0)
-        for devs in ([0, 0], [0, 0, 0], None, [0] * 11):
+        for devs in ([0, 0], [0, 0, 0], None, "all", [0] * 11):
             got = _internal.m4ri_solve_many(systems, cols, mode, devs)
             for eqs, g, w in zip(systems, got, one):
                 o = O.m4ri_solve(list(eqs), cols, mode)
@@ -305,6 +305,8 @@ def test_batch_sharded_over_devices_from_the_python_boundary(monkeypatch):
     assert m4ri_solve(list(systems[0]), cols, 0, 0) == m4ri_solve(list(systems[0]), cols, 0)
     with pytest.raises(ValueError, match="out of range"):
         _internal.m4ri_solve_many(systems, cols, 0, [0, _internal.device_count()])
+    with pytest.raises(ValueError, match="'all'"):
+        _internal.m4ri_solve_many(systems, cols, 0, "every")
     lin = LinearSystem([8, 8])
     a, b = lin.gens()
     zl = [[a ^ b ^ k, b ^ (k * 7 & 255)] for k in range(9)]

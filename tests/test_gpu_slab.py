@@ -113,6 +113,16 @@ def test_sharded_solve_equals_single_gpu_solve(world, n, seed):
     _run(world, n, seed)
 
 
+@pytest.mark.parametrize("K", [2, 3])
+def test_slab_handle_ignores_a_forced_two_level_plan(K, monkeypatch):
+    """A slab handle is driven block by block (slab_factor_on / slab_apply_on) and never runs outer passes: with
+    GF2BV_TWO_LEVEL forced -- or by default from ~68000^2 up -- plan_two_level used to give it outer panels all the same
+    (world size 1: no look-ahead at a panel's last block, stale window, silently wrong elimination).  ADVICE round 3."""
+    monkeypatch.setenv("GF2BV_TWO_LEVEL", str(K))
+    _run(1, 3000, 11)
+    _run(2, 4096, 12)
+
+
 @pytest.mark.parametrize("shape,want_status", [((1500, 1300, 1000, True), 0), ((1500, 1300, 1000, False), 1),
                                                ((2600, 2050, None, True), 0)])
 def test_sharded_solve_rank_deficient_and_inconsistent(shape, want_status):
