@@ -47,7 +47,8 @@ from gf2bv_amd import batch, hip  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 # synthetic-generator seeds whose N x N matrix has full rank (found with tools/find_full_rank_seed.py)
-FULL_RANK_SEEDS = {65536: 1234, 32768: 1234}
+FULL_RANK_SEEDS = {65536: 1234, 32768: 1234, 262144: 1242}
+LDS_BYTES_PER_CLK_CU = 256.0   # ds_read_b128, conflict-free (MI355X_MICROARCH.md, LDS table)
 BATCH_SEED0 = 5000             # system i of the batch workload uses generator seed BATCH_SEED0 + i
 
 
@@ -72,6 +73,8 @@ def parse():
                     help="single: skip the `batch_c4` block (the configs[3] job of --batch-total x --batch-n systems over the ranks)")
     ap.add_argument("--target-n", type=int, default=262144,
                     help="single: also run the north-star size (1 warm-up + 2 steps) as `target_262144` (0 = skip)")
+    ap.add_argument("--no-extra-legs", action="store_true",
+                    help="single, N = 1: skip c3_mt19937 (configs[2]), c5_xoshiro (configs[4]) and the host-resident 65536^2 solve")
     ap.add_argument("--no-kernel-events", action="store_true",
                     help="do not bracket bulk-update launches with HIP events (roofline becomes null)")
     return ap.parse_args()
@@ -118,6 +121,18 @@ def cpu_baseline(n: int, seed: int) -> dict:
     }
 
 
+def cpu_baseline_list(eqs, cols: int, mode: int, reps: int) -> dict:
+    """The CPU oracle on a list-of-int system (the boundary the reference's m4ri_solve takes): median wall time of `reps`
+    calls and the result -- the timed CPU baseline beside the c3 / c5 legs, and their checker."""
+    from oracle import gf2_oracle as O
+    ts, res = [], None
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        res = O.m4ri_solve(list(eqs), cols, mode)
+        ts.append(time.perf_counter() - t0)
+    return {"ms_median": sorted(ts)[len(ts) // 2] * 1e3, "result": res, "threads": int(O.lib().gf2o_max_threads())}
+
+
 def gpu_equals_oracle(cb: dict, m: int, seed: int, device: int) -> bool:
     """parity gate, second half: the CPU sample solved on the GPU must give the oracle's answer word for word"""
     st2 = hip.padded_stride(m)
@@ -142,6 +157,19 @@ def pmc_traffic(n: int, g: int, t: int, kernel: str = "k_update16"):
     return None
 
 
+_LDS_CLOCK = {}
+
+
+def lds_clock(device: int) -> dict:
+    """shader clock under an LDS-bound load + CU count of this device, measured once per process"""
+    if device not in _LDS_CLOCK:
+        c = hip.lds_clock(device)
+        c["cus"] = torch.cuda.get_device_properties(device).multi_processor_count
+        c["lds_peak_GBs"] = c["cus"] * LDS_BYTES_PER_CLK_CU * c["shader_mhz"] * 1e6 / 1e9
+        _LDS_CLOCK[device] = c
+    return _LDS_CLOCK[device]
+
+
 def roofline_block(stats_list, sweep_ms_total: float, n: int, device: int, ceil: dict | None, note: str | None = None):
     """`stats_list`: the gf2bv_stats of the solves whose bulk-update launches took `sweep_ms_total` (HIP events)."""
     if sweep_ms_total <= 0:
@@ -152,9 +180,26 @@ def roofline_block(stats_list, sweep_ms_total: float, n: int, device: int, ceil:
     achieved = alg_bytes / (sweep_ms_total * 1e-3) / 1e9
     g = s0["panels_per_sweep"]
     t = s0["tables_per_sweep"] // g
+    # What bounds the dominant kernel.  One block per trip through HBM (k_update16): the memory side -- "hbm".  Outer passes
+    # of the two-level elimination (k_update16k) apply K blocks per trip: HBM moves 1/K of the sweep-word bytes and the
+    # kernel is bound by its table lookups in the LDS -- "lds": every 64-bit sweep-word costs g x t lookups of 16 B per
+    # 16-byte row segment = 8 x g x t bytes of ds_read_b128 traffic (256 B for g = 4, t = 8); `lds` prices that against
+    # CUs x 256 B/clk x the shader clock measured under an LDS-bound load in this run.  `frac` stays the HBM-unit figure
+    #  in both cases, so lines of all rounds compare.
+    outer_dominant = 2 * s0.get("outer_blocks", 0) > s0["n_sweeps"]
+    lds = None
+    if outer_dominant:
+        clk = lds_clock(device)
+        lds_bytes = 8.0 * g * t * float(sum(s["sweep_words"] for s in stats_list))
+        lds_rate = lds_bytes / (sweep_ms_total * 1e-3) / 1e9
+        lds = {"lookup_bytes_total": lds_bytes, "achieved_GBs": lds_rate, "peak_GBs": clk["lds_peak_GBs"],
+               "frac": lds_rate / clk["lds_peak_GBs"], "shader_mhz_under_lds_load": clk["shader_mhz"], "cus": clk["cus"],
+               "probe_bytes_per_clk_cu": clk["lds_bytes_per_clk_cu"],
+               "note": "table lookups only (the table builds, ~9 % more LDS traffic, are not counted); kernel time = sum of the "
+                       "launches' durations, the next panel's elimination runs beside them"}
     out = {
-        "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS,
+        "bound": "lds" if outer_dominant else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": achieved / HBM_PEAK_GBS, "lds": lds,
         # PMC bytes per launch of the kernel that dominates this solve (k_update16k where outer passes cover most blocks)
         "traffic": pmc_traffic(n, g, t, "k_update16k" if 2 * s0.get("outer_blocks", 0) > s0["n_sweeps"] else "k_update16"),
         "kernel": (f"k_update16 (bulk update on 16-byte tiles, {g} panels = {64 * g} pivots = {g * t} byte-field tables per pass)"
@@ -294,7 +339,9 @@ def run_single(args, world, rank, local_rank, dev):
                           "backsub": float(np.mean([s.stats["ms_backsub"] for s in stats])),
                           "export": float(np.mean([s.stats["ms_export"] for s in stats])),
                           "total_host": float(np.mean([s.stats["ms_total"] for s in stats]))},
-        "parity_gate": {"residual_rows": int(bad), "all_ranks_ok": bool(ok.item())},
+        "parity_gate": {"residual_rows": int(bad), "all_ranks_ok": bool(ok.item()),
+                        "x_equals_planted": (bool(all(np.array_equal(s.origin, hip.planted_solution(n, seed + rank)) for s in stats))
+                                             if stats[-1].rank == n else None)},
         # table-count independent work rate: (alive rows x 64-column panels) eliminated per second, whole job
         "row_panels_per_s": world * n * ((n + 63) // 64) / 2 / (elapsed / args.steps),
         "roofline": roofline,
@@ -303,6 +350,13 @@ def run_single(args, world, rank, local_rank, dev):
         out[f"target_{args.target_n}"] = target
     if c4 is not None:
         out["batch_c4"] = c4
+    if world == 1 and not args.no_extra_legs:
+        # the reference's own example timings (examples/mt.py:16,32,35; examples/xoshiro.py) and the host-resident headline
+        # system: extra fields, never `value`
+        torch.cuda.empty_cache()
+        out["c3_mt19937"] = c3_mt19937_leg(local_rank, not args.no_cpu_baseline)
+        out["c5_xoshiro"] = c5_xoshiro_leg(local_rank, not args.no_cpu_baseline)
+        out["h2d_inclusive"] = h2d_leg(n, seed, local_rank, dev)
     if world == 1 and not args.no_cpu_baseline:
         m = args.cpu_n or 65536
         cb = cpu_baseline(m, seed)
@@ -321,7 +375,7 @@ def target_leg(n: int, device: int, dev, ceil: dict) -> dict:
         return {"skipped": f"needs {need / 2**30:.1f} GiB of free HBM, {free_b / 2**30:.1f} available"}
     mat = torch.empty(n * stride, dtype=torch.int64, device=dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    seed = 1234
+    seed = FULL_RANK_SEEDS.get(n, 1234)               # full rank: the planted solution is the only one (bit-exactness by uniqueness)
     hip.synth_device(mat.data_ptr(), n, n, stride, seed, device=device, stream=stream)
     torch.cuda.synchronize(dev)
     steps = 2
@@ -343,9 +397,136 @@ def target_leg(n: int, device: int, dev, ceil: dict) -> dict:
                                                      for a, b in zip(stats, plain_stats))),
             "row_xors_per_s": float(sum(s.stats["row_xors"] for s in stats)) / elapsed,
             "rank": int(stats[-1].rank), "residual_rows": int(bad), "all_solved": all(s.solved for s in stats),
+            "full_rank": bool(stats[-1].rank == n),
+            # rank = N: A x = b has ONE solution, so equality with the generator's planted vector is bit-exactness (SURVEY hard part 7)
+            "x_equals_planted": bool(all(np.array_equal(s.origin, hip.planted_solution(n, seed)) for s in stats + plain_stats)),
             "solve_wall_ms": {"eliminate": float(np.mean([s.stats["ms_eliminate"] for s in stats])),
                               "backsub": float(np.mean([s.stats["ms_backsub"] for s in stats]))},
             "roofline": roofline}
+
+
+MT_VARIANTS = ((32, None), (17, None), (9, None), (1, None), (1337, 19968 // 1337 + 10), (137, 19968 // 137 + 60))
+
+
+def c3_mt19937_leg(device: int, with_oracle: bool) -> dict:
+    """BASELINE configs[2]: MT19937 state recovery, the six (bits per output, samples) variants the reference's examples/mt.py
+    times (`generate system` :16,32 and `solve_one` :35), end to end through the list-of-int boundary the reference's own
+    `m4ri_solve` takes: generate (symbolic MT19937 on BitVecs) . get_eqs . m4ri_solve (digits -> device pack kernel, elimination,
+    back-substitution, export) . convert_sol, and the known answer of examples/mt.py:38 (the state of random.Random(3142)).
+    Beside each: the CPU oracle on the same equation list (test infrastructure, here as the timed baseline only).  Warm = the
+    second call of the same shape.  Never `value`."""
+    import random
+
+    from gf2bv_amd import LinearSystem, _internal
+    from gf2bv_amd.crypto import MT19937
+    out, threads = [], None
+    for bs, samples in MT_VARIANTS:
+        rand = random.Random(3142)
+        state = tuple(rand.getstate()[1][:-1])
+        eff = ((bs - 1) & bs) or bs
+        ns = 624 * 32 // eff if samples is None else samples
+        obs = [rand.getrandbits(bs) for _ in range(ns)]
+        lin = LinearSystem([32] * 624)
+        mt = lin.gens()
+        sym = MT19937(mt)
+        t0 = time.perf_counter()
+        zeros = [sym.getrandbits(bs) ^ o for o in obs] + [mt[0] ^ 0x80000000]
+        t1 = time.perf_counter()
+        eqs = lin.get_eqs(zeros)
+        eqs += [0] * max(0, lin._cols - len(eqs))
+        t2 = time.perf_counter()
+        walls = []
+        for _ in range(2):                                # cold (first call of this shape), warm
+            ta = time.perf_counter()
+            raw = _internal.m4ri_solve(eqs, lin._cols, 0, device)
+            walls.append(time.perf_counter() - ta)
+        ok = raw is not None and lin.convert_sol(raw) == state
+        # device-side split of the same call (the ctypes twin of the boundary: digits -> gf2bv_solve_digits)
+        st = _digits_stats(eqs, lin._cols, device)
+        rec = {"bits_per_output": bs, "outputs": ns, "rows": len(eqs), "cols": lin._cols,
+               "generate_ms": (t1 - t0) * 1e3, "get_eqs_ms": (t2 - t1) * 1e3,
+               "m4ri_solve_ms": {"first": walls[0] * 1e3, "warm": walls[1] * 1e3},
+               "device_ms": st, "recovered_state_equals_known_answer": bool(ok)}
+        if with_oracle:
+            cb = cpu_baseline_list(eqs, lin._cols, 0, 1)
+            rec["cpu_oracle_ms"] = cb["ms_median"]
+            rec["gpu_equals_cpu_oracle"] = bool(cb["result"] == raw)
+            threads = cb["threads"]
+        out.append(rec)
+    return {"workload": "MT19937 state recovery (19968 unknowns), the six variants of the reference's examples/mt.py, list-of-int boundary",
+            "cpu_oracle_threads": threads if with_oracle else None, "variants": out}
+
+
+def _digits_stats(eqs, cols: int, device: int) -> dict:
+    """pack / H2D . elimination . back-substitution . export of one solve through gf2bv_solve_digits (what m4ri_solve calls)"""
+    nd = (cols + 1 + 31) // 32                             # 32-bit digits, the same count for every equation
+    mask = (1 << (32 * nd)) - 1
+    dig = np.frombuffer(b"".join((abs(e) & mask).to_bytes(4 * nd, "little") for e in eqs), dtype=np.uint32)
+    off = np.arange(len(eqs) + 1, dtype=np.int64) * nd
+    s = hip.solve_digits(dig, off, 32, len(eqs), cols, hip.MODE_SINGLE, device=device).stats
+    return {"pack_h2d": s["ms_pack"], "eliminate": s["ms_eliminate"], "backsub": s["ms_backsub"], "export": s["ms_export"],
+            "total_host": s["ms_total"]}
+
+
+def c5_xoshiro_leg(device: int, with_oracle: bool) -> dict:
+    """BASELINE configs[4]: xoshiro256** seed recovery with solve_all (640 x 256, unique solution, kernel-basis path), the
+    scenario of the reference's examples/xoshiro.py: cold = the first solve of this shape in the process, warm = median of 200."""
+    import random
+
+    from gf2bv_amd import LinearSystem
+    from gf2bv_amd.crypto import Xoshiro256starstar
+    rnd = random.Random(1)
+    gen = Xoshiro256starstar([rnd.getrandbits(64) for _ in range(4)])
+    secret = tuple(gen.s)
+    outs = [gen() for _ in range(10)]
+    lin = LinearSystem([64] * 4)
+    sym = Xoshiro256starstar(lin.gens())
+    t0 = time.perf_counter()
+    zeros = [sym.step() ^ Xoshiro256starstar.untemper(o) for o in outs]
+    t1 = time.perf_counter()
+    sols = list(lin.solve_all(zeros))
+    cold = time.perf_counter() - t1
+    warm = []
+    for _ in range(200):
+        ta = time.perf_counter()
+        again = list(lin.solve_all(zeros))
+        warm.append(time.perf_counter() - ta)
+    warm.sort()
+    rec = {"workload": "xoshiro256** seed recovery, solve_all, 640 x 256 (reference examples/xoshiro.py)",
+           "generate_ms": (t1 - t0) * 1e3, "solve_all_ms": {"cold": cold * 1e3, "warm_median": warm[len(warm) // 2] * 1e3,
+                                                            "warm_p99": warm[int(len(warm) * .99)] * 1e3},
+           "solutions": len(sols), "recovered_seed_equals_known_answer": bool(sols == [secret] and again == sols)}
+    if with_oracle:
+        eqs = lin.get_eqs(zeros)
+        eqs += [0] * max(0, 256 - len(eqs))
+        cb = cpu_baseline_list(eqs, 256, 1, 21)
+        rec["cpu_oracle_ms_median"] = cb["ms_median"]
+        rec["gpu_equals_cpu_oracle"] = bool([lin.convert_sol(s) for s in cb["result"]] == sols)
+    return rec
+
+
+def h2d_leg(n: int, seed: int, device: int, dev) -> dict:
+    """The headline system starting on the HOST (SURVEY 8d phase list: pack/H2D . elimination . back-subst . export): the same
+    65536^2 solve through gf2bv_solve_words, i.e. from a row-major uint64 buffer in host memory (pageable, as a caller's numpy
+    array is).  Never `value` (inputs of the timed region of `value` are resident in HBM)."""
+    stride = hip.padded_stride(n)
+    buf = hip.DeviceBuffer(n * stride * 8, device)
+    hip.synth_device(buf.ptr, n, n, stride, seed, device=device)
+    host = buf.download().view(np.uint64).reshape(n, stride)
+    buf.free()
+    walls, st = [], None
+    for _ in range(2):
+        ta = time.perf_counter()
+        sol = hip.solve_words(host, n, n, hip.MODE_SINGLE, device=device)
+        walls.append(time.perf_counter() - ta)
+        st = sol.stats
+    ok = bool(sol.rank == n and np.array_equal(sol.origin, hip.planted_solution(n, seed))) if n in FULL_RANK_SEEDS else None
+    return {"n": n, "input": f"{n * stride * 8 / 2**20:.0f} MiB row-major uint64 in pageable host memory",
+            "ms_per_solve": {"first": walls[0] * 1e3, "second": walls[1] * 1e3},
+            "phases_ms": {"pack_h2d": st["ms_pack"], "eliminate": st["ms_eliminate"], "backsub": st["ms_backsub"],
+                          "export": st["ms_export"], "total_host": st["ms_total"]},
+            "h2d_GBs": n * stride * 8 / (st["ms_pack"] * 1e-3) / 1e9 if st["ms_pack"] > 0 else None,
+            "x_equals_planted": ok}
 
 
 def batch_job(args, world, rank, local_rank, dev, steps: int, warmup: int):

@@ -264,24 +264,46 @@ __global__ void k_pack_digits(const uint32_t *__restrict__ digits, const i64 *__
 	}
 }
 
-// Row-major augmented words (the C ABI layout) -> tile-major working layout, 16 bytes per lane.
+// Row-major augmented words (the C ABI layout) -> tile-major working layout, through the LDS (round 4): a workgroup takes 64
+// rows x 16 tiles, READS them row by row (16 lanes = 256 contiguous bytes of a row) and WRITES them tile by tile (64 lanes = one
+// contiguous KiB of a slab).  The one-lane-per-row form of rounds 1-3 read 16 bytes out of every row stride -- a 64-byte sector
+// per 16 useful bytes -- and ran 0.86 TB/s (read + written) on the 8 GiB of a 262144^2 system: 20 ms of every solve.
+// LDS: [tile][row] with a row pitch of 65 entries, so that the 16 tiles a wavefront stores side by side fall into 16 different
+// groups of four banks.
 __global__ void __launch_bounds__(256)
 k_to_tiled(const u64 *__restrict__ src, i64 stride, i64 rows, i64 ntiles, i64 wt, i64 srows, u64 *__restrict__ dst,
            i64 src_sys_words, SysStride ss)
 {
-	// grid: x = (row, lane) pairs, y = tile, z = system of a gang (one launch dimension holds < 2^32 work-items)
+	static_assert(GF2_TW == 2, "16-byte tiles");
+	// grid: x = blocks of 64 rows, y = groups of 16 tiles, z = system of a gang
 	src += blockIdx.z * src_sys_words;
 	dst += blockIdx.z * ss.m_words;
-	const i64 t = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-	const int lr = (int)(t % GF2_LPR);
-	const i64 row = t / GF2_LPR;
-	const i64 tile = blockIdx.y;
-	if (row >= rows || tile >= ntiles) return;
-	const i64 w = tile * GF2_TW + 2 * lr;
-	u64 a = (w < wt) ? src[row * stride + w] : 0ull;
-	u64 b = (w + 1 < wt) ? src[row * stride + w + 1] : 0ull;
-	dst[(tile * srows + row) * GF2_TW + 2 * lr] = a;
-	dst[(tile * srows + row) * GF2_TW + 2 * lr + 1] = b;
+	__shared__ uint4 buf[16 * 65];
+	const int t = threadIdx.x;
+	const i64 row0 = (i64)blockIdx.x * 64, tile0 = (i64)blockIdx.y * 16;
+	const bool even = ((stride & 1) == 0) && ((reinterpret_cast<size_t>(src) & 15) == 0);      // 16-byte loads are aligned
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		const int r = (t >> 4) + 16 * i, c = t & 15;
+		const i64 row = row0 + r, w = (tile0 + c) * 2;
+		uint4 v = make_uint4(0, 0, 0, 0);
+		if (row < rows && w < wt) {
+			const u64 *p = src + row * stride + w;
+			if (even && w + 1 < wt) v = *reinterpret_cast<const uint4 *>(p);
+			else {
+				const u64 a = p[0], b2 = (w + 1 < wt) ? p[1] : 0ull;
+				v = make_uint4((unsigned)a, (unsigned)(a >> 32), (unsigned)b2, (unsigned)(b2 >> 32));
+			}
+		}
+		buf[c * 65 + r] = v;
+	}
+	__syncthreads();
+#pragma unroll
+	for (int i = 0; i < 4; i++) {
+		const int c = (t >> 6) + 4 * i, r = t & 63;
+		const i64 row = row0 + r, tile = tile0 + c;
+		if (row < rows && tile < ntiles) reinterpret_cast<uint4 *>(dst)[tile * srows + row] = buf[c * 65 + r];
+	}
 }
 
 // ==========================================================================================
@@ -2001,11 +2023,24 @@ __global__ void __launch_bounds__(LB)
 k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
            const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
            const u64 *__restrict__ mult4, const int *__restrict__ blk_first,
-           int tile_begin, int ntiles, int world, int wrank, const uint4 *__restrict__ Pc, SysStride ss)
+           int tile_begin, int ntiles, int world, int wrank, const uint4 *__restrict__ Pc, SysStride ss, int xcd_nsys)
 {
+	// Which system, which span.  A gang's launch is normally (spans, systems); with xcd_nsys > 0 (a gang of a multiple of 8
+	// systems, round 4) it is ONE line of spans x systems workgroups decoded so that all workgroups of a system sit on ONE
+	// XCD -- the dispatcher is observed to place workgroup b on XCD b % 8 (MI355X_MICROARCH.md: for speed only, and this is
+	// only speed): a system's per-row multipliers (32 B per row and block, re-read for every tile) then stay in that XCD's
+	// 4 MiB L2 instead of being fetched into all eight (a gang of 24: 24 MiB of multipliers against 8 x 4 MiB of L2;
+	// PMC, gangs of 6: FETCH_SIZE = 1.53 x the algorithmic reads, profiles/r04_batch_pmc.txt).
+	unsigned bx = blockIdx.x, gx = gridDim.x, by = blockIdx.y;
+	if (xcd_nsys > 0) {
+		const unsigned g8 = (unsigned)xcd_nsys >> 3, slot = bx >> 3;
+		by = (slot % g8) * 8 + (bx & 7);
+		gx = gx / (unsigned)xcd_nsys;
+		bx = slot / g8;
+	}
 	{
-		const i64 ao = blockIdx.y * ss.arena_bytes;
-		M += blockIdx.y * ss.m_words;
+		const i64 ao = (i64)by * ss.arena_bytes;
+		M += (i64)by * ss.m_words;
 		panels = sys_at(panels, ao); aux = sys_at(aux, ao); mult4 = sys_at(mult4, ao); blk_first = sys_at(blk_first, ao);
 		if (Pc) Pc = sys_at(Pc, ao);
 	}
@@ -2026,9 +2061,9 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	constexpr int ALIGN = NW * 64;
 	const i64 R = (R64 - rlo + ALIGN - 1) / ALIGN * ALIGN;
 	const i64 total = (i64)ntiles * R;
-	i64 chunk = (total + gridDim.x - 1) / gridDim.x;
+	i64 chunk = (total + gx - 1) / gx;
 	chunk = (chunk + ALIGN - 1) / ALIGN * ALIGN;
-	i64 pos = (i64)blockIdx.x * chunk;
+	i64 pos = (i64)bx * chunk;
 	const i64 pend = (pos + chunk < total) ? pos + chunk : total;
 
 	// lane constants: byte s % 3 of KC[s / 3] = 16 * (table read at step s), byte 3 = 1 (the page bit of group 1)
@@ -2265,9 +2300,14 @@ template <int WPW, bool IDENT>
 __global__ void __launch_bounds__(64 * WPW)
 k_outer_trsm(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int npan, int group_begin,
              const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
-             const u64 *__restrict__ mult, i64 set_words, int set0, int nsets, int upd_T, u64 *__restrict__ Tm)
+             const u64 *__restrict__ mult, i64 set_words, int set0, int nsets, int upd_T, u64 *__restrict__ Tm, SysStride ss)
 {
 	static_assert(WPW == 4, "thread <-> table entry mapping below");
+	{       // gang: blockIdx.y = system
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		M += blockIdx.y * ss.m_words;
+		panels = sys_at(panels, ao); aux = sys_at(aux, ao); mult = sys_at(mult, ao); Tm = sys_at(Tm, ao);
+	}
 	constexpr int NP = GF2_KMAX * GF2_GMAX;
 	__shared__ u64 S[NP * 64 * WPW];           // [panel][slot][word] source rows (64 KiB)
 	__shared__ u64 Pb[64 * WPW];               // current panel's pivot rows by pivot BIT, zero where there is none
@@ -2380,8 +2420,12 @@ k_outer_trsm(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int npan, int gro
 //                       of k_outer_apply) and at the same time the row pivot k is stored in (its output rows)
 #define GF2_OUTER_LISTS (2 * GF2_KMAX * GF2_GMAX * 64 + GF2_KMAX)
 __global__ void __launch_bounds__(256)
-k_outer_prow(int j0, int nblk, const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux, int *__restrict__ out)
+k_outer_prow(int j0, int nblk, const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux, int *__restrict__ out, SysStride ss)
 {
+	{
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		panels = sys_at(panels, ao); aux = sys_at(aux, ao); out = sys_at(out, ao);
+	}
 	constexpr int NQ = GF2_KMAX * GF2_GMAX * 64;
 	__shared__ int anyb[GF2_KMAX];
 	if (threadIdx.x < GF2_KMAX) anyb[threadIdx.x] = 0;
@@ -2411,10 +2455,15 @@ template <int SEG>
 __global__ void __launch_bounds__(512)
 k_update16k(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__restrict__ gprow,
             const u64 *__restrict__ mult, i64 set_words, int set0, int nsets,
-            const int *__restrict__ blk_first, const int *__restrict__ died, int j_end, int tile_begin, int ntiles)
+            const int *__restrict__ blk_first, const int *__restrict__ died, int j_end, int tile_begin, int ntiles, SysStride ss)
 {
 	constexpr int NT = 512, NW = 8;
 	static_assert(GF2_KMAX * GF2_GMAX * 64 % 512 == 0, "k_outer_apply: whole pivots per lane");
+	{       // gang: blockIdx.y = system (wave-uniform rebasing, scalar registers)
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		M += blockIdx.y * ss.m_words;
+		gprow = sys_at(gprow, ao); mult = sys_at(mult, ao); blk_first = sys_at(blk_first, ao); died = sys_at(died, ao);
+	}
 	__shared__ __attribute__((aligned(256))) uint4 tab[2 * 256 * 16];      // 128 KiB, must sit at LDS address 0 (checked below)
 	__shared__ uint4 stage[GF2_GMAX * 64];
 	__shared__ int anyb[GF2_KMAX];
@@ -2567,8 +2616,13 @@ k_update16k(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__res
 // the very end, into the rows of the same set), the lookups go by the T row's 32 bytes of that block -- the table and lookup
 // code of the bulk update, accumulating from zero.  ~5 us per source block and tile instead of a 0.3 ms chain per word group.
 __global__ void __launch_bounds__(512)
-k_outer_apply(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__restrict__ lists, const u64 *__restrict__ Tm, int tile_begin)
+k_outer_apply(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__restrict__ lists, const u64 *__restrict__ Tm, int tile_begin, SysStride ss)
 {
+	{
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		M += blockIdx.y * ss.m_words;
+		lists = sys_at(lists, ao); Tm = sys_at(Tm, ao);
+	}
 	constexpr int NT = 512, NW = 8, SEG = GF2_KMAX * GF2_GMAX * 64 / NT, NQ = GF2_KMAX * GF2_GMAX * 64;      // 4 pivots per lane
 	__shared__ __attribute__((aligned(256))) uint4 tab[2 * 256 * 16];      // 128 KiB at LDS address 0
 	__shared__ uint4 stage[GF2_GMAX * 64];
@@ -3094,6 +3148,27 @@ k_rmw_stream(uint4 *__restrict__ a, i64 per_wg, unsigned c)
 		p[i] = v0;
 		if (two) { v1.x ^= c; v1.y ^= c; v1.z ^= c; v1.w ^= c; p[i + 1024] = v1; }
 	}
+}
+// Shader clock under an LDS-bound load (bench only): every workgroup reads its 64 KiB of LDS with ds_read_b128 round after
+// round; workgroup 0 brackets the loop with the shader-clock counter (s_memtime) and the 100 MHz real-time counter.
+// out[0] = shader clocks, out[1] = real-time ticks, out[2] = ds_read_b128 wave-instructions this workgroup issued.
+__global__ void __launch_bounds__(512)
+k_lds_clock(unsigned long long *__restrict__ out, int rounds, unsigned *__restrict__ sink)
+{
+	__shared__ uint4 buf[4096];
+	for (int i = threadIdx.x; i < 4096; i += 512) buf[i] = make_uint4(i, i * 3u, i * 5u, i * 7u);
+	__syncthreads();
+	const unsigned long long c0 = clock64(), w0 = wall_clock64();
+	uint4 acc = make_uint4(0, 0, 0, 0);
+	unsigned at = threadIdx.x;
+	for (int r = 0; r < rounds; r++) {
+#pragma unroll
+		for (int k = 0; k < 8; k++) { acc = xor4(acc, buf[(at + 512 * k) & 4095]); }
+		at = (at + 64 + (acc.x & 1)) & 4095;
+	}
+	const unsigned long long c1 = clock64(), w1 = wall_clock64();
+	if (acc.x == 0x9E3779B9u && acc.y == 1u) sink[0] = acc.z;
+	if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = c1 - c0; out[1] = w1 - w0; out[2] = (unsigned long long)rounds * 8 * 8; }
 }
 __global__ void __launch_bounds__(1024)
 k_read_stream(const uint4 *__restrict__ a, i64 per_wg, unsigned *__restrict__ sink)

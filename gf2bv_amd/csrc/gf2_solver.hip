@@ -233,7 +233,7 @@ void forget_concurrency(int device);
 struct UpdateImpl {
 	int G, T, lds_bytes, threads;
 	hipError_t (*update)(dim3, hipStream_t, u64 *, i64, i64, int, int, int, const PanelRec *, const PanelAux *,
-	                     const u64 *, const int *, int, int, int, int, int, int, const uint4 *, SysStride, hipEvent_t, hipEvent_t);
+	                     const u64 *, const int *, int, int, int, int, int, int, const uint4 *, SysStride, hipEvent_t, hipEvent_t, int);
 };
 
 // 16-byte tiles: G = 4 panels, T = 8 byte fields per panel.  nw_lo < 0 selects the HALF instance (only the tile's second
@@ -242,15 +242,16 @@ template <int NT, int DEPTH, bool PIPE, int LB>
 hipError_t launch_update16(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows, int j0, int gb, int wlo,
                            const PanelRec *panels, const PanelAux *aux, const u64 *multset, const int *blk_first,
                            int tile_begin, int ntiles, int world, int wrank, int nw_lo, int nw_hi, const uint4 *Pc, SysStride ss,
-                           hipEvent_t begun, hipEvent_t done)
+                           hipEvent_t begun, hipEvent_t done, int xcd_nsys)
 {
 	(void)nw_hi;
+	if (xcd_nsys > 0) grid = dim3(grid.x * grid.y);          // one line of workgroups, decoded in the kernel (a system per XCD)
 	if (nw_lo < 0)
 		hipExtLaunchKernelGGL((k_update16<NT, true, DEPTH, PIPE, LB>), grid, dim3(NT), 0, s, begun, done, 0, M, rows, srows, j0, gb, wlo,
-		                      panels, aux, multset, blk_first, tile_begin, ntiles, world, wrank, Pc, ss);
+		                      panels, aux, multset, blk_first, tile_begin, ntiles, world, wrank, Pc, ss, xcd_nsys);
 	else
 		hipExtLaunchKernelGGL((k_update16<NT, false, DEPTH, PIPE, LB>), grid, dim3(NT), 0, s, begun, done, 0, M, rows, srows, j0, gb, wlo,
-		                      panels, aux, multset, blk_first, tile_begin, ntiles, world, wrank, Pc, ss);
+		                      panels, aux, multset, blk_first, tile_begin, ntiles, world, wrank, Pc, ss, xcd_nsys);
 	return hipGetLastError();
 }
 #define UPDATE16_IMPL(NT, D, P, LB) { 4, 8, 2 * 256 * 256 + GF2_GMAX * 64 * 20, NT, launch_update16<NT, D, P, LB> }
@@ -368,6 +369,7 @@ struct Solver {
 	int sparse_mode = 2;          // search skips absent columns: 0 never, 1 always, 2 per chunk by density (GF2BV_SPARSE)
 	int fused_rpt = 0;            // GF2BV_FUSED_RPT: row blocks of 256 per narrowing workgroup of k_block_fast_narrow (0 = by size)
 	bool use_pc = true;           // GF2BV_PC=0: the bulk update fetches the pivot rows through the panel records, as before round 3
+	bool xcd_pin = true;          // gangs of a multiple of 8 systems: every system's bulk-update workgroups on one XCD (GF2BV_XCD_PIN=0: plain 2-D grid)
 	bool fused_narrow = true;     // optimistic blocks: search and narrow step in ONE launch (k_block_fast_narrow); GF2BV_FUSED_NARROW=0: two
 	int narrow_rpt = 1;           // row blocks of 256 per narrow workgroup of a panel step (set in solver_alloc; GF2BV_NARROW_RPT)
 	int self_wait = 5000;         // ticks (100 MHz) unit 0 of a panel search waits for the other units before it leaves
@@ -499,11 +501,17 @@ void plan_two_level(Solver &S)
 	S.tl_K = 0; S.tl_bend = 0; S.nsets = 2;
 	// (a column-slab handle -- ext_M, at world size 1 too -- is driven block by block through slab_factor_on / slab_apply_on, which
 	// know nothing of outer panels: with a plan it would skip the look-ahead at every panel end and never run an outer pass)
-	if (S.world != 1 || S.ext_M || S.nsys != 1 || S.impl->G != GF2_GMAX) return;
+	if (S.world != 1 || S.ext_M || S.impl->G != GF2_GMAX) return;
+	// gangs (round 4): every outer kernel takes blockIdx.y = system, and GF2BV_GANG_TWO_LEVEL=1 gives a gang the same plan with
+	// its matrices taken together -- bit-exact (tests/test_gpu_stress.py), but NOT the default: 192 x 32768^2 ran 4.4 ms per
+	// system against 3.9 on the one-level schedule (profiles/r04_batch_scans.txt): a gang's inner elimination is a chain of
+	// all-rows launches of thousands of workgroups that do not fit beside k_update16k (217 VGPRs), so the chain and the pass
+	// wait for each other instead of overlapping.
+	if (S.nsys != 1 && !(getenv("GF2BV_GANG_TWO_LEVEL") && atoi(getenv("GF2BV_GANG_TWO_LEVEL")) != 0)) return;
 	// outer panels of 12 blocks from 3 GiB up, of 8 below: the outer pass gains with K (isolated 5.20 / 5.30 / 5.38 TB/s of
 	// sweep-words for K = 8 / 10 / 12), the inner elimination and the T chain grow with it -- 262144^2 1.303 -> 1.269 s,
 	// 196608^2 566 -> 557 ms, 393216^2 4.26 -> 4.13 s, but 131072^2 184.0 -> 185.3 ms (profiles/r03_two_level.txt)
-	int K = (double)S.rows * (double)S.wt * 8.0 >= 3.0 * 1073741824.0 ? GF2_KMAX : 8;
+	int K = (double)S.rows * (double)S.wt * 8.0 >= 3.0 * 1073741824.0 ? GF2_KMAX : 8;       // (per system: a gang's panels stay at 8 blocks)
 	double min_bytes = 0.5 * 1073741824.0;
 	if (const char *e = getenv("GF2BV_TWO_LEVEL"); e && *e) {
 		const int v = atoi(e);
@@ -518,7 +526,7 @@ void plan_two_level(Solver &S)
 	for (int b0 = 0; b0 + K < S.nblocks; b0 += K) {            // (the last block never ends an outer panel: it may be short)
 		const i64 rows_left = S.rows - (i64)(b0 + K) * 64 * G, words_left = S.wt - (i64)(b0 + K) * G;
 		if ((i64)(b0 + K) * 64 * G > S.cols || rows_left <= 0 || words_left <= 0) break;
-		if ((double)rows_left * (double)words_left * 8.0 < min_bytes) break;
+		if ((double)rows_left * (double)words_left * 8.0 * (double)S.nsys < min_bytes) break;
 		bend = b0 + K;
 	}
 	if (!bend) return;
@@ -539,8 +547,7 @@ int solver_alloc(Solver &S)
 	S.m_stride = S.ntiles * TW * S.srows;
 	if (!S.M) HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * S.m_stride * S.nsys + kOuterSlackBytes, S.device));
 	if (S.src && S.rows > 0) {
-		const i64 threads = S.rows * GF2_LPR;
-		k_to_tiled<<<dim3((unsigned)((threads + 255) / 256), (unsigned)S.ntiles, S.nsys), dim3(256), 0, S.sA>>>(
+		k_to_tiled<<<dim3((unsigned)((S.rows + 63) / 64), (unsigned)((S.ntiles + 15) / 16), S.nsys), dim3(256), 0, S.sA>>>(
 			S.src, S.stride, S.rows, S.ntiles, std::min(S.wt, S.stride), S.srows, S.M, S.src_sys_words, S.ss());
 	}
 	const int G = S.impl->G;
@@ -556,6 +563,7 @@ int solver_alloc(Solver &S)
 	if (const char *e = getenv("GF2BV_OPTIMISTIC")) S.optimistic = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_FUSED_NARROW")) S.fused_narrow = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_PC")) S.use_pc = atoi(e) != 0;
+	if (const char *e = getenv("GF2BV_XCD_PIN")) S.xcd_pin = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_FUSED_RPT")) S.fused_rpt = atoi(e);
 	// narrow workgroups: as many rows each as keeps ~256 of them (all systems of a gang together) busy, at most 8 blocks
 	{
@@ -713,7 +721,8 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 	hipEvent_t begun = nullptr, done = nullptr;
 	if (S.ext_events) { begun = ka; done = S.time_kernels ? kb : (last && !S.flag_sync ? S.evPrio[b] : nullptr); }
 	HIPCHK(S.impl->update(dim3((unsigned)wgs, S.nsys), st, S.M, S.rows, S.srows, j0, gb, wlo, S.panels, S.aux, mset,
-	                      S.blk_first + b, tile_begin, ntiles, S.world, S.wrank, nw_lo, nw_hi, (const uint4 *)S.Pc, S.ss(), begun, done));
+	                      S.blk_first + b, tile_begin, ntiles, S.world, S.wrank, nw_lo, nw_hi, (const uint4 *)S.Pc, S.ss(), begun, done,
+	                      S.xcd_pin && S.nsys >= 8 && S.nsys % 8 == 0 ? S.nsys : 0));
 	if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, st));
 	if (!last || S.flag_sync) return GF2BV_OK;
 	if (S.ext_events) *handoff = done;
@@ -941,10 +950,10 @@ int enqueue_outer_prepare(Solver &S, hipStream_t st, int b0, int b1)
 	// (lists: two buffers by panel parity, T: two as well -- the previous panel's outer pass may still be reading its own)
 	int *gprow = S.oprow + (size_t)((b0 / S.tl_K) & 1) * GF2_OUTER_LISTS;
 	u64 *Tm = S.Tm + (size_t)((b0 / S.tl_K) & 1) * ((size_t)GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX);
-	k_outer_prow<<<dim3(1), dim3(256), 0, st>>>(b0 * G, b1 - b0, S.panels, S.aux, gprow);
+	k_outer_prow<<<dim3(1, S.nsys), dim3(256), 0, st>>>(b0 * G, b1 - b0, S.panels, S.aux, gprow, S.ss());
 	if (!S.outer_chain)
-		k_outer_trsm<4, true><<<dim3((unsigned)(npan / 4)), dim3(256), 0, st>>>(S.M, S.rows, S.srows, b0 * G, npan, 0, S.panels, S.aux, S.mult,
-		                                                                       set_words, b0 % S.nsets, S.nsets, S.impl->T, Tm);
+		k_outer_trsm<4, true><<<dim3((unsigned)(npan / 4), S.nsys), dim3(256), 0, st>>>(S.M, S.rows, S.srows, b0 * G, npan, 0, S.panels, S.aux, S.mult,
+		                                                                               set_words, b0 % S.nsets, S.nsets, S.impl->T, Tm, S.ss());
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
@@ -959,11 +968,11 @@ int enqueue_outer_apply(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, 
 	const int npan = (b1 - b0) * G;
 	if (S.outer_chain) {
 		const i64 g_begin = t_begin * TW / 4, ng = t_end * TW / 4 - g_begin;
-		k_outer_trsm<4, false><<<dim3((unsigned)ng), dim3(256), 0, st>>>(S.M, S.rows, S.srows, b0 * G, npan, (int)g_begin, S.panels, S.aux,
-		                                                                  S.mult, set_words, b0 % S.nsets, S.nsets, S.impl->T, (u64 *)nullptr);
+		k_outer_trsm<4, false><<<dim3((unsigned)ng, S.nsys), dim3(256), 0, st>>>(S.M, S.rows, S.srows, b0 * G, npan, (int)g_begin, S.panels, S.aux,
+		                                                                          S.mult, set_words, b0 % S.nsets, S.nsets, S.impl->T, (u64 *)nullptr, S.ss());
 	} else
-		k_outer_apply<<<dim3((unsigned)nt), dim3(512), 0, st>>>(S.M, S.rows, S.srows, b1 - b0, (const int *)gprow,
-		                                                        (const u64 *)(S.Tm + (size_t)((b0 / S.tl_K) & 1) * ((size_t)GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX)), (int)t_begin);
+		k_outer_apply<<<dim3((unsigned)nt, S.nsys), dim3(512), 0, st>>>(S.M, S.rows, S.srows, b1 - b0, (const int *)gprow,
+		                                                                (const u64 *)(S.Tm + (size_t)((b0 / S.tl_K) & 1) * ((size_t)GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX)), (int)t_begin, S.ss());
 	HIPCHK(hipGetLastError());
 	hipEvent_t ka = nullptr, kb = nullptr;
 	if (S.time_kernels) {
@@ -975,9 +984,9 @@ int enqueue_outer_apply(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, 
 	const i64 est_lo = std::min<i64>(S.rows, (i64)b0 * 64 * G) & ~(i64)63, R64 = round_up(S.rows, 64);
 	const i64 nch = std::max<i64>(1, (R64 - est_lo + (i64)GF2_KSEG * 512 - 1) / ((i64)GF2_KSEG * 512));
 	const i64 wgs = std::min<i64>(nch * nt, (i64)1 << 30);
-	hipExtLaunchKernelGGL((k_update16k<GF2_KSEG>), dim3((unsigned)wgs), dim3(512), 0, st, S.ext_events ? ka : nullptr, S.ext_events ? kb : nullptr, 0,
+	hipExtLaunchKernelGGL((k_update16k<GF2_KSEG>), dim3((unsigned)wgs, S.nsys), dim3(512), 0, st, S.ext_events ? ka : nullptr, S.ext_events ? kb : nullptr, 0,
 	                      S.M, S.rows, S.srows, b1 - b0, (const int *)gprow, (const u64 *)S.mult,
-	                      set_words, b0 % S.nsets, S.nsets, (const int *)(S.blk_first + b0), (const int *)S.died, b1 * G, (int)t_begin, (int)nt);
+	                      set_words, b0 % S.nsets, S.nsets, (const int *)(S.blk_first + b0), (const int *)S.died, b1 * G, (int)t_begin, (int)nt, S.ss());
 	HIPCHK(hipGetLastError());
 	if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, st));
 	if (S.dbg_sync & 2) HIPCHK(hipDeviceSynchronize());
@@ -2247,6 +2256,28 @@ int gf2bv_stream_ceiling_device(int device, int64_t bytes, double *rmw_gbs, doub
 	*read_gbs = (double)per * wgs * 16 * reps / (ms * 1e-3) / 1e9;
 	(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 	(void)hipFree(buf); (void)hipFree(sink);
+	return GF2BV_OK;
+}
+
+int gf2bv_lds_clock_device(int device, double *shader_mhz, double *lds_bytes_per_clk_cu)
+{
+	if (!shader_mhz || !lds_bytes_per_clk_cu) return fail(GF2BV_ERR_ARG, "null pointer");
+	int rc = check_device(device);
+	if (rc) return rc;
+	unsigned long long *d = nullptr, h[3] = { 0, 0, 0 };
+	unsigned *sink = nullptr;
+	HIPCHK(hipMalloc(&d, sizeof h));
+	HIPCHK(hipMalloc(&sink, 64));
+	int cus = 256;
+	(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+	k_lds_clock<<<dim3(cus), dim3(512)>>>(d, 2000, sink);                   // warm-up (clocks ramp)
+	k_lds_clock<<<dim3(cus), dim3(512)>>>(d, 40000, sink);                  // ~5 ms of ds_read_b128 on every CU
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
+	(void)hipFree(d); (void)hipFree(sink);
+	if (!h[1]) return fail(GF2BV_ERR_HIP, "the clock probe measured nothing");
+	*shader_mhz = (double)h[0] / ((double)h[1] / 100.0);                    // real-time counter: 100 MHz
+	*lds_bytes_per_clk_cu = (double)h[2] * 1024.0 / (double)h[0];           // a ds_read_b128 wave-instruction moves 1 KiB
 	return GF2BV_OK;
 }
 

@@ -35,7 +35,7 @@ EXPORTS = [
     "gf2bv_slab_finish_local", "gf2bv_slab_solve",
     "gf2bv_slab_close",
     "gf2bv_synth_device", "gf2bv_residual_device",
-    "gf2bv_stream_ceiling_device", "gf2bv_kernel_resources",
+    "gf2bv_stream_ceiling_device", "gf2bv_lds_clock_device", "gf2bv_kernel_resources",
     "gf2bv_device_alloc", "gf2bv_device_free", "gf2bv_device_upload", "gf2bv_device_download",
 ]
 
@@ -117,6 +117,7 @@ def lib():
         L.gf2bv_synth_device.argtypes = [vp, i64, i64, i64, ctypes.c_uint64, i32, vp]
         L.gf2bv_residual_device.argtypes = [vp, i64, i64, i64, vp, i32, vp, ctypes.POINTER(i64)]
         L.gf2bv_stream_ceiling_device.argtypes = [i32, i64, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
+        L.gf2bv_lds_clock_device.argtypes = [i32, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]
         L.gf2bv_kernel_resources.argtypes = [i32, ctypes.POINTER(ctypes.c_int32), i32]
         L.gf2bv_device_alloc.argtypes = [i32, i64, pp]
         L.gf2bv_device_free.argtypes = [i32, vp]
@@ -283,6 +284,26 @@ def synth_device(d_ptr: int, rows: int, cols: int, stride: int, seed: int, devic
     _check(lib().gf2bv_synth_device(d_ptr, rows, cols, stride, seed, device, stream or None))
 
 
+def _mix64(x: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def planted_solution(cols: int, seed: int) -> np.ndarray:
+    """The solution the synthetic generator plants (gf2bv_synth_device / k_synth: pseudo-row 0xFFFFF of the same counter-based
+    generator, RHS = <row, planted>): ceil(cols / 64) words.  A full-rank system has no other solution -- what the bench's
+    parity gate and the large-size tests compare solve_one with."""
+    cw = (cols + 63) // 64
+    s = _mix64(np.array([seed], dtype=np.uint64))[0]
+    x = _mix64(s ^ (np.uint64(0xFFFFF << 20) | np.arange(cw, dtype=np.uint64)))
+    if cols & 63:
+        x[-1] &= np.uint64((1 << (cols & 63)) - 1)
+    return x
+
+
 def residual_device(d_ptr: int, rows: int, cols: int, stride: int, x: np.ndarray, device: int = 0,
                     stream: int = 0) -> int:
     x = np.ascontiguousarray(x, dtype=np.uint64)
@@ -297,6 +318,13 @@ def stream_ceiling(nbytes: int = 2 << 30, device: int = 0) -> dict:
     rmw, rd = ctypes.c_double(0), ctypes.c_double(0)
     _check(lib().gf2bv_stream_ceiling_device(device, nbytes, ctypes.byref(rmw), ctypes.byref(rd)))
     return {"rmw_gbs": rmw.value, "read_gbs": rd.value}
+
+
+def lds_clock(device: int = 0) -> dict:
+    """Shader clock (MHz) under an LDS-bound load and the LDS bytes per clock and CU that load reached."""
+    mhz, bpc = ctypes.c_double(0), ctypes.c_double(0)
+    _check(lib().gf2bv_lds_clock_device(device, ctypes.byref(mhz), ctypes.byref(bpc)))
+    return {"shader_mhz": mhz.value, "lds_bytes_per_clk_cu": bpc.value}
 
 
 def kernel_resources(device: int = 0) -> dict:

@@ -229,6 +229,12 @@ int gf2bv_residual_device(const void *d_aug, int64_t rows, int64_t cols, int64_t
  * read_gbs = read-only.  Reported by bench.py next to the 8 TB/s spec peak. */
 int gf2bv_stream_ceiling_device(int device, int64_t bytes, double *rmw_gbs, double *read_gbs);
 
+/* Shader clock of this device under an LDS-bound load (every CU issuing ds_read_b128 back to back for ~5 ms), from the
+ * shader-clock and the 100 MHz real-time counters inside the kernel, and the LDS bytes per clock and CU that load reached
+ * (MI355X_MICROARCH.md: 256 B/clk/CU for ds_read_b128).  bench.py prices the table lookups of the K-fused outer pass
+ * (k_update16k, LDS-bound) against CUs x 256 B x this clock. */
+int gf2bv_lds_clock_device(int device, double *shader_mhz, double *lds_bytes_per_clk_cu);
+
 /* Registers per lane and static LDS bytes of the kernels that must fit on a compute unit TOGETHER -- the panel path of
  * block b+1 runs beside the bulk update of block b, and a panel kernel that does not fit next to an update workgroup
  * (two wavefronts per SIMD, 128 KiB of tables) silently waits for one to retire: out[0..1] the default bulk-update

@@ -87,6 +87,10 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(ROOT, sub, f), errors="replace").read()
                 assert "import gf2_oracle" not in src and "from oracle" not in src, os.path.join(sub, f)
     bench = open(os.path.join(ROOT, "bench.py")).read()
-    at = bench.index("from oracle import")
-    assert bench.count("from oracle import") == 1
-    assert bench[:at].rsplit("\ndef ", 1)[-1].startswith("cpu_baseline(")          # the import sits inside cpu_baseline()
+    # every import of the oracle sits inside a cpu_baseline* function (the synthetic headline sample; the list-of-int systems
+    # of the c3 / c5 legs): timed beside the GPU numbers and used as their checker, never as the thing measured
+    parts = bench.split("from oracle import")
+    assert 2 <= len(parts) <= 3
+    for head in (("from oracle import".join(parts[:k])) for k in range(1, len(parts))):
+        assert head.rsplit("\ndef ", 1)[-1].startswith("cpu_baseline"), head.rsplit("\ndef ", 1)[-1][:40]
+    assert "oracle" not in bench.split("def timed_single")[1].split("def run_single")[0]      # the timed region itself

@@ -130,6 +130,30 @@ def test_bench_two_ranks_sharing_the_gpu():
     assert c4["systems_per_s"] > 0 and c4["roofline"]["achieved"] > 0
 
 
+@pytest.mark.timeout(1200)
+def test_bench_eight_ranks_sharing_the_gpu():
+    """Multi-GPU readiness without an 8-GPU node (no scaling curve can be taken here: N > 1 is UNMEASURED on hardware):
+    `bench.py --gpus 8` exactly as the driver launches it -- eight ranks under torch.distributed.run -- all pinned to this
+    box's one GPU with gloo standing in for RCCL, at reduced sizes: the shard bounds of configs[3] at world 8 (64 systems
+    -> 8 per rank, what 512 / 8 = 64 per rank exercises), gang sizing for a rank's share, the order of the gathered records,
+    barriers and max-over-ranks timing, one JSON line from rank 0."""
+    env = dict(os.environ, GF2BV_BENCH_DEVICE="0", GF2BV_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
+           "--size", "4096", "--batch-total", "64", "--batch-n", "2048"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1100, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["parity_gate"]["all_ranks_ok"]
+    assert "cpu_baseline" not in line and "c3_mt19937" not in line and line["value"] > 0
+    c4 = line["batch_c4"]
+    assert c4["n_gpus"] == 8 and c4["scaling"] == "strong" and c4["config"]["systems_total"] == 64
+    assert c4["config"]["systems_per_gpu"] == 8 and c4["parity_gate"]["all_ranks_ok"] and c4["parity_gate"]["gathered_records"] == 64
+    assert c4["systems_per_s"] > 0
+
+
 @pytest.mark.timeout(600)
 def test_bench_default_line_carries_the_scale_anchor():
     """N = 1: the same line shape (headline + `batch_c4` with its roofline), here at reduced sizes."""
@@ -142,3 +166,11 @@ def test_bench_default_line_carries_the_scale_anchor():
     c4 = line["batch_c4"]
     assert c4["n_gpus"] == 1 and c4["config"]["systems_total"] == 6 and c4["parity_gate"]["all_ranks_ok"]
     assert c4["roofline"]["frac"] > 0 and c4["roofline"]["end_to_end_frac"] > 0
+    # the reference's own example timings ride along at N = 1: configs[2] x 6 variants, configs[4], host-resident input
+    c3 = line["c3_mt19937"]["variants"]
+    assert [v["bits_per_output"] for v in c3] == [32, 17, 9, 1, 1337, 137]
+    assert all(v["recovered_state_equals_known_answer"] and v["m4ri_solve_ms"]["warm"] > 0 and v["device_ms"]["eliminate"] > 0 for v in c3)
+    c5 = line["c5_xoshiro"]
+    assert c5["recovered_seed_equals_known_answer"] and c5["solutions"] == 1 and c5["solve_all_ms"]["warm_median"] > 0
+    h2d = line["h2d_inclusive"]
+    assert h2d["phases_ms"]["pack_h2d"] > 0 and h2d["ms_per_solve"]["second"] > 0

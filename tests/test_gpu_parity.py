@@ -293,7 +293,7 @@ def test_batch_sharded_over_devices_from_the_python_boundary(monkeypatch):
     assert _internal.device_count() >= 1 and _internal.get_default_device() == 0
     for mode in (0, 1):
         one = _internal.m4ri_solve_many(systems, cols, mode, 0)
-        for devs in ([0, 0], [0, 0, 0], None, "all", [0] * 11):
+        for devs in ([0, 0], [0, 0, 0], None, "all", [0] * 8, [0] * 11):
             got = _internal.m4ri_solve_many(systems, cols, mode, devs)
             for eqs, g, w in zip(systems, got, one):
                 o = O.m4ri_solve(list(eqs), cols, mode)

@@ -108,7 +108,7 @@ def test_schedule_over_rccl_world_size_1():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,n,seed", [(1, 3000, 11), (2, 4096, 12), (2, 5000, 13), (3, 6200, 14)])
+@pytest.mark.parametrize("world,n,seed", [(1, 3000, 11), (2, 4096, 12), (2, 5000, 13), (3, 6200, 14), (4, 8300, 15)])
 def test_sharded_solve_equals_single_gpu_solve(world, n, seed):
     _run(world, n, seed)
 

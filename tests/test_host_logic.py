@@ -144,6 +144,8 @@ def test_m4ri_solve_many_argument_errors():
         many([[1, 2]], 2, 0, [-1])
     with pytest.raises(TypeError):
         many([[1, 2]], 2, 0, ["gpu0"])
+    with pytest.raises(ValueError, match="'all'"):           # devices: None (default device) | "all" | int | sequence of ints
+        many([[1, 2]], 2, 0, "gpu0")
     # "1 = 0" systems are decided on the host, the others would go to the GPU together
     lin = LinearSystem([2])
     (v,) = lin.gens()
@@ -161,6 +163,16 @@ def test_device_selection_surface():
         _internal.m4ri_solve([1, 2], 2, 0, 0, 0)
     sp = _internal._space_from_ints(4, 1, (5,))
     assert sp.device == -1                       # host-built: walked on the host
+
+
+def test_planted_solution_of_the_synthetic_generator_matches_the_oracle_definition():
+    """hip.planted_solution (the product's own statement of the generator's planted vector: what bench.py and the large-size
+    tests compare a full-rank solve_one with) against the oracle's C definition."""
+    import numpy as np
+
+    from gf2bv_amd import hip
+    for cols, seed in ((1, 0), (63, 1), (64, 5), (65, 5), (777, 99), (65536, 1234), (262144, 1242)):
+        assert np.array_equal(hip.planted_solution(cols, seed), O.planted_solution(cols, seed)), (cols, seed)
 
 
 def test_solve_fails_loudly_without_gpu():

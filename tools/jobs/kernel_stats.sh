@@ -5,6 +5,7 @@
 # KEEP_TRACE=1 keeps the per-dispatch csv (tools/outer_timeline.py, tools/b_idle.py, tools/gang_budget.py read it).
 tag=$1; shift
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O
+args=(); for a in "$@"; do if [ -e "$R/$a" ]; then args+=("$R/$a"); else args+=("$a"); fi; done; set -- "${args[@]}"      # (the command runs in /tmp)
 cd /tmp && export TMPDIR=/tmp
 timeout ${JOB_TIMEOUT:-900} rocprofv3 --kernel-trace --stats --output-format csv -d $O/${tag}_trace -- "$@" > $O/${tag}_trace.log 2>&1
 cd $R

@@ -8,6 +8,7 @@ range=()
 if [ "$1" == "--range" ]; then range=(--kernel-iteration-range "$2"); shift 2; fi
 [ "$1" == "--" ] && shift
 R=$(pwd); O=$R/gpurun_out; mkdir -p $O
+args=(); for a in "$@"; do if [ -e "$R/$a" ]; then args+=("$R/$a"); else args+=("$a"); fi; done; set -- "${args[@]}"      # (the command runs in /tmp)
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout ${JOB_TIMEOUT:-900} rocprofv3 --pmc $c --kernel-include-regex "$regex" "${range[@]}" --kernel-trace --output-format csv -d $O/${tag}_$c -- "$@" > $O/${tag}_$c.log 2>&1

@@ -17,7 +17,7 @@ template <int NT, int DEPTH, bool PIPE>
 void run(const char *name, u64 *M, i64 rows, i64 srows, int ntiles, PanelRec *panels, PanelAux *aux, u64 *mult4, int *blkf, int wgs)
 {
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-	auto launch = [&] { k_update16<NT, false, DEPTH, PIPE, NT><<<dim3(wgs), dim3(NT), 0>>>(M, rows, srows, 0, GF2_GMAX, 0, panels, aux, mult4, blkf, 0, ntiles, 1, 0, nullptr, SysStride{0, 0}); };
+	auto launch = [&] { k_update16<NT, false, DEPTH, PIPE, NT><<<dim3(wgs), dim3(NT), 0>>>(M, rows, srows, 0, GF2_GMAX, 0, panels, aux, mult4, blkf, 0, ntiles, 1, 0, nullptr, SysStride{0, 0}, 0); };
 	launch(); CK(hipDeviceSynchronize());
 	const int reps = getenv("MB_REPS") ? atoi(getenv("MB_REPS")) : 5;      // MB_REPS=400: sustained load (clocks settle)
 	CK(hipEventRecord(e0)); for (int r = 0; r < reps; r++) launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
@@ -65,7 +65,7 @@ int main(int argc, char **argv)
 		std::vector<u64> h0((size_t)ctiles * csr * 2), h1(h0.size());
 		for (auto &v : h0) v = rnd();
 		CK(hipMemcpy(M, h0.data(), h0.size() * 8, hipMemcpyHostToDevice));
-		k_update16<768, false, 3, true, 768><<<dim3(7), dim3(768), 0>>>(M, crow, csr, 0, GF2_GMAX, 0, panels, aux, mult4, blkf, 0, ctiles, 1, 0, nullptr, SysStride{0, 0});
+		k_update16<768, false, 3, true, 768><<<dim3(7), dim3(768), 0>>>(M, crow, csr, 0, GF2_GMAX, 0, panels, aux, mult4, blkf, 0, ctiles, 1, 0, nullptr, SysStride{0, 0}, 0);
 		CK(hipDeviceSynchronize());
 		CK(hipMemcpy(h1.data(), M, h1.size() * 8, hipMemcpyDeviceToHost));
 		i64 bad = 0, checked = 0;
