@@ -144,16 +144,17 @@ def gpu_equals_oracle(cb: dict, m: int, seed: int, device: int) -> bool:
     return bool(g.rank == cb["rank"] and g.status == o_status and np.array_equal(g.origin, o_origin))
 
 
-def pmc_traffic(n: int, g: int, t: int, kernel: str = "k_update16"):
+def pmc_traffic(n: int, g: int, t: int, kernel: str = "k_update16", gang: int = 0):
     """HBM bytes per launch of the dominant bulk kernel from the committed rocprofv3 PMC passes (FETCH_SIZE doubled per the
-    gfx950 note in MI355X_MICROARCH.md, WRITE_SIZE as is); None when no profile of this config is committed."""
+    gfx950 note in MI355X_MICROARCH.md, WRITE_SIZE as is); None when no profile of this config is committed.
+    gang > 0: a launch of the bulk update of a gang of that many n x n systems (the PMC pass measured one gang; per system and launch)."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
         return None
     for rec in json.load(open(path)):
         if (rec["n"] == n and rec["G"] == g and rec["T"] == t and rec.get("current", True)
-                and rec.get("kernel", "k_update16") == kernel):
-            return rec["hbm_bytes_per_pass"]
+                and rec.get("kernel", "k_update16") == kernel and bool(rec.get("gang")) == (gang > 0)):
+            return rec["hbm_bytes_per_pass_per_system"] * gang if gang else rec["hbm_bytes_per_pass"]
     return None
 
 
@@ -598,7 +599,8 @@ def batch_job(args, world, rank, local_rank, dev, steps: int, warmup: int):
         g = s0["panels_per_sweep"]
         roofline = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            # PMC (profiles/r04_batch_pmc.txt): HBM bytes of an average launch of one gang, scaled to this gang size
+            "traffic": pmc_traffic(n, g, s0["tables_per_sweep"] // g, "k_update16", int(s0.get("gang_systems", 0))),
             "kernel": f"k_update16<G={g},T={s0['tables_per_sweep'] // g}> (bulk update of a gang: "
                       f"{s0.get('gang_systems', 0)} systems x {64 * g} pivots per launch)",
             "launches": launches, "alg_bytes_per_launch": alg_bytes / max(launches, 1),

@@ -2018,7 +2018,12 @@ typedef __attribute__((address_space(3))) const u32x4 *lds_u4_ptr;
 // LB: the thread count the register budget is taken from (__launch_bounds__).  768 threads at the budget of 1024
 // (128 VGPRs) leave a quarter of every SIMD's register file -- and 27 KiB of LDS -- to the panel kernels of the next
 // block, which then run NEXT TO this kernel instead of queueing for a CU behind it.
-template <int NT, bool HALF, int DEPTH, bool PIPE, int LB>
+// STREAM (round 4): the row segments are loaded and stored with the non-temporal hint -- for GANGS, whose working set (24 x
+// 128 MiB) passes through once per block with nothing to find in the caches afterwards, while the 32 B of multipliers per
+// row ARE re-read (once per tile) and should keep their place in the XCD's L2: 192 x 32768^2 3.51 -> 3.34 ms per system
+// (loads alone 3.44, stores alone 3.58; profiles/r04_batch_scans.txt).  Single systems keep plain accesses: the kernels
+// behind a pass (TRSM, look-ahead, table builds) find their rows in L2 / MALL (65536^2 41 -> 51 ms with streaming stores, round 2).
+template <int NT, bool HALF, int DEPTH, bool PIPE, int LB, bool STREAM = false>
 __global__ void __launch_bounds__(LB)
 k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
            const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
@@ -2031,12 +2036,17 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 	// only speed): a system's per-row multipliers (32 B per row and block, re-read for every tile) then stay in that XCD's
 	// 4 MiB L2 instead of being fetched into all eight (a gang of 24: 24 MiB of multipliers against 8 x 4 MiB of L2;
 	// PMC, gangs of 6: FETCH_SIZE = 1.53 x the algorithmic reads, profiles/r04_batch_pmc.txt).
+	// Order: ONE system after the other on its XCD.  Workgroups are handed out in line order as CUs come free, so with a system's
+	// workgroups consecutive on their XCD -- up to 32 of them, one per CU -- the XCD streams one system at a time and its L2
+	// holds one system's multipliers (1 MiB at 32768 rows).  PMC, one gang of 24 x 32768^2 (profiles/r04_batch_pmc.txt): FETCH_SIZE =
+	// 2.97 x the algorithmic reads on the plain (spans, systems) grid, 1.54 x with a system per XCD but the XCD's three systems
+	// interleaved, 1.08 x one after the other; 192 systems: 3.75 -> 3.51 ms per system.
 	unsigned bx = blockIdx.x, gx = gridDim.x, by = blockIdx.y;
 	if (xcd_nsys > 0) {
-		const unsigned g8 = (unsigned)xcd_nsys >> 3, slot = bx >> 3;
-		by = (slot % g8) * 8 + (bx & 7);
+		const unsigned slot = bx >> 3, xcd = bx & 7;
 		gx = gx / (unsigned)xcd_nsys;
-		bx = slot / g8;
+		by = (slot / gx) * 8 + xcd;
+		bx = slot % gx;
 	}
 	{
 		const i64 ao = (i64)by * ss.arena_bytes;
@@ -2113,7 +2123,8 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 #elif defined(GF2_NT_LOAD)     /* cache-policy experiments (tools/microbench_update16.hip) */
 			{ const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Mw + row)); H.d = make_uint4(t.x, t.y, t.z, t.w); }
 #else
-			H.d = Mw[row];
+			if (STREAM) { const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Mw + row)); H.d = make_uint4(t.x, t.y, t.z, t.w); }
+			else H.d = Mw[row];
 #endif
 		};
 		// the span's first batches are requested BEFORE its tables are built: the build (~1.5 us, LDS only) then runs under
@@ -2222,6 +2233,7 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 #ifdef GF2_NT_STORE
 			else { const u32x4 t = { acc.x, acc.y, acc.z, acc.w }; __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(Mw + q)); }
 #else
+			else if (STREAM) { const u32x4 t = { acc.x, acc.y, acc.z, acc.w }; __builtin_nontemporal_store(t, reinterpret_cast<u32x4 *>(Mw + q)); }
 			else Mw[q] = acc;
 #endif
 		};

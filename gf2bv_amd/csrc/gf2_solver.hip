@@ -245,7 +245,19 @@ hipError_t launch_update16(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows
                            hipEvent_t begun, hipEvent_t done, int xcd_nsys)
 {
 	(void)nw_hi;
-	if (xcd_nsys > 0) grid = dim3(grid.x * grid.y);          // one line of workgroups, decoded in the kernel (a system per XCD)
+	if (xcd_nsys > 0) {                                      // one line of workgroups, decoded in the kernel (a system per XCD)
+		grid = dim3(grid.x * grid.y);
+		const bool stream = !(getenv("GF2BV_GANG_NT") && atoi(getenv("GF2BV_GANG_NT")) == 0);
+		if (stream && NT == 512 && DEPTH == 3) {            // (the default instance: streaming row accesses for gangs, see k_update16)
+			if (nw_lo < 0)
+				hipExtLaunchKernelGGL((k_update16<512, true, 3, true, 512, true>), grid, dim3(512), 0, s, begun, done, 0, M, rows, srows, j0, gb, wlo,
+				                      panels, aux, multset, blk_first, tile_begin, ntiles, world, wrank, Pc, ss, xcd_nsys);
+			else
+				hipExtLaunchKernelGGL((k_update16<512, false, 3, true, 512, true>), grid, dim3(512), 0, s, begun, done, 0, M, rows, srows, j0, gb, wlo,
+				                      panels, aux, multset, blk_first, tile_begin, ntiles, world, wrank, Pc, ss, xcd_nsys);
+			return hipGetLastError();
+		}
+	}
 	if (nw_lo < 0)
 		hipExtLaunchKernelGGL((k_update16<NT, true, DEPTH, PIPE, LB>), grid, dim3(NT), 0, s, begun, done, 0, M, rows, srows, j0, gb, wlo,
 		                      panels, aux, multset, blk_first, tile_begin, ntiles, world, wrank, Pc, ss, xcd_nsys);
@@ -369,7 +381,9 @@ struct Solver {
 	int sparse_mode = 2;          // search skips absent columns: 0 never, 1 always, 2 per chunk by density (GF2BV_SPARSE)
 	int fused_rpt = 0;            // GF2BV_FUSED_RPT: row blocks of 256 per narrowing workgroup of k_block_fast_narrow (0 = by size)
 	bool use_pc = true;           // GF2BV_PC=0: the bulk update fetches the pivot rows through the panel records, as before round 3
-	bool xcd_pin = true;          // gangs of a multiple of 8 systems: every system's bulk-update workgroups on one XCD (GF2BV_XCD_PIN=0: plain 2-D grid)
+	bool xcd_pin = true;          // gangs of a multiple of 8 systems: every system's bulk-update workgroups on ONE XCD, one system after the
+	                              // other there, xcd_wgs workgroups each (GF2BV_XCD_WGS); GF2BV_XCD_PIN=0: the plain (spans, systems) grid
+	int xcd_wgs = 32;
 	bool fused_narrow = true;     // optimistic blocks: search and narrow step in ONE launch (k_block_fast_narrow); GF2BV_FUSED_NARROW=0: two
 	int narrow_rpt = 1;           // row blocks of 256 per narrow workgroup of a panel step (set in solver_alloc; GF2BV_NARROW_RPT)
 	int self_wait = 5000;         // ticks (100 MHz) unit 0 of a panel search waits for the other units before it leaves
@@ -564,6 +578,7 @@ int solver_alloc(Solver &S)
 	if (const char *e = getenv("GF2BV_FUSED_NARROW")) S.fused_narrow = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_PC")) S.use_pc = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_XCD_PIN")) S.xcd_pin = atoi(e) != 0;
+	if (const char *e = getenv("GF2BV_XCD_WGS")) S.xcd_wgs = std::min(256, std::max(1, atoi(e)));
 	if (const char *e = getenv("GF2BV_FUSED_RPT")) S.fused_rpt = atoi(e);
 	// narrow workgroups: as many rows each as keeps ~256 of them (all systems of a gang together) busy, at most 8 blocks
 	{
@@ -669,10 +684,11 @@ int streams_run_concurrently(int device, hipStream_t a, hipStream_t b, int *ok)
 // line (see k_update), so the count is free of the tile count: one workgroup per CU, fewer when a span
 // would fall under ~4096 rows (a table build costs as much as streaming ~800 rows), shared among the
 // systems of a gang.
-int pick_update_wgs(i64 est_rows, int ntiles, int nsys)
+int pick_update_wgs(i64 est_rows, int ntiles, int nsys, int pinned_wgs = 0)
 {
 	i64 want = 256;
 	want = std::max<i64>(1, want / std::max(1, nsys));
+	if (pinned_wgs > 0) want = pinned_wgs;          // XCD-pinned gangs: a system's workgroups fill ITS XCD (32 CUs), one system after the other
 	// (a span below ~min_rows rows of a 64-byte column is not worth a workgroup of its own: a table build costs as much
 	// as streaming ~1000 of them -- but small passes are latency, not throughput: the chip is mostly idle, so they take
 	// as many workgroups as have at least that much to do)
@@ -717,12 +733,13 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 		if (!S.ext_events) HIPCHK(hipEventRecord(ka, st));
 	}
 	const i64 est_rows = std::max<i64>(256, S.rows - (i64)j0 * 64);      // alive rows of a dense system (the kernel uses the true bound)
-	const int wgs = pick_update_wgs(est_rows, ntiles, S.nsys);
+	const bool pin = S.xcd_pin && S.nsys >= 8 && S.nsys % 8 == 0;
+	const int wgs = pick_update_wgs(est_rows, ntiles, S.nsys, pin ? S.xcd_wgs : 0);
 	hipEvent_t begun = nullptr, done = nullptr;
 	if (S.ext_events) { begun = ka; done = S.time_kernels ? kb : (last && !S.flag_sync ? S.evPrio[b] : nullptr); }
 	HIPCHK(S.impl->update(dim3((unsigned)wgs, S.nsys), st, S.M, S.rows, S.srows, j0, gb, wlo, S.panels, S.aux, mset,
 	                      S.blk_first + b, tile_begin, ntiles, S.world, S.wrank, nw_lo, nw_hi, (const uint4 *)S.Pc, S.ss(), begun, done,
-	                      S.xcd_pin && S.nsys >= 8 && S.nsys % 8 == 0 ? S.nsys : 0));
+	                      pin ? S.nsys : 0));
 	if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, st));
 	if (!last || S.flag_sync) return GF2BV_OK;
 	if (S.ext_events) *handoff = done;
@@ -1397,7 +1414,7 @@ int solve_gang(Solver &S, gf2bv_result **out)
 		if (rc) return rc;
 	}
 	if (S.mode == GF2BV_MODE_SINGLE) {
-		static const bool per_system = getenv("GF2BV_GANG_BS") && atoi(getenv("GF2BV_GANG_BS")) == 0;      // (A/B: one chain per system, as rounds 1-3)
+		const bool per_system = getenv("GF2BV_GANG_BS") && atoi(getenv("GF2BV_GANG_BS")) == 0;      // (A/B: one chain per system, as rounds 1-3)
 		if (per_system)
 			for (int s = 0; s < S.nsys; s++) {
 				rc = enqueue_backward_single(V[s]);
@@ -1435,12 +1452,14 @@ int solve_gang(Solver &S, gf2bv_result **out)
 // Gang size for nsys same-shape systems.
 i64 pick_gang(i64 nsys, i64 rows, i64 cols)
 {
-	// gang size: ~3.5 GiB of working matrices per gang (32768^2: 24 systems, 4096^2: 64), at least four gangs (round 3, 144 x
+	// gang size: ~4.5 GiB of working matrices per gang (32768^2: 32 systems -- round 4: 192 x 32768^2 run 3.22 ms per system in gangs
+	// of 32 against 3.22-3.32 in gangs of 24, and 512 systems are 16 equal gangs instead of 21 + a part gang; 4096^2: 64), at
+	// least four gangs (round 3, 144 x
 	// 32768^2 on one box: gangs of 4 / 8 / 12 / 18 / 24 / 36 -> 231 / 248 / 250 / 239-254 / 255-256 / 255 systems per second)
 	// when there are enough systems (measured on MI355X, 48 x 32768^2: gang 4/8/16 -> 7.6/6.3/6.0 ms per
 	// system, one system at a time 15-28; 64 x 4096^2: 0.22 ms per system against 1.8)
 	const double per_sys = 1.05 * 8.0 * (double)(rows + 64) * (double)((cols + 64) / 64 + TW + 4 * GF2_GMAX);
-	i64 gang = std::max<i64>(2, std::min<i64>(64, (i64)(3.5 * 1073741824.0 / per_sys)));
+	i64 gang = std::max<i64>(2, std::min<i64>(64, (i64)(4.5 * 1073741824.0 / per_sys)));
 	gang = std::min(gang, std::max<i64>(1, (nsys + 3) / 4));
 	// equal gangs, an even number of them (two host threads take alternate gangs): 64 systems of 32768^2 go as 4 x 16
 	// (3.90 ms per system) rather than 4 x 14 + 8 (4.10)
@@ -1449,6 +1468,8 @@ i64 pick_gang(i64 nsys, i64 rows, i64 cols)
 		if (ngangs > 1 && (ngangs & 1)) ngangs++;
 		gang = (nsys + ngangs - 1) / ngangs;
 	}
+	// whole multiples of 8 systems: the bulk update of such a gang keeps every system on ONE XCD (k_update16: xcd_nsys)
+	if (gang >= 8) gang = gang / 8 * 8;
 	if (const char *e = getenv("GF2BV_GANG")) { int v = atoi(e); if (v >= 1) gang = v; }
 	gang = std::max<i64>(1, std::min<i64>(gang, nsys));
 	{
@@ -1530,17 +1551,17 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 	// NS host threads each take every NS-th gang on their own stream pair (one gang's back-substitution
 	// and export then overlap the next gang's elimination).
 	const i64 gang = pick_gang(nsys, rows, cols);
-	// Gangs in flight: NS host threads, each with its own stream pair, take the next gang off a shared list.  STAGGERED: a gang's
-	// elimination is bulk-bound (the chip is full) in its first half and a chain of small panel kernels in its second, and its
-	// back-substitution and export leave the chip nearly idle -- two threads that start together stay in phase for the whole
-	// job (round 3: both gangs in the tail at once, 14 % of the wall time with nothing to stream, profiles/r04_batch_budget.txt).
-	// The list therefore begins with part gangs, thread t's first gang being (t + 1) / NS of a full one: the threads then run
-	// 1 / NS of a period apart, one gang's tail beside another's head.  GF2BV_STAGGER=0: equal gangs, as before.
+	// Gangs in flight: NS host threads, each with its own stream pair, take the next gang off a shared list.  Two threads that
+	// start together stay in phase for the whole job -- both gangs bulk-bound at once, both in their tails at once.  Starting them
+	// apart (GF2BV_STAGGER=1: the list begins with part gangs, thread t's first gang (t + 1) / NS of a full one) was built and
+	// measured in round 4: 3.56 ms per system against 3.42 in phase on 192 x 32768^2 (profiles/r04_batch_scans.txt) -- the bulk
+	// update runs throughout a gang's elimination (its launches are in flight 89 % of the wall time), there is no idle tail to
+	// fill, and part gangs only make smaller launches.  Not the default.
 	std::vector<std::pair<i64, int>> ranges;       // (first system, systems)
 	int NS = 2;
 	if (const char *e = getenv("GF2BV_BATCH_THREADS")) { int v = atoi(e); if (v >= 1) NS = std::min(v, 16); }
 	{
-		const bool stagger = !(getenv("GF2BV_STAGGER") && atoi(getenv("GF2BV_STAGGER")) == 0);
+		const bool stagger = getenv("GF2BV_STAGGER") && atoi(getenv("GF2BV_STAGGER")) != 0;
 		i64 s0 = 0;
 		if (stagger && gang >= 2 * NS && nsys > gang * NS)
 			for (int t = 0; t + 1 < NS && s0 < nsys; t++) {

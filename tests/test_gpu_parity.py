@@ -243,6 +243,30 @@ def test_gang_batch_parity(monkeypatch, gang):
     buf.free()
 
 
+@pytest.mark.parametrize("gang,pin,nt,wgs", [("8", "1", "1", "32"), ("16", "1", "1", "3"), ("16", "1", "0", "32"), ("8", "0", "1", "32"),
+                                              ("16", "1", "1", "64")])
+def test_gang_bulk_update_with_a_system_per_xcd(monkeypatch, gang, pin, nt, wgs):
+    """Round 4: gangs of a multiple of 8 systems launch their bulk update as ONE line of workgroups decoded so that a system's
+    workgroups sit on one XCD, one system after the other there (k_update16: xcd_nsys), with streaming row accesses
+    (GF2BV_GANG_NT) -- a different grid shape, span partition and instance than single systems use.  16 systems of mixed kind
+    (+ a remainder gang of 3: the plain grid), both modes, against the oracle; pinning / streaming off and odd workgroup
+    counts per system give the same bits."""
+    monkeypatch.setenv("GF2BV_GANG", gang)
+    monkeypatch.setenv("GF2BV_XCD_PIN", pin)
+    monkeypatch.setenv("GF2BV_GANG_NT", nt)
+    monkeypatch.setenv("GF2BV_XCD_WGS", wgs)
+    rng = random.Random(8242)
+    rows, cols = 2700, 2600
+    kinds = [(None, .5, True), (600, .5, True), (None, .01, True), (900, .5, False), (1, .5, True), (cols - 1, .5, True)]
+    systems = [random_system(rng, rows, cols, d, cap, cons, 0) for cap, d, cons in (kinds * 4)[:18]] + [[0] * rows]
+    augs = np.stack([O.eqs_to_aug(e, cols) for e in systems])
+    for mode in (0, 1):
+        got = hip.solve_batch_words(augs, rows, cols, mode)
+        for a, g in zip(augs, got):
+            assert_same(g, O.solve_words(a, rows, cols, mode), mode)
+    assert got[0].stats["gang_systems"] == int(gang)
+
+
 def test_batched_list_of_int_boundary(monkeypatch):
     """m4ri_solve_many / LinearSystem.solve_*_many == the single-system calls, element by element."""
     monkeypatch.setenv("GF2BV_GANG", "3")

@@ -13,7 +13,7 @@ for i in range(nsys):
 times = []
 for rep in range(reps):
     t = time.time()
-    sols = hip.solve_batch_device(buf.ptr, nsys, n * stride, n, n, stride, 0)
+    sols = hip.solve_batch_device(buf.ptr, nsys, n * stride, n, n, stride, 0, time_kernels=os.environ.get("TIME_KERNELS", "0") == "1")
     times.append(time.time() - t)
 bad = sum(hip.residual_device(buf.ptr + i * n * stride * 8, n, n, stride, s.origin) for i, s in enumerate(sols))
 best = min(times[1:] or times)
