@@ -2467,7 +2467,8 @@ template <int SEG>
 __global__ void __launch_bounds__(512)
 k_update16k(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__restrict__ gprow,
             const u64 *__restrict__ mult, i64 set_words, int set0, int nsets,
-            const int *__restrict__ blk_first, const int *__restrict__ died, int j_end, int tile_begin, int ntiles, SysStride ss)
+            const int *__restrict__ blk_first, const int *__restrict__ died, int j_end, int tile_begin, int ntiles, SysStride ss,
+            int xcd_map)
 {
 	constexpr int NT = 512, NW = 8;
 	static_assert(GF2_KMAX * GF2_GMAX * 64 % 512 == 0, "k_outer_apply: whole pivots per lane");
@@ -2513,7 +2514,18 @@ k_update16k(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__res
 	const i64 items = nch * ntiles;
 	const uint4 *mbase = reinterpret_cast<const uint4 *>(mult);
 	i64 it = blockIdx.x;
-	if (it >= items) return;
+	// xcd_map (round 4): workgroup b sits on XCD b % 8 (observed placement: speed only).  An item reads nblk x 32 B of multipliers per
+	// row of its chunk -- K x 256 KiB, 3 MiB for K = 12 -- and every tile re-reads them; in tile-major item order an XCD meets
+	// nch / 8 chunks per tile, 12 MiB and more between two uses of the same multipliers: they come from the MALL.  Here XCD c takes
+	// the chunks c, c + 8, ... and walks them CHUNK-major (all tiles of one chunk, then the next chunk): its 32 concurrent
+	// workgroups share one chunk's multipliers out of its L2.  The launch then has 8 x ceil(nch / 8) x ntiles workgroups.
+	// MEASURED SLOWER (262144^2 1.305 -> 1.370 s, 131072^2 185 -> 210 ms) and therefore off (GF2BV_OUTER_XCD=1 turns it on): the
+	// pass is bound by its LDS lookups, not by where the multipliers come from, and 32 workgroups of an XCD on 32 different tiles
+	// fetch 32 sets of pivot rows per block where tile-major neighbours share them.
+	// (the host sizes the launch from the DENSE estimate of the alive bound; a system with fewer pivots has more chunks: the loop
+	// below then comes round again, gridDim.x / 8 slots further)
+	const i64 xcd = it & 7, gslots = (i64)(gridDim.x >> 3);
+	i64 slot = it >> 3;
 	// Every address below = a wave-uniform 64-bit base (scalar registers) + a 32-BIT lane offset (batch j of a wavefront =
 	// rows base + 512 j + lane): nothing per batch lives in a 64-bit VGPR pair -- with per-lane 64-bit row indices, clamped to
 	// the row range, the compiler kept 16 address pairs per stream across the block loop and spilled up to 1700 registers.
@@ -2523,7 +2535,13 @@ k_update16k(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__res
 	// tile-major items: neighbouring workgroups take neighbouring row chunks of ONE tile.
 	auto item_rows = [&](i64 item) { return rlo + (item % nch) * CH + (i64)wvu * 64; };
 	auto item_tile = [&](i64 item) { return reinterpret_cast<uint4 *>(M) + ((i64)tile_begin + item / nch) * srows; };
-	for (; it < items; it += gridDim.x) {
+	for (;; it += gridDim.x) {
+		if (xcd_map) {
+			const i64 chunk = xcd + 8 * (slot / ntiles);
+			if (chunk >= nch) break;
+			it = (slot % ntiles) * nch + chunk;        // (tile-major item index of (tile, chunk), what the lambdas below decode)
+			slot += gslots;
+		} else if (it >= items) break;
 		uint4 *Mw = item_tile(it);
 		const i64 rb0 = item_rows(it);
 		uint4 *Mrow = Mw + rb0;

@@ -245,10 +245,12 @@ hipError_t launch_update16(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows
                            hipEvent_t begun, hipEvent_t done, int xcd_nsys)
 {
 	(void)nw_hi;
-	if (xcd_nsys > 0) {                                      // one line of workgroups, decoded in the kernel (a system per XCD)
-		grid = dim3(grid.x * grid.y);
-		const bool stream = !(getenv("GF2BV_GANG_NT") && atoi(getenv("GF2BV_GANG_NT")) == 0);
-		if (stream && NT == 512 && DEPTH == 3) {            // (the default instance: streaming row accesses for gangs, see k_update16)
+	if (xcd_nsys > 0) grid = dim3(grid.x * grid.y);          // one line of workgroups, decoded in the kernel (a system per XCD)
+	{
+		// streaming row accesses: pinned gangs (GF2BV_GANG_NT=0: plain); single systems only as an experiment (GF2BV_SINGLE_NT=1)
+		const bool stream = xcd_nsys > 0 ? !(getenv("GF2BV_GANG_NT") && atoi(getenv("GF2BV_GANG_NT")) == 0)
+		                                 : (getenv("GF2BV_SINGLE_NT") && atoi(getenv("GF2BV_SINGLE_NT")) != 0);
+		if (stream && NT == 512 && DEPTH == 3) {            // (the default instance, see k_update16)
 			if (nw_lo < 0)
 				hipExtLaunchKernelGGL((k_update16<512, true, 3, true, 512, true>), grid, dim3(512), 0, s, begun, done, 0, M, rows, srows, j0, gb, wlo,
 				                      panels, aux, multset, blk_first, tile_begin, ntiles, world, wrank, Pc, ss, xcd_nsys);
@@ -367,6 +369,8 @@ struct Solver {
 	u64 *Uwin = nullptr;          // rank x GMAX: pivot rows' words of the following window (k_prio_window -> k_unwind)
 	int *oprow = nullptr;         // k_outer_prow -> k_outer_apply / k_update16k: row lists of the outer panel being applied
 	u64 *Tm = nullptr;            // k_outer_trsm<IDENT> -> k_outer_apply: the panel's pivot rows as combinations of its source rows
+	bool outer_xcd = false;       // GF2BV_OUTER_XCD=1: the outer pass walks its items chunk-major per XCD (k_update16k: xcd_map) -- built and
+	                              // measured in round 4, SLOWER: 262144^2 1.305 -> 1.370 s, 131072^2 185 -> 210 ms (profiles/r04_target_scans.txt)
 	bool outer_chain = false;     // GF2BV_OUTER_CHAIN=1: the chain itself on every word group instead (the first form; tests)
 	u64 *Pc = nullptr;            // final pivot rows of the current block, compact: [tile][panel][pivot bit] x 16 B (k_block_trsm -> k_update16)
 	u64 *Pfast = nullptr;         // scratch of k_block_fast: the pivot rows' window words of a block, [panel][word][column]
@@ -546,6 +550,7 @@ void plan_two_level(Solver &S)
 	if (!bend) return;
 	S.tl_K = K; S.tl_bend = bend;
 	if (const char *e = getenv("GF2BV_OUTER_CHAIN"); e && *e) S.outer_chain = atoi(e) != 0;
+	if (const char *e = getenv("GF2BV_OUTER_XCD"); e && *e) S.outer_xcd = atoi(e) != 0;
 	S.nsets = 2 * K;              // the outer pass of panel p reads its K sets while the blocks of panel p + 1 write theirs
 }
 
@@ -1000,10 +1005,12 @@ int enqueue_outer_apply(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, 
 	// items of a dense system: the kernel derives the true count from the alive bound and loops if there are more
 	const i64 est_lo = std::min<i64>(S.rows, (i64)b0 * 64 * G) & ~(i64)63, R64 = round_up(S.rows, 64);
 	const i64 nch = std::max<i64>(1, (R64 - est_lo + (i64)GF2_KSEG * 512 - 1) / ((i64)GF2_KSEG * 512));
-	const i64 wgs = std::min<i64>(nch * nt, (i64)1 << 30);
+	const bool xmap = S.outer_xcd && S.nsys == 1;
+	// (xcd_map: one workgroup per item exactly -- the kernel's own chunk count may be smaller than this estimate, never larger)
+	const i64 wgs = xmap ? 8 * ((nch + 7) / 8) * nt : std::min<i64>(nch * nt, (i64)1 << 30);
 	hipExtLaunchKernelGGL((k_update16k<GF2_KSEG>), dim3((unsigned)wgs, S.nsys), dim3(512), 0, st, S.ext_events ? ka : nullptr, S.ext_events ? kb : nullptr, 0,
 	                      S.M, S.rows, S.srows, b1 - b0, (const int *)gprow, (const u64 *)S.mult,
-	                      set_words, b0 % S.nsets, S.nsets, (const int *)(S.blk_first + b0), (const int *)S.died, b1 * G, (int)t_begin, (int)nt, S.ss());
+	                      set_words, b0 % S.nsets, S.nsets, (const int *)(S.blk_first + b0), (const int *)S.died, b1 * G, (int)t_begin, (int)nt, S.ss(), xmap ? 1 : 0);
 	HIPCHK(hipGetLastError());
 	if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, st));
 	if (S.dbg_sync & 2) HIPCHK(hipDeviceSynchronize());
