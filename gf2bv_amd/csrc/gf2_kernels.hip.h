@@ -3103,6 +3103,352 @@ k_space_enumerate(const u64 *__restrict__ origin, const u64 *__restrict__ basis,
 	}
 }
 
+// ==========================================================================================
+// SMALL SYSTEMS: the whole solve in ONE launch (round 4)
+// ==========================================================================================
+// The reference's own examples are tiny next to the synthetic benchmark -- README 4 x 4, examples/simple.py 128 x 128,
+// examples/xoshiro.py 640 x 256 -- and the blocked path above costs them ~25 launches and four copies: 0.26 ms for a
+// warm 640 x 256 solve, most of it launch latency.  k_small_solve keeps the augmented matrix of such a system in the LDS
+// of ONE workgroup and runs the elimination to the reduced row echelon form there, panel by panel with the method of the
+// blocked path: per pass over a panel (64 columns = one word) up to 64 candidate rows go to wavefront 0, which reduces
+// their words of the panel against each other column by column (ascending: the first candidate that has the bit becomes
+// the pivot of the column) and records every row's combination of candidates; the candidates' other words follow through
+// that combination, then every other row -- earlier pivot rows included: Gauss-Jordan, so no back-substitution is left --
+// takes the new pivot rows selected by its bits in their columns.  Passes repeat until no row that is not a pivot has a
+// bit in a pivot-less column of the panel (a dense panel: two passes, 62-63 pivots + the rest).  Pivot columns = the
+// column rank profile whatever rows were picked (contract S1: when a row becomes the pivot of column d it is zero in every
+// pivot-less column left of d, and nothing added to it later has a bit there), so origin, consistency, pivots and the
+// kernel vectors read off the RREF are what _mzd_pluq + _mzd_pluq_solve_left + _mzd_kernel_left_pluq give
+// (gf2bv/_internal.c:431-455, 309-357): origin[c] = RHS bit of the pivot row of c; kernel vector of a free column f:
+// bit c = entry (pivot row of c, f), the host sets bit f and orders the vectors (S4).  A column-at-a-time Gauss-Jordan in
+// one wavefront was round 3's attempt (1.15 ms for 640 x 256: a barrier and ten LDS round trips per COLUMN, removed).
+//
+// Input: row-major words (src, stride) or CPython digits (digits / off / bpd, as k_pack_digits).  Output, one buffer
+// (all of it copied back in one piece): out[0] = rank, out[1] = inconsistent, out[2] = number of free columns written;
+// int32 pivcols[cols] from byte 16; then from the next 8-byte boundary cw words of origin and, want_basis, nfree x cw
+// words Y -- row j belongs to the j-th pivot-less column in ascending order.
+#define GF2_SMALL_MAXCOLS 1023
+#define GF2_SMALL_MAXROWS 4096
+#define GF2_SMALL_LDS_WORDS 18432          /* (rows + 2 x 256 table entries) x row pitch in 64-bit words: 144 KiB of the 160 (SmallLds: 12 KiB) */
+__host__ __device__ __forceinline__ i64 small_pitch(i64 wt) { return wt | 1; }      // odd: equal words of neighbouring rows in different banks
+struct SmallLds {
+	short rowpiv[GF2_SMALL_MAXROWS];       // row -> its pivot column, -1
+	short pivrow[GF2_SMALL_MAXCOLS + 1];   // column -> its pivot row, -1
+	u64 have[16];                          // panel -> pivot columns found
+	int base[17];                          // panel -> pivots in the panels before it
+	int list[64];                          // this pass's candidate rows
+	u64 comb[64];                          // candidate l after the pass = XOR of the candidates in comb[l]
+	int newrow[64];                        // column of the panel -> its new pivot row (this pass)
+	int newlane[64];                       // ... and that row's index among the candidates
+	u64 newmask;
+	int ncand;
+	int bad;
+};
+template <int NT>
+__global__ void __launch_bounds__(NT)
+k_small_solve(const u64 *__restrict__ src, i64 stride, const uint32_t *__restrict__ digits, const i64 *__restrict__ off, int bpd,
+              int rows, int cols, int want_basis, unsigned *__restrict__ out, unsigned long long *__restrict__ probe)
+{
+	extern __shared__ __attribute__((aligned(16))) u64 lds_small[];
+	// probe (GF2BV_SMALL_PROBE=1): 100 MHz ticks per phase, summed over the passes: 0 load, 1 candidates, 2 wavefront 0, 3 candidate
+	// rows, 4 tables, 5 all rows, 6 read-out, 7 passes
+	unsigned long long pt[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, pl = probe ? wall_clock64() : 0;
+#define SMALL_PROBE(k) do { if (probe && threadIdx.x == 0) { const unsigned long long now = wall_clock64(); pt[k] += now - pl; pl = now; } } while (0)
+	const int wt = (cols + 1 + 63) >> 6, cw = (cols + 63) >> 6, ws = (int)small_pitch(wt), npan = cw;
+	u64 *A = lds_small;
+	u64 *T = lds_small + (size_t)rows * ws;              // 16 nibble tables of 16 entries of a row (pitch ws): the new pivot rows by column
+	u64 *TC = T + (size_t)256 * ws;                      // ... and the pass's candidate rows (old values) by candidate index
+	SmallLds &L = *reinterpret_cast<SmallLds *>(TC + (size_t)256 * ws);
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	constexpr int NW = NT / 64;
+	// ---- load: bits above column `cols` (the RHS) are ignored (_internal.c:414) ----
+	const u64 topmask = (((cols + 1) & 63) ? ((1ull << ((cols + 1) & 63)) - 1) : ~0ull);
+	// (four items per thread in flight: offsets of all four first, then their digits -- at most four per word for 30-bit digits --
+	// one memory round trip each instead of one per digit)
+	for (int e0 = t; e0 < rows * wt; e0 += 4 * NT) {
+		int rr[4], ww[4];
+		i64 o0[4], nd[4];
+		u64 vv[4];
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const int e = e0 + k * NT, ec = e < rows * wt ? e : 0;
+			rr[k] = ec / wt; ww[k] = ec - rr[k] * wt;
+			if (src) vv[k] = src[(i64)rr[k] * stride + ww[k]];
+			else { o0[k] = off[rr[k]]; nd[k] = off[rr[k] + 1] - o0[k]; }
+		}
+		if (!src) {
+			uint32_t dg[4][5];
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				const i64 di0 = ((i64)ww[k] * 64 + 1) / bpd;
+#pragma unroll
+				for (int u = 0; u < 4; u++) dg[k][u] = (di0 + u < nd[k]) ? digits[o0[k] + di0 + u] : 0u;
+				dg[k][4] = nd[k] > 0 ? digits[o0[k]] : 0u;
+			}
+#pragma unroll
+			for (int k = 0; k < 4; k++) {
+				// word w holds columns 64 w .. 64 w + 63 = int bits 64 w + 1 ..; the RHS (int bit 0) goes to column `cols`
+				const i64 p0 = (i64)ww[k] * 64 + 1, di0 = p0 / bpd;
+				int sh = (int)(p0 % bpd), filled = 0;
+				u64 v = 0;
+#pragma unroll
+				for (int u = 0; u < 4; u++)
+					if (filled < 64) { v |= (u64)(dg[k][u] >> sh) << filled; filled += bpd - sh; sh = 0; }
+				// (bpd < 22 needs more than four digits per word: the tail, one by one)
+				for (i64 di = di0 + 4; filled < 64 && di < nd[k]; di++) { v |= (u64)digits[o0[k] + di] << filled; filled += bpd; }
+				const i64 c0 = (i64)ww[k] * 64;
+				if (c0 + 64 > cols) v &= (cols - c0 > 0) ? ((1ull << (cols - c0)) - 1) : 0ull;
+				if (ww[k] == (cols >> 6) && (dg[k][4] & 1u)) v |= 1ull << (cols & 63);
+				vv[k] = v;
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < 4; k++) {
+			const int e = e0 + k * NT;
+			if (e < rows * wt) A[rr[k] * ws + ww[k]] = (ww[k] == wt - 1) ? (vv[k] & topmask) : vv[k];
+		}
+	}
+	for (int r = t; r < rows; r += NT) L.rowpiv[r] = -1;
+	for (int c = t; c <= GF2_SMALL_MAXCOLS; c += NT) L.pivrow[c] = -1;
+	if (t < 16) L.have[t] = 0;
+	if (t == 0) L.bad = 0;
+	if (t < ws) { T[t] = 0; TC[t] = 0; }          // entry (nibble 0, value 0) of both table sets: zero from the start (and every build writes 0 there)
+	__syncthreads();
+	SMALL_PROBE(0);
+
+	for (int q = 0; q < npan; q++) {
+		const u64 colmask = (cols - 64 * q >= 64) ? ~0ull : ((1ull << (cols - 64 * q)) - 1);
+		for (;;) {
+			// ---- candidates: rows that are no pivots and have a bit in a pivot-less column of the panel (any 64 of them) ----
+			if (t == 0) { L.ncand = 0; L.newmask = 0; }
+			__syncthreads();
+			const u64 open = colmask & ~L.have[q];
+			if (open)
+				for (int r0 = 64 * wv; r0 < rows && L.ncand < 64; r0 += NT) {       // (a wavefront at a time: one atomic per 64 rows)
+					const int r = r0 + lane;
+					const bool cand = r < rows && L.rowpiv[r] < 0 && (A[r * ws + q] & open);
+					const u64 bal = __ballot(cand);
+					if (!bal) continue;
+					int base = 0;
+					if (lane == 0) base = atomicAdd(&L.ncand, __popcll(bal));
+					base = uniform(base);
+					const int slot = base + __popcll(bal & lanemask_lt(lane));
+					if (cand && slot < 64) L.list[slot] = r;
+				}
+			__syncthreads();
+			const int n = L.ncand < 64 ? L.ncand : 64;
+			SMALL_PROBE(1);
+			if (n == 0) break;                          // (uniform) the panel is complete
+			pt[7]++;
+			// ---- wavefront 0: the candidates' words of this panel against each other, column by column ----
+			if (wv == 0) {
+				const int r = lane < n ? L.list[lane] : 0;
+				u64 w = lane < n ? (A[r * ws + q] & colmask) : 0ull;       // (pivot columns found earlier are zero in every such row)
+				int pcol = -1;
+				u64 todo = wave_or(w) & open;           // columns somebody has a bit in -- it only shrinks: a column nobody has stays empty
+				// The loop is the serial part of a pass (one wavefront, 64 dependent steps): everything that can be scalar is -- the
+				// column, its bit mask, the lanes that are no pivots yet (`unpiv`), the pivot lane -- and the vector side is 32-bit:
+				// test the bit, four v_readlane, four XORs.  (On 64-bit lane values with a per-lane pivot flag the same loop took
+				// 6.4 us per panel, half of a 640 x 256 solve.)
+				unsigned wlo = (unsigned)w, whi = (unsigned)(w >> 32), clo = lane < 32 ? 1u << lane : 0u, chi = lane >= 32 ? 1u << (lane - 32) : 0u;
+				u64 unpiv = ~0ull;
+				while (todo) {
+					const int c = ctz64(todo);
+					todo &= todo - 1;
+					const unsigned bit = 1u << (c & 31);
+					const u64 hasm = __ballot(((c < 32 ? wlo : whi) & bit) != 0);
+					const u64 m = hasm & unpiv;
+					if (!m) continue;
+					const int p = ctz64(m);
+					unpiv &= ~(1ull << p);
+					const unsigned s0 = __builtin_amdgcn_readlane(wlo, p), s1 = __builtin_amdgcn_readlane(whi, p);
+					const unsigned s2 = __builtin_amdgcn_readlane(clo, p), s3 = __builtin_amdgcn_readlane(chi, p);
+					if (lane == p) pcol = c;
+					else if ((hasm >> lane) & 1) { wlo ^= s0; whi ^= s1; clo ^= s2; chi ^= s3; }
+				}
+				const u64 comb = ((u64)chi << 32) | clo;
+				L.comb[lane] = comb;
+				const u64 nmk = wave_or(pcol >= 0 ? 1ull << pcol : 0ull);
+				if (lane == 0) L.newmask = nmk;
+				if (pcol >= 0) {
+					L.newrow[pcol] = r;
+					L.newlane[pcol] = lane;
+					L.rowpiv[r] = (short)(64 * q + pcol);
+					L.pivrow[64 * q + pcol] = (short)r;
+				}
+			}
+			__syncthreads();
+			SMALL_PROBE(2);
+			const u64 nm = L.newmask;
+			if (__popcll(nm) <= 4) {
+				// ---- a pass that found a handful of pivots (a dense panel's second pass: the one or two columns the first 64
+				// candidates left open): every combination has at most five bits, every row takes at most four pivot rows -- bit
+				// loops on the rows themselves, no tables ----
+				constexpr int MAXI = (64 * 16 + NT - 1) / NT;
+				u64 nv[MAXI];                              // (static indices only)
+#pragma unroll
+				for (int k = 0; k < MAXI; k++) {
+					const int e = t + k * NT;
+					u64 acc = 0;
+					if (e < n * wt) {
+						const int l = e / wt, j = e - l * wt;
+						u64 cb = L.comb[l];
+						while (cb) { const int s2 = ctz64(cb); cb &= cb - 1; acc ^= A[L.list[s2] * ws + j]; }
+					}
+					nv[k] = acc;
+				}
+				__syncthreads();
+#pragma unroll
+				for (int k = 0; k < MAXI; k++) {
+					const int e = t + k * NT;
+					if (e < n * wt) { const int l = e / wt, j = e - l * wt; A[L.list[l] * ws + j] = nv[k]; }
+				}
+				__syncthreads();
+				SMALL_PROBE(3);
+				for (int r = t; r < rows; r += NT) {
+					const int rp = L.rowpiv[r];
+					if (rp >= 64 * q && ((nm >> (rp - 64 * q)) & 1) && L.newrow[rp - 64 * q] == r) continue;
+					u64 m = A[r * ws + q] & nm;
+					if (!m) continue;
+					const u64 *pr[4];                      // the <= 4 pivot rows this row takes (the rest: the zero entry of the tables)
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						pr[k] = m ? A + L.newrow[ctz64(m)] * ws : T;
+						m &= m - 1;
+					}
+					u64 *row = A + r * ws;
+					for (int j = 0; j < wt; j++) {
+						const u64 a0 = pr[0][j], a1 = pr[1][j], a2 = pr[2][j], a3 = pr[3][j];
+						row[j] ^= (a0 ^ a1) ^ (a2 ^ a3);
+					}
+				}
+				__syncthreads();
+				SMALL_PROBE(5);
+			} else {
+			// ---- nibble tables TC of the candidates' OLD rows by candidate index: everything the pass changes is a combination of
+			// these 64 rows, selected by the bits of a 64-bit value -- 16 lookups instead of one row XOR per set bit ----
+			for (int e = t; e < 256 * wt; e += NT) {
+				const int nv = e / wt, j = e - nv * wt, nb = nv >> 4, v = nv & 15;
+				u64 r4[4];
+#pragma unroll
+				for (int k = 0; k < 4; k++) {               // (four independent reads, then the select: no round trip per set bit)
+					const int l = 4 * nb + k;
+					r4[k] = A[L.list[l < n ? l : 0] * ws + j];
+					if (l >= n || !((v >> k) & 1)) r4[k] = 0;
+				}
+				TC[nv * ws + j] = (r4[0] ^ r4[1]) ^ (r4[2] ^ r4[3]);
+			}
+			__syncthreads();
+			SMALL_PROBE(3);
+			// ---- the candidates' new rows (row l = TC x comb[l]) and the nibble tables T of the NEW pivot rows by column for the
+			// all-rows step below: entry (nb, v) = XOR of the pivot rows of the columns 4 nb + k, k in v = TC x (XOR of their
+			// combinations) -- both straight from TC, no pass over the new rows in between ----
+			for (int e = t; e < (n + 256) * wt; e += NT) {
+				const int i = e / wt, j = e - i * wt;
+				u64 sel;
+				u64 *dst;
+				if (i < n) { sel = L.comb[i]; dst = A + L.list[i] * ws + j; }
+				else {
+					const int nv = i - n, nb = nv >> 4, v = nv & 15;
+					sel = 0;
+#pragma unroll
+					for (int k = 0; k < 4; k++) {
+						const int c = 4 * nb + k;
+						if (((v >> k) & 1) && ((nm >> c) & 1)) sel ^= L.comb[L.newlane[c]];
+					}
+					dst = T + nv * ws + j;
+				}
+				u64 v16[16];
+#pragma unroll
+				for (int nb = 0; nb < 16; nb++) v16[nb] = TC[(nb * 16 + (int)((unsigned)(sel >> (4 * nb)) & 15u)) * ws + j];
+				u64 acc = 0;
+#pragma unroll
+				for (int nb = 0; nb < 16; nb += 2) acc ^= v16[nb] ^ v16[nb + 1];
+				*dst = acc;
+			}
+			__syncthreads();
+			SMALL_PROBE(4);
+			// ---- every other row takes the new pivot rows its bits select (Gauss-Jordan: earlier pivot rows too) ----
+			for (int r = t; r < rows; r += NT) {
+				const int rp = L.rowpiv[r];
+				if (rp >= 64 * q && ((nm >> (rp - 64 * q)) & 1) && L.newrow[rp - 64 * q] == r) continue;      // a pivot row of this pass
+				const u64 m = A[r * ws + q] & nm;
+				if (!m) continue;
+				// (word by word in a real loop, 16 lookups each at offsets fixed by m: a register array of the row's words under `j < wt`
+				// conditions compiled to 7800 v_mov_b64 of phi copies and 24 us per pass)
+				int tb[16];
+#pragma unroll
+				for (int nb = 0; nb < 16; nb++) tb[nb] = (nb * 16 + (int)((unsigned)(m >> (4 * nb)) & 15u)) * ws;
+				u64 *row = A + r * ws;
+				for (int j = 0; j < wt; j++) {
+					// (all 16 lookups requested before the first is used: written as one XOR chain the compiler waited for each
+					// LDS round trip in turn)
+					u64 v[16];
+#pragma unroll
+					for (int nb = 0; nb < 16; nb++) v[nb] = T[tb[nb] + j];
+					u64 acc = row[j];
+#pragma unroll
+					for (int nb = 0; nb < 16; nb += 2) acc ^= v[nb] ^ v[nb + 1];
+					row[j] = acc;
+				}
+			}
+			__syncthreads();
+			}
+			if (t == 0) L.have[q] |= nm;
+			__syncthreads();
+			SMALL_PROBE(5);
+		}
+	}
+	// ---- read the result off the reduced row echelon form ----
+	if (t == 0) {
+		int b = 0;
+		for (int q = 0; q < npan; q++) { L.base[q] = b; b += __popcll(L.have[q]); }
+		L.base[npan] = b;
+	}
+	// consistency: a row that is no pivot is zero in A by now; its RHS bit must be zero too (_internal.c:440)
+	for (int r = t; r < rows; r += NT)
+		if (L.rowpiv[r] < 0 && ((A[r * ws + (cols >> 6)] >> (cols & 63)) & 1)) L.bad = 1;
+	__syncthreads();
+	const int rank = L.base[npan], nfree = cols - rank;
+	int *pivcols = reinterpret_cast<int *>(out + 4);
+	u64 *origin = reinterpret_cast<u64 *>(out + 4 + ((cols + 1) & ~1));
+	u64 *Y = origin + cw;
+	if (t == 0) { out[0] = (unsigned)rank; out[1] = (unsigned)L.bad; out[2] = (unsigned)(want_basis && !L.bad ? nfree : 0); out[3] = 0; }
+	for (int c = t; c < cols; c += NT) {
+		const int q = c >> 6, b = c & 63;
+		if ((L.have[q] >> b) & 1) pivcols[L.base[q] + __popcll(L.have[q] & ((1ull << b) - 1))] = c;
+	}
+	// origin: bit c = RHS bit of the pivot row of c (free variables 0); a wavefront forms a word with one ballot
+	for (int wq = wv; wq < cw; wq += NW) {
+		const int c = 64 * wq + lane;
+		const int pr = c < cols ? L.pivrow[c] : -1;
+		const u64 word = __ballot(pr >= 0 && ((A[pr * ws + (cols >> 6)] >> (cols & 63)) & 1));
+		if (lane == 0) origin[wq] = word;
+	}
+	if (want_basis && !L.bad) {
+		// kernel vectors: row j = the j-th pivot-less column f (ascending); bit c = entry (pivot row of c, f)
+		for (int e = wv; e < nfree * cw; e += NW) {
+			const int j = e / cw, wq = e - j * cw;
+			// the j-th pivot-less column: panel by the running count of free columns, then the bit by rank within ~have
+			int f = -1, left = j;
+			for (int q2 = 0; q2 < npan; q2++) {
+				const u64 cm = (cols - 64 * q2 >= 64) ? ~0ull : ((1ull << (cols - 64 * q2)) - 1);
+				u64 fr = cm & ~L.have[q2];
+				const int cnt = __popcll(fr);
+				if (left < cnt) { for (int k = 0; k < left; k++) fr &= fr - 1; f = 64 * q2 + ctz64(fr); break; }
+				left -= cnt;
+			}
+			const int c = 64 * wq + lane;
+			const int pr = c < cols ? L.pivrow[c] : -1;
+			const u64 word = __ballot(pr >= 0 && f >= 0 && ((A[pr * ws + (f >> 6)] >> (f & 63)) & 1));
+			if (lane == 0) Y[(i64)j * cw + wq] = word;
+		}
+	}
+	SMALL_PROBE(6);
+	if (probe && t == 0) for (int k = 0; k < 8; k++) probe[k] = pt[k];
+#undef SMALL_PROBE
+}
+
 // ------------------------------------------------------------------------------------------
 // Synthetic dense systems + independent residual check (bench / tests).
 __device__ __forceinline__ u64 mix64(u64 x)

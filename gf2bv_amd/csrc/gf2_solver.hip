@@ -1498,6 +1498,160 @@ int check_shape(i64 rows, i64 cols, int mode)
 	return GF2BV_OK;
 }
 
+// ---- small systems: the whole solve in one launch (k_small_solve) ---------------------------------------------------
+// Eligible: the augmented matrix + two sets of nibble tables fit the LDS of one workgroup ((rows + 512) x odd row pitch <= 18432 words = 144 KiB, cols <= 1023,
+// rows <= 4096).  Per call: ONE host-to-device copy out of a pinned staging buffer (offsets + digits, or the packed words;
+// none when the matrix already lives on the device), one launch, and the result written by the kernel straight into pinned
+// host memory -- no device-to-host copy.  GF2BV_SMALL=0 sends these systems down the blocked path instead (tests compare both).
+struct SmallStage {            // per host thread and device: pinned staging (never freed: the runtime may be gone at thread exit)
+	int device = -1;
+	char *h_in = nullptr, *h_out = nullptr;
+	size_t in_cap = 0, out_cap = 0;
+};
+thread_local SmallStage g_small;
+
+bool small_eligible(i64 rows, i64 cols)
+{
+	if (const char *e = getenv("GF2BV_SMALL")) if (atoi(e) == 0) return false;
+	const i64 wt = (cols + 1 + 63) / 64;
+	return cols <= GF2_SMALL_MAXCOLS && rows <= GF2_SMALL_MAXROWS && (rows + 512) * small_pitch(wt) <= GF2_SMALL_LDS_WORDS;
+}
+
+int small_stage(int device, size_t in_bytes, size_t out_bytes)
+{
+	SmallStage &G = g_small;
+	if (G.device != device) { G = SmallStage(); G.device = device; }       // (a thread that changes devices gets fresh buffers; the old ones stay pinned)
+	if (in_bytes > G.in_cap) {
+		if (G.h_in) (void)hipHostFree(G.h_in);
+		G.h_in = nullptr; G.in_cap = 0;
+		const size_t cap = std::max<size_t>(in_bytes * 2, (size_t)256 << 10);
+		HIPCHK(hipHostMalloc((void **)&G.h_in, cap, hipHostMallocDefault));
+		G.in_cap = cap;
+	}
+	if (out_bytes > G.out_cap) {
+		if (G.h_out) (void)hipHostFree(G.h_out);
+		G.h_out = nullptr; G.out_cap = 0;
+		const size_t cap = std::max<size_t>(out_bytes * 2, (size_t)64 << 10);
+		HIPCHK(hipHostMalloc((void **)&G.h_out, cap, hipHostMallocDefault));
+		G.out_cap = cap;
+	}
+	return GF2BV_OK;
+}
+
+// One of: d_words (device, row-major, d_stride) | h_words (host, row-major, h_stride) | h_digits + h_off (host, bpd bits per digit)
+struct SmallInput {
+	const u64 *d_words = nullptr; i64 d_stride = 0;
+	const u64 *h_words = nullptr; i64 h_stride = 0;
+	const uint32_t *h_digits = nullptr; const i64 *h_off = nullptr; int bpd = 0;
+};
+
+int small_solve(const SmallInput &in, i64 rows, i64 cols, int mode, int device, hipStream_t stream, gf2bv_result **out)
+{
+	const auto t_begin = std::chrono::steady_clock::now();
+	const i64 wt = (cols + 1 + 63) / 64, cw = (cols + 63) / 64;
+	const bool want_basis = mode == GF2BV_MODE_AFFINE_SPACE;
+	const size_t head = 16 + 4 * (size_t)((cols + 1) & ~(i64)1);
+	const size_t res_bytes = head + 8 * (size_t)cw * (1 + (want_basis ? (size_t)cols : 0));
+	const size_t out_bytes = res_bytes + 64;                 // (+ 8 phase counters of the probe, GF2BV_SMALL_PROBE=1)
+	const bool probe = getenv("GF2BV_SMALL_PROBE") != nullptr;
+	size_t in_bytes = 0;
+	i64 ndig = 0;
+	if (in.h_digits) { ndig = in.h_off[rows]; in_bytes = sizeof(i64) * (size_t)(rows + 1) + sizeof(uint32_t) * (size_t)std::max<i64>(ndig, 1); }
+	else if (in.h_words) in_bytes = sizeof(u64) * (size_t)(rows * wt);
+	int rc = small_stage(device, in_bytes, out_bytes);
+	if (rc) return rc;
+	SmallStage &G = g_small;
+	hipStream_t st = stream;
+	bool own_stream = false;
+	if (!st) { HIPCHK(pool().stream(&st, device, false)); own_stream = true; }
+	struct Back { hipStream_t st; int device; bool own; void *d_in; ~Back() { if (own) pool().release_stream(st, device, false); pool().release(d_in); } } back{ st, device, own_stream, nullptr };
+	const u64 *d_src = in.d_words;
+	i64 d_stride = in.d_stride;
+	const uint32_t *d_dig = nullptr;
+	const i64 *d_off = nullptr;
+	// inputs up to 32 KiB: no copy at all -- the kernel reads the pinned staging buffer over the link (two batched round trips;
+	// 2-6 us less than a host-to-device copy in front of the launch: profiles/r04_small.txt).  GF2BV_SMALL_ZC=0 / 1 forces either.
+	bool zero_copy = in_bytes <= ((size_t)32 << 10);
+	if (const char *e = getenv("GF2BV_SMALL_ZC")) zero_copy = atoi(e) != 0;
+	if (in_bytes) {
+		if (!zero_copy) HIPCHK(pool().alloc(&back.d_in, in_bytes, device));
+		char *d_base = zero_copy ? G.h_in : (char *)back.d_in;
+		if (in.h_digits) {
+			memcpy(G.h_in, in.h_off, sizeof(i64) * (size_t)(rows + 1));
+			if (ndig) memcpy(G.h_in + sizeof(i64) * (size_t)(rows + 1), in.h_digits, sizeof(uint32_t) * (size_t)ndig);
+			d_off = (const i64 *)d_base;
+			d_dig = (const uint32_t *)(d_base + sizeof(i64) * (size_t)(rows + 1));
+		} else {
+			for (i64 r = 0; r < rows; r++) memcpy(G.h_in + sizeof(u64) * (size_t)(r * wt), in.h_words + r * in.h_stride, sizeof(u64) * (size_t)wt);
+			d_src = (const u64 *)d_base; d_stride = wt;
+		}
+		if (!zero_copy) HIPCHK(hipMemcpyAsync(back.d_in, G.h_in, in_bytes, hipMemcpyHostToDevice, st));
+	}
+	// 16 wavefronts: every phase but wavefront 0's column loop is a few dependent LDS round trips per item, i.e. latency --
+	// 640 x 256: 143 us with 256 threads (profiles/r04_small.txt)
+	constexpr int NT = 1024;
+	const size_t lds = sizeof(u64) * (size_t)((rows + 512) * small_pitch(wt)) + sizeof(SmallLds);
+	{
+		static std::mutex mu;
+		static std::map<int, bool> raised;          // device -> the > 64 KiB dynamic-LDS attribute has been raised there
+		std::lock_guard<std::mutex> lk(mu);
+		if (!raised[device]) {
+			HIPCHK(hipFuncSetAttribute((const void *)k_small_solve<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+			raised[device] = true;
+		}
+	}
+	memset(G.h_out, 0, 16);
+	k_small_solve<NT><<<dim3(1), dim3(NT), lds, st>>>(d_src, d_stride, d_dig, d_off, in.bpd, (int)rows, (int)cols, want_basis ? 1 : 0, (unsigned *)G.h_out,
+	                                                   probe ? (unsigned long long *)(G.h_out + res_bytes) : nullptr);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(st));
+	const unsigned *ho = (const unsigned *)G.h_out;
+	if (probe) {
+		const unsigned long long *p = (const unsigned long long *)(G.h_out + res_bytes);
+		fprintf(stderr, "[gf2bv small %lld x %lld] us: load %.1f candidates %.1f wavefront0 %.1f candidate rows %.1f tables %.1f all rows %.1f read-out %.1f; passes %llu\n",
+		        (long long)rows, (long long)cols, p[0] / 100.0, p[1] / 100.0, p[2] / 100.0, p[3] / 100.0, p[4] / 100.0, p[5] / 100.0, p[6] / 100.0, p[7]);
+	}
+	const i64 rank = ho[0];
+	const bool bad = ho[1] != 0;
+	if (rank < 0 || rank > cols) return fail(GF2BV_ERR_HIP, "small solve returned an impossible rank");
+	gf2bv_result *R = new gf2bv_result();
+	R->status = bad ? GF2BV_STATUS_INCONSISTENT : GF2BV_STATUS_SOLVED;
+	R->rank = rank; R->cw = cw; R->dim = cols - rank;
+	const int32_t *pv = (const int32_t *)(G.h_out + 16);
+	R->pivots.assign(pv, pv + rank);
+	R->origin.assign(std::max<i64>(1, cw), 0);
+	const u64 *org = (const u64 *)(G.h_out + head);
+	if (!bad) {
+		std::copy(org, org + cw, R->origin.begin());
+		if (want_basis) {
+			// free columns in M4RI's kernel order (_internal.c:348); the kernel wrote the vectors in ascending column order
+			std::vector<int> order(cols), slot(cols, -1);
+			for (i64 i = 0; i < cols; i++) order[i] = (int)i;
+			for (i64 i = 0; i < rank; i++) std::swap(order[i], order[pv[i]]);
+			std::vector<char> isp(cols, 0);
+			for (i64 i = 0; i < rank; i++) isp[pv[i]] = 1;
+			int j = 0;
+			for (i64 c = 0; c < cols; c++) if (!isp[c]) slot[c] = j++;
+			const u64 *Y = org + cw;
+			R->basis.assign((size_t)R->dim * std::max<i64>(1, cw), 0);
+			for (i64 t = 0; t < R->dim; t++) {
+				const int f = order[rank + t];
+				u64 *v = R->basis.data() + (size_t)t * cw;
+				std::copy(Y + (size_t)slot[f] * cw, Y + (size_t)(slot[f] + 1) * cw, v);
+				v[f >> 6] |= 1ull << (f & 63);
+			}
+		}
+	}
+	gf2bv_stats &s = R->stats;
+	s.rows = rows; s.cols = cols; s.stride_words = wt;
+	s.rank = rank; s.dimension = R->dim; s.status = R->status;
+	s.n_panels = (int)cw; s.gang_systems = 1; s.tile_words = 0;
+	s.small_path = 1;
+	s.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
+	*out = R;
+	return GF2BV_OK;
+}
+
 }  // namespace
 
 // =================================================================================================
@@ -1526,6 +1680,10 @@ int gf2bv_solve_device(void *d_aug, int64_t rows, int64_t cols, int64_t stride_w
 		return fail(GF2BV_ERR_ARG, "device matrix needs 16-byte alignment and an even stride_words covering cols+1 bits");
 	rc = check_device(device);
 	if (rc) return rc;
+	if (small_eligible(rows, cols) && !time_kernels) {
+		SmallInput in; in.d_words = (const u64 *)d_aug; in.d_stride = stride_words;
+		return small_solve(in, rows, cols, mode, device, (hipStream_t)stream, out);
+	}
 	Solver S;
 	S.t_begin = std::chrono::steady_clock::now();
 	S.device = device;
@@ -1648,6 +1806,10 @@ int gf2bv_solve_words(const uint64_t *aug, int64_t rows, int64_t cols, int64_t s
 	if (stride_words < wt) return fail(GF2BV_ERR_ARG, "stride_words does not cover cols+1 bits");
 	rc = check_device(device);
 	if (rc) return rc;
+	if (small_eligible(rows, cols)) {
+		SmallInput in; in.h_words = reinterpret_cast<const u64 *>(aug); in.h_stride = stride_words;
+		return small_solve(in, rows, cols, mode, device, nullptr, out);
+	}
 	Solver S;
 	S.t_begin = std::chrono::steady_clock::now();
 	S.device = device;
@@ -1791,6 +1953,13 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 	if (bits_per_digit < 1 || bits_per_digit > 32) return fail(GF2BV_ERR_ARG, "bits_per_digit must be 1..32");
 	rc = check_device(device);
 	if (rc) return rc;
+	if (digit_off[0] != 0) return fail(GF2BV_ERR_ARG, "digit offsets must start at 0");
+	for (i64 r = 0; r < rows; r++)
+		if (digit_off[r + 1] < digit_off[r]) return fail(GF2BV_ERR_ARG, "digit offsets must not decrease");
+	if (small_eligible(rows, cols)) {
+		SmallInput in; in.h_digits = digits; in.h_off = reinterpret_cast<const i64 *>(digit_off); in.bpd = bits_per_digit;
+		return small_solve(in, rows, cols, mode, device, nullptr, out);
+	}
 	Solver S;
 	S.t_begin = std::chrono::steady_clock::now();
 	S.device = device;
@@ -1802,9 +1971,6 @@ int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bit
 	S.stride = ntiles * TW;
 	HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * ntiles * TW * slab_rows(rows) + kOuterSlackBytes, device));     // packed straight into tiles
 	const i64 ndig = digit_off[rows];
-	if (digit_off[0] != 0) return fail(GF2BV_ERR_ARG, "digit offsets must start at 0");
-	for (i64 r = 0; r < rows; r++)
-		if (digit_off[r + 1] < digit_off[r]) return fail(GF2BV_ERR_ARG, "digit offsets must not decrease");
 	Scratch scratch;                  // digits, offsets and the pack events go back to the pool on every path
 	scratch.sync_first = S.sA;
 	uint32_t *d_dig = nullptr;

@@ -52,7 +52,7 @@ class Stats(ctypes.Structure):
         ("ms_backsub", ctypes.c_float), ("ms_export", ctypes.c_float), ("ms_total", ctypes.c_float),
         ("search_handovers", ctypes.c_int32), ("fast_blocks", ctypes.c_int32),
         ("hbm_words", ctypes.c_double), ("bulk_launches", ctypes.c_int32), ("outer_blocks", ctypes.c_int32),
-        ("handover_retries", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("handover_retries", ctypes.c_int32), ("small_path", ctypes.c_int32),
     ]
 
     def as_dict(self) -> dict:

@@ -73,7 +73,8 @@ typedef struct gf2bv_stats {
 	int32_t outer_blocks;      /* blocks applied through outer passes (0: one-level schedule)                         */
 	int32_t handover_retries;  /* 1: a stream hand-over gate expired on the device and this is the result of the SECOND attempt,
 	                              made with events (the device stays on events for this process); 0 normally        */
-	int32_t reserved0;
+	int32_t small_path;        /* 1: solved by the one-launch kernel for systems that fit the LDS of one workgroup (k_small_solve; the
+	                              phase times and sweep counters above are then 0 except ms_total); GF2BV_SMALL=0 disables that path */
 } gf2bv_stats;
 
 /* ---- library / device ------------------------------------------------------------------ */
