@@ -601,8 +601,59 @@ def test_large_dense_properties():
 
 @pytest.mark.timeout(300)
 def test_target_262144_properties():
-    """The north-star size (SURVEY 8a "target": 262144 x 262144, 8 GiB + the 8 GiB working copy): the same properties."""
-    _dense_properties(262144, 1234)
+    """The north-star size (SURVEY 8a "target": 262144 x 262144, 8 GiB + the 8 GiB working copy): the same properties on the
+    FULL-RANK seed 1242 (round 4; tools/find_full_rank_seed.py): rank = N, so A x = b has exactly one solution and equality with
+    the generator's planted vector is bit-exactness by uniqueness (SURVEY hard part 7) -- asserted, not conditional."""
+    sol = _dense_properties(262144, 1242)
+    assert sol.rank == 262144 and np.array_equal(sol.origin, hip.planted_solution(262144, 1242))
+
+
+def _rank_profile_properties(n, seed):
+    """A rank-deficient dense system in mode 1: what pins the COLUMN RANK PROFILE without a CPU re-solve.  The kernel vector of
+    free column f expresses column f by pivot columns; under the column rank profile (M4RI's PLE, contract S1) only pivot
+    columns LEFT of f can occur -- so the vector's highest set bit is f itself.  Checked for every vector in M4RI's order (S4:
+    free = the tail of the transposition replay), together with pivots = sorted complement of the free columns, A (origin ^ v) = b
+    by the independent residual kernel (v is in the kernel), origin zero at every free column."""
+    stride = hip.padded_stride(n)
+    buf = hip.DeviceBuffer(n * stride * 8)
+    hip.synth_device(buf.ptr, n, n, stride, seed)
+    sp = hip.solve_device(buf.ptr, n, n, stride, 1)
+    hip.synth_device(buf.ptr, n, n, stride, seed)
+    assert sp.status == 0 and 1 <= sp.dimension <= 8 and sp.rank == n - sp.dimension and sp.stats["handover_retries"] == 0
+    piv = sp.pivots
+    assert (np.diff(piv) > 0).all()
+    order = list(range(n))
+    for i, c in enumerate(piv.tolist()):
+        order[i], order[c] = order[c], order[i]
+    free = order[sp.rank:]
+    assert sorted(free) == np.setdiff1d(np.arange(n), piv).tolist()
+    assert hip.residual_device(buf.ptr, n, n, stride, sp.origin) == 0
+    for f, v in zip(free, sp.basis):
+        top = int(np.flatnonzero(v)[-1])
+        assert 64 * top + int(v[top]).bit_length() - 1 == f                 # nothing right of the free column
+        assert not (int(sp.origin[f >> 6]) >> (f & 63)) & 1
+        assert hip.residual_device(buf.ptr, n, n, stride, sp.origin ^ v) == 0
+    buf.free()
+    return sp
+
+
+def test_rank_deficient_65536_keeps_the_column_rank_profile():
+    for seed in range(1235, 1260):                          # (P(full rank) = 0.29: the first deficient seed after the headline's)
+        stride = hip.padded_stride(65536)
+        buf = hip.DeviceBuffer(65536 * stride * 8)
+        hip.synth_device(buf.ptr, 65536, 65536, stride, seed)
+        rank = hip.solve_device(buf.ptr, 65536, 65536, stride, 0).rank
+        buf.free()
+        if rank < 65536:
+            break
+    _rank_profile_properties(65536, seed)
+
+
+@pytest.mark.timeout(300)
+def test_rank_deficient_262144_keeps_the_column_rank_profile():
+    """seed 1234 at the north-star size has rank 262143 (round 3's bench seed): the second case beside the full-rank one."""
+    sp = _rank_profile_properties(262144, 1234)
+    assert sp.dimension == 1
 
 
 @pytest.mark.timeout(300)
@@ -645,7 +696,7 @@ def _dense_properties(n, seed, repeat=True):
     x = sol.origin
     assert all(not (int(x[f >> 6]) >> (f & 63)) & 1 for f in free)
     if sol.rank == n:
-        assert np.array_equal(x, O.planted_solution(n, seed))
+        assert np.array_equal(x, O.planted_solution(n, seed)) and np.array_equal(x, hip.planted_solution(n, seed))
     # linearity: the solution of the system with RHS flipped on a pivot-consistent way is covered by
     # mode 1 at a smaller size (test_words_path_matches_oracle); here: solving twice is deterministic
     if repeat:
@@ -653,3 +704,4 @@ def _dense_properties(n, seed, repeat=True):
         again = hip.solve_device(buf.ptr, n, n, stride, 0)
         assert np.array_equal(again.origin, sol.origin) and again.rank == sol.rank
     buf.free()
+    return sol
