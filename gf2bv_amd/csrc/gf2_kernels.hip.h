@@ -1410,6 +1410,15 @@ k_block_fast_narrow(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 	const int t = threadIdx.x, e_ = t >> 6, sl = t & 63;
 	// wait until the search workgroup has got as far as `stage` (1..3: panel stage - 1 formed; 5: published); 0 = it gave up
 	// (or a spinner timed out): nothing to narrow.  By all threads.
+	// Visibility (ADVICE round 3 asked for an acquire here): the protocol is the "16-byte sc1 stores AND sc1 loads" recipe of
+	// MI355X_MICROARCH.md (inter-workgroup visibility), not release / acquire fences: the producer writes Pfast, PanelAux, the
+	// records and died[] with agent-scope (write-through) stores, waits for them (s_waitcnt vmcnt(0)) and a workgroup barrier,
+	// THEN stores the counter; here one lane polls the counter with an agent-scope load, the barrier below orders every other
+	// lane's loads behind it in time (loads are not issued speculatively), and every load of the producer's data that follows is
+	// itself an agent-scope load (GF2_LD), which does not hit a stale line of this XCD's L2.  An acquire fence would be a
+	// buffer_inv of this XCD's L2 -- per narrowing workgroup and panel, beside a bulk update that lives on its L2 hits (a release
+	// on the producer side, the L2 write-back of everything that update has dirtied: 32768^2 9.0 -> 11.1 ms when it was tried).
+	// tests/test_gpu_stress.py::test_soak_many_solves_in_flight keeps the timing-dependent part under load in the suite.
 	auto wait_for = [&](int stage) -> bool {
 		if (t == 0) {
 			int go = 1;

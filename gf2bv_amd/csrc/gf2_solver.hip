@@ -1503,12 +1503,29 @@ int check_shape(i64 rows, i64 cols, int mode)
 // rows <= 4096).  Per call: ONE host-to-device copy out of a pinned staging buffer (offsets + digits, or the packed words;
 // none when the matrix already lives on the device), one launch, and the result written by the kernel straight into pinned
 // host memory -- no device-to-host copy.  GF2BV_SMALL=0 sends these systems down the blocked path instead (tests compare both).
-struct SmallStage {            // per host thread and device: pinned staging (never freed: the runtime may be gone at thread exit)
+struct SmallStage {            // pinned staging of one call in flight (input copy / zero-copy source, and the result)
 	int device = -1;
 	char *h_in = nullptr, *h_out = nullptr;
 	size_t in_cap = 0, out_cap = 0;
 };
-thread_local SmallStage g_small;
+// Stages are handed out per call and go back afterwards: as many exist as calls were ever in flight at once on a device (a
+// thread_local pair per host thread would pin 320 KiB for every thread a pool ever creates).  Never freed at exit: the HIP runtime
+// may be gone by then.
+struct StagePool {
+	std::mutex mu;
+	std::map<int, std::vector<SmallStage *>> idle;
+	SmallStage *take(int device)
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		auto &v = idle[device];
+		if (!v.empty()) { SmallStage *s = v.back(); v.pop_back(); return s; }
+		SmallStage *s = new SmallStage();
+		s->device = device;
+		return s;
+	}
+	void give(SmallStage *s) { std::lock_guard<std::mutex> lk(mu); idle[s->device].push_back(s); }
+};
+StagePool &stage_pool() { static StagePool *p = new StagePool(); return *p; }
 
 bool small_eligible(i64 rows, i64 cols)
 {
@@ -1517,10 +1534,8 @@ bool small_eligible(i64 rows, i64 cols)
 	return cols <= GF2_SMALL_MAXCOLS && rows <= GF2_SMALL_MAXROWS && (rows + 512) * small_pitch(wt) <= GF2_SMALL_LDS_WORDS;
 }
 
-int small_stage(int device, size_t in_bytes, size_t out_bytes)
+int small_stage(SmallStage &G, size_t in_bytes, size_t out_bytes)
 {
-	SmallStage &G = g_small;
-	if (G.device != device) { G = SmallStage(); G.device = device; }       // (a thread that changes devices gets fresh buffers; the old ones stay pinned)
 	if (in_bytes > G.in_cap) {
 		if (G.h_in) (void)hipHostFree(G.h_in);
 		G.h_in = nullptr; G.in_cap = 0;
@@ -1558,12 +1573,15 @@ int small_solve(const SmallInput &in, i64 rows, i64 cols, int mode, int device, 
 	i64 ndig = 0;
 	if (in.h_digits) { ndig = in.h_off[rows]; in_bytes = sizeof(i64) * (size_t)(rows + 1) + sizeof(uint32_t) * (size_t)std::max<i64>(ndig, 1); }
 	else if (in.h_words) in_bytes = sizeof(u64) * (size_t)(rows * wt);
-	int rc = small_stage(device, in_bytes, out_bytes);
+	struct Stage { SmallStage *s; ~Stage() { stage_pool().give(s); } } stage{ stage_pool().take(device) };
+	SmallStage &G = *stage.s;
+	int rc = small_stage(G, in_bytes, out_bytes);
 	if (rc) return rc;
-	SmallStage &G = g_small;
+	// Stream: a matrix that already lives on the device is whatever `stream` (NULL = the null stream) has produced -- the launch goes
+	// onto that very stream, as on the blocked path.  Host inputs depend on nothing: a pool stream of their own (non-blocking).
 	hipStream_t st = stream;
 	bool own_stream = false;
-	if (!st) { HIPCHK(pool().stream(&st, device, false)); own_stream = true; }
+	if (!st && !in.d_words) { HIPCHK(pool().stream(&st, device, false)); own_stream = true; }
 	struct Back { hipStream_t st; int device; bool own; void *d_in; ~Back() { if (own) pool().release_stream(st, device, false); pool().release(d_in); } } back{ st, device, own_stream, nullptr };
 	const u64 *d_src = in.d_words;
 	i64 d_stride = in.d_stride;

@@ -120,6 +120,21 @@ def test_bits_above_cols_and_the_sign_are_ignored_and_trivial_systems():
                                                                    O.m4ri_solve(lin.get_eqs([x ^ y ^ 1, (x & 1) ^ (y >> 1)]) + [0, 0], 4, 1)]
 
 
+def test_device_resident_small_system_is_ordered_after_its_producer():
+    """gf2bv_solve_device on a small system: the matrix is whatever the caller's stream (here the null stream) has produced -- the
+    one launch goes onto that stream like the blocked path's launches.  A generator kernel and the solve back to back, 60 times,
+    new contents each time, against the oracle on the generator's definition."""
+    rows, cols = 640, 256
+    stride = hip.padded_stride(cols)
+    buf = hip.DeviceBuffer(rows * stride * 8)
+    for seed in range(60):
+        hip.synth_device(buf.ptr, rows, cols, stride, 900 + seed)            # asynchronous, null stream
+        got = hip.solve_device(buf.ptr, rows, cols, stride, 1)
+        assert got.stats["small_path"] == 1
+        assert_same(got, O.solve_words(O.gen_synthetic(rows, cols, 900 + seed), rows, cols, 1), 1)
+    buf.free()
+
+
 def test_many_small_solves_from_many_threads():
     """the staging buffers are per host thread: 12 threads x 40 solves of three shapes, every answer against the oracle"""
     from concurrent.futures import ThreadPoolExecutor

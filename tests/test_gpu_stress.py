@@ -143,6 +143,18 @@ def test_two_level_elimination_of_a_gang(monkeypatch, K, gang, chain):
     assert got[0].stats["outer_blocks"] == 0
 
 
+@pytest.mark.timeout(600)
+def test_soak_many_solves_in_flight():
+    """A reduced run of tests/manual/soak_concurrent.py in the automated suite: 2 rounds of 40 solves from 16
+    threads -- more solves in flight than the runtime has hardware queues -- over ten shapes with rank caps, every result against
+    the oracle.  The in-kernel hand-overs are timing-dependent: k_block_fast_narrow's progress counter (sc1 write-through stores
+    of the data, vmcnt(0), then the counter; sc1 loads behind the counter on the consumer side: the second visibility recipe of
+    MI355X_MICROARCH.md, no L2 write-back / invalidate beside a running bulk update), the stream gates."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "manual", "soak_concurrent.py"), "2", "16", "4711"],
+                         capture_output=True, text=True, timeout=560, cwd=ROOT)
+    assert out.returncode == 0 and "SOAK ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+
+
 _RETRY_SCRIPT = r"""
 import sys, numpy as np
 sys.path.insert(0, %r)
