@@ -107,10 +107,13 @@ struct Pool {
 	std::map<std::pair<int, int>, std::vector<hipEvent_t>> events;   // (device, timing?) -> events
 	std::map<std::pair<int, int>, std::vector<hipStream_t>> streams;  // (device, low priority?) -> streams
 	static constexpr size_t kMaxBucket = (size_t)64 << 20, kMaxCached = (size_t)512 << 20;
-	// One LARGE buffer per device (the working matrix of the last big solve) is kept as well: hipMalloc +
-	// hipFree of 2-8 GiB cost 10-100 ms per call, a visible part of a 0.3-2 s solve.  GF2BV_KEEP_BIG=0 disables.
+	// A few LARGE buffers per device (the working matrices of the last big solves) are kept as well: hipMalloc +
+	// hipFree of 2-8 GiB cost 10-100 ms per call, a visible part of a 0.3-2 s solve.  Up to kMaxBig of them (round 4: the
+	// batch entry runs two or three gangs at a time, each with a working buffer of 3-4 GiB -- with ONE kept buffer every other
+	// gang paid an allocation and a free).
 	struct Big { void *p = nullptr; size_t bytes = 0; };
-	std::map<int, Big> big_free;                                      // device -> idle large buffer
+	static constexpr size_t kMaxBig = 6, kMaxBigBytes = (size_t)48 << 30;      // (a gang holds two: working matrices and the side-array arena)
+	std::map<int, std::vector<Big>> big_free;                         // device -> idle large buffers
 	std::unordered_map<void *, std::pair<int, size_t>> big_live;      // handed-out large buffers
 	static bool keep_big() { return true; }
 
@@ -127,13 +130,14 @@ struct Pool {
 			void *stale = nullptr;
 			{
 				std::lock_guard<std::mutex> lk(mu);
-				Big &b = big_free[device];
-				if (b.p && b.bytes >= bytes && b.bytes <= bytes + bytes / 2) {
-					*out = b.p; big_live[b.p] = {device, b.bytes};
-					b = Big();
-					return hipSuccess;
-				}
-				if (b.p) { stale = b.p; b = Big(); }              // wrong size: make room before allocating
+				auto &v = big_free[device];
+				for (size_t i = 0; i < v.size(); i++)
+					if (v[i].bytes >= bytes && v[i].bytes <= bytes + bytes / 2) {
+						*out = v[i].p; big_live[v[i].p] = {device, v[i].bytes};
+						v.erase(v.begin() + i);
+						return hipSuccess;
+					}
+				if (v.size() >= kMaxBig) { stale = v.front().p; v.erase(v.begin()); }     // none fits: make room (the oldest goes) before allocating
 			}
 			if (stale) (void)hipFree(stale);
 			hipError_t e = hipMalloc(out, bytes);
@@ -164,9 +168,16 @@ struct Pool {
 				const int device = bl->second.first;
 				const size_t bytes = bl->second.second;
 				big_live.erase(bl);
-				Big &b = big_free[device];
-				if (!b.p) { b.p = p; b.bytes = bytes; return; }
-				if (b.bytes < bytes) std::swap(b.p, p), b.bytes = bytes;     // keep the larger one, free the other
+				auto &v = big_free[device];
+				Big nb; nb.p = p; nb.bytes = bytes;
+				v.push_back(nb);
+				size_t sum = 0;
+				for (const Big &b : v) sum += b.bytes;
+				std::vector<void *> drop;
+				while (v.size() > 1 && (v.size() > kMaxBig || sum > kMaxBigBytes)) { sum -= v.front().bytes; drop.push_back(v.front().p); v.erase(v.begin()); }     // the oldest go
+				if (drop.empty()) return;
+				p = drop.back(); drop.pop_back();
+				for (void *q : drop) (void)hipFree(q);
 			}
 			auto it = live.find(p);
 			if (it != live.end()) {
