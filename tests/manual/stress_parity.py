@@ -11,7 +11,9 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 configs = ["0", "1", "2", "3", "4", "5"]          # instances of k_update16 (GF2_TW = 2 builds)
 knobs = [{}, {}, {"GF2BV_FAST": "0"}, {"GF2BV_OPTIMISTIC": "0"}, {"GF2BV_SELF_WAIT_US": "0"}, {"GF2BV_FLAG_SYNC": "0"},
-         {"GF2BV_TWO_LEVEL": "2"}, {"GF2BV_TWO_LEVEL": "3"}, {"GF2BV_TWO_LEVEL": "4"}, {"GF2BV_TWO_LEVEL": "8"}, {"GF2BV_TWO_LEVEL": "2", "GF2BV_FLAG_SYNC": "0"}]
+         {"GF2BV_TWO_LEVEL": "2"}, {"GF2BV_TWO_LEVEL": "3"}, {"GF2BV_TWO_LEVEL": "4"}, {"GF2BV_TWO_LEVEL": "8"}, {"GF2BV_TWO_LEVEL": "2", "GF2BV_FLAG_SYNC": "0"},
+         # round 4: systems that fit the LDS take the one-launch kernel unless GF2BV_SMALL=0; its input by copy or straight from pinned memory
+         {"GF2BV_SMALL": "0"}, {"GF2BV_SMALL": "0"}, {"GF2BV_SMALL_ZC": "0"}, {"GF2BV_SMALL_ZC": "1"}]
 t0, n, worst = time.time(), 0, 0
 while time.time() - t0 < budget:
     cols = rng.choice([rng.randint(1, 130), rng.randint(131, 700), rng.randint(700, 2600), 64 * rng.randint(1, 40), 256 * rng.randint(1, 10) + rng.choice([-1, 0, 1]),
@@ -24,7 +26,7 @@ while time.time() - t0 < budget:
     zero_rows = rng.choice([0, 0, rng.randint(0, rows // 2)])
     mode = rng.randint(0, 1)
     os.environ["GF2BV_UPDATE"] = rng.choice(configs)
-    for k in ("GF2BV_FAST", "GF2BV_OPTIMISTIC", "GF2BV_SELF_WAIT_US", "GF2BV_FLAG_SYNC", "GF2BV_TWO_LEVEL"):
+    for k in ("GF2BV_FAST", "GF2BV_OPTIMISTIC", "GF2BV_SELF_WAIT_US", "GF2BV_FLAG_SYNC", "GF2BV_TWO_LEVEL", "GF2BV_SMALL", "GF2BV_SMALL_ZC"):
         os.environ.pop(k, None)
     os.environ.update(rng.choice(knobs))
     eqs = random_system(rng, rows, cols, density, cap, consistent, min(zero_rows, rows - 1))
