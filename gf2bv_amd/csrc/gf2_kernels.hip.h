@@ -2835,6 +2835,112 @@ k_bs_far(const u64 *__restrict__ M, i64 srows, i64 cw, int qa, int qb, const Pan
 	}
 }
 
+// ---- round 4: the diagonal blocks INVERTED up front, the chain one launch per group -----------------------------------
+// The chain above is 2 x ceil(npanels / 16) dependent launches, and half of every link is k_bs_near: ONE workgroup walking
+// the 16 panels of a group one after the other (12 us; 65536^2: 64 x (5 + 12 us + two launch gaps) = 1.74 ms of a 33 ms
+// solve).  But the walk is a LINEAR map: with a_i = the word of (far part ^ right-hand side) bits of panel i at their pivot
+// columns, X = Minv x a for a 1024 x 1024 bit matrix Minv that depends on the group's diagonal block alone.  k_bs_inv forms
+// Minv for every group AT ONCE (one workgroup per group, ~50 us for the whole launch, off the chain): back-substitution on the
+// identity -- row (i, b) of R is the functional that gives X bit b of panel i; R_i = E_i ^ SUM_{j > i} U_ij R_j, the
+// product by the bits of U_ij's words through nibble tables of R_j (16 lookups per word instead of one row XOR per set bit).
+// The chain is then k_bs_far + k_bs_near2 per group: the far part as before, then Minv applied -- 1024 parities of 16-word ANDs,
+// one ballot per word -- in ~4 us by one workgroup of 16 wavefronts instead of the 12 us walk.
+#define GF2_BSINV_LDS (16 * 64 * 16 * 8 + 256 * 8 * 8 + 1024 + 64)
+__global__ void __launch_bounds__(1024)
+k_bs_inv(const u64 *__restrict__ Dg, int npanels, const PanelRec *__restrict__ panels, const int *__restrict__ pivcol,
+         u64 *__restrict__ Minv)
+{
+	extern __shared__ __attribute__((aligned(16))) u64 lds_inv[];
+	u64 *R = lds_inv;                                    // [panel i][column bit b][word w of a]: 128 KiB
+	u64 *T = R + 16 * 64 * 16;                           // nibble tables of R_j, 8 words of a at a time: [n][v][8]
+	unsigned char *pcs = reinterpret_cast<unsigned char *>(T + 256 * 8);      // (i, r) -> column bit of pivot r of panel i, 255: none
+	// (groups count from the END, as the chain walks them: group g = panels [npanels - 16 (g + 1), npanels - 16 g), the first one may be short)
+	const int g = blockIdx.x, qb = npanels - g * GF2_BSG, qa = qb > GF2_BSG ? qb - GF2_BSG : 0, nb = qb - qa;
+	const int t = threadIdx.x;
+	{
+		const int i = t >> 6, r = t & 63;
+		unsigned char pc = 255;
+		if (i < nb) { const PanelRec rec = panels[qa + i]; if (r < rec.p) pc = (unsigned char)(pivcol[rec.start + r] & 63); }
+		pcs[t] = pc;
+	}
+	for (int e = t; e < 16 * 64 * 16; e += 1024) R[e] = 0;
+	__syncthreads();
+	if (pcs[t] != 255) { const int i = t >> 6; R[(i * 64 + pcs[t]) * 16 + i] = 1ull << pcs[t]; }      // E_i: X bit = a bit
+	__syncthreads();
+	for (int j = nb - 1; j >= 1; j--) {
+		const int nrows = j * 64;                        // the pivots of the panels before j: their word of panel j selects rows of R_j
+		for (int h = (j >> 3); h < 2; h++) {             // (R_j is zero in the words before j: a half below it is skipped)
+			for (int e = t; e < 256 * 8; e += 1024) {
+				const int nv = e >> 3, w = e & 7, n = nv >> 4, v = nv & 15;
+				u64 a0 = R[(j * 64 + 4 * n + 0) * 16 + 8 * h + w], a1 = R[(j * 64 + 4 * n + 1) * 16 + 8 * h + w];
+				u64 a2 = R[(j * 64 + 4 * n + 2) * 16 + 8 * h + w], a3 = R[(j * 64 + 4 * n + 3) * 16 + 8 * h + w];
+				if (!(v & 1)) a0 = 0;
+				if (!(v & 2)) a1 = 0;
+				if (!(v & 4)) a2 = 0;
+				if (!(v & 8)) a3 = 0;
+				T[e] = (a0 ^ a1) ^ (a2 ^ a3);
+			}
+			__syncthreads();
+			// items = (row, word of the half that R_j reaches), spread over ALL threads (a thread per row left the rows of the
+			// early panels with 3 x the work of the average: 107 us per launch)
+			const int w0 = (j > 8 * h) ? j - 8 * h : 0, nw = 8 - w0;
+			for (int e = t; e < nrows * nw; e += 1024) {
+				const int row = e % nrows, w = w0 + e / nrows;
+				const unsigned char pc = pcs[row];
+				if (pc == 255) continue;
+				const int i = row >> 6, r = row & 63;
+				const u64 u = Dg[((i64)(qa + i) * 64 + r) * 16 + (j - i - 1)];
+				if (!u) continue;
+				u64 v16[16];
+#pragma unroll
+				for (int n = 0; n < 16; n++) v16[n] = T[(n * 16 + (int)((unsigned)(u >> (4 * n)) & 15u)) * 8 + w];
+				u64 acc = 0;
+#pragma unroll
+				for (int n = 0; n < 16; n += 2) acc ^= v16[n] ^ v16[n + 1];
+				R[(i * 64 + pc) * 16 + 8 * h + w] ^= acc;
+			}
+			__syncthreads();
+		}
+	}
+	u64 *dst = Minv + (i64)g * (16 * 64 * 16);
+	for (int e = t; e < 16 * 64 * 16; e += 1024) dst[e] = R[e];
+}
+
+// The walk's replacement in the chain: X of the group = Minv x a, right-hand side by right-hand side.  One workgroup of 16
+// wavefronts: wavefront i = panel i of the group, lane = column bit; a_i = the accumulator bits of panel i (k_bs_far) at their
+// pivot columns.  The Minv rows are requested first, the gathering of a runs under their round trip.
+// (Fused into the far part -- every workgroup counting itself in, the last arriver applying Minv -- the link took 15-17 us
+// instead of 5 + 4 + a launch gap: a 256-way fan-in on one counter and write-through / sc1 accesses for the accumulator bytes
+// cost more than the launch they save.  Built, measured, removed.)
+__global__ void __launch_bounds__(1024)
+k_bs_near2(i64 cw, int qa, int qb, const PanelRec *__restrict__ panels, const int *__restrict__ pivcol, int ny,
+           u64 *__restrict__ X, const unsigned char *__restrict__ accv, i64 nacc, const u64 *__restrict__ Minv, int gidx)
+{
+	__shared__ u64 aL[GF2_BSG];
+	const int lane = threadIdx.x & 63, i = threadIdx.x >> 6, nb = qb - qa;
+	const bool onp = i < nb;
+	const uint4 *rowp = reinterpret_cast<const uint4 *>(Minv + (i64)gidx * (16 * 64 * 16) + ((i64)(onp ? i : 0) * 64 + lane) * 16);
+	uint4 q[8];
+#pragma unroll
+	for (int z = 0; z < 8; z++) q[z] = rowp[z];
+	const PanelRec rec = panels[qa + (onp ? i : 0)];
+	const int kk = rec.start + lane;
+	const bool piv = onp && lane < rec.p;
+	const int pcb = piv ? (pivcol[kk] & 63) : 0;
+	for (int v = 0; v < ny; v++) {
+		const u64 word = wave_or(piv ? (u64)(accv[(i64)v * nacc + kk] & 1) << pcb : 0ull);
+		if (lane == 0) aL[i] = word;                     // (0 for the panels a short first group does not have)
+		__syncthreads();
+		u64 acc = 0;
+#pragma unroll
+		for (int z = 0; z < 8; z++)
+			acc ^= ((((u64)q[z].y << 32) | q[z].x) & aL[2 * z]) ^ ((((u64)q[z].w << 32) | q[z].z) & aL[2 * z + 1]);
+		const u64 xw = __ballot(__popcll(acc) & 1);
+		if (lane == 0 && onp) X[(i64)v * cw + qa + i] = xw;
+		__syncthreads();
+	}
+}
+
 // The diagonal blocks of U in compact form: Dg[(q * 64 + r) * 16 + j] = word q + 1 + j of the row of pivot r of panel q
 // (0 beyond the panel's pivots / the coefficient words).  One workgroup per panel, the whole chip at once -- the rows
 // are scattered 64-byte segments in HBM, and k_bs_near, ONE workgroup on a serial chain, spent 14 of its 20 us

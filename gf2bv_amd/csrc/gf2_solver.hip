@@ -338,6 +338,7 @@ struct Solver {
 	const u64 *src = nullptr;     // caller's row-major matrix on the device (stride words per row)
 	u64 *tmp_src = nullptr;       // row-major staging buffer when the input came from the host
 	u64 *Ybuf = nullptr;
+	u64 *Minv = nullptr;          // inverted diagonal blocks of the back-substitution (k_bs_inv -> k_bs_near2)
 	i64 rows = 0, cols = 0, stride = 0;
 	i64 ntiles = 0, srows = 0;    // tiles, rows per tile slab (padded)
 	// gang: nsys same-shape systems eliminated in lock-step by the same launches (blockIdx.y = system);
@@ -433,10 +434,10 @@ struct Solver {
 		if (view) {               // owns only what its own back-substitution allocated
 			if (sA && (Y || ycols || out)) (void)hipStreamSynchronize(sA);
 			Pool &P = pool();
-			if (own_bs) for (void *p : { (void *)Y, (void *)ycols, (void *)out }) P.release(p);
+			if (own_bs) for (void *p : { (void *)Y, (void *)ycols, (void *)out, (void *)Minv }) P.release(p);
 			P.release_event(ev2, true);
 			P.release_event(evx, true); evx = nullptr;
-			Y = nullptr; ycols = nullptr; out = nullptr; ev2 = nullptr;
+			Y = nullptr; ycols = nullptr; out = nullptr; Minv = nullptr; ev2 = nullptr;
 			arena = nullptr; M = nullptr; tmp_src = nullptr; sA = sB = nullptr;
 			ev0 = ev1 = ev3 = nullptr;
 			kev.clear(); evA.clear(); evPrio.clear();
@@ -447,8 +448,8 @@ struct Solver {
 		if (sB) (void)hipStreamSynchronize(sB);
 		if (arena || M) (void)hipStreamSynchronize(sA);
 		Pool &P = pool();
-		for (void *p : { arena, (void *)Y, (void *)ycols, (void *)out, (void *)(ext_M ? nullptr : M), (void *)tmp_src }) P.release(p);
-		arena = nullptr; Y = nullptr; ycols = nullptr; out = nullptr; M = nullptr; tmp_src = nullptr;
+		for (void *p : { arena, (void *)Y, (void *)ycols, (void *)out, (void *)Minv, (void *)(ext_M ? nullptr : M), (void *)tmp_src }) P.release(p);
+		arena = nullptr; Y = nullptr; ycols = nullptr; out = nullptr; Minv = nullptr; M = nullptr; tmp_src = nullptr;
 		st = nullptr; panels = nullptr; aux = nullptr; fu = nullptr; died = nullptr; pivcol = nullptr;
 		urow = nullptr; blk_first = nullptr; mult = nullptr; Wb = nullptr;
 		for (hipEvent_t *e : { &ev0, &ev1, &ev2, &ev3, &evx }) { P.release_event(*e, true); *e = nullptr; }
@@ -1192,6 +1193,24 @@ int enqueue_backward_parity(Solver &S, const std::vector<int> &ycols_host)
 	HIPCHK(pool().alloc((void **)&S.Y, sizeof(u64) * 64 * 16 * std::max(1, S.npanels), S.device));
 	if (S.npanels > 0)
 		k_bs_diag<<<dim3(S.npanels), dim3(256), 0, S.sA>>>(S.M, S.srows, S.npanels, S.panels, S.urow, S.Y, SysStride{0, 0}, (i64)0);
+	// Round 4: from four groups up the diagonal blocks are inverted up front (k_bs_inv, all groups in one launch, ~90 us) and the
+	// serial walk of a link (k_bs_near, 12 us) becomes a matrix-vector product (k_bs_near2, ~4 us).  GF2BV_BS_INV=0 / 1: never / always.
+	const int ngroups = (S.npanels + GF2_BSG - 1) / GF2_BSG;
+	bool inv = ngroups >= 16;
+	if (const char *e = getenv("GF2BV_BS_INV")) inv = atoi(e) != 0 && ngroups >= 1;
+	if (inv) {
+		HIPCHK(pool().alloc((void **)&S.Minv, sizeof(u64) * (size_t)ngroups * 16 * 64 * 16, S.device));
+		static std::mutex mu;
+		static std::map<int, bool> raised;          // device -> the > 64 KiB dynamic-LDS attribute has been raised there
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			if (!raised[S.device]) {
+				HIPCHK(hipFuncSetAttribute((const void *)k_bs_inv, hipFuncAttributeMaxDynamicSharedMemorySize, GF2_BSINV_LDS));
+				raised[S.device] = true;
+			}
+		}
+		k_bs_inv<<<dim3(ngroups), dim3(1024), GF2_BSINV_LDS, S.sA>>>(S.Y, S.npanels, S.panels, S.pivcol, S.Minv);
+	}
 	// right-hand sides in groups of GF2_BSV (U is streamed once per group; the groups are independent)
 	for (int v0 = 0; v0 < S.ny; v0 += GF2_BSV) {
 		const int nv = std::min(GF2_BSV, S.ny - v0);
@@ -1200,8 +1219,12 @@ int enqueue_backward_parity(Solver &S, const std::vector<int> &ycols_host)
 			const int waves = (qb - qa) * 64;
 			k_bs_far<<<dim3((waves + 3) / 4), dim3(256), 0, S.sA>>>(S.M, S.srows, cw, qa, qb, S.panels, S.urow, S.pivcol, S.ycols + v0, nv,
 			                                                        S.out + (i64)v0 * cw, accv, nacc, SysStride{0, 0}, (i64)0);
-			k_bs_near<<<dim3(1), dim3(256), 0, S.sA>>>(S.Y, cw, qa, qb, S.panels, S.pivcol, nv, S.out + (i64)v0 * cw, accv, nacc,
-			                                           SysStride{0, 0}, (i64)0, (i64)0);
+			if (inv)
+				k_bs_near2<<<dim3(1), dim3(1024), 0, S.sA>>>(cw, qa, qb, S.panels, S.pivcol, nv, S.out + (i64)v0 * cw, accv, nacc, S.Minv,
+				                                             (S.npanels - qb) / GF2_BSG);
+			else
+				k_bs_near<<<dim3(1), dim3(256), 0, S.sA>>>(S.Y, cw, qa, qb, S.panels, S.pivcol, nv, S.out + (i64)v0 * cw, accv, nacc,
+				                                           SysStride{0, 0}, (i64)0, (i64)0);
 		}
 	}
 	HIPCHK(hipGetLastError());
@@ -1411,7 +1434,7 @@ int make_view(const Solver &S, int s, Solver &V)
 	V.M = S.M + S.m_stride * s;
 	V.arena = (char *)S.arena + ao;
 	mv(V.st); mv(V.panels); mv(V.aux); mv(V.fu); mv(V.died); mv(V.pivcol); mv(V.urow); mv(V.blk_first); mv(V.mult); mv(V.Wb); mv(V.Uwin); mv(V.Pfast); if (V.Pc) mv(V.Pc);
-	V.Y = nullptr; V.ycols = nullptr; V.out = nullptr;
+	V.Y = nullptr; V.ycols = nullptr; V.out = nullptr; V.Minv = nullptr;
 	V.ev2 = nullptr;
 	HIPCHK(pool().event(&V.ev2, true));
 	return GF2BV_OK;

@@ -143,6 +143,26 @@ def test_two_level_elimination_of_a_gang(monkeypatch, K, gang, chain):
     assert got[0].stats["outer_blocks"] == 0
 
 
+@pytest.mark.parametrize("inv", ["1", "0"])
+def test_back_substitution_with_inverted_diagonal_blocks(monkeypatch, inv):
+    """Round 4: from four groups of 16 panels up the back-substitution inverts the diagonal blocks up front (k_bs_inv) and a link
+    of its chain is one launch (k_bs_step: far part, then X = Minv x a by the last workgroup to arrive) -- GF2BV_BS_INV=1 forces
+    that path onto every size, =0 the two-launch chain with the serial walk (k_bs_far + k_bs_near).  Shapes with a short first
+    group, one group, rank caps (panels with few or no pivots), rows >> cols, inconsistent systems, kernel bases of 0 ... 40
+    vectors (several passes of 8 right-hand sides), both modes, against the oracle."""
+    monkeypatch.setenv("GF2BV_BS_INV", inv)
+    monkeypatch.setenv("GF2BV_SMALL", "0")
+    rng = random.Random(99)
+    shapes = [(70, 64, .5, None, True, 0), (1100, 1023, .5, 900, True, 0), (1100, 1025, .5, None, True, 0), (2100, 2048, .5, None, True, 0),
+              (4200, 4100, .5, 4060, True, 0), (5000, 4097, .5, 2600, True, 100), (9000, 2049, .003, None, True, 0), (6000, 5200, .5, 5199, False, 0),
+              (8300, 8200, .5, None, True, 0), (3000, 2900, .5, 64 * 17 + 3, True, 0)]
+    for i, (rows, cols, density, cap, cons, zr) in enumerate(shapes):
+        eqs = random_system(rng, rows, cols, density, cap, cons, zr)
+        aug = O.eqs_to_aug(eqs, cols)
+        for mode in (0, 1):
+            _same(hip.solve_words(aug, rows, cols, mode), O.solve_words(aug, rows, cols, mode), mode)
+
+
 @pytest.mark.timeout(600)
 def test_soak_many_solves_in_flight():
     """A reduced run of tests/manual/soak_concurrent.py in the automated suite: 2 rounds of 40 solves from 16
