@@ -5,7 +5,7 @@ cd $R
 timeout 2400 python -m pytest tests -m gpu -q > $O/r04_pytest_final.log 2>&1; echo "full suite rc=$?" > $O/r04_final.summary
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $O/r04_smoke_final.log 2>&1; echo "smoke rc=$?" >> $O/r04_final.summary
 python bench.py > $O/r04_bench_final.json 2> $O/r04_bench_final.err; echo "bench rc=$?" >> $O/r04_final.summary
-timeout 900 python tests/manual/stress_parity.py 600 404 > $O/r04_stress_final.log 2>&1; echo "stress rc=$?" >> $O/r04_final.summary
+timeout 500 python tests/manual/stress_parity.py 300 505 > $O/r04_stress_final.log 2>&1; echo "stress rc=$?" >> $O/r04_final.summary
 if [ -n "$WITH_PROFILES" ]; then
   bash tools/jobs/kernel_stats.sh r04_bench python bench.py --no-cpu-baseline --no-batch-c4 --no-extra-legs --target-n 0
   bash tools/jobs/kernel_stats.sh r04_65536 python tools/profile_one.py 65536 1
