@@ -110,18 +110,73 @@ struct Pool {
 	// A few LARGE buffers per device (the working matrices of the last big solves) are kept as well: hipMalloc +
 	// hipFree of 2-8 GiB cost 10-100 ms per call, a visible part of a 0.3-2 s solve.  Up to kMaxBig of them (round 4: the
 	// batch entry runs two or three gangs at a time, each with a working buffer of 3-4 GiB -- with ONE kept buffer every other
-	// gang paid an allocation and a free).
+	// gang paid an allocation and a free).  Round 5: what is kept is bounded by the DEVICE (a sixth of its memory, 48 GiB at
+	// most; GF2BV_KEEP_BIG=0: nothing is kept), an allocation that fails frees everything idle on that device and is
+	// repeated once, gf2bv_pool_trim() does the same on request, and no hipFree runs under the pool's mutex.
 	struct Big { void *p = nullptr; size_t bytes = 0; };
 	static constexpr size_t kMaxBig = 6, kMaxBigBytes = (size_t)48 << 30;      // (a gang holds two: working matrices and the side-array arena)
 	std::map<int, std::vector<Big>> big_free;                         // device -> idle large buffers
 	std::unordered_map<void *, std::pair<int, size_t>> big_live;      // handed-out large buffers
-	static bool keep_big() { return true; }
+	std::map<int, size_t> big_cap;                                    // device -> bytes of idle large buffers kept there
+	static bool keep_big()
+	{
+		static const bool keep = !(getenv("GF2BV_KEEP_BIG") && atoi(getenv("GF2BV_KEEP_BIG")) == 0);
+		return keep;
+	}
+	// (mu held) idle large buffers of `device` may hold this many bytes: a sixth of the device's memory, 48 GiB at most
+	size_t big_cap_locked(int device)
+	{
+		auto it = big_cap.find(device);
+		if (it != big_cap.end()) return it->second;
+		size_t cap = kMaxBigBytes, fr = 0, total = 0;
+		int cur = -1;
+		(void)hipGetDevice(&cur);
+		if (cur == device && hipMemGetInfo(&fr, &total) == hipSuccess && total) cap = std::min(cap, total / 6);
+		else if (cur != device) return cap;       // (not the calling thread's device: ask again later)
+		big_cap[device] = cap;
+		return cap;
+	}
 
 	static size_t bucket(size_t bytes)
 	{
 		size_t b = 4096;
 		while (b < bytes) b <<= 1;
 		return b;
+	}
+	// every idle buffer of `device` (large ones and the bucket cache) leaves the pool; the caller frees them OUTSIDE the lock
+	void take_idle_locked(int device, std::vector<void *> &drop)
+	{
+		auto bf = big_free.find(device);
+		if (bf != big_free.end()) { for (const Big &b : bf->second) drop.push_back(b.p); bf->second.clear(); }
+		for (auto &kv : free_bufs)
+			if (kv.first.first == device) {
+				for (void *q : kv.second) { drop.push_back(q); cached_bytes -= kv.first.second; }
+				kv.second.clear();
+			}
+	}
+	// gf2bv_pool_trim: returns the bytes given back to the device
+	size_t trim(int device)
+	{
+		std::vector<void *> drop;
+		size_t bytes = 0;
+		{
+			std::lock_guard<std::mutex> lk(mu);
+			auto bf = big_free.find(device);
+			if (bf != big_free.end()) for (const Big &b : bf->second) bytes += b.bytes;
+			for (auto &kv : free_bufs) if (kv.first.first == device) bytes += kv.first.second * kv.second.size();
+			take_idle_locked(device, drop);
+		}
+		for (void *q : drop) (void)hipFree(q);
+		return bytes;
+	}
+	// hipMalloc; on out-of-memory everything idle on the device is freed and the allocation repeated once
+	hipError_t malloc_retry(void **out, size_t bytes, int device)
+	{
+		hipError_t e = hipMalloc(out, bytes);
+		if (e != hipErrorOutOfMemory) return e;
+		(void)hipGetLastError();
+		if (trim(device) == 0) return e;
+		return hipMalloc(out, bytes);
 	}
 	hipError_t alloc(void **out, size_t bytes, int device)
 	{
@@ -140,7 +195,7 @@ struct Pool {
 				if (v.size() >= kMaxBig) { stale = v.front().p; v.erase(v.begin()); }     // none fits: make room (the oldest goes) before allocating
 			}
 			if (stale) (void)hipFree(stale);
-			hipError_t e = hipMalloc(out, bytes);
+			hipError_t e = malloc_retry(out, bytes, device);
 			if (e == hipSuccess && keep_big()) { std::lock_guard<std::mutex> lk(mu); big_live[*out] = {device, bytes}; }
 			return e;
 		}
@@ -154,16 +209,18 @@ struct Pool {
 				return hipSuccess;
 			}
 		}
-		hipError_t e = hipMalloc(out, b);
+		hipError_t e = malloc_retry(out, b, device);
 		if (e == hipSuccess) { std::lock_guard<std::mutex> lk(mu); live[*out] = {device, b}; }
 		return e;
 	}
 	void release(void *p)
 	{
 		if (!p) return;
+		std::vector<void *> drop;          // freed after the lock is gone: hipFree of a multi-GiB buffer synchronises the device
 		{
 			std::lock_guard<std::mutex> lk(mu);
 			auto bl = big_live.find(p);
+			auto it = live.find(p);
 			if (bl != big_live.end()) {
 				const int device = bl->second.first;
 				const size_t bytes = bl->second.second;
@@ -173,23 +230,18 @@ struct Pool {
 				v.push_back(nb);
 				size_t sum = 0;
 				for (const Big &b : v) sum += b.bytes;
-				std::vector<void *> drop;
-				while (v.size() > 1 && (v.size() > kMaxBig || sum > kMaxBigBytes)) { sum -= v.front().bytes; drop.push_back(v.front().p); v.erase(v.begin()); }     // the oldest go
-				if (drop.empty()) return;
-				p = drop.back(); drop.pop_back();
-				for (void *q : drop) (void)hipFree(q);
+				const size_t cap = big_cap_locked(device);
+				while (!v.empty() && (v.size() > kMaxBig || sum > cap)) { sum -= v.front().bytes; drop.push_back(v.front().p); v.erase(v.begin()); }     // the oldest go
 			}
-			auto it = live.find(p);
-			if (it != live.end()) {
+			else if (it != live.end()) {
 				const auto key = it->second;
 				live.erase(it);
-				if (cached_bytes + key.second <= kMaxCached) {
-					free_bufs[key].push_back(p); cached_bytes += key.second;
-					return;
-				}
+				if (cached_bytes + key.second <= kMaxCached) { free_bufs[key].push_back(p); cached_bytes += key.second; }
+				else drop.push_back(p);
 			}
+			else drop.push_back(p);
 		}
-		(void)hipFree(p);
+		for (void *q : drop) (void)hipFree(q);
 	}
 	hipError_t event(hipEvent_t *e, bool timing)
 	{
@@ -255,13 +307,13 @@ hipError_t launch_update16(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows
                            int tile_begin, int ntiles, int world, int wrank, int nw_lo, int nw_hi, const uint4 *Pc, SysStride ss,
                            hipEvent_t begun, hipEvent_t done, int xcd_nsys)
 {
-	(void)nw_hi;
 	if (xcd_nsys > 0) grid = dim3(grid.x * grid.y);          // one line of workgroups, decoded in the kernel (a system per XCD)
 	{
-		// streaming row accesses: pinned gangs (GF2BV_GANG_NT=0: plain); single systems only as an experiment (GF2BV_SINGLE_NT=1)
-		const bool stream = xcd_nsys > 0 ? !(getenv("GF2BV_GANG_NT") && atoi(getenv("GF2BV_GANG_NT")) == 0)
-		                                 : (getenv("GF2BV_SINGLE_NT") && atoi(getenv("GF2BV_SINGLE_NT")) != 0);
-		if (stream && NT == 512 && DEPTH == 3) {            // (the default instance, see k_update16)
+		// streaming row accesses (Solver::nt_rows, read from the environment once per solve): pinned gangs (GF2BV_GANG_NT=0: plain);
+		// single systems only as an experiment (GF2BV_SINGLE_NT=1).  The streaming form exists for the default instance only: with
+		// GF2BV_UPDATE != 0 the selected instance runs with plain accesses.
+		const bool stream = nw_hi != 0;
+		if (stream && NT == 512 && DEPTH == 3 && PIPE && LB == 512) {
 			if (nw_lo < 0)
 				hipExtLaunchKernelGGL((k_update16<512, true, 3, true, 512, true>), grid, dim3(512), 0, s, begun, done, 0, M, rows, srows, j0, gb, wlo,
 				                      panels, aux, multset, blk_first, tile_begin, ntiles, world, wrank, Pc, ss, xcd_nsys);
@@ -400,6 +452,10 @@ struct Solver {
 	bool xcd_pin = true;          // gangs of a multiple of 8 systems: every system's bulk-update workgroups on ONE XCD, one system after the
 	                              // other there, xcd_wgs workgroups each (GF2BV_XCD_WGS); GF2BV_XCD_PIN=0: the plain (spans, systems) grid
 	int xcd_wgs = 32;
+	bool nt_gang = true, nt_single = false;     // streaming (non-temporal) row accesses of the bulk update: pinned gangs (GF2BV_GANG_NT=0: plain) /
+	                                            // single systems (GF2BV_SINGLE_NT=1, an experiment: <= 1 %)
+	bool gang_two_level = false;  // GF2BV_GANG_TWO_LEVEL=1: outer panels for gangs too (measured slower: DESIGN 7)
+	bool gang_bs = true;          // GF2BV_GANG_BS=0: one back-substitution chain per system of a gang, as rounds 1-3
 	bool fused_narrow = true;     // optimistic blocks: search and narrow step in ONE launch (k_block_fast_narrow); GF2BV_FUSED_NARROW=0: two
 	int narrow_rpt = 1;           // row blocks of 256 per narrow workgroup of a panel step (set in solver_alloc; GF2BV_NARROW_RPT)
 	int self_wait = 5000;         // ticks (100 MHz) unit 0 of a panel search waits for the other units before it leaves
@@ -596,6 +652,9 @@ int solver_alloc(Solver &S)
 	if (const char *e = getenv("GF2BV_PC")) S.use_pc = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_XCD_PIN")) S.xcd_pin = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_XCD_WGS")) S.xcd_wgs = std::min(256, std::max(1, atoi(e)));
+	if (const char *e = getenv("GF2BV_GANG_NT")) S.nt_gang = atoi(e) != 0;
+	if (const char *e = getenv("GF2BV_SINGLE_NT")) S.nt_single = atoi(e) != 0;
+	if (const char *e = getenv("GF2BV_GANG_BS")) S.gang_bs = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_FUSED_RPT")) S.fused_rpt = atoi(e);
 	// narrow workgroups: as many rows each as keeps ~256 of them (all systems of a gang together) busy, at most 8 blocks
 	{
@@ -754,9 +813,10 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 	const int wgs = pick_update_wgs(est_rows, ntiles, S.nsys, pin ? S.xcd_wgs : 0);
 	hipEvent_t begun = nullptr, done = nullptr;
 	if (S.ext_events) { begun = ka; done = S.time_kernels ? kb : (last && !S.flag_sync ? S.evPrio[b] : nullptr); }
+	(void)nw_hi;                     // (the launcher's slot of that name carries the streaming-access flag since round 5)
 	HIPCHK(S.impl->update(dim3((unsigned)wgs, S.nsys), st, S.M, S.rows, S.srows, j0, gb, wlo, S.panels, S.aux, mset,
-	                      S.blk_first + b, tile_begin, ntiles, S.world, S.wrank, nw_lo, nw_hi, (const uint4 *)S.Pc, S.ss(), begun, done,
-	                      pin ? S.nsys : 0));
+	                      S.blk_first + b, tile_begin, ntiles, S.world, S.wrank, nw_lo, (pin ? S.nt_gang : S.nt_single) ? 1 : 0,
+	                      (const uint4 *)S.Pc, S.ss(), begun, done, pin ? S.nsys : 0));
 	if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, st));
 	if (!last || S.flag_sync) return GF2BV_OK;
 	if (S.ext_events) *handoff = done;
@@ -1193,7 +1253,7 @@ int enqueue_backward_parity(Solver &S, const std::vector<int> &ycols_host)
 	HIPCHK(pool().alloc((void **)&S.Y, sizeof(u64) * 64 * 16 * std::max(1, S.npanels), S.device));
 	if (S.npanels > 0)
 		k_bs_diag<<<dim3(S.npanels), dim3(256), 0, S.sA>>>(S.M, S.srows, S.npanels, S.panels, S.urow, S.Y, SysStride{0, 0}, (i64)0);
-	// Round 4: from four groups up the diagonal blocks are inverted up front (k_bs_inv, all groups in one launch, ~90 us) and the
+	// Round 4: from sixteen groups (16384 columns) up the diagonal blocks are inverted up front (k_bs_inv, all groups in one launch, ~90 us) and the
 	// serial walk of a link (k_bs_near, 12 us) becomes a matrix-vector product (k_bs_near2, ~4 us).  GF2BV_BS_INV=0 / 1: never / always.
 	const int ngroups = (S.npanels + GF2_BSG - 1) / GF2_BSG;
 	bool inv = ngroups >= 16;
@@ -1455,7 +1515,7 @@ int solve_gang(Solver &S, gf2bv_result **out)
 		if (rc) return rc;
 	}
 	if (S.mode == GF2BV_MODE_SINGLE) {
-		const bool per_system = getenv("GF2BV_GANG_BS") && atoi(getenv("GF2BV_GANG_BS")) == 0;      // (A/B: one chain per system, as rounds 1-3)
+		const bool per_system = !S.gang_bs;      // (GF2BV_GANG_BS=0, A/B: one chain per system, as rounds 1-3)
 		if (per_system)
 			for (int s = 0; s < S.nsys; s++) {
 				rc = enqueue_backward_single(V[s]);
@@ -2512,15 +2572,15 @@ int gf2bv_lds_clock_device(int device, double *shader_mhz, double *lds_bytes_per
 	if (rc) return rc;
 	unsigned long long *d = nullptr, h[3] = { 0, 0, 0 };
 	unsigned *sink = nullptr;
-	HIPCHK(hipMalloc(&d, sizeof h));
-	HIPCHK(hipMalloc(&sink, 64));
+	struct Free { unsigned long long *&d; unsigned *&sink; ~Free() { pool().release(d); pool().release(sink); } } guard{ d, sink };     // (error paths too)
+	HIPCHK(pool().alloc((void **)&d, sizeof h, device));
+	HIPCHK(pool().alloc((void **)&sink, 64, device));
 	int cus = 256;
 	(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
 	k_lds_clock<<<dim3(cus), dim3(512)>>>(d, 2000, sink);                   // warm-up (clocks ramp)
 	k_lds_clock<<<dim3(cus), dim3(512)>>>(d, 40000, sink);                  // ~5 ms of ds_read_b128 on every CU
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
-	(void)hipFree(d); (void)hipFree(sink);
 	if (!h[1]) return fail(GF2BV_ERR_HIP, "the clock probe measured nothing");
 	*shader_mhz = (double)h[0] / ((double)h[1] / 100.0);                    // real-time counter: 100 MHz
 	*lds_bytes_per_clk_cu = (double)h[2] * 1024.0 / (double)h[0];           // a ds_read_b128 wave-instruction moves 1 KiB
@@ -2532,9 +2592,27 @@ int gf2bv_device_alloc(int device, int64_t bytes, void **d_ptr)
 	if (!d_ptr || bytes < 0) return fail(GF2BV_ERR_ARG, "bad alloc request");
 	int rc = check_device(device);
 	if (rc) return rc;
-	hipError_t e = hipMalloc(d_ptr, (size_t)std::max<i64>(bytes, 16));
+	// (not pooled: the buffer is the caller's; but a request the device cannot serve while the pool sits on idle buffers
+	// gets them first)
+	hipError_t e = pool().malloc_retry(d_ptr, (size_t)std::max<i64>(bytes, 16), device);
 	if (e != hipSuccess) return fail(GF2BV_ERR_NOMEM, "hipMalloc", e);
 	return GF2BV_OK;
+}
+int64_t gf2bv_pool_trim(int device)
+{
+	if (check_device(device)) return -1;
+	return (int64_t)pool().trim(device);
+}
+int64_t gf2bv_pool_idle_bytes(int device)
+{
+	if (device < 0) return -1;
+	Pool &P = pool();
+	std::lock_guard<std::mutex> lk(P.mu);
+	size_t bytes = 0;
+	auto bf = P.big_free.find(device);
+	if (bf != P.big_free.end()) for (const Pool::Big &b : bf->second) bytes += b.bytes;
+	for (auto &kv : P.free_bufs) if (kv.first.first == device) bytes += kv.first.second * kv.second.size();
+	return (int64_t)bytes;
 }
 int gf2bv_device_free(int device, void *d_ptr)
 {

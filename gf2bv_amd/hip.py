@@ -37,6 +37,7 @@ EXPORTS = [
     "gf2bv_synth_device", "gf2bv_residual_device",
     "gf2bv_stream_ceiling_device", "gf2bv_lds_clock_device", "gf2bv_kernel_resources",
     "gf2bv_device_alloc", "gf2bv_device_free", "gf2bv_device_upload", "gf2bv_device_download",
+    "gf2bv_pool_trim", "gf2bv_pool_idle_bytes",
 ]
 
 
@@ -123,6 +124,10 @@ def lib():
         L.gf2bv_device_free.argtypes = [i32, vp]
         L.gf2bv_device_upload.argtypes = [i32, vp, vp, i64]
         L.gf2bv_device_download.argtypes = [i32, vp, vp, i64]
+        L.gf2bv_pool_trim.argtypes = [i32]
+        L.gf2bv_pool_trim.restype = i64
+        L.gf2bv_pool_idle_bytes.argtypes = [i32]
+        L.gf2bv_pool_idle_bytes.restype = i64
         _lib = L
     return _lib
 
@@ -336,6 +341,16 @@ def kernel_resources(device: int = 0) -> dict:
     res["update_outer"] = {"vgprs": int(out[10]), "lds": int(out[11]), "scratch": int(out[12])}      # k_update16k (two-level)
     res["block_fast_narrow"] = {"vgprs": int(out[13]), "lds": int(out[14])}                          # search + narrow step in one launch
     return res
+
+
+def pool_trim(device: int = 0) -> int:
+    """Return every idle buffer of the library's pool on `device` to the device; bytes freed (gf2bv_pool_trim)."""
+    return int(lib().gf2bv_pool_trim(device))
+
+
+def pool_idle_bytes(device: int = 0) -> int:
+    """Bytes of idle buffers the pool keeps on `device` right now."""
+    return int(lib().gf2bv_pool_idle_bytes(device))
 
 
 class DeviceBuffer:

@@ -16,8 +16,10 @@
  * Threading: every call owns its device buffers and stream; no global mutable state except
  * the last-error string, which is thread-local, and a thread-safe pool that recycles idle
  * device buffers, streams and events between calls (small buffers up to 512 MiB in total,
- * plus the working matrix of the last large solve per device; GF2BV_KEEP_BIG=0 in the
- * environment turns the latter off).  Matches the reference releasing the GIL around the
+ * plus up to six large working buffers per device, at most a sixth of the device's memory and
+ * never more than 48 GiB; GF2BV_KEEP_BIG=0 in the environment keeps none; gf2bv_pool_trim()
+ * returns all of them to the device, and an allocation the device refuses -- the library's own or
+ * gf2bv_device_alloc -- frees them and is repeated once).  Matches the reference releasing the GIL around the
  * whole factor/solve/kernel section (_internal.c:429-492).
  */
 #ifndef GF2BV_HIP_H
@@ -89,6 +91,7 @@ const char *gf2bv_last_error(void);            /* thread-local, never NULL */
  * row r occupies digits[digit_off[r] .. digit_off[r+1]), little-endian digits of
  * `bits_per_digit` payload bits (30 on 64-bit CPython) in uint32; sign already dropped;
  * bit 0 = affine term, bit k = coefficient of variable k-1; bits above `cols` ignored.
+ * digit_off[0] must be 0 (offsets are relative to `digits`); GF2BV_ERR_ARG otherwise.
  * Requires rows >= cols > 0 (_internal.c:372-395). */
 int gf2bv_solve_digits(const uint32_t *digits, const int64_t *digit_off, int bits_per_digit,
                        int64_t rows, int64_t cols, int mode, int device, gf2bv_result **out);
@@ -136,7 +139,8 @@ int gf2bv_solve_batch_digits(const uint32_t *digits, const int64_t *digit_off, i
  * what the one-device call returns.  A device may be listed more than once (its shares then run as concurrent gangs).
  * The reference solves one system per m4ri_solve call (gf2bv/_internal.c:359-502): independent systems -- one per
  * output bit / per instance in the recovery examples -- are the natural shard unit; this is what
- * m4ri_solve_many(..., devices=None) binds, None = every visible device. */
+ * m4ri_solve_many(..., devices) binds: devices=None = the module's default device (as m4ri_solve: a process pinned to one
+ * GPU stays on it), devices="all" = every visible device, or an explicit list. */
 int gf2bv_solve_batch_digits_multi(const uint32_t *digits, const int64_t *digit_off, int bits_per_digit,
                                    int64_t nsys, int64_t rows, int64_t cols, int mode,
                                    const int *devices, int ndevices, gf2bv_result **out);
@@ -245,11 +249,21 @@ int gf2bv_lds_clock_device(int device, double *shader_mhz, double *lds_bytes_per
  * lane in registers: scratch must be 0).  With n >= 15: out[13..14] = registers, LDS of k_block_fast_narrow. */
 int gf2bv_kernel_resources(int device, int32_t *out, int n);
 
-/* plain device buffer helpers so a host language without a HIP binding can stage data */
+/* plain device buffer helpers so a host language without a HIP binding can stage data.  gf2bv_device_alloc: when the device
+ * is out of memory the pool's idle buffers are freed and the allocation is repeated once. */
 int gf2bv_device_alloc(int device, int64_t bytes, void **d_ptr);
 int gf2bv_device_free(int device, void *d_ptr);
 int gf2bv_device_upload(int device, void *d_dst, const void *h_src, int64_t bytes);
 int gf2bv_device_download(int device, void *h_dst, const void *d_src, int64_t bytes);
+
+
+/* ---- the buffer pool (see "Threading" at the top) ----------------------------------------------- */
+/* Frees every IDLE buffer the pool keeps on `device` (large working buffers and the small-buffer cache; nothing a running
+ * solve holds).  Returns the bytes given back to the device, -1 without a usable device.  A caller that shares the GPU
+ * (a tensor framework, another library) calls this between jobs; the library calls it itself when hipMalloc reports out of memory. */
+int64_t gf2bv_pool_trim(int device);
+/* Bytes of idle buffers the pool currently keeps on `device` (what gf2bv_pool_trim would free). */
+int64_t gf2bv_pool_idle_bytes(int device);
 
 #ifdef __cplusplus
 }

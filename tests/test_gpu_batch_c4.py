@@ -174,3 +174,32 @@ def test_bench_default_line_carries_the_scale_anchor():
     assert c5["recovered_seed_equals_known_answer"] and c5["solutions"] == 1 and c5["solve_all_ms"]["warm_median"] > 0
     h2d = line["h2d_inclusive"]
     assert h2d["phases_ms"]["pack_h2d"] > 0 and h2d["ms_per_solve"]["second"] > 0
+
+
+@pytest.mark.timeout(600)
+def test_pool_gives_idle_buffers_back_when_the_device_runs_out_of_memory():
+    """Round 5 (VERDICT / ADVICE): the pool keeps large working buffers between calls.  A request the device cannot serve while
+    they sit idle -- here through gf2bv_device_alloc, the same retry serves the library's own allocations -- frees them and is
+    repeated; gf2bv_pool_trim() does it on request; what is kept is bounded by a sixth of the device."""
+    n, nsys = 16384, 32
+    seeds = [7000 + i for i in range(nsys)]
+    mats = batch.synth_shard(n, seeds, 0)
+    recs, sols = batch.solve_shard(n, mats, 0)
+    assert all(s.solved for s in sols)
+    del mats, recs
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()
+    idle = hip.pool_idle_bytes(0)
+    free, total = torch.cuda.mem_get_info(0)
+    assert idle >= 8 * n * n // 8, idle                         # a gang's working matrices (8 x 32 MiB at least) are among the kept buffers
+    assert idle <= total // 6 + (64 << 20), (idle, total)         # ... and the cap holds
+    want = free + idle * 3 // 4                                  # more than the device has free NOW, less than it has without the pool
+    buf = hip.DeviceBuffer(want, 0)                              # hipMalloc fails -> the pool is trimmed -> the retry succeeds
+    assert hip.pool_idle_bytes(0) == 0
+    buf.free()
+    # the next job simply allocates again, and an explicit trim returns what it kept
+    mats = batch.synth_shard(n, seeds[:8], 0)
+    recs, sols = batch.solve_shard(n, mats, 0)
+    assert all(s.solved for s in sols)
+    kept = hip.pool_idle_bytes(0)
+    assert kept > 0 and hip.pool_trim(0) == kept and hip.pool_idle_bytes(0) == 0
