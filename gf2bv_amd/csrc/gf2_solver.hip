@@ -425,6 +425,19 @@ struct Solver {
 	// two-level elimination (large systems; see k_update16k): blocks [0, tl_bend) go in outer panels of tl_K blocks
 	int tl_K = 0, tl_bend = 0;
 	i64 tile_hi = 0;              // bulk kernels touch tiles < tile_hi (= ntiles; the outer panel's end while it is eliminated)
+	// three-level elimination (round 5; see "THREE-LEVEL ELIMINATION" in gf2_kernels.hip.h): blocks [0, sp_bend) go in super-panels
+	// of sp_P outer panels; right of a super-panel its blocks are applied by ONE matrix product (Strassen-Winograd levels over
+	// k_mul16k) instead of one outer pass per panel
+	int sp_P = 0, sp_bend = 0;
+	int sp_force_levels = -1;     // GF2BV_STRASSEN=L: Strassen-Winograd levels of every product (default: by size)
+	int nlist = 2;                // row lists / T matrices kept: panel parity (two-level), 2 sp_P with super-panels (the replay needs all of a super-panel's)
+	uint4 *spB = nullptr;         // compact pivot rows of the super-panel being applied: [block][tile][256] x 16 B
+	size_t spB_elems = 0;
+	struct SpTemps { uint4 *S = nullptr, *T = nullptr, *U = nullptr, *V = nullptr; size_t ns = 0, nt = 0, nc = 0; };
+	std::vector<SpTemps> sp_t;    // Strassen temporaries by depth: A-quadrant, B-quadrant, two C-quadrants
+	int sp_products = 0, sp_levels_used = 0;
+	double sp_add_bytes = 0, sp_mul_words = 0;      // what the products' additions moved / the lookups they did (in sweep-words)
+	std::vector<size_t> sp_kev;   // indices into kev of the event pairs that bracket super-panel products (ms_product)
 	hipStream_t sC = nullptr;     // outer passes: panel p's runs BESIDE the inner elimination of panel p + 1 (sA + sB)
 	hipEvent_t evOuter = nullptr, evPri = nullptr, evPanelDone = nullptr;
 	bool bulk_waits_outer = false;     // the next bulk launch of the one-level schedule has to wait for the last outer pass
@@ -504,7 +517,9 @@ struct Solver {
 		if (sB) (void)hipStreamSynchronize(sB);
 		if (arena || M) (void)hipStreamSynchronize(sA);
 		Pool &P = pool();
-		for (void *p : { arena, (void *)Y, (void *)ycols, (void *)out, (void *)Minv, (void *)(ext_M ? nullptr : M), (void *)tmp_src }) P.release(p);
+		for (void *p : { arena, (void *)Y, (void *)ycols, (void *)out, (void *)Minv, (void *)(ext_M ? nullptr : M), (void *)tmp_src, (void *)spB }) P.release(p);
+		for (SpTemps &t : sp_t) for (void *p : { (void *)t.S, (void *)t.T, (void *)t.U, (void *)t.V }) P.release(p);
+		sp_t.clear(); spB = nullptr; spB_elems = 0;
 		arena = nullptr; Y = nullptr; ycols = nullptr; out = nullptr; Minv = nullptr; M = nullptr; tmp_src = nullptr;
 		st = nullptr; panels = nullptr; aux = nullptr; fu = nullptr; died = nullptr; pivcol = nullptr;
 		urow = nullptr; blk_first = nullptr; mult = nullptr; Wb = nullptr;
@@ -622,6 +637,43 @@ void plan_two_level(Solver &S)
 	S.nsets = 2 * K;              // the outer pass of panel p reads its K sets while the blocks of panel p + 1 write theirs
 }
 
+// Three-level elimination: which blocks go in super-panels.  A super-panel = sp_P outer panels (e.g. 10 x 12 blocks = 30720
+// columns): its Schur update is one matrix product with an inner dimension large enough for the rows to stay in registers through
+// 120 table builds (5.8 TB/s of sweep-words in isolation against 4.9 for an outer pass of 12 blocks inside a solve) and for
+// Strassen-Winograd to pay (profiles/r05_strassen.txt: 0.87 / 0.82 of the classical time with one / two levels).
+// OPT-IN (GF2BV_THREE_LEVEL=P, super-panels of P outer panels wherever the two-level plan has that many whole panels and more than
+// GF2BV_THREE_LEVEL_MIN_MIB -- default 1024 -- lie right of the super-panel; tests force it onto small systems together with
+// GF2BV_TWO_LEVEL=K), NOT the default plan: built, bit-exact, and measured SLOWER than the two-level elimination at 262144^2 --
+// 1.31-1.34 s against 1.22-1.27 s on the same boxes (profiles/r05_three_level.txt).  The products do run faster than the outer
+// passes they replace (4.62 TB of sweep-words in 0.78 s = 5.9 TB/s with two Strassen levels against 4.9), but the triangular part
+// the recursion needs -- the replay of every outer panel on the rows that die later in the super-panel -- costs 0.21 s where the
+// ideal D^2 / 2 share is 0.1 s (whole chunks of 8192 rows are looked up for a few thousand dying rows, and every replay launch walks
+// all items of the trailing matrix to find them), and a super-panel exposes ~12 ms of panel path that an outer pass used to hide.
+void plan_three_level(Solver &S)
+{
+	S.sp_P = 0; S.sp_bend = 0; S.nlist = 2;
+	if (!S.tl_K || S.nsys != 1) return;
+	int P = 0;
+	double min_bytes = 1.0 * 1073741824.0;
+	if (const char *e = getenv("GF2BV_THREE_LEVEL"); e && *e) P = std::max(0, std::min(atoi(e), 64));
+	if (P < 2) return;
+	// (a forced two-level plan -- tests on small systems -- takes super-panels wherever it has whole ones)
+	if (getenv("GF2BV_TWO_LEVEL") && *getenv("GF2BV_TWO_LEVEL")) min_bytes = 0;
+	if (const char *e = getenv("GF2BV_THREE_LEVEL_MIN_MIB"); e && *e) min_bytes = 1048576.0 * atof(e);
+	if (const char *e = getenv("GF2BV_STRASSEN"); e && *e) S.sp_force_levels = std::max(0, std::min(atoi(e), 4));
+	const int G = S.impl->G, spb = P * S.tl_K;
+	int bend = 0;
+	for (int b0 = 0; b0 + spb <= S.tl_bend; b0 += spb) {
+		const i64 rows_left = S.rows - (i64)(b0 + spb) * 64 * G, words_left = S.wt - (i64)(b0 + spb) * G;
+		if (rows_left <= 0 || words_left <= 0 || (double)rows_left * (double)words_left * 8.0 < min_bytes) break;
+		bend = b0 + spb;
+	}
+	if (!bend) return;
+	S.sp_P = P; S.sp_bend = bend;
+	S.nlist = 2 * P;
+	S.nsets = 2 * spb;            // a super-panel's multipliers stay until its product has run, beside the next super-panel's
+}
+
 int solver_alloc(Solver &S)
 {
 	S.wt = (S.cols + 1 + 63) / 64;
@@ -641,6 +693,7 @@ int solver_alloc(Solver &S)
 	S.nblocks = (S.npanels + G - 1) / G;
 	S.tile_hi = S.ntiles;
 	plan_two_level(S);
+	plan_three_level(S);
 	S.units = (int)std::min<i64>(256, std::max<i64>(1, (S.rows + 255) / 256));
 	if (const char *e = getenv("GF2BV_DEBUG_SYNC")) S.dbg_sync = atoi(e);
 	if (const char *e = getenv("GF2BV_FAST")) S.fast_blocks = atoi(e) != 0;
@@ -684,8 +737,8 @@ int solver_alloc(Solver &S)
 		             o_piv = carve(sizeof(int) * (S.maxr + 64)), o_urow = carve(sizeof(int) * (S.maxr + 64)),
 		             o_blk = carve(sizeof(int) * std::max(1, S.nblocks)), o_mult = carve(sizeof(u64) * S.nsets * G * mult_rows(R) + (S.tl_K ? kOuterSlackBytes : 0)),
 		             o_wb = carve(sizeof(u64) * 2 * GF2_GMAX * R), o_uw = carve(sizeof(u64) * GF2_GMAX * (S.maxr + 64)),
-		             o_pf = carve(sizeof(u64) * GF2_GMAX * GF2_GMAX * 64), o_opr = carve(sizeof(int) * GF2_OUTER_LISTS * 2),
-		             o_tm = carve(S.tl_K ? 2 * sizeof(u64) * GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX : 0),
+		             o_pf = carve(sizeof(u64) * GF2_GMAX * GF2_GMAX * 64), o_opr = carve(sizeof(int) * GF2_OUTER_LISTS * S.nlist),
+		             o_tm = carve(S.tl_K ? S.nlist * sizeof(u64) * GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX : 0),
 		             o_pc = carve(S.use_pc ? sizeof(u64) * 2 * GF2_GMAX * 64 * (size_t)S.ntiles : 0);
 		S.arena_stride = off;
 		S.sync_base = 0;
@@ -1042,8 +1095,8 @@ int enqueue_outer_prepare(Solver &S, hipStream_t st, int b0, int b1)
 	const i64 set_words = (i64)G * mult_rows(S.rows);
 	const int npan = (b1 - b0) * G;
 	// (lists: two buffers by panel parity, T: two as well -- the previous panel's outer pass may still be reading its own)
-	int *gprow = S.oprow + (size_t)((b0 / S.tl_K) & 1) * GF2_OUTER_LISTS;
-	u64 *Tm = S.Tm + (size_t)((b0 / S.tl_K) & 1) * ((size_t)GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX);
+	int *gprow = S.oprow + (size_t)((b0 / S.tl_K) % S.nlist) * GF2_OUTER_LISTS;
+	u64 *Tm = S.Tm + (size_t)((b0 / S.tl_K) % S.nlist) * ((size_t)GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX);
 	k_outer_prow<<<dim3(1, S.nsys), dim3(256), 0, st>>>(b0 * G, b1 - b0, S.panels, S.aux, gprow, S.ss());
 	if (!S.outer_chain)
 		k_outer_trsm<4, true><<<dim3((unsigned)(npan / 4), S.nsys), dim3(256), 0, st>>>(S.M, S.rows, S.srows, b0 * G, npan, 0, S.panels, S.aux, S.mult,
@@ -1052,13 +1105,15 @@ int enqueue_outer_prepare(Solver &S, hipStream_t st, int b0, int b1)
 	return GF2BV_OK;
 }
 
-int enqueue_outer_apply(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, i64 t_end)
+// j_lim < INT_MAX: the REPLAY of the panel right of its super-panel (three-level elimination) -- only rows that became pivot sources
+// in later panels of the super-panel (panels [b1 G, j_lim)) take it
+int enqueue_outer_apply(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, i64 t_end, int j_lim = 0x7fffffff)
 {
 	const int G = S.impl->G;
 	const i64 nt = t_end - t_begin;
 	if (nt <= 0) return GF2BV_OK;
 	const i64 set_words = (i64)G * mult_rows(S.rows);
-	int *gprow = S.oprow + (size_t)((b0 / S.tl_K) & 1) * GF2_OUTER_LISTS;
+	int *gprow = S.oprow + (size_t)((b0 / S.tl_K) % S.nlist) * GF2_OUTER_LISTS;
 	const int npan = (b1 - b0) * G;
 	if (S.outer_chain) {
 		const i64 g_begin = t_begin * TW / 4, ng = t_end * TW / 4 - g_begin;
@@ -1066,7 +1121,7 @@ int enqueue_outer_apply(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, 
 		                                                                          S.mult, set_words, b0 % S.nsets, S.nsets, S.impl->T, (u64 *)nullptr, S.ss());
 	} else
 		k_outer_apply<<<dim3((unsigned)nt, S.nsys), dim3(512), 0, st>>>(S.M, S.rows, S.srows, b1 - b0, (const int *)gprow,
-		                                                                (const u64 *)(S.Tm + (size_t)((b0 / S.tl_K) & 1) * ((size_t)GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX)), (int)t_begin, S.ss());
+		                                                                (const u64 *)(S.Tm + (size_t)((b0 / S.tl_K) % S.nlist) * ((size_t)GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX)), (int)t_begin, S.ss());
 	HIPCHK(hipGetLastError());
 	hipEvent_t ka = nullptr, kb = nullptr;
 	if (S.time_kernels) {
@@ -1082,10 +1137,152 @@ int enqueue_outer_apply(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, 
 	const i64 wgs = xmap ? 8 * ((nch + 7) / 8) * nt : std::min<i64>(nch * nt, (i64)1 << 30);
 	hipExtLaunchKernelGGL((k_update16k<GF2_KSEG>), dim3((unsigned)wgs, S.nsys), dim3(512), 0, st, S.ext_events ? ka : nullptr, S.ext_events ? kb : nullptr, 0,
 	                      S.M, S.rows, S.srows, b1 - b0, (const int *)gprow, (const u64 *)S.mult,
-	                      set_words, b0 % S.nsets, S.nsets, (const int *)(S.blk_first + b0), (const int *)S.died, b1 * G, (int)t_begin, (int)nt, S.ss(), xmap ? 1 : 0);
+	                      set_words, b0 % S.nsets, S.nsets, (const int *)(S.blk_first + b0), (const int *)S.died, b1 * G, (int)t_begin, (int)nt, S.ss(), xmap ? 1 : 0, j_lim);
 	HIPCHK(hipGetLastError());
 	if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, st));
 	if (S.dbg_sync & 2) HIPCHK(hipDeviceSynchronize());
+	return GF2BV_OK;
+}
+
+// ---- three-level elimination: the Schur update of a super-panel as one matrix product ------------------------------------
+// C ^= A x B (zero: C = A x B) with `level` Strassen-Winograd levels over the base case k_mul16k.  R: rows of the views (a multiple
+// of 64 << level), T tiles and nb blocks (multiples of 1 << level).  Winograd's form, signs dropped (GF(2)):
+//   S1 = A21 + A22, S2 = S1 + A11, S3 = A11 + A21, S4 = A12 + S2;  T1 = B12 + B11, T2 = B22 + T1, T3 = B22 + B12, T4 = T2 + B21
+//   P1 = A11 B11, P2 = A12 B21, P3 = S4 B22, P4 = A22 T4, P5 = S1 T1, P6 = S2 T2, P7 = S3 T3
+//   C11 += P1 + P2, C12 += P1 + P6 + P5 + P3, C21 += P1 + P6 + P7 + P4, C22 += P1 + P6 + P7 + P5
+// scheduled with one A-quadrant, one B-quadrant and two C-quadrant temporaries per level; every product accumulates straight into
+// its target where it can (P2, P3, P4), so the additions move 22 C-quadrants + 12 A-quadrants + 12 B-quadrants per level.
+int sp_mul(Solver &S, hipStream_t st, MulC C, i64 R, int T, MulA A, MulB B, int nb, int level, bool zero, int depth)
+{
+	if (level == 0) {
+		constexpr i64 CH = (i64)GF2_KSEG * 512;
+		const i64 items = (R + CH - 1) / CH * T;
+		const unsigned wgs = (unsigned)std::min<i64>(items, (i64)1 << 30);
+		if (zero) hipLaunchKernelGGL((k_mul16k<GF2_KSEG, true>), dim3(wgs), dim3(512), 0, st, C, R, T, A, B, nb);
+		else hipLaunchKernelGGL((k_mul16k<GF2_KSEG, false>), dim3(wgs), dim3(512), 0, st, C, R, T, A, B, nb);
+		HIPCHK(hipGetLastError());
+		S.sp_mul_words += (double)R * T * 2 * nb;
+		return GF2BV_OK;
+	}
+	const Solver::SpTemps &t = S.sp_t[depth];
+	const i64 R2 = R / 2; const int T2 = T / 2, n2 = nb / 2;
+	const MulC C11{ C.p, C.ts }, C12{ C.p + (i64)T2 * C.ts, C.ts }, C21{ C.p + R2, C.ts }, C22{ C.p + (i64)T2 * C.ts + R2, C.ts };
+	const MulA A11{ A.p, A.bs }, A12{ A.p + (i64)n2 * A.bs, A.bs }, A21{ A.p + R2 * 2, A.bs }, A22{ A.p + (i64)n2 * A.bs + R2 * 2, A.bs };
+	const MulB B11{ B.p, B.bs }, B12{ B.p + (i64)T2 * 256, B.bs }, B21{ B.p + (i64)n2 * B.bs, B.bs }, B22{ B.p + (i64)n2 * B.bs + (i64)T2 * 256, B.bs };
+	const MulA Sq{ t.S, R2 * 2 }; const MulB Tq{ t.T, (i64)T2 * 256 }; const MulC U{ t.U, R2 }, V{ t.V, R2 };
+	auto xr = [&](uint4 *X, i64 xs, const uint4 *Y, i64 ys, const uint4 *Z, i64 zs, const uint4 *W, i64 ws, i64 inner, i64 outer) {
+		k_xor16<<<dim3((unsigned)((inner + 255) / 256), (unsigned)outer), dim3(256), 0, st>>>(X, xs, Y, ys, Z, zs, W, ws, inner);
+		S.sp_add_bytes += (double)inner * outer * 16 * (W ? 4 : 3);
+	};
+	auto xa = [&](const MulA &y, const MulA &z) { xr(t.S, Sq.bs, y.p, y.bs, z.p, z.bs, nullptr, 0, R2 * 2, n2); };
+	auto xb = [&](const MulB &y, const MulB &z) { xr(t.T, Tq.bs, y.p, y.bs, z.p, z.bs, nullptr, 0, (i64)T2 * 256, n2); };
+	auto xc = [&](const MulC &x, const MulC &u, const MulC *v) { xr(x.p, x.ts, x.p, x.ts, u.p, u.ts, v ? v->p : nullptr, v ? v->ts : 0, R2, T2); };
+	int rc;
+#define SPM(...) do { if ((rc = sp_mul(S, st, __VA_ARGS__))) return rc; } while (0)
+	if (zero) {       // (an overwriting product at an inner level: cleared, then accumulated into)
+		k_zero16<<<dim3((unsigned)((R + 255) / 256), (unsigned)T), dim3(256), 0, st>>>(C.p, C.ts, R);
+		S.sp_add_bytes += (double)R * T * 16;
+	}
+	xa(A21, A22); xb(B12, B11);                                    // S1, T1
+	SPM(V, R2, T2, Sq, Tq, n2, level - 1, true, depth + 1);        // V = P5
+	xa(Sq, A11); xb(B22, Tq);                                      // S2, T2
+	SPM(U, R2, T2, A11, B11, n2, level - 1, true, depth + 1);      // U = P1
+	xc(C11, U, nullptr);                                           // C11 += P1
+	SPM(C11, R2, T2, A12, B21, n2, level - 1, false, depth + 1);   // C11 += P2
+	SPM(U, R2, T2, Sq, Tq, n2, level - 1, false, depth + 1);       // U = P1 + P6
+	xc(C12, U, &V);                                                // C12 += P1 + P6 + P5
+	xa(A12, Sq);                                                   // S4
+	SPM(C12, R2, T2, Sq, B22, n2, level - 1, false, depth + 1);    // C12 += P3
+	xb(Tq, B21);                                                   // T4
+	SPM(C21, R2, T2, A22, Tq, n2, level - 1, false, depth + 1);    // C21 += P4
+	xa(A11, A21); xb(B22, B12);                                    // S3, T3
+	SPM(U, R2, T2, Sq, Tq, n2, level - 1, false, depth + 1);       // U = P1 + P6 + P7
+	xc(C21, U, nullptr);                                           // C21 += P1 + P6 + P7
+	xc(C22, U, &V);                                                // C22 += P1 + P6 + P7 + P5
+#undef SPM
+	HIPCHK(hipGetLastError());
+	return GF2BV_OK;
+}
+
+// The end of the super-panel of blocks [B0, B1): everything right of it (tiles [t_hi, ntiles)) takes the super-panel in three steps
+// on the outer stream -- the replay of its outer panels on the rows that died inside it (U12), B gathered / the dead rows'
+// multipliers cleared, the product -- with the tiles of the NEXT outer panel first (evPri: its elimination starts behind them).
+// The host has to know the alive bound (the product's row range): it waits for the panel stream here, once per super-panel.
+int enqueue_super_panel_finish(Solver &S, hipStream_t so, int B0, int B1)
+{
+	const int G = S.impl->G, K = S.tl_K, nb = B1 - B0;
+	const i64 t_hi = (i64)B1 * G / TW, T_all = S.ntiles - t_hi;
+	if (T_all <= 0) return GF2BV_OK;
+	int h_first = 0;
+	HIPCHK(hipMemcpyAsync(&h_first, S.blk_first + (B1 - 1), sizeof(int), hipMemcpyDeviceToHost, S.sA));
+	HIPCHK(hipStreamSynchronize(S.sA));
+	const i64 R64 = mult_rows(S.rows);
+	const i64 first64 = std::min<i64>(std::max(0, h_first), R64 - 64) & ~(i64)63;
+	// Strassen-Winograd levels by size (profiles/r05_strassen.txt: inner dimension 30720 -- two levels pay from ~100000 rows and
+	// columns, one from ~30000), bounded by what the shapes divide by
+	const i64 Tp_min = std::min<i64>(T_all, (i64)K * G / TW);       // the next outer panel's tiles: first, classically
+	int L = (R64 - first64 >= 98304 && T_all - Tp_min >= 768) ? 2 : (R64 - first64 >= 32768 && T_all - Tp_min >= 256) ? 1 : 0;
+	if (S.sp_force_levels >= 0) L = S.sp_force_levels;
+	while (L > 0 && (nb % (1 << L) || (T_all - Tp_min) < (2 << L) || R64 < ((i64)64 << L))) L--;
+	i64 lo = first64, R = R64 - first64;
+	if (L > 0) {
+		const i64 al = (i64)64 << L;
+		R = (R64 - first64 + al - 1) / al * al;
+		lo = R64 - R;
+		while (lo < 0) { L--; const i64 a2 = (i64)64 << L; R = (R64 - first64 + a2 - 1) / a2 * a2; lo = R64 - R; }
+	}
+	const i64 Ts = L > 0 ? (T_all - Tp_min) / (1 << L) * (1 << L) : T_all - Tp_min, Tp = T_all - Ts;
+	// buffers: B, and the temporaries of the levels (the first super-panel is the largest)
+	const size_t slack = kOuterSlackBytes / 16;
+	const size_t needB = (size_t)nb * T_all * 256;
+	if (S.spB_elems < needB) {
+		pool().release(S.spB); S.spB = nullptr; S.spB_elems = 0;
+		HIPCHK(pool().alloc((void **)&S.spB, needB * 16 + kOuterSlackBytes, S.device));
+		S.spB_elems = needB;
+	}
+	if ((int)S.sp_t.size() < L) S.sp_t.resize(L);
+	{
+		i64 r = R; i64 t = Ts; int n = nb;
+		for (int d = 0; d < L; d++) {
+			r /= 2; t /= 2; n /= 2;
+			Solver::SpTemps &q = S.sp_t[d];
+			const size_t ns = (size_t)n * r * 2, nt = (size_t)n * t * 256, nc = (size_t)r * t;
+			if (q.ns < ns) { pool().release(q.S); q.S = nullptr; HIPCHK(pool().alloc((void **)&q.S, (ns + slack) * 16, S.device)); q.ns = ns; }
+			if (q.nt < nt) { pool().release(q.T); q.T = nullptr; HIPCHK(pool().alloc((void **)&q.T, (nt + slack) * 16, S.device)); q.nt = nt; }
+			if (q.nc < nc) {
+				pool().release(q.U); pool().release(q.V); q.U = q.V = nullptr;
+				HIPCHK(pool().alloc((void **)&q.U, (nc + slack) * 16, S.device)); HIPCHK(pool().alloc((void **)&q.V, (nc + slack) * 16, S.device));
+				q.nc = nc;
+			}
+		}
+	}
+	hipEvent_t ka = nullptr, kb = nullptr;
+	if (S.time_kernels) {
+		HIPCHK(pool().event(&ka, true)); HIPCHK(pool().event(&kb, true));
+		S.sp_kev.push_back(S.kev.size());
+		S.kev.push_back(ka); S.kev.push_back(kb);
+	}
+	int rc;
+	// (1) replay: panel by panel, the rows that die later in this super-panel
+	for (int p0 = B0; p0 < B1; p0 += K)
+		if ((rc = enqueue_outer_apply(S, so, p0, p0 + K, t_hi, S.ntiles, B1 * G))) return rc;
+	if (ka) HIPCHK(hipEventRecord(ka, so));
+	// (2) B, and the multipliers of the rows that died inside the super-panel
+	const i64 set_u4 = (i64)G * mult_rows(S.rows) / 2;
+	uint4 *Aset = reinterpret_cast<uint4 *>(S.mult) + (i64)(B0 % S.nsets) * set_u4;
+	k_gather_b<<<dim3((unsigned)T_all, (unsigned)nb), dim3(256), 0, so>>>((const u64 *)S.M, S.srows, (int)t_hi, (const int *)S.oprow, (B0 / K) % S.nlist, S.nlist, K,
+	                                                                     S.spB, T_all * 256);
+	k_zero_dead_mults<<<dim3((unsigned)((S.rows + 255) / 256)), dim3(256), 0, so>>>((const int *)S.died, S.rows, 0, B0 * G, B1 * G, Aset, set_u4, nb);
+	HIPCHK(hipGetLastError());
+	// (3) the product: the next outer panel's tiles (and what the levels' shapes leave over) first
+	uint4 *Cb = reinterpret_cast<uint4 *>(S.M) + t_hi * S.srows + lo;
+	const MulA A{ Aset + lo * 2, set_u4 };
+	if (Tp > 0 && (rc = sp_mul(S, so, MulC{ Cb, S.srows }, R, (int)Tp, A, MulB{ S.spB, T_all * 256 }, nb, 0, false, 0))) return rc;
+	HIPCHK(hipEventRecord(S.evPri, so));
+	if (Ts > 0 && (rc = sp_mul(S, so, MulC{ Cb + Tp * S.srows, S.srows }, R, (int)Ts, A, MulB{ S.spB + Tp * 256, T_all * 256 }, nb, L, false, 0))) return rc;
+	if (kb) HIPCHK(hipEventRecord(kb, so));
+	S.sp_products++;
+	S.sp_levels_used = std::max(S.sp_levels_used, L);
 	return GF2BV_OK;
 }
 
@@ -1157,10 +1354,20 @@ int enqueue_forward(Solver &S)
 			if ((rc = enqueue_outer_prepare(S, S.sA, p0, p1))) return rc;
 			HIPCHK(hipEventRecord(S.evPanelDone, S.sA));
 			HIPCHK(hipStreamWaitEvent(so, S.evPanelDone, 0));
-			const i64 t0 = (i64)p1 * G / TW, t1 = std::min<i64>(S.ntiles, t0 + (i64)S.tl_K * G / TW);
+			// three-level: inside a super-panel the outer pass stops at the super-panel's last tile; right of it the whole
+			// super-panel is applied at its end (replay + product)
+			const int spb = S.sp_P * S.tl_K;
+			const bool in_sp = p0 < S.sp_bend;
+			const int sp1 = in_sp ? (p0 / spb + 1) * spb : 0;
+			const i64 t_out = in_sp ? (i64)sp1 * G / TW : S.ntiles;
+			const i64 t0 = (i64)p1 * G / TW, t1 = std::min<i64>(t_out, t0 + (i64)S.tl_K * G / TW);
 			if ((rc = enqueue_outer_apply(S, so, p0, p1, t0, t1))) return rc;
-			HIPCHK(hipEventRecord(S.evPri, so));
-			if ((rc = enqueue_outer_apply(S, so, p0, p1, t1, S.ntiles))) return rc;
+			if (in_sp && p1 == sp1) {
+				if ((rc = enqueue_super_panel_finish(S, so, sp1 - spb, sp1))) return rc;       // (records evPri behind the next panel's tiles)
+			} else {
+				HIPCHK(hipEventRecord(S.evPri, so));
+				if ((rc = enqueue_outer_apply(S, so, p0, p1, t1, t_out))) return rc;
+			}
 		}
 		HIPCHK(hipEventRecord(S.evOuter, so));
 		b = S.tl_bend;
@@ -1183,6 +1390,7 @@ int enqueue_forward(Solver &S)
 			// applied to its own tiles by the bulk kernels and to everything right of it by its outer pass -- every tile has seen
 			// exactly the blocks before pb -- so the rest runs as a one-level schedule)
 			if (S.tl_K && pb < S.tl_bend) S.tl_bend = pb / S.tl_K * S.tl_K;
+			if (S.sp_bend > S.tl_bend) S.sp_bend = S.tl_bend;       // (never entered again: the resumed blocks run one level)
 			S.bulk_waits_outer = false;
 			HIPCHK(hipMemsetAsync(&S.st->poison, 0, sizeof(int), S.sA));
 			S.sync_base += S.nblocks + 1;
@@ -1449,9 +1657,14 @@ int finish_end(Solver &S, gf2bv_result **out)
 			// rest of the row takes the whole panel in one outer pass (counted at the panel's last block, two launches)
 			if (S.tl_K && b < S.tl_bend) {
 				const int pend_w = (b / S.tl_K + 1) * S.tl_K * G;
+				// three-level: the outer pass of a panel inside a super-panel stops at the super-panel's end; right of it the rows make
+				// one trip per super-panel (the product; its Strassen additions are reported apart: product_add_bytes)
+				const int spb = S.sp_P * S.tl_K;
+				const i64 out_w = b < S.sp_bend ? std::min<i64>(S.wt, (i64)(b / spb + 1) * spb * G) : S.wt;
 				st.outer_blocks++;
 				if (pend_w > wlo) { st.hbm_words += rows_swept * (double)(std::min<i64>(pend_w, S.wt) - wlo); st.bulk_launches++; }
-				if ((b + 1) % S.tl_K == 0 && S.wt > pend_w) { st.hbm_words += rows_swept * (double)(S.wt - pend_w); st.bulk_launches += 2; }
+				if ((b + 1) % S.tl_K == 0 && out_w > pend_w) { st.hbm_words += rows_swept * (double)(out_w - pend_w); st.bulk_launches += 2; }
+				if (b < S.sp_bend && (b + 1) % spb == 0 && S.wt > out_w) { st.hbm_words += rows_swept * (double)(S.wt - out_w); st.bulk_launches += 2; }
 			} else { st.hbm_words += rows_swept * (double)(S.wt - wlo); st.bulk_launches++; }
 		}
 	}
@@ -1464,7 +1677,12 @@ int finish_end(Solver &S, gf2bv_result **out)
 		float ms = 0;
 		(void)hipEventElapsedTime(&ms, S.kev[i], S.kev[i + 1]);
 		st.ms_sweep += ms;
+		if (std::find(S.sp_kev.begin(), S.sp_kev.end(), i) != S.sp_kev.end()) st.ms_product += ms;
 	}
+	st.super_panels = S.sp_products;
+	st.strassen_levels = S.sp_levels_used;
+	st.product_add_bytes = S.sp_add_bytes;
+	st.product_lookup_words = S.sp_mul_words;
 	st.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - S.t_begin).count();
 	tr.mark("finish: result");
 	*out = R;

@@ -54,6 +54,8 @@ class Stats(ctypes.Structure):
         ("search_handovers", ctypes.c_int32), ("fast_blocks", ctypes.c_int32),
         ("hbm_words", ctypes.c_double), ("bulk_launches", ctypes.c_int32), ("outer_blocks", ctypes.c_int32),
         ("handover_retries", ctypes.c_int32), ("small_path", ctypes.c_int32),
+        ("super_panels", ctypes.c_int32), ("strassen_levels", ctypes.c_int32), ("ms_product", ctypes.c_float), ("reserved0", ctypes.c_float),
+        ("product_add_bytes", ctypes.c_double), ("product_lookup_words", ctypes.c_double),
     ]
 
     def as_dict(self) -> dict:

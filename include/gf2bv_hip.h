@@ -77,6 +77,15 @@ typedef struct gf2bv_stats {
 	                              made with events (the device stays on events for this process); 0 normally        */
 	int32_t small_path;        /* 1: solved by the one-launch kernel for systems that fit the LDS of one workgroup (k_small_solve; the
 	                              phase times and sweep counters above are then 0 except ms_total); GF2BV_SMALL=0 disables that path */
+	/* round 5 (three-level elimination): super-panels whose Schur update ran as ONE matrix product, the Strassen-Winograd levels
+	 * of the largest of them, the time inside the products (part of ms_sweep when `time_kernels` is set), what their additions
+	 * moved through HBM, and the table lookups they did in sweep-words (less than the sweep_words they stand for) */
+	int32_t super_panels;
+	int32_t strassen_levels;
+	float   ms_product;
+	float   reserved0;
+	double  product_add_bytes;
+	double  product_lookup_words;
 } gf2bv_stats;
 
 /* ---- library / device ------------------------------------------------------------------ */

@@ -39,7 +39,7 @@ int main(int argc, char **argv)
 	// default: one workgroup per item (as the solver launches it); MB_WGS=256: persistent workgroups
 	const i64 nitems = (R64 + (i64)GF2_KSEG * 512 - 1) / ((i64)GF2_KSEG * 512) * ntiles;
 	const int wgs = getenv("MB_WGS") ? atoi(getenv("MB_WGS")) : (int)nitems;
-	auto launch = [&] { k_update16k<GF2_KSEG><<<dim3(wgs), dim3(512)>>>(M, rows, srows, K, gprow, mult, set_words, 0, K, blkf, died, npan, 0, ntiles); };
+	auto launch = [&] { k_update16k<GF2_KSEG><<<dim3(wgs), dim3(512)>>>(M, rows, srows, K, gprow, mult, set_words, 0, K, blkf, died, npan, 0, ntiles, SysStride{0, 0}, 0, 0x7fffffff); };
 	launch(); launch(); CK(hipDeviceSynchronize());
 	const int reps = 6;
 	CK(hipEventRecord(e0)); for (int r = 0; r < reps; r++) launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
