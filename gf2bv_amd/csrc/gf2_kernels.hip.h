@@ -119,6 +119,7 @@ struct SolveState {
 	// k_block_fast_narrow: progress of the search workgroup for the narrowing workgroups of the same launch -- 8 blk + g + 1 once
 	// panel g's reduced pivot rows are in Pfast, 8 blk + 5 once the block is published (monotone over a solve)
 	int fast_pub;
+	int sp_chunk;        // k_block_sparse: 0 = the "first 64 rows with a bit in the panel" attempt completed the last panel it was tried on
 };
 
 // Hand-over between the panel stream and the bulk stream through memory instead of events.  An event wait costs a
@@ -1339,6 +1340,351 @@ __device__ __forceinline__ int block_fast_body(FastLds &F, u64 *__restrict__ M, 
 }
 #undef PST
 
+// ---- sparse blocks (round 5): all panels of a block from the rows that HAVE something in its window, in ONE launch ----------------
+// The one-launch search above wants dense candidates next to the alive bound.  The reference's own workloads are the opposite
+// (examples/mt.py: 0.05-0.8 % density; a panel's pivot rows are a few of the 500-3700 rows that carry a bit in the block's 256
+// columns, hundreds to thousands of rows apart), every block went through G + 1 general panel steps of 21-55 us, and the elimination of
+// a 20000-column system took 10-23 ms around 2-4 ms of bulk work (BENCH_r04 c3_mt19937, fast_blocks 0 of 78).  k_block_sparse:
+//   pool      the first GF2_SP_NC alive rows with a NON-ZERO window, taken from the bit masks the look-ahead leaves (k_prio_window /
+//             k_window_masks: one bit per row) -- a prefix sum over <= 1024 mask words and one gather, whatever the rows' distance;
+//             a thread keeps its GF2_SP_CPT candidates' four window words in REGISTERS (the kernel fits beside a bulk-update workgroup);
+//   selection per panel, all threads: rounds of "reduce every candidate's word by the echelon basis so far (lowest pivot first, a few
+//             LDS reads per sparse row), the first candidate with each new lowest bit joins the basis" until 64 columns are covered --
+//             any 64 independent rows will do: the pivots are the column rank profile whoever supplies them (contract S1);
+//   then      the 64 chosen rows' CURRENT words go through gj_columns on wavefront 0 (full rank by construction: combinations and
+//             sources exactly as the dense search leaves them) and the rest is the dense body: pivot rows' window words through
+//             nibble tables, PanelAux, the narrow step of the pool.
+// Gives up (fast_off, poison when no general steps are enqueued behind it) when the pool cannot complete a panel.
+#define GF2_SP_NW 1024                                  /* mask words looked at from the alive bound on (65536 rows) */
+template <int NC>
+struct SparseLds {
+	StepLds L;
+	int crow[NC];                            // pool slot -> row
+	u64 srcw[64][GF2_GMAX];                  // the panel's 64 chosen rows: current window words, by basis column
+	int srcrow[64];
+	u64 ebasis[64];
+	int prop[64];
+	u64 combs[GF2_GMAX][64];
+	int srcs[GF2_GMAX][64];                  // [panel][pivot column] -> index into srcw (of that panel)
+	int srow_all[GF2_GMAX][64];              // [panel][index into srcw] -> row
+	u64 have;
+	int wsum[8], min_free, min_zero, ok, chunk_ok;
+};
+#ifdef GF2_SPARSE_DEBUG
+__device__ unsigned long long gf2_sparse_probe[8];      // ticks (100 MHz) in: pool, selection, gj, tables + narrow, publish
+#endif
+// NT threads x CPT candidates per thread = the pool.  <256, 4> (1024 rows; one wavefront per SIMD at 124 registers and 22 KiB of LDS:
+// the kernel fits beside a bulk-update workgroup, like every panel kernel must) is what the host launches first; <512, 8> (4096
+// rows) after a give-up (examples/mt.py with 9 bits or one bit per output: 1100-3700 rows carry a bit in a block's window).
+template <int NT, int CPT>
+__global__ void __launch_bounds__(NT)
+k_block_sparse(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_only, int blk,
+               const u64 *__restrict__ Wb_in, SolveState *__restrict__ st, int *__restrict__ died,
+               PanelRec *__restrict__ panels, PanelAux *__restrict__ aux, int *__restrict__ pivcol, int *__restrict__ urow,
+               int *__restrict__ blk_first_out, const u64 *__restrict__ wmask, SysStride ss)
+{
+	constexpr int NC = CPT * NT, NWV = NT / 64;
+	__builtin_amdgcn_s_setprio(3);
+	{
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		M += blockIdx.y * ss.m_words;
+		Wb_in = sys_at(Wb_in, ao); st = sys_at(st, ao); died = sys_at(died, ao); panels = sys_at(panels, ao);
+		aux = sys_at(aux, ao); pivcol = sys_at(pivcol, ao); urow = sys_at(urow, ao); blk_first_out = sys_at(blk_first_out, ao);
+		wmask = sys_at(wmask, ao);
+	}
+	__shared__ SparseLds<NC> F;
+#ifdef GF2_SPARSE_DEBUG
+	unsigned long long pt = wall_clock64();
+#define SP_PROBE(i) do { if (threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&gf2_sparse_probe[i], n_ - pt); pt = n_; } } while (0)
+#else
+#define SP_PROBE(i) do { } while (0)
+#endif
+	StepLds &L = F.L;
+	const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+	const int first = st->first, r0 = st->rank;
+	if (st->poison) return;
+#ifdef GF2_SPARSE_DEBUG
+	auto give_up = [&](int why = 0, long long detail = 0) { if (t == 0) { st->fast_off = 1; if (fast_only) st->poison = blk + 1; printf("k_block_sparse<%d,%d> block %d gives up: reason %d detail %lld first %d\n", NT, CPT, blk, why, detail, first); } };
+#else
+	auto give_up = [&](int why = 0, long long detail = 0) { (void)why; (void)detail; if (t == 0) { st->fast_off = 1; if (fast_only) st->poison = blk + 1; } };
+#endif
+	if (gb != GF2_GMAX) { give_up(1); return; }
+	// ---- the pool: mask words in passes of one word per thread (a run of candidate rows spreads over neighbouring threads) ----
+	const i64 mask_words = (rows + 63) >> 6;
+	const i64 w0 = first >> 6;
+	if (t == 0) { F.min_zero = 0x7fffffff; F.min_free = 0x7fffffff; F.ok = 1; F.have = 0; }
+	u64 nzw[GF2_SP_NW / NT], alw[GF2_SP_NW / NT];
+#pragma unroll
+	for (int q = 0; q < GF2_SP_NW / NT; q++) {
+		const i64 w = w0 + (i64)q * NT + t;
+		u64 al = 0, nz = 0;
+		if (w < mask_words) { al = wmask[w]; nz = wmask[mask_words + w]; }
+		if (w == w0 && (first & 63)) { const u64 keep = ~0ull << (first & 63); al &= keep; nz &= keep; }
+		nzw[q] = nz; alw[q] = al;
+	}
+	int base = 0, zmin = 0x7fffffff;
+#pragma unroll
+	for (int q = 0; q < GF2_SP_NW / NT; q++) {
+		const int cnt = __popcll(nzw[q]);
+		int inc = cnt;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+		__syncthreads();                                    // (the previous pass has read wsum)
+		if (lane == 63) F.wsum[wv] = inc;
+		__syncthreads();
+		int c = base + inc - cnt, tot = 0;
+#pragma unroll
+		for (int v = 0; v < NWV; v++) { if (v < wv) c += F.wsum[v]; tot += F.wsum[v]; }
+		u64 nz = nzw[q];
+		const i64 wbase = (w0 + (i64)q * NT + t) * 64;
+		while (nz && c < NC) { F.crow[c++] = (int)wbase + ctz64(nz); nz &= nz - 1; }
+		base += tot;
+		const u64 z = alw[q] & ~nzw[q];
+		if (z && zmin == 0x7fffffff) zmin = (int)wbase + ctz64(z);
+	}
+	if (zmin != 0x7fffffff) atomicMin(&F.min_zero, zmin);
+	__syncthreads();
+	const int have_c = base < NC ? base : NC;
+	if (have_c < 64 * GF2_GMAX) { give_up(2, have_c); return; }      // (uniform) fewer candidates than pivots
+	u64 cw[CPT][GF2_GMAX];
+	unsigned usedk = 0, validk = 0;
+#pragma unroll
+	for (int k = 0; k < CPT; k++) {
+		const int c = t + NT * k;
+		const bool v = c < have_c;
+		const int crw = F.crow[v ? c : 0];         // (the pool's row list stays in LDS: read again where a row is needed)
+		const uint4 *src = reinterpret_cast<const uint4 *>(Wb_in + (i64)crw * GF2_GMAX);
+		const uint4 lo = src[0], hi = src[1];
+		cw[k][0] = v ? ((u64)lo.y << 32) | lo.x : 0ull; cw[k][1] = v ? ((u64)lo.w << 32) | lo.z : 0ull;
+		cw[k][2] = v ? ((u64)hi.y << 32) | hi.x : 0ull; cw[k][3] = v ? ((u64)hi.w << 32) | hi.z : 0ull;
+		if (v) validk |= 1u << k;
+	}
+	const int e_ = (t >> 6) & 3, sl = t & 63;
+	const bool tab_thread = t < 256;                        // (the table / pivot-row phases are written for 256 threads: the others wait)
+	u64 Pk[GF2_GMAX] = { 0, 0, 0, 0 };
+	bool try_chunk = st->sp_chunk == 0;
+	SP_PROBE(0);
+#pragma unroll 1
+	for (int g = 0; g < GF2_GMAX; g++) {
+		// ---- selection: 64 independent candidates of panel g ----
+		// (A) the first 64 pool rows that have a bit in the panel, straight through gj_columns: complete for systems whose rows come in
+		// runs that determine a panel (examples/mt.py with whole words per output) and for anything dense; tried while it worked on
+		// the panel before (st->sp_chunk: 0 = try)
+		bool done = false;
+		if (try_chunk) {
+			int pos[CPT];
+			int basec = 0;
+#pragma unroll
+			for (int k = 0; k < CPT; k++) {
+				u64 w = 0;
+#pragma unroll
+				for (int e = 0; e < GF2_GMAX; e++) if (e == g) w = cw[k][e];
+				const bool nzc = (((validk & ~usedk) >> k) & 1) && w != 0;
+				const u64 bal = __ballot(nzc);
+				__syncthreads();
+				if (lane == 0) F.wsum[wv] = __popcll(bal);
+				__syncthreads();
+				int c = basec, tot = 0;
+#pragma unroll
+				for (int v = 0; v < NWV; v++) { if (v < wv) c += F.wsum[v]; tot += F.wsum[v]; }
+				pos[k] = nzc ? c + __popcll(bal & lanemask_lt(lane)) : 0x7fffffff;
+				basec += tot;
+			}
+			if (basec >= 64) {                                  // (uniform)
+#pragma unroll
+				for (int k = 0; k < CPT; k++)
+					if (pos[k] < 64) {
+#pragma unroll
+						for (int e = 0; e < GF2_GMAX; e++) F.srcw[pos[k]][e] = cw[k][e];
+						F.srcrow[pos[k]] = F.crow[t + NT * k];
+					}
+				__syncthreads();
+				if (wv == 0) {
+					u64 w = 0;
+#pragma unroll
+					for (int e = 0; e < GF2_GMAX; e++) if (e == g) w = F.srcw[lane][e];
+					FindState S;
+					S.bw = 0; S.bc = 0; S.have = 0; S.nslots = 0; S.colslots = false; S.srow = 0;
+					(void)gj_columns(S, w, lane, lane);
+					if (lane == 0) F.chunk_ok = S.nslots == 64;
+					if (S.nslots == 64) { F.combs[g][lane] = S.bc; F.srcs[g][lane] = S.srow; L.Cm[lane] = S.bc; }
+				}
+				__syncthreads();
+				done = F.chunk_ok != 0;
+				if (done) {
+#pragma unroll
+					for (int k = 0; k < CPT; k++) if (pos[k] < 64) usedk |= 1u << k;
+				}
+			}
+			try_chunk = done;
+			SP_PROBE(5);
+		}
+		if (!done) {
+		// (B) rounds: every candidate's word reduced by the echelon basis so far (lowest pivot first), the first candidate with each
+		// new lowest bit joins the basis
+		if (t < 64) F.prop[t] = 0x7fffffff;
+		if (t == 0) F.have = 0;
+		u64 xr[CPT];
+		unsigned ownk = 0;
+		u64 owncols = 0;                                      // 8 bits per candidate: the basis column it took
+#pragma unroll
+		for (int k = 0; k < CPT; k++) {
+			u64 w = 0;
+#pragma unroll
+			for (int e = 0; e < GF2_GMAX; e++) if (e == g) w = cw[k][e];
+			xr[k] = ((validk & ~usedk) >> k) & 1 ? w : 0ull;
+		}
+		__syncthreads();
+		u64 hv = 0;
+		for (int round = 0; round < 66; round++) {
+#pragma unroll
+			for (int k = 0; k < CPT; k++) {
+				u64 x = xr[k];
+				if (x) {
+					u64 h = x & hv;
+					while (h) { x ^= F.ebasis[ctz64(h)]; h = x & hv; }
+					xr[k] = x;
+					if (x) atomicMin(&F.prop[ctz64(x)], t + NT * k);
+				}
+			}
+			__syncthreads();
+#pragma unroll
+			for (int k = 0; k < CPT; k++) {
+				const u64 x = xr[k];
+				if (x) {
+					const int b = ctz64(x);
+					if (F.prop[b] == t + NT * k) {
+						F.ebasis[b] = x;
+						atomicOr((unsigned long long *)&F.have, 1ull << b);
+						ownk |= 1u << k; owncols |= (u64)b << (8 * k);
+						xr[k] = 0;
+					}
+				}
+			}
+			__syncthreads();
+			const u64 nh = F.have;
+#ifdef GF2_SPARSE_DEBUG
+			if (t == 0) st->self_giveups++;
+#endif
+			if (nh == hv || nh == ~0ull) { hv = nh; break; }
+			hv = nh;
+		}
+		SP_PROBE(1);
+		if (hv != ~0ull) { give_up(3, 1000000ll * g + 10000ll * __popcll(hv) + base); return; }              // (uniform) the pool does not hold 64 independent rows for this panel
+		// the chosen rows: current words and rows by basis column; they are this panel's sources
+#pragma unroll
+		for (int k = 0; k < CPT; k++)
+			if ((ownk >> k) & 1) {
+				const int b = (int)((owncols >> (8 * k)) & 63);
+#pragma unroll
+				for (int e = 0; e < GF2_GMAX; e++) F.srcw[b][e] = cw[k][e];
+				F.srcrow[b] = F.crow[t + NT * k];
+				usedk |= 1u << k;
+			}
+		__syncthreads();
+		if (wv == 0) {
+			u64 w = 0;
+#pragma unroll
+			for (int e = 0; e < GF2_GMAX; e++) if (e == g) w = F.srcw[lane][e];
+			FindState S;
+			S.bw = 0; S.bc = 0; S.have = 0; S.nslots = 0; S.colslots = false; S.srow = 0;
+			(void)gj_columns(S, w, lane, lane);
+			if (S.nslots != 64) { if (lane == 0) F.ok = 0; }
+			else { F.combs[g][lane] = S.bc; F.srcs[g][lane] = S.srow; L.Cm[lane] = S.bc; }
+		}
+		}
+		if (t < 64) F.srow_all[g][t] = F.srcrow[t];
+		__syncthreads();
+		SP_PROBE(2);
+		if (!F.ok) { give_up(4, g); return; }
+		// the pivot rows' window words right of the panel = comb x source words (nibble tables of the 64 sources)
+		const bool use = e_ >= g;
+		if (tab_thread) L.Pb[e_][sl] = use ? F.srcw[F.srcs[g][sl]][e_] : 0ull;
+		__syncthreads();
+		if (tab_thread) build_nibble_tables(L, t);
+		__syncthreads();
+		const u64 acc = (use && tab_thread) ? nibble_word(L.Tn, L.Cm[sl], e_) : 0ull;
+#pragma unroll
+		for (int q = 0; q < GF2_GMAX; q++) if (q == g) Pk[q] = acc;
+		__syncthreads();
+		if (tab_thread) L.Pb[e_][sl] = (e_ > g) ? acc : 0ull;
+		if (t < 64) {
+			PanelAux *A = aux + j0 + g;
+			const int si = F.srcs[g][t];
+			A->slot_row[t] = F.srcrow[si];
+			A->comb[t] = F.combs[g][t];
+#pragma unroll
+			for (int e = 0; e < GF2_GMAX; e++) A->src_mult[t][e] = (e < g) ? F.srcw[si][e] : 0ull;
+		}
+		__syncthreads();
+		if (g + 1 < GF2_GMAX) {
+			if (tab_thread) build_nibble_tables(L, t);
+			__syncthreads();
+#pragma unroll
+			for (int k = 0; k < CPT; k++) {
+				u64 m = 0;
+#pragma unroll
+				for (int e = 0; e < GF2_GMAX; e++) if (e == g) m = cw[k][e];
+				if (!(((validk & ~usedk) >> k) & 1)) m = 0;
+				if (m) {
+					u64 a4[GF2_GMAX];
+					nibble_rows(L.Tn, m, a4);
+#pragma unroll
+					for (int e = 0; e < GF2_GMAX; e++) if (e > g) cw[k][e] ^= a4[e];
+				}
+			}
+			__syncthreads();
+		}
+		SP_PROBE(3);
+	}
+	// ---- every panel is complete: publish the block (as k_block_fast does) ----
+	{
+		int mf = 0x7fffffff;
+#pragma unroll
+		for (int k = 0; k < CPT; k++) if (((validk & ~usedk) >> k) & 1) { const int r = F.crow[t + NT * k]; mf = r < mf ? r : mf; }
+		if (mf != 0x7fffffff) atomicMin(&F.min_free, mf);
+	}
+	if (tab_thread) {
+#pragma unroll
+		for (int g = 0; g < GF2_GMAX; g++)
+			if (e_ >= g) M[tidx(F.srow_all[g][F.srcs[g][sl]], j0 + e_, srows)] = Pk[g];
+	}
+	if (t < 64) {
+#pragma unroll
+		for (int g = 0; g < GF2_GMAX; g++) {
+			const int row = F.srow_all[g][F.srcs[g][t]];
+			died[row] = j0 + g;
+			urow[r0 + 64 * g + t] = row;
+			pivcol[r0 + 64 * g + t] = 64 * (j0 + g) + t;
+		}
+	}
+	__syncthreads();
+	if (t == 0) {
+		// the new alive bound: nothing alive lies below the first alive row without a bit in this window, the first pool row that was
+		// not taken, and the end of the mask words that were looked at
+		i64 nf = F.min_zero < F.min_free ? F.min_zero : F.min_free;
+		const i64 seen_end = (w0 + GF2_SP_NW) * 64;
+		if (seen_end < nf) nf = seen_end;
+		if (nf > rows) nf = rows;
+		if (nf < first) nf = first;
+		const int new_first = (int)nf;
+#pragma unroll
+		for (int g = 0; g < GF2_GMAX; g++) {
+			panels[j0 + g].start = r0 + 64 * g; panels[j0 + g].p = 64; panels[j0 + g].mask = ~0ull;
+			aux[j0 + g].first_after = (g == GF2_GMAX - 1) ? new_first : first;
+		}
+		st->rank = r0 + 64 * GF2_GMAX;
+		st->first = new_first;
+		st->wide = 1;
+		*blk_first_out = new_first;
+		st->fast_off = 0;
+		st->fast_done = blk + 1;
+		st->fast_blocks = st->fast_blocks + 1;
+		st->sp_chunk = try_chunk ? 0 : ((st->sp_chunk + 1) & 7);      // (after a miss: the rounds for seven blocks, then another try)
+	}
+	SP_PROBE(4);
+}
+
 __global__ void __launch_bounds__(256)
 k_block_fast(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fast_only, int blk,
              const u64 *__restrict__ Wb_in, SolveState *__restrict__ st, int *__restrict__ died,
@@ -1699,8 +2045,11 @@ __global__ void __launch_bounds__(256)
 k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo, int gnext,
               const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux,
               const u64 *__restrict__ multset, const int *__restrict__ blk_first, u64 *__restrict__ Wb_out,
-              u64 *__restrict__ Uwin, int upd_T, const SolveState *__restrict__ st, SysStride ss)
+              u64 *__restrict__ Uwin, int upd_T, const SolveState *__restrict__ st, SysStride ss,
+              const int *__restrict__ died, u64 *__restrict__ wmask)
 {
+	// wmask (round 5, sparse systems; nullptr: not wanted): per 64 rows, which of them are alive / alive with a non-zero word in the
+	// NEXT block's window -- the candidate pool of k_block_sparse (wmask[w] = alive, wmask[nw + w] = non-zero, nw = words of a mask)
 	__builtin_amdgcn_s_setprio(3);
 	if (sys_at(st, blockIdx.y * ss.arena_bytes)->poison) return;     // (the window buffer must stay what the resumed block needs)
 	{
@@ -1708,7 +2057,9 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 		M += blockIdx.y * ss.m_words;
 		panels = sys_at(panels, ao); aux = sys_at(aux, ao); multset = sys_at(multset, ao); blk_first = sys_at(blk_first, ao);
 		Wb_out = sys_at(Wb_out, ao); Uwin = sys_at(Uwin, ao);
+		if (wmask) { died = sys_at(died, ao); wmask = sys_at(wmask, ao); }
 	}
+	const i64 mask_words = (rows + 63) >> 6;
 	constexpr int W = GF2_GMAX;
 	static_assert(W == 4, "thread <-> table entry mapping below");
 	// [panel][slot][word] source rows; once panel g's tables are built its slice is dead and takes the pivot rows
@@ -1742,8 +2093,12 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 	u64 wv[W];
 #pragma unroll
 	for (int e = 0; e < W; e++) wv[e] = M[tidx(ic, wlo + (e < gnext ? e : 0), srows)];
+	const int my_died = wmask ? died[ic] : 0;
 	// every row of this workgroup is dead (uniform); workgroup 0 still runs: it records the pivot rows' window words
-	if (blockIdx.x != 0 && (i64)(blockIdx.x + 1) * 256 <= first) return;
+	if (blockIdx.x != 0 && (i64)(blockIdx.x + 1) * 256 <= first) {
+		if (wmask && (t & 63) == 0 && (i >> 6) < mask_words) { wmask[i >> 6] = 0; wmask[mask_words + (i >> 6)] = 0; }
+		return;
+	}
 	int anyp = 0;
 #pragma unroll
 	for (int g = 0; g < GF2_GMAX; g++) anyp |= rec[g].p;
@@ -1793,10 +2148,36 @@ k_prio_window(const u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, in
 			__syncthreads();
 		}
 	}
+	if (wmask) {
+		u64 any = 0;
+#pragma unroll
+		for (int e = 0; e < W; e++) if (e < gnext) any |= wv[e];
+		const bool alive = i < rows && my_died == GF2_NEVER;
+		const u64 ba = __ballot(alive), bn = __ballot(alive && any != 0);
+		if ((t & 63) == 0 && (i >> 6) < mask_words) { wmask[i >> 6] = ba; wmask[mask_words + (i >> 6)] = bn; }
+	}
 	if (i >= rows) return;
 #pragma unroll
 	for (int e = 0; e < W; e++)
 		if (e < gnext) Wb_out[i * GF2_GMAX + e] = wv[e];
+}
+
+// The same two masks for a window that k_win_gather has just fetched (block 0, a block behind an outer pass, a resumed block).
+__global__ void __launch_bounds__(256)
+k_window_masks(const u64 *__restrict__ Wb, i64 rows, int gb, const int *__restrict__ died, u64 *__restrict__ wmask, const SolveState *__restrict__ st, SysStride ss)
+{
+	{
+		const i64 ao = blockIdx.y * ss.arena_bytes;
+		Wb = sys_at(Wb, ao); died = sys_at(died, ao); wmask = sys_at(wmask, ao); st = sys_at(st, ao);
+	}
+	if (st->poison) return;
+	const i64 mask_words = (rows + 63) >> 6;
+	const i64 i = (i64)blockIdx.x * 256 + threadIdx.x, ic = i < rows ? i : rows - 1;
+	u64 any = 0;
+	for (int e = 0; e < gb; e++) any |= Wb[ic * GF2_GMAX + e];
+	const bool alive = i < rows && died[ic] == GF2_NEVER;
+	const u64 ba = __ballot(alive), bn = __ballot(alive && any != 0);
+	if ((threadIdx.x & 63) == 0 && (i >> 6) < mask_words) { wmask[i >> 6] = ba; wmask[mask_words + (i >> 6)] = bn; }
 }
 
 // After the elimination: pivot row k of block b gets its words of block b+1's window (parked in Uwin by

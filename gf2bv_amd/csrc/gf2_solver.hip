@@ -469,6 +469,12 @@ struct Solver {
 	                                            // single systems (GF2BV_SINGLE_NT=1, an experiment: <= 1 %)
 	bool gang_two_level = false;  // GF2BV_GANG_TWO_LEVEL=1: outer panels for gangs too (measured slower: DESIGN 7)
 	bool gang_bs = true;          // GF2BV_GANG_BS=0: one back-substitution chain per system of a gang, as rounds 1-3
+	// sparse systems (round 5): blocks the dense one-launch search cannot take go through k_block_sparse -- candidates = the alive rows
+	// with a non-zero window, from the bit masks the look-ahead leaves in wmask (GF2BV_SPARSE_FAST=0: the general panel steps)
+	bool sparse_fast = true;      // allowed at all
+	bool sparse_on = false;       // this solve has switched to it (after block 0 went the general way)
+	int sparse_giveups = 0;
+	u64 *wmask = nullptr;         // 2 x ceil(rows / 64) words: alive / alive with a non-zero window, per 64 rows
 	bool fused_narrow = true;     // optimistic blocks: search and narrow step in ONE launch (k_block_fast_narrow); GF2BV_FUSED_NARROW=0: two
 	int narrow_rpt = 1;           // row blocks of 256 per narrow workgroup of a panel step (set in solver_alloc; GF2BV_NARROW_RPT)
 	int self_wait = 5000;         // ticks (100 MHz) unit 0 of a panel search waits for the other units before it leaves
@@ -702,6 +708,7 @@ int solver_alloc(Solver &S)
 	if (getenv("GF2BV_SERIAL")) S.flag_sync = false;      // (one stream: the panel gate would wait for a gate queued behind it)
 	if (const char *e = getenv("GF2BV_OPTIMISTIC")) S.optimistic = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_FUSED_NARROW")) S.fused_narrow = atoi(e) != 0;
+	if (const char *e = getenv("GF2BV_SPARSE_FAST")) S.sparse_fast = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_PC")) S.use_pc = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_XCD_PIN")) S.xcd_pin = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_XCD_WGS")) S.xcd_wgs = std::min(256, std::max(1, atoi(e)));
@@ -739,7 +746,8 @@ int solver_alloc(Solver &S)
 		             o_wb = carve(sizeof(u64) * 2 * GF2_GMAX * R), o_uw = carve(sizeof(u64) * GF2_GMAX * (S.maxr + 64)),
 		             o_pf = carve(sizeof(u64) * GF2_GMAX * GF2_GMAX * 64), o_opr = carve(sizeof(int) * GF2_OUTER_LISTS * S.nlist),
 		             o_tm = carve(S.tl_K ? S.nlist * sizeof(u64) * GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX : 0),
-		             o_pc = carve(S.use_pc ? sizeof(u64) * 2 * GF2_GMAX * 64 * (size_t)S.ntiles : 0);
+		             o_pc = carve(S.use_pc ? sizeof(u64) * 2 * GF2_GMAX * 64 * (size_t)S.ntiles : 0),
+		             o_wm = carve(sizeof(u64) * 2 * (size_t)((R + 63) / 64 + 1));
 		S.arena_stride = off;
 		S.sync_base = 0;
 		HIPCHK(pool().alloc(&S.arena, off * S.nsys, S.device));
@@ -749,6 +757,7 @@ int solver_alloc(Solver &S)
 		S.urow = (int *)(base + o_urow); S.blk_first = (int *)(base + o_blk); S.mult = (u64 *)(base + o_mult);
 		S.Wb = (u64 *)(base + o_wb); S.Uwin = (u64 *)(base + o_uw); S.Pfast = (u64 *)(base + o_pf); S.oprow = (int *)(base + o_opr); S.Tm = (u64 *)(base + o_tm);
 		S.Pc = S.use_pc ? (u64 *)(base + o_pc) : nullptr;
+		S.wmask = (u64 *)(base + o_wm);
 		// zero everything that is read before it is written: state, panel records, unit scratch, block bounds, multipliers
 		for (int s = 0; s < S.nsys; s++) {
 			char *b = base + (size_t)s * off;
@@ -921,11 +930,28 @@ int panel_handover(Solver &S, int b)      // general panel steps: a launch for t
 	return GF2BV_OK;
 }
 
-int enqueue_block_panel(Solver &S, int b, bool fast_only = false)
+int enqueue_block_panel(Solver &S, int b, bool fast_only = false, bool sparse = false)
 {
 	const BlockGeom g = block_geom(S, b);
 	const unsigned row_blocks = (unsigned)((S.rows + 255) / 256);
 	u64 *const half[2] = { S.Wb, S.Wb + (i64)GF2_GMAX * S.rows };
+	if (fast_only && sparse) {
+		// sparse systems: the pool of the search = alive rows with a non-zero window (wmask, left by the look-ahead of the block before)
+		if (S.sparse_giveups == 0)
+			k_block_sparse<256, 4><<<dim3(1, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, 1, b, (const u64 *)half[0], S.st, S.died,
+			                                                                 S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, (const u64 *)S.wmask, S.ss());
+		else          // (after a give-up: the pool of 4096 rows)
+			k_block_sparse<512, 8><<<dim3(1, S.nsys), dim3(512), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, 1, b, (const u64 *)half[0], S.st, S.died,
+			                                                                 S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, (const u64 *)S.wmask, S.ss());
+		hipExtLaunchKernelGGL(k_narrow_all, dim3((row_blocks + S.narrow_rpt - 1) / S.narrow_rpt, S.nsys), dim3(256), 0, S.sA, nullptr,
+		                      S.ext_events && !S.flag_sync ? S.evA[b] : nullptr, 0, (const u64 *)S.M, S.rows, S.srows, g.j0, b, (const u64 *)half[0],
+		                      (const SolveState *)S.st, (const int *)S.died, (const PanelAux *)S.aux, g.mset, S.impl->T, S.narrow_rpt,
+		                      S.flag_sync ? DoneSignal{ &S.sf->cnt_narrow, &S.sf->narrow_done, S.sync_base + b + 1 } : DoneSignal{}, S.ss());
+		HIPCHK(hipGetLastError());
+		if (S.flag_sync) return GF2BV_OK;
+		if (!S.ext_events) HIPCHK(hipEventRecord(S.evA[b], S.sA));
+		return GF2BV_OK;
+	}
 	if (fast_only && S.fused_narrow && S.nsys == 1) {
 		// search + narrow step in one launch: workgroup 0 searches, the others narrow each panel as soon as it is formed
 		// (single systems: a gang is throughput-bound, and its ~130 x nsys narrowing workgroups would hold their LDS for the whole
@@ -1044,7 +1070,7 @@ int enqueue_block_prio(Solver &S, int b)
 	}
 	k_prio_window<<<dim3(row_blocks, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, g.wlo, std::max(g.gnext, 1),
 	                                                             S.panels, S.aux, g.mset, S.blk_first + b, S.Wb, S.Uwin,
-	                                                             S.impl->T, S.st, S.ss());
+	                                                             S.impl->T, S.st, S.ss(), (const int *)S.died, S.sparse_on ? S.wmask : (u64 *)nullptr);
 	HIPCHK(hipGetLastError());
 	return GF2BV_OK;
 }
@@ -1317,15 +1343,59 @@ int enqueue_forward(Solver &S)
 		// rows left when the block starts: at most 64 leftover candidates sit below the bound besides the pivots found
 		return fast_block_possible(S, block_geom(S, blk)) && S.rows - (i64)blk * 64 * S.impl->G >= GF2_FAST_NC + 128;
 	};
+	// Sparse systems (round 5): when block 0 did NOT take the dense search, the following full blocks get k_block_sparse + k_narrow_all
+	// instead of the G + 1 general panel steps (one-level schedules only; the look-ahead of every block leaves the masks the next
+	// block's pool is taken from).  A block it cannot take poisons the panel path like a failed optimistic block: the host resumes
+	// there with the general steps for THAT block and goes on sparse behind it (three times at most, then general to the end).
+	const bool may_sparse = may_probe && S.sparse_fast && S.tl_K == 0;
+	int general_only = -1;                      // (resume) this one block takes the general steps whatever the mode
+	auto sparse_ok = [&](int blk) { return S.sparse_on && blk != general_only && fast_block_possible(S, block_geom(S, blk)); };
+	// after a poisoned block pb: everything in flight drained, the plan cut back to what has run, the counters rebased
+	auto recover = [&](int pb) -> int {
+		if (S.sC) HIPCHK(hipStreamSynchronize(S.sC));
+		HIPCHK(hipStreamSynchronize(S.sB));
+		// (two-level: the outer panels before the poisoned one are complete; the published blocks of the poisoned panel have been
+		// applied to its own tiles by the bulk kernels and to everything right of it by its outer pass -- every tile has seen
+		// exactly the blocks before pb -- so the rest runs as a one-level schedule)
+		if (S.tl_K && pb < S.tl_bend) S.tl_bend = pb / S.tl_K * S.tl_K;
+		if (S.sp_bend > S.tl_bend) S.sp_bend = S.tl_bend;       // (never entered again: the resumed blocks run one level)
+		S.bulk_waits_outer = false;
+		HIPCHK(hipMemsetAsync(&S.st->poison, 0, sizeof(int), S.sA));
+		S.sync_base += S.nblocks + 1;
+		return GF2BV_OK;
+	};
+	// the first block of each pool size is looked at before anything is enqueued behind it: a pool that cannot serve the system (too
+	// many rows carry a bit in a window) costs one block, not a poisoned pipeline of all the blocks behind it
+	int sparse_probes = 1;
 	auto one_block = [&](int blk) -> int {
 		int r;
-		if ((r = enqueue_block_panel(S, blk, optimistic && fast_only_ok(blk)))) return r;
+		bool sp = sparse_ok(blk);
+		if ((r = enqueue_block_panel(S, blk, sp || (optimistic && fast_only_ok(blk)), sp))) return r;
+		if (sp && sparse_probes > 0) {
+			sparse_probes--;
+			HIPCHK(hipMemcpyAsync(&hst, S.st, sizeof hst, hipMemcpyDeviceToHost, S.sA));
+			HIPCHK(hipStreamSynchronize(S.sA));
+			if (hst.poison) {
+				if ((r = recover(blk))) return r;
+				if (++S.sparse_giveups >= 2) S.sparse_on = false; else sparse_probes = 1;      // (the larger pool gets one look, too)
+				general_only = blk;
+				if ((r = enqueue_block_panel(S, blk, false, false))) return r;
+			}
+		}
 		if ((r = enqueue_block_bulk(S, blk))) return r;
 		if ((r = enqueue_block_prio(S, blk))) return r;
 		if (blk == 0 && may_probe) {
 			HIPCHK(hipMemcpyAsync(&hst, S.st, sizeof hst, hipMemcpyDeviceToHost, S.sA));
 			HIPCHK(hipStreamSynchronize(S.sA));
 			optimistic = hst.fast_done == 1;
+			if (!optimistic && may_sparse && S.nblocks > 1) {
+				// block 1's window is in place (the look-ahead above ran without masks): its masks by a launch of their own
+				S.sparse_on = true;
+				const BlockGeom g1 = block_geom(S, 1);
+				k_window_masks<<<dim3((unsigned)((S.rows + 255) / 256), S.nsys), dim3(256), 0, S.sA>>>((const u64 *)S.Wb, S.rows, g1.gb, (const int *)S.died, S.wmask,
+				                                                                                      (const SolveState *)S.st, S.ss());
+				HIPCHK(hipGetLastError());
+			}
 		}
 		return GF2BV_OK;
 	};
@@ -1379,22 +1449,17 @@ int enqueue_forward(Solver &S)
 		if ((rc = one_block(b))) return rc;
 	if ((rc = enqueue_forward_join(S))) return rc;
 	tr.mark("forward: all blocks submitted");          // (host side only: the device is still working; what follows waits for it)
-	if (optimistic) {
+	while (optimistic || S.sparse_on) {
 		HIPCHK(hipMemcpyAsync(&hst, S.st, sizeof hst, hipMemcpyDeviceToHost, S.sA));
 		HIPCHK(hipStreamSynchronize(S.sA));
-		if (hst.poison) {                               // a block the fast search could not take: resume there, both paths
+		if (!hst.poison) break;
+		{                                               // a block the fast search could not take: resume there, both paths
 			const int pb = hst.poison - 1;
-			if (S.sC) HIPCHK(hipStreamSynchronize(S.sC));
-			HIPCHK(hipStreamSynchronize(S.sB));
-			// (two-level: the outer panels before the poisoned one are complete; the published blocks of the poisoned panel have been
-			// applied to its own tiles by the bulk kernels and to everything right of it by its outer pass -- every tile has seen
-			// exactly the blocks before pb -- so the rest runs as a one-level schedule)
-			if (S.tl_K && pb < S.tl_bend) S.tl_bend = pb / S.tl_K * S.tl_K;
-			if (S.sp_bend > S.tl_bend) S.sp_bend = S.tl_bend;       // (never entered again: the resumed blocks run one level)
-			S.bulk_waits_outer = false;
-			HIPCHK(hipMemsetAsync(&S.st->poison, 0, sizeof(int), S.sA));
-			S.sync_base += S.nblocks + 1;
+			if ((rc = recover(pb))) return rc;
 			optimistic = false;
+			if (S.sparse_on && ++S.sparse_giveups > 2) S.sparse_on = false;
+			general_only = pb;
+			// (the poisoned block's window is in place; the blocks behind it take their masks from the look-aheads again)
 			for (b = pb; b < S.nblocks; b++)
 				if ((rc = one_block(b))) return rc;
 			if ((rc = enqueue_forward_join(S))) return rc;
@@ -2854,6 +2919,15 @@ int gf2bv_device_download(int device, void *h_dst, const void *d_src, int64_t by
 	return GF2BV_OK;
 }
 
+#ifdef GF2_SPARSE_DEBUG
+extern "C" int gf2bv_sparse_probe_read(unsigned long long *w, int reset)
+{
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpyFromSymbol(w, HIP_SYMBOL(gf2_sparse_probe), sizeof(gf2_sparse_probe)));
+	if (reset) { unsigned long long z[8] = { 0 }; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gf2_sparse_probe), z, sizeof z)); }
+	return GF2BV_OK;
+}
+#endif
 #ifdef GF2_STEP_PROBE
 // Probe build only (tools/probe_step.py): choose the block whose panel steps are recorded, fetch the records.
 int gf2bv_probe_set(int j0)

@@ -110,6 +110,32 @@ def test_two_level_elimination_forced_on_small_systems(monkeypatch, K, chain):
     # the default plan (no forcing) on a system large enough to take outer panels is covered by test_target_262144_properties
 
 
+@pytest.mark.parametrize("sparse", ["1", "0"])
+def test_sparse_block_search(monkeypatch, sparse):
+    """Round 5: systems whose first block the dense one-launch search cannot take go through k_block_sparse -- the pool = alive rows
+    with a non-zero window (bit masks left by the look-ahead), a parallel selection of 64 independent rows per panel, then the dense
+    body.  Sparse systems of 0.1-3 % density with rows >= cols and rows >> cols, shuffled, with rank caps (a panel the pool cannot
+    complete: the search gives up, the host resumes that block with the general steps and goes on sparse), inconsistent ones, both
+    modes, flags and events; GF2BV_SPARSE_FAST=0: the same systems through the general steps only.  Against the oracle."""
+    monkeypatch.setenv("GF2BV_SPARSE_FAST", sparse)
+    rng = random.Random(77)
+    shapes = [(5000, 4600, .002, None, True, 0), (9000, 4100, .004, None, True, 0), (6000, 5200, .01, None, True, 100),
+              (5200, 5000, .03, None, True, 0), (7000, 4200, .003, 3000, True, 0), (7000, 4200, .003, 3000, False, 0),
+              (12000, 3100, .001, None, True, 0), (4700, 4600, .0015, None, True, 0)]
+    took = 0
+    for i, (rows, cols, density, cap, cons, zr) in enumerate(shapes):
+        eqs = random_system(rng, rows, cols, density, cap, cons, zr)
+        if i % 2 == 0:
+            rng.shuffle(eqs)
+        aug = O.eqs_to_aug(eqs, cols)
+        monkeypatch.setenv("GF2BV_FLAG_SYNC", "0" if i % 3 == 2 else "1")
+        for mode in ((0, 1) if i < 3 else (i % 2,)):
+            got = hip.solve_words(aug, rows, cols, mode)
+            _same(got, O.solve_words(aug, rows, cols, mode), mode)
+            took += got.stats["fast_blocks"]
+    assert took > 0 or sparse == "0"           # (GF2BV_SPARSE_FAST=0: the dense search may still take the densest systems' later blocks)
+
+
 @pytest.mark.parametrize("K,P,L", [(2, 2, 0), (2, 2, 1), (2, 2, 2), (2, 4, 2), (3, 2, 1), (2, 3, 0), (4, 2, 3), (2, 2, -1)])
 def test_three_level_elimination_forced_on_small_systems(monkeypatch, K, P, L):
     """Round 5: super-panels of P outer panels of K blocks (GF2BV_THREE_LEVEL=P with GF2BV_TWO_LEVEL=K) -- inside a super-panel the
