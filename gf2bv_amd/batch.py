@@ -60,6 +60,27 @@ def gather_records(local: torch.Tensor, nsys: int, group=None) -> torch.Tensor:
     return out
 
 
+def rank_plan(total: int, n: int, world: int, rank: int, hbm_bytes: int = 288 * 10 ** 9) -> dict:
+    """What rank `rank` of `world` does in the batch job of `total` independent n x n systems -- WITHOUT touching a GPU (bench.py
+    --dry-run-ranks; the gang size comes from the library's own planner, gf2bv_plan_gang): its block of systems, the gangs it runs
+    them in, where its records land in the gathered table, and what it keeps resident in HBM."""
+    from . import hip
+    lo, hi = shard_bounds(total, world, rank)
+    nsys = hi - lo
+    stride = hip.padded_stride(n)
+    in_bytes = nsys * n * stride * 8
+    free_b = max(0, hbm_bytes - in_bytes)
+    gang = int(hip.lib().gf2bv_plan_gang(nsys, n, n, free_b)) if nsys else 0
+    gangs = [(lo + g0, min(hi, lo + g0 + gang)) for g0 in range(0, nsys, gang)] if gang else []
+    work = gang * n * stride * 8                       # one gang's tile-major working copies (the library pools up to six such buffers)
+    rw = record_words(n)
+    return {"rank": rank, "device": rank, "systems": [lo, hi], "gang_size": gang, "gangs": gangs, "host_threads": min(2, max(1, len(gangs))),
+            "record_words": rw, "record_rows_in_gathered_table": [lo, hi], "record_bytes": nsys * rw * 8,
+            "all_gather_rows_per_rank": (total + world - 1) // world,
+            "resident_bytes": {"inputs": in_bytes, "working_per_gang": work, "pool_cap": min(48 << 30, hbm_bytes // 6),
+                               "peak_estimate": in_bytes + 3 * work + 3 * (work // 8)}, "hbm_bytes": hbm_bytes}
+
+
 def synth_shard(n: int, seeds: list, device_index: int, mats: torch.Tensor | None = None) -> torch.Tensor:
     """This rank's block of synthetic n x n systems, generated in HBM on torch's current stream (asynchronous)."""
     from . import hip

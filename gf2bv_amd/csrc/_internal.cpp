@@ -385,7 +385,8 @@ struct DigitGather {
 	std::vector<int64_t> off = std::vector<int64_t>(1, 0);    // off[r] .. off[r+1]: digits of row r
 	std::vector<const uint32_t *> src;                         // first digit of row r
 	uint32_t *digits = nullptr;
-	~DigitGather() { free(digits); }
+	bool pinned = false;                                       // digits came from gf2bv_host_alloc (page-locked, recycled)
+	~DigitGather() { if (pinned) gf2bv_host_free(digits); else free(digits); }
 	bool add(PyObject *list, Py_ssize_t cols)
 	{
 		const Py_ssize_t need = (cols + 1 + PyLong_SHIFT - 1) / PyLong_SHIFT;
@@ -406,7 +407,11 @@ struct DigitGather {
 	bool gather()
 	{
 		const size_t total = (size_t)off.back();
-		digits = static_cast<uint32_t *>(malloc((total + 1) * sizeof(uint32_t)));
+		// page-locked staging from the library when the copy is worth a DMA of its own (no GPU, or no pinned memory left: malloc)
+		void *hp = nullptr;
+		if ((total + 1) * sizeof(uint32_t) >= (256u << 10) && gf2bv_host_alloc((int64_t)((total + 1) * sizeof(uint32_t)), &hp) == GF2BV_OK && hp) {
+			digits = static_cast<uint32_t *>(hp); pinned = true;
+		} else digits = static_cast<uint32_t *>(malloc((total + 1) * sizeof(uint32_t)));
 		if (!digits) { PyErr_NoMemory(); return false; }
 		const size_t rows = src.size();
 		auto copy_rows = [this](size_t a, size_t b) {

@@ -368,6 +368,15 @@ __global__ void k_probe_wait(int *flag, int *result, unsigned long long ticks)
 	*result = ok ? 1 : 2;
 }
 __global__ void k_probe_set(int *flag) { GF2_ST(flag, 1); }
+// Which XCD does workgroup b of a one-dimensional launch land on?  (XCC_ID, hardware register 20 of the gfx940 family, bits 3:0.)
+// The gang bulk update places a system per XCD on the ASSUMPTION b -> XCD b % 8 (k_update16: xcd_nsys); the host checks it once per
+// device with this kernel and falls back to the plain grid where it does not hold (another partition mode, a driver that dispatches
+// differently): see xcd_dispatch_is_round_robin.
+__global__ void __launch_bounds__(64)
+k_probe_xcc(int *out)
+{
+	if (threadIdx.x == 0) out[blockIdx.x] = (int)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u);
+}
 __global__ void __launch_bounds__(64)
 k_gate(SyncFlags *__restrict__ sf, SolveState *__restrict__ st, int set_narrow, int set_bulk, int need_narrow, int need_bulk,
        SysStride ss)

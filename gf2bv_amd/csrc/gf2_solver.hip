@@ -291,6 +291,7 @@ Pool &pool()
 // ---- kernel configurations -----------------------------------------------------------------
 // Bulk update: G panels fused per HBM pass, T grease tables per panel (balanced bit-fields).
 int streams_run_concurrently(int device, hipStream_t a, hipStream_t b, int *ok);
+int xcd_dispatch_is_round_robin(int device, hipStream_t st, int *ok);
 void forget_concurrency(int device);
 
 struct UpdateImpl {
@@ -467,7 +468,6 @@ struct Solver {
 	int xcd_wgs = 32;
 	bool nt_gang = true, nt_single = false;     // streaming (non-temporal) row accesses of the bulk update: pinned gangs (GF2BV_GANG_NT=0: plain) /
 	                                            // single systems (GF2BV_SINGLE_NT=1, an experiment: <= 1 %)
-	bool gang_two_level = false;  // GF2BV_GANG_TWO_LEVEL=1: outer panels for gangs too (measured slower: DESIGN 7)
 	bool gang_bs = true;          // GF2BV_GANG_BS=0: one back-substitution chain per system of a gang, as rounds 1-3
 	// sparse systems (round 5): blocks the dense one-launch search cannot take go through k_block_sparse -- candidates = the alive rows
 	// with a non-zero window, from the bit masks the look-ahead leaves in wmask (GF2BV_SPARSE_FAST=0: the general panel steps)
@@ -609,12 +609,13 @@ void plan_two_level(Solver &S)
 	// (a column-slab handle -- ext_M, at world size 1 too -- is driven block by block through slab_factor_on / slab_apply_on, which
 	// know nothing of outer panels: with a plan it would skip the look-ahead at every panel end and never run an outer pass)
 	if (S.world != 1 || S.ext_M || S.impl->G != GF2_GMAX) return;
-	// gangs (round 4): every outer kernel takes blockIdx.y = system, and GF2BV_GANG_TWO_LEVEL=1 gives a gang the same plan with
-	// its matrices taken together -- bit-exact (tests/test_gpu_stress.py), but NOT the default: 192 x 32768^2 ran 4.4 ms per
-	// system against 3.9 on the one-level schedule (profiles/r04_batch_scans.txt): a gang's inner elimination is a chain of
-	// all-rows launches of thousands of workgroups that do not fit beside k_update16k (217 VGPRs), so the chain and the pass
-	// wait for each other instead of overlapping.
-	if (S.nsys != 1 && !(getenv("GF2BV_GANG_TWO_LEVEL") && atoi(getenv("GF2BV_GANG_TWO_LEVEL")) != 0)) return;
+	// gangs keep the one-level schedule.  Round 4 built outer panels for gangs (every outer kernel takes blockIdx.y = system) as an
+	// opt-in, bit-exact and slower: 4.4 against 3.9 ms per system; round 5 measured it again on the final gang layout (a system per
+	// XCD, streaming row accesses, gangs of 32 and of 8): 3.50-3.60 against 3.20-3.29 ms per system of 32768^2, K = 4 / 8 / 12 and
+	// thresholds alike (profiles/r05_batch_scans.txt) -- a gang's inner elimination is a chain of all-rows launches of thousands of
+	// workgroups that do not fit beside k_update16k, so chain and pass wait for each other instead of overlapping.  The knob
+	// (GF2BV_GANG_TWO_LEVEL) and its test are gone with round 5.
+	if (S.nsys != 1) return;
 	// outer panels of 12 blocks from 3 GiB up, of 8 below: the outer pass gains with K (isolated 5.20 / 5.30 / 5.38 TB/s of
 	// sweep-words for K = 8 / 10 / 12), the inner elimination and the T chain grow with it -- 262144^2 1.303 -> 1.269 s,
 	// 196608^2 566 -> 557 ms, 393216^2 4.26 -> 4.13 s, but 131072^2 184.0 -> 185.3 ms (profiles/r03_two_level.txt)
@@ -711,6 +712,12 @@ int solver_alloc(Solver &S)
 	if (const char *e = getenv("GF2BV_SPARSE_FAST")) S.sparse_fast = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_PC")) S.use_pc = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_XCD_PIN")) S.xcd_pin = atoi(e) != 0;
+	else if (S.nsys >= 8 && S.nsys % 8 == 0) {           // a gang that would be pinned: is the dispatch order what the pinning assumes?
+		int ok = 0;
+		int rc = xcd_dispatch_is_round_robin(S.device, S.sA, &ok);
+		if (rc) return rc;
+		S.xcd_pin = ok != 0;
+	}
 	if (const char *e = getenv("GF2BV_XCD_WGS")) S.xcd_wgs = std::min(256, std::max(1, atoi(e)));
 	if (const char *e = getenv("GF2BV_GANG_NT")) S.nt_gang = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_SINGLE_NT")) S.nt_single = atoi(e) != 0;
@@ -815,6 +822,34 @@ int streams_run_concurrently(int device, hipStream_t a, hipStream_t b, int *ok)
 	int h[2] = { 0, 0 };
 	HIPCHK(hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost));
 	*ok = known[device] = (h[1] == 1);
+	return GF2BV_OK;
+}
+
+// Does workgroup b of a one-dimensional launch sit on XCD b % 8 on this device?  The gang bulk update keeps a system's multipliers
+// in ONE XCD's L2 on that assumption (speed only: results do not depend on it).  Asked once per device with k_probe_xcc -- 64
+// workgroups report their XCC_ID: b and b + 8 must agree, 0..7 must differ.  Where it does not hold the gangs take the plain
+// (spans, systems) grid of rounds 1-3.  GF2BV_XCD_PIN=1 / 0 skips the question.
+int xcd_dispatch_is_round_robin(int device, hipStream_t st, int *ok)
+{
+	static std::mutex mu;
+	static std::map<int, int> known;
+	std::lock_guard<std::mutex> lk(mu);
+	auto it = known.find(device);
+	if (it != known.end()) { *ok = it->second; return GF2BV_OK; }
+	int *d = nullptr;
+	HIPCHK(pool().alloc((void **)&d, 64 * sizeof(int), device));
+	struct Free { int *p; ~Free() { pool().release(p); } } guard{d};
+	int h[64];
+	int good = 1;
+	for (int rep = 0; rep < 2 && good; rep++) {          // (twice: the second launch starts where the first one left the dispatcher)
+		k_probe_xcc<<<dim3(64), dim3(64), 0, st>>>(d);
+		HIPCHK(hipGetLastError());
+		HIPCHK(hipMemcpyAsync(h, d, sizeof h, hipMemcpyDeviceToHost, st));
+		HIPCHK(hipStreamSynchronize(st));
+		for (int b = 0; b < 64; b++) if (h[b] != h[b & 7]) good = 0;
+		for (int a = 0; a < 8; a++) for (int b = a + 1; b < 8; b++) if (h[a] == h[b]) good = 0;
+	}
+	*ok = known[device] = good;
 	return GF2BV_OK;
 }
 
@@ -1833,8 +1868,8 @@ int solve_gang(Solver &S, gf2bv_result **out)
 	return GF2BV_OK;
 }
 
-// Gang size for nsys same-shape systems.
-i64 pick_gang(i64 nsys, i64 rows, i64 cols)
+// Gang size for nsys same-shape systems (free_b: free device memory, < 0 = ask the current device).
+i64 pick_gang(i64 nsys, i64 rows, i64 cols, i64 free_bytes = -1)
 {
 	// gang size: ~4.5 GiB of working matrices per gang (32768^2: 32 systems -- round 4: 192 x 32768^2 run 3.22 ms per system in gangs
 	// of 32 against 3.22-3.32 in gangs of 24, and 512 systems are 16 equal gangs instead of 21 + a part gang; 4096^2: 64), at
@@ -1858,7 +1893,8 @@ i64 pick_gang(i64 nsys, i64 rows, i64 cols)
 	gang = std::max<i64>(1, std::min<i64>(gang, nsys));
 	{
 		size_t free_b = 0, total_b = 0;
-		if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+		if (free_bytes >= 0) gang = std::max<i64>(1, std::min<i64>(gang, (i64)(0.4 * (double)free_bytes / per_sys)));
+		else if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
 			gang = std::max<i64>(1, std::min<i64>(gang, (i64)(0.4 * (double)free_b / per_sys)));
 	}
 	return gang;
@@ -2808,6 +2844,13 @@ int gf2bv_kernel_resources(int device, int32_t *out, int n)
 		HIPCHK(hipFuncGetAttributes(&a, (const void *)k_block_fast_narrow));
 		out[13] = a.numRegs; out[14] = (int32_t)a.sharedSizeBytes;
 	}
+	if (n >= 20) {                 // round 5: the sparse block search (first pool size: beside the bulk update), the product kernel of the
+		hipFuncAttributes a{};     // three-level elimination (registers, LDS, scratch: must not spill)
+		HIPCHK(hipFuncGetAttributes(&a, (const void *)k_block_sparse<256, 4>));
+		out[15] = a.numRegs; out[16] = (int32_t)a.sharedSizeBytes;
+		HIPCHK(hipFuncGetAttributes(&a, (const void *)k_mul16k<GF2_KSEG, false>));
+		out[17] = a.numRegs; out[18] = (int32_t)a.sharedSizeBytes; out[19] = (int32_t)a.localSizeBytes;
+	}
 	return GF2BV_OK;
 	});
 }
@@ -2881,6 +2924,73 @@ int gf2bv_device_alloc(int device, int64_t bytes, void **d_ptr)
 	if (e != hipSuccess) return fail(GF2BV_ERR_NOMEM, "hipMalloc", e);
 	return GF2BV_OK;
 }
+// ---- pinned host staging for bindings (round 5) ------------------------------------------------------------------------------
+// A binding that has to assemble its input on the host (the CPython shim copies every equation's ob_digit array into one buffer)
+// gets that buffer here: page-locked, so the host-to-device copy of gf2bv_solve_digits is ONE DMA instead of the runtime's
+// chunk-by-chunk staging of pageable memory, and recycled between calls (no page faults on a fresh 50 MB allocation every call).
+// Up to four idle buffers are kept (256 MiB in all at most); larger ones are freed on return.
+namespace {
+struct HostPool {
+	std::mutex mu;
+	struct Buf { void *p; size_t bytes; };
+	std::vector<Buf> idle;
+	std::unordered_map<void *, size_t> live;
+};
+HostPool &host_pool() { static HostPool *p = new HostPool(); return *p; }
+}
+int gf2bv_host_alloc(int64_t bytes, void **h_ptr)
+{
+	if (!h_ptr || bytes < 0) return fail(GF2BV_ERR_ARG, "bad alloc request");
+	*h_ptr = nullptr;
+	const size_t need = std::max<size_t>((size_t)bytes, 64);
+	HostPool &P = host_pool();
+	{
+		std::lock_guard<std::mutex> lk(P.mu);
+		for (size_t i = 0; i < P.idle.size(); i++)
+			if (P.idle[i].bytes >= need && P.idle[i].bytes <= 2 * need + ((size_t)1 << 20)) {
+				*h_ptr = P.idle[i].p; P.live[*h_ptr] = P.idle[i].bytes;
+				P.idle.erase(P.idle.begin() + i);
+				return GF2BV_OK;
+			}
+	}
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(GF2BV_ERR_NODEVICE, "no HIP device visible");
+	void *p = nullptr;
+	const size_t cap = need + need / 8;
+	hipError_t e = hipHostMalloc(&p, cap, hipHostMallocDefault);
+	if (e != hipSuccess) { (void)hipGetLastError(); return fail(GF2BV_ERR_NOMEM, "hipHostMalloc", e); }
+	std::lock_guard<std::mutex> lk(P.mu);
+	P.live[p] = cap;
+	*h_ptr = p;
+	return GF2BV_OK;
+}
+void gf2bv_host_free(void *h_ptr)
+{
+	if (!h_ptr) return;
+	HostPool &P = host_pool();
+	void *drop = nullptr;
+	{
+		std::lock_guard<std::mutex> lk(P.mu);
+		auto it = P.live.find(h_ptr);
+		if (it == P.live.end()) return;
+		const size_t bytes = it->second;
+		P.live.erase(it);
+		size_t kept = 0;
+		for (const auto &b : P.idle) kept += b.bytes;
+		if (P.idle.size() < 4 && kept + bytes <= ((size_t)256 << 20)) P.idle.push_back({ h_ptr, bytes });
+		else drop = h_ptr;
+	}
+	if (drop) (void)hipHostFree(drop);
+}
+
+// The gang size gf2bv_solve_batch_* would choose for nsys systems of rows x cols with free_bytes of device memory free -- a pure
+// function (no device is touched): bench.py --dry-run-ranks prints every rank's plan of the multi-GPU batch job with it.
+int64_t gf2bv_plan_gang(int64_t nsys, int64_t rows, int64_t cols, int64_t free_bytes)
+{
+	if (nsys <= 0 || rows <= 0 || cols <= 0 || free_bytes < 0) return 0;
+	return pick_gang(nsys, rows, cols, free_bytes);
+}
+
 int64_t gf2bv_pool_trim(int device)
 {
 	if (check_device(device)) return -1;

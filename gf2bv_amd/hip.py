@@ -37,7 +37,7 @@ EXPORTS = [
     "gf2bv_synth_device", "gf2bv_residual_device",
     "gf2bv_stream_ceiling_device", "gf2bv_lds_clock_device", "gf2bv_kernel_resources",
     "gf2bv_device_alloc", "gf2bv_device_free", "gf2bv_device_upload", "gf2bv_device_download",
-    "gf2bv_pool_trim", "gf2bv_pool_idle_bytes",
+    "gf2bv_pool_trim", "gf2bv_pool_idle_bytes", "gf2bv_host_alloc", "gf2bv_host_free", "gf2bv_plan_gang",
 ]
 
 
@@ -126,6 +126,11 @@ def lib():
         L.gf2bv_device_free.argtypes = [i32, vp]
         L.gf2bv_device_upload.argtypes = [i32, vp, vp, i64]
         L.gf2bv_device_download.argtypes = [i32, vp, vp, i64]
+        L.gf2bv_host_alloc.argtypes = [i64, pp]
+        L.gf2bv_host_free.argtypes = [vp]
+        L.gf2bv_host_free.restype = None
+        L.gf2bv_plan_gang.argtypes = [i64, i64, i64, i64]
+        L.gf2bv_plan_gang.restype = i64
         L.gf2bv_pool_trim.argtypes = [i32]
         L.gf2bv_pool_trim.restype = i64
         L.gf2bv_pool_idle_bytes.argtypes = [i32]
@@ -336,12 +341,14 @@ def lds_clock(device: int = 0) -> dict:
 
 def kernel_resources(device: int = 0) -> dict:
     """VGPRs per lane and static LDS bytes of the bulk-update kernel and of the panel kernels that run beside it."""
-    out = (ctypes.c_int32 * 15)()
-    _check(lib().gf2bv_kernel_resources(device, out, 15))
+    out = (ctypes.c_int32 * 20)()
+    _check(lib().gf2bv_kernel_resources(device, out, 20))
     names = ("update", "block_fast", "narrow_all", "prio_window", "panel_step")
     res = {nm: {"vgprs": int(out[2 * k]), "lds": int(out[2 * k + 1])} for k, nm in enumerate(names)}
     res["update_outer"] = {"vgprs": int(out[10]), "lds": int(out[11]), "scratch": int(out[12])}      # k_update16k (two-level)
     res["block_fast_narrow"] = {"vgprs": int(out[13]), "lds": int(out[14])}                          # search + narrow step in one launch
+    res["block_sparse"] = {"vgprs": int(out[15]), "lds": int(out[16])}                               # k_block_sparse<256, 4> (round 5)
+    res["product"] = {"vgprs": int(out[17]), "lds": int(out[18]), "scratch": int(out[19])}           # k_mul16k (three-level, round 5)
     return res
 
 

@@ -255,7 +255,9 @@ int gf2bv_lds_clock_device(int device, double *shader_mhz, double *lds_bytes_per
  * instance, then k_block_fast, k_narrow_all, k_prio_window, k_panel_step (registers, LDS each; n >= 10).  A test holds the
  * budget: registers <= 512 - 2 x round_up(update's, 8), LDS <= 160 KiB - update's.  With n >= 13: out[10..12] = registers,
  * LDS and SCRATCH bytes per lane of k_update16k, the outer pass of the two-level elimination (it keeps 16 row segments per
- * lane in registers: scratch must be 0).  With n >= 15: out[13..14] = registers, LDS of k_block_fast_narrow. */
+ * lane in registers: scratch must be 0).  With n >= 15: out[13..14] = registers, LDS of k_block_fast_narrow.  With n >= 20:
+ * out[15..16] = registers, LDS of k_block_sparse<256, 4> (the sparse block search, first pool size: beside the bulk update like
+ * every panel kernel), out[17..19] = registers, LDS, scratch of k_mul16k (the product of the three-level elimination). */
 int gf2bv_kernel_resources(int device, int32_t *out, int n);
 
 /* plain device buffer helpers so a host language without a HIP binding can stage data.  gf2bv_device_alloc: when the device
@@ -266,6 +268,13 @@ int gf2bv_device_upload(int device, void *d_dst, const void *h_src, int64_t byte
 int gf2bv_device_download(int device, void *h_dst, const void *d_src, int64_t bytes);
 
 
+/* Page-locked host staging for bindings that assemble their input on the host (the CPython shim gathers every equation's digit
+ * array -- gf2bv/_internal.c:403-426 walks them bit by bit instead -- into ONE buffer before gf2bv_solve_digits): the
+ * host-to-device copy out of such a buffer is a single DMA, and the buffers are recycled between calls (up to four idle ones,
+ * 256 MiB in all).  Any host pointer remains valid input for every entry point; this is an optimisation, not a requirement. */
+int  gf2bv_host_alloc(int64_t bytes, void **h_ptr);
+void gf2bv_host_free(void *h_ptr);
+
 /* ---- the buffer pool (see "Threading" at the top) ----------------------------------------------- */
 /* Frees every IDLE buffer the pool keeps on `device` (large working buffers and the small-buffer cache; nothing a running
  * solve holds).  Returns the bytes given back to the device, -1 without a usable device.  A caller that shares the GPU
@@ -273,6 +282,9 @@ int gf2bv_device_download(int device, void *h_dst, const void *d_src, int64_t by
 int64_t gf2bv_pool_trim(int device);
 /* Bytes of idle buffers the pool currently keeps on `device` (what gf2bv_pool_trim would free). */
 int64_t gf2bv_pool_idle_bytes(int device);
+/* The gang size gf2bv_solve_batch_* would choose for `nsys` systems of rows x cols with `free_bytes` of device memory free: a pure
+ * function, no device is touched (bench.py --dry-run-ranks: every rank's plan of the multi-GPU batch job, testable without GPUs). */
+int64_t gf2bv_plan_gang(int64_t nsys, int64_t rows, int64_t cols, int64_t free_bytes);
 
 #ifdef __cplusplus
 }

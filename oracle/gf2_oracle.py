@@ -32,8 +32,25 @@ def build(force: bool = False) -> str:
     so = os.path.join(_HERE, "libgf2oracle.so")
     src = os.path.join(_HERE, "gf2_oracle.c")
     if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libgf2oracle.so"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libgf2oracle.so", "libgf2m4ritime.so"])
     return so
+
+
+def m4ri_time(n: int) -> dict:
+    """True M4RI (mzd_pluq + mzd_pluq_solve_left on an n x n mzd_randomize matrix) timed through libgf2m4ritime.so, when the box has
+    a libm4ri.so; {"found": False} otherwise (every box so far).  bench.py's cpu_baseline leg reports it beside the port."""
+    so = os.path.join(_HERE, "libgf2m4ritime.so")
+    src = os.path.join(_HERE, "m4ri_timing.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "libgf2m4ritime.so"])
+    L = ctypes.CDLL(so)
+    sp, ss, rk = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_int(0)
+    name = ctypes.create_string_buffer(128)
+    rc = L.gf2o_m4ri_time(ctypes.c_int(n), ctypes.byref(sp), ctypes.byref(ss), ctypes.byref(rk), name, 128)
+    if rc != 0:
+        return {"found": False, "why": "no libm4ri.so on this host" if rc == 1 else "libm4ri.so lacks an expected symbol"}
+    return {"found": True, "library": name.value.decode(), "n": n, "seconds_pluq": sp.value, "seconds_solve_left": ss.value, "rank": rk.value,
+            "input": "mzd_randomize (M4RI's generator), not the synthetic generator: a timing, not a parity pin"}
 
 
 def lib():

@@ -66,3 +66,30 @@ def test_two_rank_gather_matches_single_process(nsys):
     want = _solve_block(n, [1000 + i for i in range(nsys)])
     assert got.shape == want.shape and np.array_equal(got, want)
     assert (got[:, 0] == 0).all()
+
+
+@pytest.mark.parametrize("world,total", [(8, 512), (4, 512), (8, 509)])
+def test_bench_dry_run_ranks_world_8_real_numbers(world, total):
+    """Round 5: `bench.py --gpus 8 --dry-run-ranks` under torch.distributed.run with gloo -- every rank's plan of
+    the configs[3] job (512 x 32768^2) without a GPU: the blocks tile the job in rank order, the gangs tile each block, the record
+    rows of the one all_gather do not overlap, and what a rank keeps resident (inputs + three gangs' working copies + the pool's
+    cap) fits one MI355X."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--dry-run-ranks", "--batch-total", str(total)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert res.returncode == 0, res.stderr[-2000:]
+    d = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["blocks_tile_the_job"] and d["gangs_tile_each_block"] and d["fits_in_hbm"] and len(d["ranks"]) == world
+    rows = [tuple(p["record_rows_in_gathered_table"]) for p in d["ranks"]]
+    assert rows == [batch.shard_bounds(total, world, r) for r in range(world)]
+    for p in d["ranks"]:
+        n = p["systems"][1] - p["systems"][0]
+        assert p["device"] == p["rank"] and p["gang_size"] >= 8 and p["gang_size"] % 8 == 0      # a system per XCD needs multiples of 8
+        assert sum(b - a for a, b in p["gangs"]) == n and p["record_bytes"] == n * batch.record_words(32768) * 8

@@ -570,13 +570,15 @@ def test_panel_kernels_fit_beside_the_bulk_update():
     upd = res["update"]
     free_vgprs = 512 - 2 * ((upd["vgprs"] + 7) // 8 * 8)
     free_lds = 160 * 1024 - upd["lds"]
-    for name in ("block_fast", "narrow_all", "prio_window", "panel_step", "block_fast_narrow"):
+    for name in ("block_fast", "narrow_all", "prio_window", "panel_step", "block_fast_narrow", "block_sparse"):
         assert res[name]["vgprs"] <= free_vgprs, (name, res)
         assert res[name]["lds"] <= free_lds, (name, res)
     # the outer pass of the two-level elimination keeps 16 row segments per lane in registers: it must not spill (a spilled
     # build ran 30 x slower and still gave the right bits) and two of its wavefronts must fit a SIMD
     outer = res["update_outer"]
     assert outer["scratch"] == 0 and outer["vgprs"] <= 256 and outer["lds"] <= 160 * 1024, outer
+    prod = res["product"]            # (round 5) the product kernel of the three-level elimination: the same loop, the same budget
+    assert prod["scratch"] == 0 and prod["vgprs"] <= 256 and prod["lds"] <= 160 * 1024, prod
 
 
 def test_stream_ceiling_reports_sane_rates():

@@ -169,39 +169,6 @@ def test_three_level_elimination_forced_on_small_systems(monkeypatch, K, P, L):
     assert took > 0                           # the plan was taken
 
 
-@pytest.mark.parametrize("K,gang,chain", [(2, 5, 0), (3, 2, 0), (4, 5, 0), (8, 3, 0), (3, 5, 1)])
-def test_two_level_elimination_of_a_gang(monkeypatch, K, gang, chain):
-    """Round 4: gangs take outer panels too (every outer kernel with blockIdx.y = system).  GF2BV_TWO_LEVEL=K forces them onto
-    gangs of small systems whose members differ in everything the outer kernels read per system -- full rank, rank caps inside
-    and at the edge of an outer panel (a member with NO pivots in some of the panel's blocks), sparse, all-zero, inconsistent --
-    both modes, events and flags, against the oracle; then the same gang with GF2BV_GANG_TWO_LEVEL=0 (the one-level schedule, the
-    default for gangs: the two-level plan is an opt-in there)."""
-    monkeypatch.setenv("GF2BV_TWO_LEVEL", str(K))
-    monkeypatch.setenv("GF2BV_GANG_TWO_LEVEL", "1")
-    monkeypatch.setenv("GF2BV_OUTER_CHAIN", str(chain))
-    monkeypatch.setenv("GF2BV_GANG", str(gang))
-    rng = random.Random(400 + K)
-    rows, cols = 2900, 2700
-    caps = [(None, .5, True), (256 * K, .5, True), (256 * K + 70, .5, False), (1000, .5, True), (None, .01, True), (1, .5, True),
-            (cols - 1, .5, True)]
-    systems = [random_system(rng, rows, cols, d, cap, cons, 0) for cap, d, cons in caps] + [[0] * rows]
-    augs = np.stack([O.eqs_to_aug(e, cols) for e in systems])
-    wants = {mode: [O.solve_words(a, rows, cols, mode) for a in augs] for mode in (0, 1)}
-    for flag in ("1", "0"):
-        monkeypatch.setenv("GF2BV_FLAG_SYNC", flag)
-        for mode in (0, 1):
-            got = hip.solve_batch_words(augs, rows, cols, mode)
-            for g, w in zip(got, wants[mode]):
-                _same(g, w, mode)
-            assert all(g.stats["handover_retries"] == 0 for g in got)
-    assert got[0].stats["outer_blocks"] > 0          # the plan was taken
-    monkeypatch.setenv("GF2BV_GANG_TWO_LEVEL", "0")
-    got = hip.solve_batch_words(augs, rows, cols, 0)
-    for g, w in zip(got, wants[0]):
-        _same(g, w, 0)
-    assert got[0].stats["outer_blocks"] == 0
-
-
 @pytest.mark.parametrize("inv", ["1", "0"])
 def test_back_substitution_with_inverted_diagonal_blocks(monkeypatch, inv):
     """Round 4: from four groups of 16 panels up the back-substitution inverts the diagonal blocks up front (k_bs_inv) and a link
