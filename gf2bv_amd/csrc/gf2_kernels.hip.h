@@ -1377,7 +1377,7 @@ struct SparseLds {
 	int srcs[GF2_GMAX][64];                  // [panel][pivot column] -> index into srcw (of that panel)
 	int srow_all[GF2_GMAX][64];              // [panel][index into srcw] -> row
 	u64 have;
-	int wsum[8], min_free, min_zero, ok, chunk_ok;
+	int wsum[16], min_free, min_zero, ok, chunk_ok;
 };
 #ifdef GF2_SPARSE_DEBUG
 __device__ unsigned long long gf2_sparse_probe[8];      // ticks (100 MHz) in: pool, selection, gj, tables + narrow, publish

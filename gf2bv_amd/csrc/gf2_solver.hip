@@ -975,9 +975,12 @@ int enqueue_block_panel(Solver &S, int b, bool fast_only = false, bool sparse = 
 		if (S.sparse_giveups == 0)
 			k_block_sparse<256, 4><<<dim3(1, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, 1, b, (const u64 *)half[0], S.st, S.died,
 			                                                                 S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, (const u64 *)S.wmask, S.ss());
-		else          // (after a give-up: the pool of 4096 rows)
+		else if (S.sparse_giveups == 1)          // (after a give-up: the pool of 4096 rows)
 			k_block_sparse<512, 8><<<dim3(1, S.nsys), dim3(512), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, 1, b, (const u64 *)half[0], S.st, S.died,
-			                                                                 S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, (const u64 *)S.wmask, S.ss());
+			                                                                S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, (const u64 *)S.wmask, S.ss());
+		else          // (after two: 6144 rows -- 1024 threads at 128 registers, the candidates' words partly in scratch: slow, but still ahead of five general steps)
+			k_block_sparse<1024, 6><<<dim3(1, S.nsys), dim3(1024), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, 1, b, (const u64 *)half[0], S.st, S.died,
+			                                                                  S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, (const u64 *)S.wmask, S.ss());
 		hipExtLaunchKernelGGL(k_narrow_all, dim3((row_blocks + S.narrow_rpt - 1) / S.narrow_rpt, S.nsys), dim3(256), 0, S.sA, nullptr,
 		                      S.ext_events && !S.flag_sync ? S.evA[b] : nullptr, 0, (const u64 *)S.M, S.rows, S.srows, g.j0, b, (const u64 *)half[0],
 		                      (const SolveState *)S.st, (const int *)S.died, (const PanelAux *)S.aux, g.mset, S.impl->T, S.narrow_rpt,
@@ -1412,7 +1415,7 @@ int enqueue_forward(Solver &S)
 			HIPCHK(hipStreamSynchronize(S.sA));
 			if (hst.poison) {
 				if ((r = recover(blk))) return r;
-				if (++S.sparse_giveups >= 2) S.sparse_on = false; else sparse_probes = 1;      // (the larger pool gets one look, too)
+				if (++S.sparse_giveups >= 3) S.sparse_on = false; else sparse_probes = 1;      // (the larger pools get one look each, too)
 				general_only = blk;
 				if ((r = enqueue_block_panel(S, blk, false, false))) return r;
 			}
@@ -1492,7 +1495,7 @@ int enqueue_forward(Solver &S)
 			const int pb = hst.poison - 1;
 			if ((rc = recover(pb))) return rc;
 			optimistic = false;
-			if (S.sparse_on && ++S.sparse_giveups > 2) S.sparse_on = false;
+			if (S.sparse_on && ++S.sparse_giveups > 3) S.sparse_on = false;
 			general_only = pb;
 			// (the poisoned block's window is in place; the blocks behind it take their masks from the look-aheads again)
 			for (b = pb; b < S.nblocks; b++)
