@@ -120,6 +120,7 @@ struct SolveState {
 	// panel g's reduced pivot rows are in Pfast, 8 blk + 5 once the block is published (monotone over a solve)
 	int fast_pub;
 	int sp_chunk;        // k_block_sparse: 0 = the "first 64 rows with a bit in the panel" attempt completed the last panel it was tried on
+	int sp_nz;           // k_block_sparse: alive rows with a non-zero window that its last launch counted (the host picks the pool size by it)
 };
 
 // Hand-over between the panel stream and the bulk stream through memory instead of events.  An event wait costs a
@@ -600,7 +601,7 @@ __device__ __forceinline__ u64 gj_columns(FindState &S, u64 w, int row, int lane
 }
 
 __device__ __forceinline__ u64 find_absorb(FindState &S, u64 w, int row, u64 colmask, int lane, int *srow_out,
-                                           int sparse_mode)
+                                           int sparse_mode, int few_max = GF2_FEW_MISSING)
 {
 	u64 c = 0, took = 0;
 	// Only columns some candidate actually has can matter -- in sparse systems (MT19937: a handful of bits
@@ -617,7 +618,7 @@ __device__ __forceinline__ u64 find_absorb(FindState &S, u64 w, int row, u64 col
 	// column c is w[c] ^ parity(w & z_c), z_c = the lanes whose basis vector has bit c -- one ballot and a
 	// popcount per missing column; only a row that becomes a pivot is reduced in full, as an XOR over the
 	// wavefront (lane b contributes its vector if the row has bit b).
-	if (S.have && __popcll(colmask & ~S.have) <= GF2_FEW_MISSING) {
+	if (S.have && __popcll(colmask & ~S.have) <= few_max) {
 		u64 todo = colmask & ~S.have;
 		int myslot = -1;
 		while (todo) {
@@ -1365,6 +1366,7 @@ __device__ __forceinline__ int block_fast_body(FastLds &F, u64 *__restrict__ M, 
 //             nibble tables, PanelAux, the narrow step of the pool.
 // Gives up (fast_off, poison when no general steps are enqueued behind it) when the pool cannot complete a panel.
 #define GF2_SP_NW 1024                                  /* mask words looked at from the alive bound on (65536 rows) */
+#define GF2_SP_NE 512                                   /* candidates with a bit in the panel that the selection on wavefront 0 looks at */
 template <int NC>
 struct SparseLds {
 	StepLds L;
@@ -1378,6 +1380,7 @@ struct SparseLds {
 	int srow_all[GF2_GMAX][64];              // [panel][index into srcw] -> row
 	u64 have;
 	int wsum[16], min_free, min_zero, ok, chunk_ok;
+	unsigned char colof[GF2_SP_NE];           // compacted entry -> basis column + 1 it supplies (selection on wavefront 0)
 };
 #ifdef GF2_SPARSE_DEBUG
 __device__ unsigned long long gf2_sparse_probe[8];      // ticks (100 MHz) in: pool, selection, gj, tables + narrow, publish
@@ -1452,6 +1455,7 @@ k_block_sparse(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fas
 		if (z && zmin == 0x7fffffff) zmin = (int)wbase + ctz64(z);
 	}
 	if (zmin != 0x7fffffff) atomicMin(&F.min_zero, zmin);
+	if (t == 0) st->sp_nz = base;
 	__syncthreads();
 	const int have_c = base < NC ? base : NC;
 	if (have_c < 64 * GF2_GMAX) { give_up(2, have_c); return; }      // (uniform) fewer candidates than pivots
@@ -1480,50 +1484,62 @@ k_block_sparse(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fas
 		// runs that determine a panel (examples/mt.py with whole words per output) and for anything dense; tried while it worked on
 		// the panel before (st->sp_chunk: 0 = try)
 		bool done = false;
+		// compaction of the candidates that have a bit in the panel, in pool order: pos[k] of this thread's candidates, basec of them in
+		// all; the words of the first GF2_SP_NE go to LDS for the selection on wavefront 0
+		int pos[CPT];
+		int basec = 0;
+		u64 *const selw = L.Tn;                               // (the nibble tables' space is free until the pivot rows are formed)
+		if (t < GF2_SP_NE / 4) reinterpret_cast<unsigned *>(F.colof)[t] = 0;
+#pragma unroll
+		for (int k = 0; k < CPT; k++) {
+			u64 w = 0;
+#pragma unroll
+			for (int e = 0; e < GF2_GMAX; e++) if (e == g) w = cw[k][e];
+			const bool nzc = (((validk & ~usedk) >> k) & 1) && w != 0;
+			const u64 bal = __ballot(nzc);
+			__syncthreads();
+			if (lane == 0) F.wsum[wv] = __popcll(bal);
+			__syncthreads();
+			int c = basec, tot = 0;
+#pragma unroll
+			for (int v = 0; v < NWV; v++) { if (v < wv) c += F.wsum[v]; tot += F.wsum[v]; }
+			pos[k] = nzc ? c + __popcll(bal & lanemask_lt(lane)) : 0x7fffffff;
+			if (pos[k] < GF2_SP_NE) selw[pos[k]] = w;
+			basec += tot;
+		}
+		if (basec < 64) { give_up(5, basec); return; }       // (uniform) fewer rows with a bit in the panel than it has columns
+		// (A) wavefront 0: the first 64 entries through gj_columns (column-wise, ~3.7 us: complete for systems whose rows come in runs
+		// that determine a panel and for anything dense), then the following chunks of 64 entries through the TARGETED completion of
+		// find_absorb (only the missing columns are looked at: a candidate's reduced bit at a missing column is w[c] ^ parity(w & z_c)
+		// against the fully reduced basis) until all 64 columns have a pivot.  Slots = columns; a source is remembered by its entry.
 		if (try_chunk) {
-			int pos[CPT];
-			int basec = 0;
-#pragma unroll
-			for (int k = 0; k < CPT; k++) {
-				u64 w = 0;
-#pragma unroll
-				for (int e = 0; e < GF2_GMAX; e++) if (e == g) w = cw[k][e];
-				const bool nzc = (((validk & ~usedk) >> k) & 1) && w != 0;
-				const u64 bal = __ballot(nzc);
-				__syncthreads();
-				if (lane == 0) F.wsum[wv] = __popcll(bal);
-				__syncthreads();
-				int c = basec, tot = 0;
-#pragma unroll
-				for (int v = 0; v < NWV; v++) { if (v < wv) c += F.wsum[v]; tot += F.wsum[v]; }
-				pos[k] = nzc ? c + __popcll(bal & lanemask_lt(lane)) : 0x7fffffff;
-				basec += tot;
+			const int ne = basec < GF2_SP_NE ? basec : GF2_SP_NE;
+			__syncthreads();
+			if (wv == 0) {
+				FindState S;
+				S.bw = 0; S.bc = 0; S.have = 0; S.nslots = 0; S.colslots = false; S.srow = 0;
+				(void)gj_columns(S, lane < ne ? selw[lane] : 0ull, lane, lane);
+				for (int c0 = 64; c0 < ne && S.nslots < 64; c0 += 64)
+					(void)find_absorb(S, c0 + lane < ne ? selw[c0 + lane] : 0ull, c0 + lane, ~0ull, lane, (int *)nullptr, 0, 64);
+				if (lane == 0) F.chunk_ok = S.nslots == 64;
+				if (S.nslots == 64) {
+					F.combs[g][lane] = S.bc; F.srcs[g][lane] = lane; L.Cm[lane] = S.bc;
+					F.colof[S.srow] = (unsigned char)(lane + 1);
+				}
 			}
-			if (basec >= 64) {                                  // (uniform)
+			__syncthreads();
+			done = F.chunk_ok != 0;
+			if (done) {
 #pragma unroll
 				for (int k = 0; k < CPT; k++)
-					if (pos[k] < 64) {
+					if (pos[k] < GF2_SP_NE && F.colof[pos[k]]) {
+						const int bcol = F.colof[pos[k]] - 1;
 #pragma unroll
-						for (int e = 0; e < GF2_GMAX; e++) F.srcw[pos[k]][e] = cw[k][e];
-						F.srcrow[pos[k]] = F.crow[t + NT * k];
+						for (int e = 0; e < GF2_GMAX; e++) F.srcw[bcol][e] = cw[k][e];
+						F.srcrow[bcol] = F.crow[t + NT * k];
+						usedk |= 1u << k;
 					}
-				__syncthreads();
-				if (wv == 0) {
-					u64 w = 0;
-#pragma unroll
-					for (int e = 0; e < GF2_GMAX; e++) if (e == g) w = F.srcw[lane][e];
-					FindState S;
-					S.bw = 0; S.bc = 0; S.have = 0; S.nslots = 0; S.colslots = false; S.srow = 0;
-					(void)gj_columns(S, w, lane, lane);
-					if (lane == 0) F.chunk_ok = S.nslots == 64;
-					if (S.nslots == 64) { F.combs[g][lane] = S.bc; F.srcs[g][lane] = S.srow; L.Cm[lane] = S.bc; }
-				}
-				__syncthreads();
-				done = F.chunk_ok != 0;
-				if (done) {
-#pragma unroll
-					for (int k = 0; k < CPT; k++) if (pos[k] < 64) usedk |= 1u << k;
-				}
+				__syncthreads();                              // (srcw / srcrow are read by other threads right below)
 			}
 			try_chunk = done;
 			SP_PROBE(5);

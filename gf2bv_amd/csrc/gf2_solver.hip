@@ -474,6 +474,7 @@ struct Solver {
 	bool sparse_fast = true;      // allowed at all
 	bool sparse_on = false;       // this solve has switched to it (after block 0 went the general way)
 	int sparse_giveups = 0;
+	int sparse_tier = 0;          // pool size of k_block_sparse: 0 = 1024 rows (beside the bulk update), 1 = 4096, 2 = 6144
 	u64 *wmask = nullptr;         // 2 x ceil(rows / 64) words: alive / alive with a non-zero window, per 64 rows
 	bool fused_narrow = true;     // optimistic blocks: search and narrow step in ONE launch (k_block_fast_narrow); GF2BV_FUSED_NARROW=0: two
 	int narrow_rpt = 1;           // row blocks of 256 per narrow workgroup of a panel step (set in solver_alloc; GF2BV_NARROW_RPT)
@@ -972,10 +973,10 @@ int enqueue_block_panel(Solver &S, int b, bool fast_only = false, bool sparse = 
 	u64 *const half[2] = { S.Wb, S.Wb + (i64)GF2_GMAX * S.rows };
 	if (fast_only && sparse) {
 		// sparse systems: the pool of the search = alive rows with a non-zero window (wmask, left by the look-ahead of the block before)
-		if (S.sparse_giveups == 0)
+		if (S.sparse_tier == 0)
 			k_block_sparse<256, 4><<<dim3(1, S.nsys), dim3(256), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, 1, b, (const u64 *)half[0], S.st, S.died,
 			                                                                 S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, (const u64 *)S.wmask, S.ss());
-		else if (S.sparse_giveups == 1)          // (after a give-up: the pool of 4096 rows)
+		else if (S.sparse_tier == 1)             // (after a give-up, or when the first block counted more rows than the small pool holds: 4096 rows)
 			k_block_sparse<512, 8><<<dim3(1, S.nsys), dim3(512), 0, S.sA>>>(S.M, S.rows, S.srows, g.j0, g.gb, 1, b, (const u64 *)half[0], S.st, S.died,
 			                                                                S.panels, S.aux, S.pivcol, S.urow, S.blk_first + b, (const u64 *)S.wmask, S.ss());
 		else          // (after two: 6144 rows -- 1024 threads at 128 registers, the candidates' words partly in scratch: slow, but still ahead of five general steps)
@@ -1413,12 +1414,19 @@ int enqueue_forward(Solver &S)
 			sparse_probes--;
 			HIPCHK(hipMemcpyAsync(&hst, S.st, sizeof hst, hipMemcpyDeviceToHost, S.sA));
 			HIPCHK(hipStreamSynchronize(S.sA));
+			// the pool for the blocks behind this one: a search that counted far more rows with a bit in its window than the middle pool
+			// holds goes straight to the largest (MT19937, one bit per output: 4500-5000).  Otherwise the SMALL pool stays while it works,
+			// truncated or not -- it is the one that fits beside the bulk update, and the first 1024 candidate rows usually hold a panel's
+			// pivots (measured: 17 / 1337 / 137 bits per output count 1100-1560 rows and run 7.4 / 6.3 / 6.7 ms on the small pool, 7.9 /
+			// 7.1 / 7.4 on the middle one); a pool that does not gives up and the next size takes over
+			const int want = hst.sp_nz > 3400 ? 2 : 0;
 			if (hst.poison) {
 				if ((r = recover(blk))) return r;
 				if (++S.sparse_giveups >= 3) S.sparse_on = false; else sparse_probes = 1;      // (the larger pools get one look each, too)
+				S.sparse_tier = std::min(2, std::max(S.sparse_tier + 1, want));
 				general_only = blk;
 				if ((r = enqueue_block_panel(S, blk, false, false))) return r;
-			}
+			} else S.sparse_tier = std::max(S.sparse_tier, want);
 		}
 		if ((r = enqueue_block_bulk(S, blk))) return r;
 		if ((r = enqueue_block_prio(S, blk))) return r;
@@ -1496,6 +1504,7 @@ int enqueue_forward(Solver &S)
 			if ((rc = recover(pb))) return rc;
 			optimistic = false;
 			if (S.sparse_on && ++S.sparse_giveups > 3) S.sparse_on = false;
+			S.sparse_tier = std::min(2, S.sparse_tier + 1);
 			general_only = pb;
 			// (the poisoned block's window is in place; the blocks behind it take their masks from the look-aheads again)
 			for (b = pb; b < S.nblocks; b++)
