@@ -13,20 +13,25 @@ configs = ["0", "1", "2", "3", "4", "5"]          # instances of k_update16 (GF2
 knobs = [{}, {}, {"GF2BV_FAST": "0"}, {"GF2BV_OPTIMISTIC": "0"}, {"GF2BV_SELF_WAIT_US": "0"}, {"GF2BV_FLAG_SYNC": "0"},
          {"GF2BV_TWO_LEVEL": "2"}, {"GF2BV_TWO_LEVEL": "3"}, {"GF2BV_TWO_LEVEL": "4"}, {"GF2BV_TWO_LEVEL": "8"}, {"GF2BV_TWO_LEVEL": "2", "GF2BV_FLAG_SYNC": "0"},
          # round 4: systems that fit the LDS take the one-launch kernel unless GF2BV_SMALL=0; its input by copy or straight from pinned memory
-         {"GF2BV_SMALL": "0"}, {"GF2BV_SMALL": "0"}, {"GF2BV_SMALL_ZC": "0"}, {"GF2BV_SMALL_ZC": "1"}]
+         {"GF2BV_SMALL": "0"}, {"GF2BV_SMALL": "0"}, {"GF2BV_SMALL_ZC": "0"}, {"GF2BV_SMALL_ZC": "1"},
+         # round 5: the sparse block search off; super-panels (three-level elimination) of 2 / 3 outer panels with 0-2 Strassen-Winograd levels
+         {"GF2BV_SPARSE_FAST": "0"}, {"GF2BV_TWO_LEVEL": "2", "GF2BV_THREE_LEVEL": "2"}, {"GF2BV_TWO_LEVEL": "2", "GF2BV_THREE_LEVEL": "2", "GF2BV_STRASSEN": "1"},
+         {"GF2BV_TWO_LEVEL": "2", "GF2BV_THREE_LEVEL": "3", "GF2BV_STRASSEN": "0"}, {"GF2BV_TWO_LEVEL": "3", "GF2BV_THREE_LEVEL": "2", "GF2BV_STRASSEN": "2"},
+         {"GF2BV_TWO_LEVEL": "2", "GF2BV_THREE_LEVEL": "2", "GF2BV_FLAG_SYNC": "0"}]
 t0, n, worst = time.time(), 0, 0
 while time.time() - t0 < budget:
     cols = rng.choice([rng.randint(1, 130), rng.randint(131, 700), rng.randint(700, 2600), 64 * rng.randint(1, 40), 256 * rng.randint(1, 10) + rng.choice([-1, 0, 1]),
-                       rng.randint(2048, 4200)])               # (>= 8 blocks: the optimistic enqueue and its resume path)
+                       rng.randint(2048, 4200), rng.randint(2048, 6200)])               # (>= 8 blocks: the optimistic enqueue, the sparse search and their resume paths)
     cols = max(cols, 1)
     rows = cols + rng.choice([0, 1, rng.randint(0, 64), rng.randint(0, cols), rng.randint(0, 3 * cols)])
-    density = rng.choice([0.5, 0.5, 0.1, 0.02, 0.004])
+    density = rng.choice([0.5, 0.5, 0.1, 0.02, 0.004, 0.0015])
     cap = rng.choice([None, None, rng.randint(1, cols), max(1, cols - rng.randint(0, 5))])
     consistent = rng.random() < 0.8
     zero_rows = rng.choice([0, 0, rng.randint(0, rows // 2)])
     mode = rng.randint(0, 1)
     os.environ["GF2BV_UPDATE"] = rng.choice(configs)
-    for k in ("GF2BV_FAST", "GF2BV_OPTIMISTIC", "GF2BV_SELF_WAIT_US", "GF2BV_FLAG_SYNC", "GF2BV_TWO_LEVEL", "GF2BV_SMALL", "GF2BV_SMALL_ZC"):
+    for k in ("GF2BV_FAST", "GF2BV_OPTIMISTIC", "GF2BV_SELF_WAIT_US", "GF2BV_FLAG_SYNC", "GF2BV_TWO_LEVEL", "GF2BV_SMALL", "GF2BV_SMALL_ZC",
+              "GF2BV_SPARSE_FAST", "GF2BV_THREE_LEVEL", "GF2BV_STRASSEN"):
         os.environ.pop(k, None)
     os.environ.update(rng.choice(knobs))
     eqs = random_system(rng, rows, cols, density, cap, consistent, min(zero_rows, rows - 1))
