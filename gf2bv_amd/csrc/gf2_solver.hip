@@ -1300,6 +1300,17 @@ int enqueue_super_panel_finish(Solver &S, hipStream_t so, int B0, int B1)
 	// buffers: B, and the temporaries of the levels (the first super-panel is the largest)
 	const size_t slack = kOuterSlackBytes / 16;
 	const size_t needB = (size_t)nb * T_all * 256;
+	// (buffers only ever grow at the first super-panel -- shapes shrink from there -- but nothing is handed back under a running product)
+	bool grow = S.spB_elems < needB || (int)S.sp_t.size() < L;
+	{
+		i64 r = R; i64 t = Ts; int n = nb;
+		for (int d = 0; d < L && d < (int)S.sp_t.size(); d++) {
+			r /= 2; t /= 2; n /= 2;
+			const Solver::SpTemps &q = S.sp_t[d];
+			grow = grow || q.ns < (size_t)n * r * 2 || q.nt < (size_t)n * t * 256 || q.nc < (size_t)r * t;
+		}
+	}
+	if (grow && S.sp_products > 0) HIPCHK(hipStreamSynchronize(so));
 	if (S.spB_elems < needB) {
 		pool().release(S.spB); S.spB = nullptr; S.spB_elems = 0;
 		HIPCHK(pool().alloc((void **)&S.spB, needB * 16 + kOuterSlackBytes, S.device));

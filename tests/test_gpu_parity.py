@@ -707,3 +707,26 @@ def _dense_properties(n, seed, repeat=True):
         assert np.array_equal(again.origin, sol.origin) and again.rank == sol.rank
     buf.free()
     return sol
+
+
+def test_pinned_host_staging_is_recycled():
+    """Round 5: gf2bv_host_alloc hands a binding page-locked staging for its digit gather and keeps up to four idle buffers: the same
+    pages come back for the next call of the same size; a solve out of such a buffer equals the solve out of pageable memory."""
+    import ctypes
+    L = hip.lib()
+    p1, p2 = ctypes.c_void_p(), ctypes.c_void_p()
+    assert L.gf2bv_host_alloc(8 << 20, ctypes.byref(p1)) == 0 and p1.value
+    L.gf2bv_host_free(p1)
+    assert L.gf2bv_host_alloc(8 << 20, ctypes.byref(p2)) == 0 and p2.value == p1.value
+    rng = random.Random(3)
+    rows, cols = 1500, 1400
+    eqs = random_system(rng, rows, cols, .5, 1300, True, 0)
+    aug = O.eqs_to_aug(eqs, cols)
+    want = hip.solve_words(aug, rows, cols, 1)
+    buf = (ctypes.c_uint64 * aug.size).from_address(p2.value)
+    np.frombuffer(buf, dtype=np.uint64)[:] = aug.reshape(-1)
+    res = ctypes.c_void_p()
+    assert L.gf2bv_solve_words(p2.value, rows, cols, aug.shape[1], 1, 0, ctypes.byref(res)) == 0
+    got = hip._take(res, 1)
+    L.gf2bv_host_free(p2)
+    assert got.rank == want.rank and np.array_equal(got.origin, want.origin) and np.array_equal(got.basis, want.basis)
