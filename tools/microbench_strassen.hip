@@ -17,132 +17,11 @@
 #include <vector>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-struct CV { uint4 *p; i64 ts; };            // tile t, row r: p[t * ts + r]
-struct AV { const uint4 *p; i64 bs; };      // block k, row r: p[k * bs + 2 r], p[k * bs + 2 r + 1]
-struct BV { const uint4 *p; i64 bs; };      // block k, tile t, pivot i: p[k * bs + 256 t + i]
-
-// Base case: every item = (tile, chunk of SEG x 512 rows); a lane keeps SEG row segments in registers through all nb blocks.
-// (The body is k_update16k's without the pivot-row indirection, the alive filter and the row clamps: R is a whole number of chunks.)
-template <int SEG, bool ZERO>
-__global__ void __launch_bounds__(512)
-k_mul16k(CV C, i64 R, int ntiles, AV A, BV B, int nb)
-{
-	constexpr int NT = 512, NW = 8;
-	__shared__ __attribute__((aligned(256))) uint4 tab[2 * 256 * 16];
-	__shared__ uint4 stage[GF2_GMAX * 64];
-	if ((unsigned)(size_t)tab != 0u) __builtin_trap();
-	const int lane = threadIdx.x & 63;
-	const unsigned ulane = (unsigned)lane;
-	const int wvu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	unsigned KC[6];
-	{
-		const int rq_lo = lane & 7, rq_hi = (lane >> 3) & 1;
-#pragma unroll
-		for (int v = 0; v < 6; v++) {
-			unsigned k = 1u << 24;
-#pragma unroll
-			for (int b = 0; b < 3; b++) {
-				const int s = 3 * v + b;
-				if (s < 16) k |= (unsigned)(16 * (8 * ((s >> 3) ^ rq_hi) + (((s & 7) + rq_lo) & 7))) << (8 * b);
-			}
-			asm volatile("" : "+v"(k));
-			KC[v] = k;
-		}
-	}
-	constexpr i64 CH = (i64)SEG * NT;
-	const i64 nch = R / CH;
-	const i64 items = nch * ntiles;
-	for (i64 it = blockIdx.x; it < items; it += gridDim.x) {
-		uint4 *Mw = C.p + (it / nch) * C.ts;
-		const i64 rb0 = (it % nch) * CH + (i64)wvu * 64;
-		uint4 *Mrow = Mw + rb0;
-		uint4 d[SEG];
-#pragma unroll
-		for (int j = 0; j < SEG; j++) d[j] = ZERO ? make_uint4(0, 0, 0, 0) : (Mrow + j * (NW * 64))[ulane];
-		const uint4 *Bt = B.p + (it / nch) * 256;
-		uint4 staged = make_uint4(0, 0, 0, 0);
-		if (threadIdx.x < GF2_GMAX * 64) staged = Bt[threadIdx.x];
-#pragma unroll 1
-		for (int k = 0; k < nb; k++) {
-			__syncthreads();
-			if (threadIdx.x < GF2_GMAX * 64) stage[threadIdx.x] = staged;
-			__syncthreads();
-			for (int e = threadIdx.x; e < 2 * 31 * 16; e += NT) {
-				const int sub = e & 15, q = (e >> 4) % 31, grp = (e >> 4) / 31;
-				const int idx = q <= 15 ? q : (q - 15) << 4;
-				const uint4 *st = stage + (2 * grp + (sub >> 3)) * 64 + 8 * (sub & 7);
-				uint4 acc = make_uint4(0, 0, 0, 0);
-				int bits = idx;
-				while (bits) { const int l = __ffs(bits) - 1; bits &= bits - 1; acc = xor4(acc, st[l]); }
-				tab[grp * 4096 + idx * 16 + sub] = acc;
-			}
-			__syncthreads();
-			for (int e = threadIdx.x; e < 2 * 225 * 16; e += NT) {
-				const int sub = e & 15, q = (e >> 4) % 225, grp = (e >> 4) / 225;
-				const int lo = 1 + q % 15, hi = (1 + q / 15) << 4;
-				uint4 *tb = tab + grp * 4096 + sub;
-				tb[(lo | hi) * 16] = xor4(tb[lo * 16], tb[hi * 16]);
-			}
-			if (k + 1 < nb && threadIdx.x < GF2_GMAX * 64) staged = Bt[(i64)(k + 1) * B.bs + threadIdx.x];
-			__syncthreads();
-			uint4 m0[2], m1[2];
-			const uint4 *mrow = A.p + (i64)k * A.bs + rb0 * 2;
-			auto loadm = [&](int j, int slot) {
-				const uint4 *mr = mrow + (j < SEG ? j : SEG - 1) * (NW * 64 * 2);
-				m0[slot] = mr[2 * ulane]; m1[slot] = mr[2 * ulane + 1];
-			};
-			auto issue = [&](u32x4 *v, const uint4 &a0, const uint4 &a1, int r) {
-				const unsigned mw[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
-				const int grp = r >> 1, hf = r & 1;
-#pragma unroll
-				for (int q = 0; q < 8; q++) {
-					const int s = 8 * hf + q;
-					const unsigned sel = (unsigned)(s % 3) | ((4u + (unsigned)(q & 3)) << 8) | ((grp ? 3u : 12u) << 16) | (12u << 24);
-					const unsigned at = __builtin_amdgcn_perm(mw[2 * (2 * grp + hf) + (q >> 2)], KC[s / 3], sel);
-					v[q] = *(lds_u4_ptr)(size_t)at;
-				}
-			};
-			auto fold = [&](uint4 &acc, const u32x4 *v) {
-#pragma unroll
-				for (int h = 0; h < 4; h++) {
-					acc.x = __builtin_amdgcn_bitop3_b32(acc.x, v[2 * h].x, v[2 * h + 1].x, 0x96);
-					acc.y = __builtin_amdgcn_bitop3_b32(acc.y, v[2 * h].y, v[2 * h + 1].y, 0x96);
-					acc.z = __builtin_amdgcn_bitop3_b32(acc.z, v[2 * h].z, v[2 * h + 1].z, 0x96);
-					acc.w = __builtin_amdgcn_bitop3_b32(acc.w, v[2 * h].w, v[2 * h + 1].w, 0x96);
-				}
-			};
-			u32x4 va[8], vb[8];
-			loadm(0, 0); loadm(1, 1);
-			issue(va, m0[0], m1[0], 0);
-#pragma unroll
-			for (int j = 0; j < SEG; j++) {
-				const int c = j & 1;
-				issue(vb, m0[c], m1[c], 1); fold(d[j], va);
-				issue(va, m0[c], m1[c], 2); fold(d[j], vb);
-				issue(vb, m0[c], m1[c], 3); fold(d[j], va);
-				const uint4 n0 = m0[c ^ 1], n1 = m1[c ^ 1];
-				loadm(j + 2, c);
-				issue(va, n0, n1, 0); fold(d[j], vb);
-			}
-		}
-#pragma unroll
-		for (int j = 0; j < SEG; j++) (Mrow + j * (NW * 64))[ulane] = d[j];
-	}
-}
-
-// additions: one 16-byte element per thread, non-temporal (the fastest in-place / copy form this chip has);
-// element i of outer slice o at p[o * stride + i]
-__global__ void __launch_bounds__(256)
-k_xor(uint4 *X, i64 xs, const uint4 *Y, i64 ys, const uint4 *Z, i64 zs, const uint4 *W, i64 ws, i64 inner)
-{
-	const i64 i = (i64)blockIdx.x * 256 + threadIdx.x, o = blockIdx.y;
-	if (i >= inner) return;
-	u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Y + o * ys + i));
-	const u32x4 b = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Z + o * zs + i));
-	a ^= b;
-	if (W) a ^= __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(W + o * ws + i));
-	__builtin_nontemporal_store(a, reinterpret_cast<u32x4 *>(X + o * xs + i));
-}
+// operand views and kernels: the solver's own (gf2_kernels.hip.h, "THREE-LEVEL ELIMINATION"): MulC / MulA / MulB, k_mul16k, k_xor16
+typedef MulC CV;
+typedef MulA AV;
+typedef MulB BV;
+#define k_xor k_xor16
 
 static double g_add_bytes = 0, g_mul_words = 0;
 static int g_base_launches = 0;
