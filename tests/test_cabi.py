@@ -94,3 +94,25 @@ def test_product_never_imports_oracle():
     for head in (("from oracle import".join(parts[:k])) for k in range(1, len(parts))):
         assert head.rsplit("\ndef ", 1)[-1].startswith("cpu_baseline"), head.rsplit("\ndef ", 1)[-1][:40]
     assert "oracle" not in bench.split("def timed_single")[1].split("def run_single")[0]      # the timed region itself
+
+
+def test_round5_entry_points_without_a_device():
+    """The planning / pool / staging entry points of round 5 on a box without a GPU: the gang planner is a pure function, the pool
+    calls report "no device" instead of touching one, pinned staging is refused (the binding then falls back to malloc), and the
+    optional true-M4RI timing says that there is no libm4ri here."""
+    import ctypes
+    L = hip.lib()
+    # 64 systems of 32768^2 with a whole MI355X free: four gangs of 16 (>= 4 gangs, multiples of 8 for a system per XCD)
+    assert L.gf2bv_plan_gang(64, 32768, 32768, 280 * 10 ** 9) == 16
+    assert L.gf2bv_plan_gang(512, 32768, 32768, 200 * 10 ** 9) == 32
+    assert L.gf2bv_plan_gang(5, 2048, 2048, 10 ** 9) >= 1 and L.gf2bv_plan_gang(0, 1, 1, 1) == 0
+    assert L.gf2bv_plan_gang(64, 32768, 32768, 2 * 10 ** 9) <= 6          # (little memory left: the gang shrinks to what fits)
+    if hip.device_count() == 0:
+        assert L.gf2bv_pool_trim(0) == -1
+        p = ctypes.c_void_p()
+        assert L.gf2bv_host_alloc(1 << 20, ctypes.byref(p)) == 2 and not p.value
+    assert L.gf2bv_pool_idle_bytes(-1) == -1
+    L.gf2bv_host_free(None)
+    from oracle import gf2_oracle as O
+    r = O.m4ri_time(256)
+    assert r["found"] in (True, False) and (r["found"] or "libm4ri" in r["why"])
