@@ -440,7 +440,7 @@ struct Solver {
 	double sp_add_bytes = 0, sp_mul_words = 0;      // what the products' additions moved / the lookups they did (in sweep-words)
 	std::vector<size_t> sp_kev;   // indices into kev of the event pairs that bracket super-panel products (ms_product)
 	hipStream_t sC = nullptr;     // outer passes: panel p's runs BESIDE the inner elimination of panel p + 1 (sA + sB)
-	hipEvent_t evOuter = nullptr, evPri = nullptr, evPanelDone = nullptr;
+	hipEvent_t evOuter = nullptr, evPri = nullptr, evPanelDone = nullptr, evSp = nullptr;
 	bool bulk_waits_outer = false;     // the next bulk launch of the one-level schedule has to wait for the last outer pass
 	bool ends_outer_panel(int b) const { return tl_K > 0 && b < tl_bend && (b + 1) % tl_K == 0; }
 	u64 *Wb = nullptr;            // 2 x rows x GMAX window words (the panel steps ping-pong between the halves)
@@ -531,7 +531,7 @@ struct Solver {
 		st = nullptr; panels = nullptr; aux = nullptr; fu = nullptr; died = nullptr; pivcol = nullptr;
 		urow = nullptr; blk_first = nullptr; mult = nullptr; Wb = nullptr;
 		for (hipEvent_t *e : { &ev0, &ev1, &ev2, &ev3, &evx }) { P.release_event(*e, true); *e = nullptr; }
-		for (hipEvent_t *e : { &evOuter, &evPri, &evPanelDone }) { P.release_event(*e, false); *e = nullptr; }
+		for (hipEvent_t *e : { &evOuter, &evPri, &evPanelDone, &evSp }) { P.release_event(*e, false); *e = nullptr; }
 		if (sC) P.release_stream(sC, device, true);
 		sC = nullptr;
 		for (hipEvent_t e : kev) P.release_event(e, true);
@@ -1343,7 +1343,13 @@ int enqueue_super_panel_finish(Solver &S, hipStream_t so, int B0, int B1)
 	for (int p0 = B0; p0 < B1; p0 += K)
 		if ((rc = enqueue_outer_apply(S, so, p0, p0 + K, t_hi, S.ntiles, B1 * G))) return rc;
 	if (ka) HIPCHK(hipEventRecord(ka, so));
-	// (2) B, and the multipliers of the rows that died inside the super-panel
+	// (2) B, and the multipliers of the rows that died inside the super-panel.  The bulk stream's last one-level launches of this
+	// super-panel still READ those multipliers (a dying row is an ordinary alive row to the blocks before its own): the clearing waits for them
+	if (S.sB != so) {
+		if (!S.evSp) HIPCHK(pool().event(&S.evSp, false));
+		HIPCHK(hipEventRecord(S.evSp, S.sB));
+		HIPCHK(hipStreamWaitEvent(so, S.evSp, 0));
+	}
 	const i64 set_u4 = (i64)G * mult_rows(S.rows) / 2;
 	uint4 *Aset = reinterpret_cast<uint4 *>(S.mult) + (i64)(B0 % S.nsets) * set_u4;
 	k_gather_b<<<dim3((unsigned)T_all, (unsigned)nb), dim3(256), 0, so>>>((const u64 *)S.M, S.srows, (int)t_hi, (const int *)S.oprow, (B0 / K) % S.nlist, S.nlist, K,
