@@ -409,7 +409,8 @@ struct DigitGather {
 		const size_t total = (size_t)off.back();
 		// page-locked staging from the library when the copy is worth a DMA of its own (no GPU, or no pinned memory left: malloc)
 		void *hp = nullptr;
-		if ((total + 1) * sizeof(uint32_t) >= (256u << 10) && gf2bv_host_alloc((int64_t)((total + 1) * sizeof(uint32_t)), &hp) == GF2BV_OK && hp) {
+		// (up to 1 GiB: page-locking more than that costs more than the staged copy it saves)
+		if ((total + 1) * sizeof(uint32_t) >= (256u << 10) && (total + 1) * sizeof(uint32_t) <= ((size_t)1 << 30) && gf2bv_host_alloc((int64_t)((total + 1) * sizeof(uint32_t)), &hp) == GF2BV_OK && hp) {
 			digits = static_cast<uint32_t *>(hp); pinned = true;
 		} else digits = static_cast<uint32_t *>(malloc((total + 1) * sizeof(uint32_t)));
 		if (!digits) { PyErr_NoMemory(); return false; }
