@@ -1908,7 +1908,9 @@ i64 pick_gang(i64 nsys, i64 rows, i64 cols, i64 free_bytes = -1)
 	// system, one system at a time 15-28; 64 x 4096^2: 0.22 ms per system against 1.8)
 	const double per_sys = 1.05 * 8.0 * (double)(rows + 64) * (double)((cols + 64) / 64 + TW + 4 * GF2_GMAX);
 	i64 gang = std::max<i64>(2, std::min<i64>(64, (i64)(4.5 * 1073741824.0 / per_sys)));
-	gang = std::min(gang, std::max<i64>(1, (nsys + 3) / 4));
+	// (at least TWO gangs -- one per host thread -- where round 3 asked for four: with a system per XCD larger gangs win; a rank's share of
+	// the configs[3] job at 8 GPUs, 64 x 32768^2: 2 x 32 run 3.25 ms per system against 3.41 for 4 x 16, profiles/r05_batch_scans.txt)
+	gang = std::min(gang, std::max<i64>(1, (nsys + 1) / 2));
 	// equal gangs, an even number of them (two host threads take alternate gangs): 64 systems of 32768^2 go as 4 x 16
 	// (3.90 ms per system) rather than 4 x 14 + 8 (4.10)
 	if (gang < nsys) {

@@ -102,8 +102,8 @@ def test_round5_entry_points_without_a_device():
     optional true-M4RI timing says that there is no libm4ri here."""
     import ctypes
     L = hip.lib()
-    # 64 systems of 32768^2 with a whole MI355X free: four gangs of 16 (>= 4 gangs, multiples of 8 for a system per XCD)
-    assert L.gf2bv_plan_gang(64, 32768, 32768, 280 * 10 ** 9) == 16
+    # 64 systems of 32768^2 with a whole MI355X free: two gangs of 32 (one per host thread, multiples of 8 for a system per XCD)
+    assert L.gf2bv_plan_gang(64, 32768, 32768, 280 * 10 ** 9) == 32
     assert L.gf2bv_plan_gang(512, 32768, 32768, 200 * 10 ** 9) == 32
     assert L.gf2bv_plan_gang(5, 2048, 2048, 10 ** 9) >= 1 and L.gf2bv_plan_gang(0, 1, 1, 1) == 0
     assert L.gf2bv_plan_gang(64, 32768, 32768, 2 * 10 ** 9) <= 6          # (little memory left: the gang shrinks to what fits)
