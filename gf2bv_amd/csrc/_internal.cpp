@@ -18,6 +18,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -381,12 +383,17 @@ bool parse_cols_mode(PyObject *cols_obj, PyObject *mode_obj, Py_ssize_t *cols, l
 // that is NOT value-initialised first, and by several threads when it is large (the GIL is held by the caller,
 // nothing can change the ints; the workers only read): for the 20000 x 19968 recovery systems of the reference's
 // examples (53 MB of digits) a zero-filled std::vector plus a single-threaded memcpy were 10 of the 24 ms of a solve.
+struct Staging {
+	uint32_t *digits = nullptr;
+	bool pinned = false;                                       // digits came from gf2bv_host_alloc (page-locked, recycled)
+	void drop() { if (pinned) gf2bv_host_free(digits); else free(digits); digits = nullptr; pinned = false; }
+	~Staging() { drop(); }
+};
 struct DigitGather {
 	std::vector<int64_t> off = std::vector<int64_t>(1, 0);    // off[r] .. off[r+1]: digits of row r
 	std::vector<const uint32_t *> src;                         // first digit of row r
-	uint32_t *digits = nullptr;
-	bool pinned = false;                                       // digits came from gf2bv_host_alloc (page-locked, recycled)
-	~DigitGather() { if (pinned) gf2bv_host_free(digits); else free(digits); }
+	Staging own;
+	uint32_t *digits = nullptr;                                // (gather(): every row, in `own`)
 	bool add(PyObject *list, Py_ssize_t cols)
 	{
 		const Py_ssize_t need = (cols + 1 + PyLong_SHIFT - 1) / PyLong_SHIFT;
@@ -406,30 +413,40 @@ struct DigitGather {
 	}
 	bool gather()
 	{
-		const size_t total = (size_t)off.back();
-		// page-locked staging from the library when the copy is worth a DMA of its own (no GPU, or no pinned memory left: malloc)
+		if (!gather_rows(0, src.size(), (size_t)1 << 30, own)) return false;
+		digits = own.digits;
+		return true;
+	}
+	// Rows r0 .. r1 into a buffer of this object's own (row r's digits at digits + off[r] - off[r0]).  Page-locked staging
+	// from the library when the copy is worth a DMA of its own and not larger than pin_max (page-locking more than a call can
+	// recycle costs more than the staged copy it saves); no GPU, or no pinned memory left: malloc.
+	bool gather_rows(size_t r0, size_t r1, size_t pin_max, Staging &st) const
+	{
+		st.drop();
+		uint32_t *digits = nullptr;
+		const int64_t base = off[r0];
+		const size_t total = (size_t)(off[r1] - base);
 		void *hp = nullptr;
-		// (up to 1 GiB: page-locking more than that costs more than the staged copy it saves)
-		if ((total + 1) * sizeof(uint32_t) >= (256u << 10) && (total + 1) * sizeof(uint32_t) <= ((size_t)1 << 30) && gf2bv_host_alloc((int64_t)((total + 1) * sizeof(uint32_t)), &hp) == GF2BV_OK && hp) {
-			digits = static_cast<uint32_t *>(hp); pinned = true;
+		if ((total + 1) * sizeof(uint32_t) >= (256u << 10) && (total + 1) * sizeof(uint32_t) <= pin_max && gf2bv_host_alloc((int64_t)((total + 1) * sizeof(uint32_t)), &hp) == GF2BV_OK && hp) {
+			digits = static_cast<uint32_t *>(hp); st.pinned = true;
 		} else digits = static_cast<uint32_t *>(malloc((total + 1) * sizeof(uint32_t)));
 		if (!digits) { PyErr_NoMemory(); return false; }
-		const size_t rows = src.size();
-		auto copy_rows = [this](size_t a, size_t b) {
+		st.digits = digits;
+		auto copy_rows = [this, base, digits](size_t a, size_t b) {
 			for (size_t r = a; r < b; r++)
-				memcpy(digits + off[r], src[r], (size_t)(off[r + 1] - off[r]) * sizeof(uint32_t));
+				memcpy(digits + (off[r] - base), src[r], (size_t)(off[r + 1] - off[r]) * sizeof(uint32_t));
 		};
 		unsigned nt = total * sizeof(uint32_t) >= (8u << 20) ? std::min(8u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
-		if (nt <= 1 || rows < 64) { copy_rows(0, rows); return true; }
+		if (nt <= 1 || r1 - r0 < 64) { copy_rows(r0, r1); return true; }
 		// equal shares of the DIGITS, not of the rows
 		std::vector<std::thread> th;
-		size_t a = 0;
+		size_t a = r0;
 		for (unsigned k = 1; k <= nt; k++) {
-			size_t b = rows;
+			size_t b = r1;
 			if (k < nt) {
-				const int64_t want = (int64_t)(total / nt * k);
-				b = (size_t)(std::lower_bound(off.begin(), off.end(), want) - off.begin());
-				if (b > rows) b = rows;
+				const int64_t want = base + (int64_t)(total / nt * k);
+				b = (size_t)(std::lower_bound(off.begin() + (ptrdiff_t)r0, off.begin() + (ptrdiff_t)r1 + 1, want) - off.begin());
+				if (b > r1) b = r1;
 				if (b < a) b = a;
 			}
 			if (k < nt) th.emplace_back(copy_rows, a, b); else copy_rows(a, b);
@@ -564,27 +581,93 @@ PyObject *py_m4ri_solve_many(PyObject *, PyObject *const *args, Py_ssize_t nargs
 		}
 		if (!dg.add(list, cols)) return nullptr;
 	}
-	if (!dg.gather()) return nullptr;
+	// The digits go to the library in CHUNKS of whole systems, at most GF2BV_BATCH_CHUNK_MB MiB each (default 2048; an even
+	// number of systems per chunk, so that the library still forms two gangs of it): chunk k + 1 is gathered (GIL held, as for
+	// one system) while chunk k is being solved by a thread of its own, and the two page-locked buffers the chunks alternate
+	// between are recycled by the library's staging pool.  Gathering ALL the digits first -- 16 MT19937 recovery systems are
+	// 800 MB, 64 systems of 32768^2 are 8.6 GB -- meant page-locking (or page-faulting) that much on every call: 226 of the
+	// 270 ms of the 16-system call, where the solves take 44 (profiles/r05_mt_many.txt).
+	const size_t total_digits = (size_t)dg.off.back();
+	size_t chunk_bytes = (size_t)2048 << 20;
+	if (const char *e = getenv("GF2BV_BATCH_CHUNK_MB")) { long v = atol(e); if (v >= 1) chunk_bytes = (size_t)v << 20; }
+	Py_ssize_t chunk_sys = nsys;
+	if (total_digits * sizeof(uint32_t) > chunk_bytes) {
+		const size_t per_sys = std::max<size_t>(1, total_digits * sizeof(uint32_t) / (size_t)nsys);
+		chunk_sys = (Py_ssize_t)std::max<size_t>(1, chunk_bytes / per_sys);
+		if (chunk_sys >= 2) chunk_sys &= ~(Py_ssize_t)1;
+		// equal chunks
+		const Py_ssize_t nchunks = (nsys + chunk_sys - 1) / chunk_sys;
+		chunk_sys = (nsys + nchunks - 1) / nchunks;
+		if (chunk_sys >= 2 && (chunk_sys & 1) && chunk_sys < nsys) chunk_sys++;
+	}
 	std::vector<gf2bv_result *> res((size_t)nsys, nullptr);
-	int rc;
-	Py_BEGIN_ALLOW_THREADS
-	rc = gf2bv_solve_batch_digits_multi(dg.digits, dg.off.data(), PyLong_SHIFT, nsys, rows, cols, (int)mode, devs.data(),
-	                                    (int)devs.size(), res.data());
-	Py_END_ALLOW_THREADS
-	if (rc != GF2BV_OK) {
+	std::vector<int> sysdev((size_t)nsys, devs[0]);
+	struct Chunk {
+		Staging st;
+		std::vector<int64_t> rel;                  // the chunk's offsets, from 0
+		Py_ssize_t s0 = 0, s1 = 0;
+		std::thread th;
+		int rc = GF2BV_OK;
+		std::string err;
+		bool running = false;
+	} ck[2];
+	int rc = GF2BV_OK;
+	std::string err;
+	auto join = [&](Chunk &c) {
+		if (!c.running) return;
+		Py_BEGIN_ALLOW_THREADS
+		c.th.join();
+		Py_END_ALLOW_THREADS
+		c.running = false;
+		c.st.drop();
+		if (c.rc != GF2BV_OK && rc == GF2BV_OK) { rc = c.rc; err = c.err; }
+	};
+	bool pyerr = false;
+	int which = 0;
+	for (Py_ssize_t s0 = 0; s0 < nsys && rc == GF2BV_OK; s0 += chunk_sys, which ^= 1) {
+		Chunk &c = ck[which];
+		join(c);                                   // (the chunk before the previous one: its buffer is free again)
+		if (rc != GF2BV_OK) break;
+		c.s0 = s0; c.s1 = std::min<Py_ssize_t>(nsys, s0 + chunk_sys);
+		const size_t r0 = (size_t)(c.s0 * rows), r1 = (size_t)(c.s1 * rows);
+		if (!dg.gather_rows(r0, r1, chunk_bytes + chunk_bytes / 2, c.st)) { pyerr = true; break; }
+		try { c.rel.assign(dg.off.begin() + (ptrdiff_t)r0, dg.off.begin() + (ptrdiff_t)r1 + 1); }
+		catch (const std::bad_alloc &) { PyErr_NoMemory(); pyerr = true; break; }
+		const int64_t base = c.rel[0];
+		for (int64_t &o : c.rel) o -= base;
+		// (the share -> device map of gf2bv_solve_batch_digits_multi: share k = systems floor(n k / shares) ..)
+		const Py_ssize_t n = c.s1 - c.s0, nsh = std::min<Py_ssize_t>((Py_ssize_t)devs.size(), n);
+		for (Py_ssize_t t = 0, share = 0; t < n; t++) {
+			while (share + 1 < nsh && n * (share + 1) / nsh <= t) share++;
+			sysdev[(size_t)(c.s0 + t)] = devs[(size_t)share];
+		}
+		join(ck[which ^ 1]);                       // one chunk on the device(s) at a time
+		if (rc != GF2BV_OK) break;
+		c.rc = GF2BV_OK; c.err.clear();
+		c.running = true;
+		try {
+			c.th = std::thread([&c, &res, &devs, rows, cols, mode]() {
+				c.rc = gf2bv_solve_batch_digits_multi(c.st.digits, c.rel.data(), PyLong_SHIFT, c.s1 - c.s0, rows, cols, (int)mode,
+				                                      devs.data(), (int)devs.size(), res.data() + c.s0);
+				if (c.rc != GF2BV_OK) c.err = gf2bv_last_error();      // (the message is per thread)
+			});
+		} catch (const std::system_error &) {
+			c.running = false;
+			rc = GF2BV_ERR_HIP; err = "could not start the solve thread";
+		}
+	}
+	join(ck[0]); join(ck[1]);
+	if (pyerr || rc != GF2BV_OK) {
 		for (gf2bv_result *r : res) if (r) gf2bv_result_free(r);
-		PyErr_Format(rc == GF2BV_ERR_ARG ? PyExc_ValueError : PyExc_RuntimeError,
-		             "gf2bv_amd: HIP solve failed (%d): %s", rc, gf2bv_last_error());
+		if (!pyerr)
+			PyErr_Format(rc == GF2BV_ERR_ARG ? PyExc_ValueError : PyExc_RuntimeError,
+			             "gf2bv_amd: HIP solve failed (%d): %s", rc, err.c_str());
 		return nullptr;
 	}
 	PyObject *out = PyList_New(nsys);
 	Py_ssize_t done = 0;
 	for (; out && done < nsys; done++) {
-		// (the share -> device map of gf2bv_solve_batch_digits_multi: share k = systems floor(nsys k / n) ..)
-		const Py_ssize_t nsh = std::min<Py_ssize_t>((Py_ssize_t)devs.size(), nsys);
-		Py_ssize_t share = 0;
-		while (share + 1 < nsh && nsys * (share + 1) / nsh <= done) share++;
-		PyObject *item = result_to_py(res[done], mode, devs[(size_t)share]);      // frees res[done]
+		PyObject *item = result_to_py(res[done], mode, sysdev[(size_t)done]);      // frees res[done]
 		if (!item) { done++; Py_CLEAR(out); break; }
 		PyList_SET_ITEM(out, done, item);
 	}

@@ -2959,7 +2959,9 @@ int gf2bv_device_alloc(int device, int64_t bytes, void **d_ptr)
 // A binding that has to assemble its input on the host (the CPython shim copies every equation's ob_digit array into one buffer)
 // gets that buffer here: page-locked, so the host-to-device copy of gf2bv_solve_digits is ONE DMA instead of the runtime's
 // chunk-by-chunk staging of pageable memory, and recycled between calls (no page faults on a fresh 50 MB allocation every call).
-// Up to four idle buffers are kept (256 MiB in all at most); larger ones are freed on return.
+// Up to four idle buffers are kept, GF2BV_HOST_POOL_MB MiB in all at most (default 4608: the two 2 GiB chunk buffers a batched
+// list-of-int call alternates between -- page-locking 800 MB anew on every call was 200 of the 270 ms of a 16-system MT19937
+// batch, profiles/r05_mt_many.txt); larger ones are freed on return, gf2bv_host_pool_trim frees the idle ones.
 namespace {
 struct HostPool {
 	std::mutex mu;
@@ -3008,10 +3010,25 @@ void gf2bv_host_free(void *h_ptr)
 		P.live.erase(it);
 		size_t kept = 0;
 		for (const auto &b : P.idle) kept += b.bytes;
-		if (P.idle.size() < 4 && kept + bytes <= ((size_t)256 << 20)) P.idle.push_back({ h_ptr, bytes });
+		size_t cap_mb = 4608;
+		if (const char *e = getenv("GF2BV_HOST_POOL_MB")) { long v = atol(e); if (v >= 0) cap_mb = (size_t)v; }
+		if (P.idle.size() < 4 && kept + bytes <= (cap_mb << 20)) P.idle.push_back({ h_ptr, bytes });
 		else drop = h_ptr;
 	}
 	if (drop) (void)hipHostFree(drop);
+}
+
+int64_t gf2bv_host_pool_trim(void)
+{
+	HostPool &P = host_pool();
+	std::vector<HostPool::Buf> drop;
+	{
+		std::lock_guard<std::mutex> lk(P.mu);
+		drop.swap(P.idle);
+	}
+	int64_t bytes = 0;
+	for (const auto &b : drop) { bytes += (int64_t)b.bytes; (void)hipHostFree(b.p); }
+	return bytes;
 }
 
 // The gang size gf2bv_solve_batch_* would choose for nsys systems of rows x cols with free_bytes of device memory free -- a pure

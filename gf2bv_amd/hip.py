@@ -37,7 +37,7 @@ EXPORTS = [
     "gf2bv_synth_device", "gf2bv_residual_device",
     "gf2bv_stream_ceiling_device", "gf2bv_lds_clock_device", "gf2bv_kernel_resources",
     "gf2bv_device_alloc", "gf2bv_device_free", "gf2bv_device_upload", "gf2bv_device_download",
-    "gf2bv_pool_trim", "gf2bv_pool_idle_bytes", "gf2bv_host_alloc", "gf2bv_host_free", "gf2bv_plan_gang",
+    "gf2bv_pool_trim", "gf2bv_pool_idle_bytes", "gf2bv_host_alloc", "gf2bv_host_free", "gf2bv_host_pool_trim", "gf2bv_plan_gang",
 ]
 
 
@@ -129,6 +129,8 @@ def lib():
         L.gf2bv_host_alloc.argtypes = [i64, pp]
         L.gf2bv_host_free.argtypes = [vp]
         L.gf2bv_host_free.restype = None
+        L.gf2bv_host_pool_trim.argtypes = []
+        L.gf2bv_host_pool_trim.restype = i64
         L.gf2bv_plan_gang.argtypes = [i64, i64, i64, i64]
         L.gf2bv_plan_gang.restype = i64
         L.gf2bv_pool_trim.argtypes = [i32]
@@ -355,6 +357,11 @@ def kernel_resources(device: int = 0) -> dict:
 def pool_trim(device: int = 0) -> int:
     """Return every idle buffer of the library's pool on `device` to the device; bytes freed (gf2bv_pool_trim)."""
     return int(lib().gf2bv_pool_trim(device))
+
+
+def host_pool_trim() -> int:
+    """Free the idle page-locked staging buffers (gf2bv_host_pool_trim); bytes released."""
+    return int(lib().gf2bv_host_pool_trim())
 
 
 def pool_idle_bytes(device: int = 0) -> int:

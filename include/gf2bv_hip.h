@@ -271,9 +271,11 @@ int gf2bv_device_download(int device, void *h_dst, const void *d_src, int64_t by
 /* Page-locked host staging for bindings that assemble their input on the host (the CPython shim gathers every equation's digit
  * array -- gf2bv/_internal.c:403-426 walks them bit by bit instead -- into ONE buffer before gf2bv_solve_digits): the
  * host-to-device copy out of such a buffer is a single DMA, and the buffers are recycled between calls (up to four idle ones,
- * 256 MiB in all).  Any host pointer remains valid input for every entry point; this is an optimisation, not a requirement. */
+ * GF2BV_HOST_POOL_MB MiB in all, default 4608; gf2bv_host_pool_trim frees the idle ones and returns their bytes).  Any host
+ * pointer remains valid input for every entry point; this is an optimisation, not a requirement. */
 int  gf2bv_host_alloc(int64_t bytes, void **h_ptr);
 void gf2bv_host_free(void *h_ptr);
+int64_t gf2bv_host_pool_trim(void);
 
 /* ---- the buffer pool (see "Threading" at the top) ----------------------------------------------- */
 /* Frees every IDLE buffer the pool keeps on `device` (large working buffers and the small-buffer cache; nothing a running

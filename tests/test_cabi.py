@@ -113,6 +113,7 @@ def test_round5_entry_points_without_a_device():
         assert L.gf2bv_host_alloc(1 << 20, ctypes.byref(p)) == 2 and not p.value
     assert L.gf2bv_pool_idle_bytes(-1) == -1
     L.gf2bv_host_free(None)
+    assert L.gf2bv_host_pool_trim() >= 0
     from oracle import gf2_oracle as O
     r = O.m4ri_time(256)
     assert r["found"] in (True, False) and (r["found"] or "libm4ri" in r["why"])

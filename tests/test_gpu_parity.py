@@ -306,6 +306,32 @@ def test_batched_list_of_int_boundary(monkeypatch):
             assert (sp.dimension, sp.origin, sp.basis) == (ref.dimension, ref.origin, ref.basis)
 
 
+@pytest.mark.parametrize("chunk_mb, devs", [("2", None), ("1", None), ("3", [0, 0, 0])])
+def test_batched_list_of_int_in_chunks(monkeypatch, chunk_mb, devs):
+    """m4ri_solve_many hands the digits over in chunks of whole systems (GF2BV_BATCH_CHUNK_MB), the gather of one chunk under the solve of
+    the one before: 7 systems of 0.94 MB in chunks of 2 / 1 / 4 systems, answers in input order and equal to the oracle's."""
+    monkeypatch.setenv("GF2BV_BATCH_CHUNK_MB", chunk_mb)
+    rng = random.Random(4711)
+    rows, cols = 2700, 2600
+    kinds = [(None, .5, True), (700, .5, True), (None, .5, False), (None, .01, True), (cols - 1, .5, True), (3, .5, True)]
+    systems = [random_system(rng, rows, cols, d, cap, cons, 0) for cap, d, cons in kinds] + [[0] * rows]
+    for mode in (0, 1):
+        got = _internal.m4ri_solve_many(systems, cols, mode) if devs is None else _internal.m4ri_solve_many(systems, cols, mode, devs)
+        assert len(got) == len(systems)
+        for eqs, g in zip(systems, got):
+            o = O.m4ri_solve(list(eqs), cols, mode)
+            if mode == 0 or o is None:
+                assert g == o
+            else:
+                assert (g.dimension, g.origin, g.basis) == (o.dimension, o.origin, o.basis)
+    # an item that is not an int, found while the first chunk is already being solved... is found BEFORE anything runs (type check first)
+    bad = [list(e) for e in systems]
+    bad[5][7] = "x"
+    with pytest.raises(TypeError):
+        _internal.m4ri_solve_many(bad, cols, 0)
+    assert hip.host_pool_trim() >= 0
+
+
 def test_batch_sharded_over_devices_from_the_python_boundary(monkeypatch):
     """m4ri_solve_many(..., devices): contiguous shares, one host thread per listed device inside the library
     (gf2bv_solve_batch_digits_multi).  The box has one GPU, so the device list names it twice or three times -- the shares
