@@ -487,8 +487,34 @@ def c3_mt19937_leg(device: int, with_oracle: bool) -> dict:
             rec["gpu_equals_cpu_oracle"] = bool(cb["result"] == raw)
             threads = cb["threads"]
         out.append(rec)
+    # a batch of such recoveries -- one system per instance -- through m4ri_solve_many (lock-step gangs; the digits in chunks of whole
+    # systems, gathered under the previous chunk's solve, round 5) beside the loop of single calls
+    nb = 8
+    systems, states = [], []
+    for k in range(nb):
+        rand = random.Random(3142 + k)
+        states.append(tuple(rand.getstate()[1][:-1]))
+        obs = [rand.getrandbits(32) for _ in range(624)]
+        lin = LinearSystem([32] * 624)
+        mt = lin.gens()
+        sym = MT19937(mt)
+        eqs = lin.get_eqs([sym.getrandbits(32) ^ o for o in obs] + [mt[0] ^ 0x80000000])
+        systems.append(eqs + [0] * max(0, lin._cols - len(eqs)))
+    walls = []
+    for _ in range(3):
+        ta = time.perf_counter()
+        many = _internal.m4ri_solve_many(systems, lin._cols, 0, device)
+        walls.append(time.perf_counter() - ta)
+    ta = time.perf_counter()
+    loop = [_internal.m4ri_solve(e, lin._cols, 0, device) for e in systems]
+    tl = time.perf_counter() - ta
+    batch = {"systems": nb, "bits_per_output": 32, "rows": len(systems[0]), "cols": lin._cols,
+             "m4ri_solve_many_ms_per_system": {"first": walls[0] * 1e3 / nb, "warm": min(walls[1:]) * 1e3 / nb},
+             "loop_of_m4ri_solve_ms_per_system": tl * 1e3 / nb,
+             "recovered_states_equal_known_answers": bool(many == loop and all(r is not None and lin.convert_sol(r) == st
+                                                                              for r, st in zip(many, states)))}
     return {"workload": "MT19937 state recovery (19968 unknowns), the six variants of the reference's examples/mt.py, list-of-int boundary",
-            "cpu_oracle_threads": threads if with_oracle else None, "variants": out}
+            "cpu_oracle_threads": threads if with_oracle else None, "variants": out, "batch": batch}
 
 
 def _digits_stats(eqs, cols: int, device: int) -> dict:

@@ -2969,14 +2969,14 @@ struct HostPool {
 	std::vector<Buf> idle;
 	std::unordered_map<void *, size_t> live;
 };
-HostPool &host_pool() { static HostPool *p = new HostPool(); return *p; }
+HostPool *host_pool_ptr() { static HostPool *p = new HostPool(); return p; }
 }
 int gf2bv_host_alloc(int64_t bytes, void **h_ptr)
 {
 	if (!h_ptr || bytes < 0) return fail(GF2BV_ERR_ARG, "bad alloc request");
 	*h_ptr = nullptr;
 	const size_t need = std::max<size_t>((size_t)bytes, 64);
-	HostPool &P = host_pool();
+	HostPool &P = *host_pool_ptr();
 	{
 		std::lock_guard<std::mutex> lk(P.mu);
 		for (size_t i = 0; i < P.idle.size(); i++)
@@ -3000,7 +3000,7 @@ int gf2bv_host_alloc(int64_t bytes, void **h_ptr)
 void gf2bv_host_free(void *h_ptr)
 {
 	if (!h_ptr) return;
-	HostPool &P = host_pool();
+	HostPool &P = *host_pool_ptr();
 	void *drop = nullptr;
 	{
 		std::lock_guard<std::mutex> lk(P.mu);
@@ -3020,7 +3020,7 @@ void gf2bv_host_free(void *h_ptr)
 
 int64_t gf2bv_host_pool_trim(void)
 {
-	HostPool &P = host_pool();
+	HostPool &P = *host_pool_ptr();
 	std::vector<HostPool::Buf> drop;
 	{
 		std::lock_guard<std::mutex> lk(P.mu);
