@@ -610,6 +610,7 @@ PyObject *py_m4ri_solve_many(PyObject *, PyObject *const *args, Py_ssize_t nargs
 		int rc = GF2BV_OK;
 		std::string err;
 		bool running = false;
+		~Chunk() { if (th.joinable()) th.join(); }      // (never left running: an exception on the way out must not meet a live thread)
 	} ck[2];
 	int rc = GF2BV_OK;
 	std::string err;

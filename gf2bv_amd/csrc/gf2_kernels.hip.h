@@ -369,6 +369,27 @@ __global__ void k_probe_wait(int *flag, int *result, unsigned long long ticks)
 	*result = ok ? 1 : 2;
 }
 __global__ void k_probe_set(int *flag) { GF2_ST(flag, 1); }
+// Stream-pair probe (round 5, Pool::low_stream_for): a kernel with the footprint of the bulk update (a workgroup of 512 per CU, 133 KiB
+// of LDS) that holds the chip for `ticks` (100 MHz) and says when it began, and one with the footprint of a panel kernel (workgroups of
+// 256, 23 KiB) that says when its LAST workgroup began.
+__global__ void __launch_bounds__(512) k_probe_hold_bulk(unsigned long long *stamp, unsigned long long ticks)
+{
+	__shared__ unsigned big[133 * 256];
+	big[threadIdx.x] = threadIdx.x;
+	__syncthreads();
+	const unsigned long long t0 = wall_clock64();
+	if (blockIdx.x == 0 && threadIdx.x == 0) *stamp = t0;
+	while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+	if (big[(threadIdx.x + 1) & 511] == 0xffffffffu) *stamp = 0;
+}
+__global__ void __launch_bounds__(256) k_probe_stamp_panel(unsigned long long *stamp)
+{
+	__shared__ unsigned mid[23 * 256];
+	mid[threadIdx.x] = threadIdx.x;
+	__syncthreads();
+	if (threadIdx.x == 0) *stamp = wall_clock64();
+	if (mid[(threadIdx.x + 1) & 255] == 0xffffffffu) *stamp = 0;
+}
 // Which XCD does workgroup b of a one-dimensional launch land on?  (XCC_ID, hardware register 20 of the gfx940 family, bits 3:0.)
 // The gang bulk update places a system per XCD on the ASSUMPTION b -> XCD b % 8 (k_update16: xcd_nsys); the host checks it once per
 // device with this kernel and falls back to the plain grid where it does not hold (another partition mode, a driver that dispatches
@@ -2544,8 +2565,11 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		}
 	}
 
-	uint4 staged = make_uint4(0, 0, 0, 0);          // this thread's pivot-row segment of the NEXT span's tile, requested while
-	bool have_staged = false;                       // the current span streams (the build then starts without a memory round trip)
+	// this thread's pivot-row segment of the NEXT span's tile, requested while the current span streams (the build then starts without
+	// a memory round trip).  Four scalars, not a uint4: the aggregate carried around the loop got a stack slot -- two dead 16-byte
+	// scratch stores that made every instance of the bulk update a kernel WITH a private segment (32 B per lane, round 5)
+	unsigned sgx = 0, sgy = 0, sgz = 0, sgw = 0;
+	bool have_staged = false;
 	for (bool first_span = true; pos < pend; first_span = false) {
 		const int ct = (int)(pos / R);
 		const i64 r0 = pos - (i64)ct * R;
@@ -2602,7 +2626,9 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		const uint4 *Mq = reinterpret_cast<const uint4 *>(M) + tile * srows;       // this tile's slab, one uint4 per row
 		if (threadIdx.x < GF2_GMAX * 64) {
 			const int pr = Pc ? 0 : prow[threadIdx.x];      // (Pc holds zeros where a panel has no pivot)
-			uint4 v = have_staged ? staged : Pc ? Pc[tile * (GF2_GMAX * 64) + threadIdx.x] : Mq[pr >= 0 ? pr : 0];
+			uint4 v;
+			if (have_staged) { v.x = sgx; v.y = sgy; v.z = sgz; v.w = sgw; }
+			else v = Pc ? Pc[tile * (GF2_GMAX * 64) + threadIdx.x] : Mq[pr >= 0 ? pr : 0];
 			// words left of wlo belong to windows the panel path owns: their table bits stay zero
 			const bool k0 = pr >= 0 && 2 * tile >= wlo, k1 = pr >= 0 && 2 * tile + 1 >= wlo;
 			if (!k0) { v.x = 0; v.y = 0; }
@@ -2638,11 +2664,13 @@ k_update16(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int wlo,
 		if (pos < pend) {
 			const i64 ntile = owned_item((int)(pos / R), tile_begin, GF2_OWN_LOG - 1, world, wrank);
 			if (threadIdx.x < GF2_GMAX * 64) {
-				if (Pc) staged = Pc[ntile * (GF2_GMAX * 64) + threadIdx.x];
+				uint4 nx;
+				if (Pc) nx = Pc[ntile * (GF2_GMAX * 64) + threadIdx.x];
 				else {
 					const int pr = prow[threadIdx.x];
-					staged = (reinterpret_cast<const uint4 *>(M) + ntile * srows)[pr >= 0 ? pr : 0];
+					nx = (reinterpret_cast<const uint4 *>(M) + ntile * srows)[pr >= 0 ? pr : 0];
 				}
+				sgx = nx.x; sgy = nx.y; sgz = nx.z; sgw = nx.w;
 			}
 			have_staged = true;
 		}

@@ -263,11 +263,15 @@ struct Pool {
 		auto &v = events[{device, timing ? 1 : 0}];
 		if (v.size() < 8192) v.push_back(e); else (void)hipEventDestroy(e);
 	}
-	hipError_t stream(hipStream_t *s, int device, bool low)
+	// cls: 0 = normal priority, 1 = low priority (the bulk side of a solve); + 2 = the same for BATCH calls and their gangs.  The two
+	// worlds do not trade streams (round 5): which low-priority stream a single solve finds on top of the pool decides whether it runs
+	// 5.4 or 12.7 ms (low_stream_for below), and batch calls with several host threads return their streams in any order.
+	hipError_t stream(hipStream_t *s, int device, int cls)
 	{
+		const bool low = cls & 1;
 		{
 			std::lock_guard<std::mutex> lk(mu);
-			auto &v = streams[{device, low ? 1 : 0}];
+			auto &v = streams[{device, cls}];
 			if (!v.empty()) { *s = v.back(); v.pop_back(); return hipSuccess; }
 		}
 		if (!low) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
@@ -275,11 +279,116 @@ struct Pool {
 		(void)hipDeviceGetStreamPriorityRange(&lo, &hi);
 		return hipStreamCreateWithPriority(s, hipStreamNonBlocking, lo);
 	}
-	void release_stream(hipStream_t s, int device, bool low)
+	void release_stream(hipStream_t s, int device, int cls)
 	{
 		if (!s) return;
 		std::lock_guard<std::mutex> lk(mu);
-		streams[{device, low ? 1 : 0}].push_back(s);
+		streams[{device, cls}].push_back(s);
+	}
+	// A low-priority stream for the bulk side of a solve whose panel path runs on `a` (round 5).  Not every pair of streams is equal on
+	// this chip: with some pairs the workgroups of a kernel on `a` are handed out at ~0.4 us apiece while a chip-filling kernel on the
+	// other stream has its successor queued behind it -- 80 workgroups take 37 us instead of 3 -- and a latency-bound solve (MT19937
+	// recovery, 78 blocks) runs 12.7 ms instead of 5.4: panel path and bulk path end up one after the other.  Which pairs: a property of
+	// the two streams (the hardware queues behind them), stable for the life of the process, the same for every solve -- seen as "the
+	// single solves after a batch call are slow this time": the batch had left another of its streams on top of the pool
+	// (profiles/r05_stream_pairs.txt).  So a pair is probed once (two holds with the bulk update's footprint on the candidate, a
+	// one-workgroup and an 80-workgroup kernel with a panel kernel's footprint on `a`: when did the last of the 80 begin) and the
+	// verdict kept; idle streams known to be good with `a` are preferred, unknown ones probed, at most kMaxLow low-priority streams per
+	// device are created, and when nothing passes the first candidate is taken as it is.  GF2BV_STREAM_PAIRS=0: any idle stream.
+	static constexpr int kMaxLow = 10;
+	std::mutex probe_mu;                                                  // one probe at a time (it wants the queues to itself)
+	std::map<std::pair<hipStream_t, hipStream_t>, int> pair_ok;           // (panel stream, low-priority stream) -> 1 good, 0 throttled
+	std::map<int, int> low_created;                                       // device -> low-priority streams created so far
+	int pairs_probed = 0, pairs_bad = 0;
+	hipError_t probe_pair(hipStream_t a, hipStream_t b, int device, int *ok)
+	{
+		*ok = 1;
+		unsigned long long *d = nullptr, h[4] = { 0, 0, 0, 0 };
+		hipError_t e = alloc((void **)&d, sizeof h, device);
+		if (e != hipSuccess) return e;
+		struct Free { Pool *p; void *q; ~Free() { p->release(q); } } guard{ this, d };
+		if ((e = hipMemsetAsync(d, 0, sizeof h, a)) != hipSuccess) return e;
+		if ((e = hipStreamSynchronize(a)) != hipSuccess) return e;
+		if ((e = hipStreamSynchronize(b)) != hipSuccess) return e;
+		int cus = 256;
+		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+		for (int k = 0; k < 2; k++) k_probe_hold_bulk<<<dim3((unsigned)cus), dim3(512), 0, b>>>(d + k, 8000ull);       // 2 x 80 us
+		k_probe_stamp_panel<<<dim3(1), dim3(256), 0, a>>>(d + 2);
+		k_probe_stamp_panel<<<dim3(80), dim3(256), 0, a>>>(d + 3);
+		if ((e = hipGetLastError()) != hipSuccess) return e;
+		if ((e = hipStreamSynchronize(a)) != hipSuccess) return e;
+		if ((e = hipStreamSynchronize(b)) != hipSuccess) return e;
+		if ((e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+		// good pairs: the 80 workgroups begin 3-4 us after the single one; throttled pairs: 35-40 us
+		const double gap_us = ((double)h[3] - (double)h[2]) / 100.0;
+		*ok = gap_us < 15.0;
+		if (getenv("GF2BV_TRACE"))
+			fprintf(stderr, "[gf2bv trace] stream pair %p / %p: 80 workgroups began %.1f us after the first kernel (%s)\n", (void *)a, (void *)b, gap_us,
+			        *ok ? "good" : "throttled");
+		return hipSuccess;
+	}
+	hipError_t low_stream_for(hipStream_t a, int device, hipStream_t *out)
+	{
+		static const bool pairing = !(getenv("GF2BV_STREAM_PAIRS") && atoi(getenv("GF2BV_STREAM_PAIRS")) == 0);
+		if (!pairing || !a) return stream(out, device, true);
+		std::lock_guard<std::mutex> pl(probe_mu);
+		std::vector<hipStream_t> rejected, with;
+		with.push_back(a);
+		hipError_t err = hipSuccess;
+		*out = nullptr;
+		// verdict of candidate c against everything in `with`, as far as known: 1 all good, 0 one throttled, -1 something unknown
+		auto known = [&](hipStream_t c) {
+			int r = 1;
+			for (hipStream_t x : with) {
+				auto it = pair_ok.find({x, c});
+				if (it == pair_ok.end()) r = r == 0 ? 0 : -1; else if (it->second == 0) r = 0;
+			}
+			return r;
+		};
+		for (int attempt = 0; attempt < kMaxLow + 2 && !*out; attempt++) {
+			hipStream_t c = nullptr;
+			bool known_good = false;
+			{
+				std::lock_guard<std::mutex> lk(mu);
+				auto &v = streams[{device, 1}];
+				for (size_t i = v.size(); i-- > 0 && !c;)
+					if (known(v[i]) == 1) { c = v[i]; v.erase(v.begin() + (ptrdiff_t)i); known_good = true; }
+				for (size_t i = v.size(); i-- > 0 && !c;)
+					if (known(v[i]) == -1) { c = v[i]; v.erase(v.begin() + (ptrdiff_t)i); }
+				if (!c) {
+					if (low_created[device] >= kMaxLow) break;
+					low_created[device]++;
+				}
+			}
+			if (known_good) { *out = c; break; }
+			if (!c) {
+				int lo = 0, hi = 0;
+				(void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+				if ((err = hipStreamCreateWithPriority(&c, hipStreamNonBlocking, lo)) != hipSuccess) break;
+			}
+			int all_ok = 1;
+			for (hipStream_t x : with) {
+				int ok = -1;
+				{
+					std::lock_guard<std::mutex> lk(mu);
+					auto it = pair_ok.find({x, c});
+					if (it != pair_ok.end()) ok = it->second;
+				}
+				if (ok < 0) {
+					ok = 1;
+					if (probe_pair(x, c, device, &ok) != hipSuccess) { (void)hipGetLastError(); ok = 1; }      // (a probe that cannot run decides nothing)
+					std::lock_guard<std::mutex> lk(mu);
+					pair_ok[{x, c}] = ok;
+					pairs_probed++; pairs_bad += !ok;
+				}
+				if (!ok) { all_ok = 0; break; }
+			}
+			if (all_ok) *out = c; else rejected.push_back(c);
+		}
+		if (!*out && !rejected.empty()) { *out = rejected.front(); rejected.erase(rejected.begin()); }
+		for (hipStream_t r : rejected) release_stream(r, device, true);
+		if (!*out && err == hipSuccess) return stream(out, device, true);
+		return err;
 	}
 };
 Pool &pool()
@@ -532,13 +641,13 @@ struct Solver {
 		urow = nullptr; blk_first = nullptr; mult = nullptr; Wb = nullptr;
 		for (hipEvent_t *e : { &ev0, &ev1, &ev2, &ev3, &evx }) { P.release_event(*e, true); *e = nullptr; }
 		for (hipEvent_t *e : { &evOuter, &evPri, &evPanelDone, &evSp }) { P.release_event(*e, false); *e = nullptr; }
-		if (sC) P.release_stream(sC, device, true);
+		if (sC) P.release_stream(sC, device, nsys > 1 ? 3 : 1);
 		sC = nullptr;
 		for (hipEvent_t e : kev) P.release_event(e, true);
 		for (hipEvent_t e : evA) P.release_event(e, false);
 		for (hipEvent_t e : evPrio) P.release_event(e, false);
 		kev.clear(); evA.clear(); evPrio.clear();
-		if (own_sB && sB) P.release_stream(sB, device, true);
+		if (own_sB && sB) P.release_stream(sB, device, nsys > 1 ? 3 : 1);
 		sB = nullptr;
 		if (own_sA && sA) P.release_stream(sA, device, false);
 		sA = nullptr;
@@ -733,7 +842,11 @@ int solver_alloc(Solver &S)
 	if (getenv("GF2BV_SERIAL")) { S.sB = S.sA; S.own_sB = false; }     // ablation: no look-ahead overlap
 	else {
 		// the bulk path yields to the (latency-critical) panel path wherever both have work queued: lowest priority
-		HIPCHK(pool().stream(&S.sB, S.device, true));
+		// (round 5: single systems take a stream that is KNOWN to run beside sA, see Pool::low_stream_for.  Gangs take any: two
+		// lock-step gangs side by side ran 16 MT19937 systems in 33 ms on whatever the pool handed out and in 36-41 ms on pairs
+		// chosen this way -- with four busy queues other relations than panel / bulk of ONE solve decide, profiles/r05_stream_pairs.txt)
+		if (S.nsys == 1) HIPCHK(pool().low_stream_for(S.sA, S.device, &S.sB));
+		else HIPCHK(pool().stream(&S.sB, S.device, 3));
 		S.own_sB = true;
 	}
 	if (S.flag_sync && S.sB != S.sA) {
@@ -780,7 +893,7 @@ int solver_alloc(Solver &S)
 	HIPCHK(pool().event(&S.ev3, true));
 	if (S.tl_K) {
 		for (hipEvent_t *e : { &S.evOuter, &S.evPri, &S.evPanelDone }) HIPCHK(pool().event(e, false));
-		if (S.sB != S.sA) HIPCHK(pool().stream(&S.sC, S.device, true));       // (GF2BV_SERIAL: everything on one stream)
+		if (S.sB != S.sA) { if (S.nsys == 1) HIPCHK(pool().low_stream_for(S.sA, S.device, &S.sC)); else HIPCHK(pool().stream(&S.sC, S.device, 3)); }       // (GF2BV_SERIAL: everything on one stream)
 	}
 	S.evA.resize(S.nblocks); S.evPrio.resize(S.nblocks); S.waitPrio.assign(S.nblocks, nullptr);
 	for (int b = 0; b < S.nblocks; b++) {
@@ -2216,7 +2329,7 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 		workers.emplace_back([&, t]() {
 			if (hipSetDevice(device) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipSetDevice"; return; }
 			hipStream_t st = nullptr;
-			if (pool().stream(&st, device, false) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipStreamCreate"; return; }
+			if (pool().stream(&st, device, 2) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipStreamCreate"; return; }
 			if (hipStreamWaitEvent(st, ready.ev, 0) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipStreamWaitEvent"; }
 			for (i64 q; (q = next_gang.fetch_add(1)) < ngangs && rcs[t] == GF2BV_OK;) {
 				try {
@@ -2246,7 +2359,7 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 				} catch (const std::bad_alloc &) { rcs[t] = GF2BV_ERR_NOMEM; errs[t] = "out of host memory"; }
 				(void)hipStreamSynchronize(st);
 			}
-			pool().release_stream(st, device, false);
+			pool().release_stream(st, device, 2);
 		});
 	}
 	for (auto &w : workers) w.join();
@@ -2325,40 +2438,100 @@ static int batch_digits_on(const uint32_t *digits, const int64_t *digit_off, int
 	if (ndig < 0) return fail(GF2BV_ERR_ARG, "digit offsets must not decrease");
 	for (i64 r = 0; r < nrows_all; r++)          // (the pack kernel reads digits[off[r] .. off[r + 1]) of the uploaded share)
 		if (digit_off[r + 1] < digit_off[r]) return fail(GF2BV_ERR_ARG, "digit offsets must not decrease");
-	// all digits and offsets go up once; every gang packs its own systems straight into tile-major slabs
+	// The offsets go up once; the DIGITS go up gang by gang, each on the stream of the host thread that takes the gang (round 5: two
+	// threads, as in gf2bv_solve_batch_device -- one gang's upload and pack run under the other's elimination, and two latency-bound
+	// gangs of sparse systems overlap; before: one upload of everything, then the gangs one after the other on one stream -- 16 MT19937
+	// recovery systems 43 ms, 15 of them the upload).  Every gang packs its own systems straight into tile-major slabs.
 	struct Staged {
-		uint32_t *dig = nullptr; i64 *off = nullptr; hipStream_t st = nullptr; int device = 0;
+		i64 *off = nullptr; hipStream_t st = nullptr; hipEvent_t ready = nullptr; int device = 0;
 		~Staged()
 		{
 			if (st) (void)hipStreamSynchronize(st);
-			pool().release(dig); pool().release(off);
-			if (st) pool().release_stream(st, device, 0);
+			pool().release(off);
+			pool().release_event(ready, false);
+			if (st) pool().release_stream(st, device, 2);
 		}
 	} G;
 	G.device = device;
-	HIPCHK(pool().stream(&G.st, device, 0));
-	HIPCHK(pool().alloc((void **)&G.dig, sizeof(uint32_t) * std::max<i64>(1, ndig), device));
+	HIPCHK(pool().stream(&G.st, device, 2));
 	HIPCHK(pool().alloc((void **)&G.off, sizeof(i64) * (nrows_all + 1), device));
-	if (ndig) HIPCHK(hipMemcpyAsync(G.dig, digits + dig0, sizeof(uint32_t) * ndig, hipMemcpyHostToDevice, G.st));
 	HIPCHK(hipMemcpyAsync(G.off, digit_off, sizeof(i64) * (nrows_all + 1), hipMemcpyHostToDevice, G.st));
+	HIPCHK(pool().event(&G.ready, false));
+	HIPCHK(hipEventRecord(G.ready, G.st));
 	const i64 gang = pick_gang(nsys, rows, cols);
-	for (i64 s0 = 0; s0 < nsys; s0 += gang) {
-		Solver S;
-		S.t_begin = std::chrono::steady_clock::now();
-		S.device = device;
-		S.sA = G.st;
-		S.nsys = (int)std::min<i64>(gang, nsys - s0);
-		S.rows = rows; S.cols = cols; S.mode = mode;
-		S.stride = ntiles * TW;
-		HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * m_stride * S.nsys + kOuterSlackBytes, device));
-		const i64 total = rows * ntiles * TW;
-		if (total > 0)
-			k_pack_digits<<<dim3((unsigned)((ntiles * TW + 255) / 256), (unsigned)std::min<i64>(rows, 65535), S.nsys), dim3(256), 0, S.sA>>>(
-				G.dig, G.off + s0 * rows, bits_per_digit, (i64)rows, (i64)cols, ntiles * TW, srows, S.M, SysStride{m_stride, 0}, dig0);
-		HIPCHK(hipGetLastError());
-		rc = solve_gang(S, &out[s0]);
-		if (rc) return rc;
+	const i64 ngangs = (nsys + gang - 1) / gang;
+	i64 max_dig = 1;
+	for (i64 q = 0; q < ngangs; q++)
+		max_dig = std::max<i64>(max_dig, digit_off[std::min<i64>(nsys, (q + 1) * gang) * rows] - digit_off[q * gang * rows]);
+	int NS = 2;
+	if (const char *e = getenv("GF2BV_BATCH_THREADS")) { int v = atoi(e); if (v >= 1) NS = std::min(v, 16); }
+	NS = (int)std::min<i64>(ngangs, NS);
+	std::atomic<i64> next_gang{0};
+	std::vector<int> rcs((size_t)NS, GF2BV_OK);
+	std::vector<std::string> errs((size_t)NS);
+	const int attempt0 = g_attempt;                    // (a whole-call retry by guarded() reaches the workers' solvers)
+	auto worker = [&](int t) {
+		struct Mine {
+			hipStream_t st = nullptr; uint32_t *dig = nullptr; int device = 0;
+			~Mine()
+			{
+				if (st) (void)hipStreamSynchronize(st);
+				pool().release(dig);
+				if (st) pool().release_stream(st, device, 2);
+			}
+		} W;
+		W.device = device;
+		auto run = [&]() -> int {
+			HIPCHK(hipSetDevice(device));
+			HIPCHK(pool().stream(&W.st, device, 2));
+			HIPCHK(hipStreamWaitEvent(W.st, G.ready, 0));
+			HIPCHK(pool().alloc((void **)&W.dig, sizeof(uint32_t) * max_dig, device));
+			for (i64 q; (q = next_gang.fetch_add(1)) < ngangs;) {
+				const i64 s0 = q * gang;
+				const int ns = (int)std::min<i64>(gang, nsys - s0);
+				const i64 d0 = digit_off[s0 * rows], nd = digit_off[(s0 + ns) * rows] - d0;
+				if (nd) HIPCHK(hipMemcpyAsync(W.dig, digits + d0, sizeof(uint32_t) * nd, hipMemcpyHostToDevice, W.st));
+				int rc = GF2BV_OK;
+				// an expired hand-over gate voids THIS gang only (as in gf2bv_solve_batch_device): packed and solved once more with events
+				for (int attempt = attempt0; attempt < 2; attempt++) {
+					g_attempt = attempt;
+					Solver S;
+					S.t_begin = std::chrono::steady_clock::now();
+					S.device = device;
+					S.sA = W.st;
+					S.nsys = ns;
+					S.rows = rows; S.cols = cols; S.mode = mode;
+					S.stride = ntiles * TW;
+					HIPCHK(pool().alloc((void **)&S.M, sizeof(u64) * m_stride * S.nsys + kOuterSlackBytes, device));
+					if (rows * ntiles * TW > 0)
+						k_pack_digits<<<dim3((unsigned)((ntiles * TW + 255) / 256), (unsigned)std::min<i64>(rows, 65535), S.nsys), dim3(256), 0, S.sA>>>(
+							W.dig, G.off + s0 * rows, bits_per_digit, (i64)rows, (i64)cols, ntiles * TW, srows, S.M, SysStride{m_stride, 0}, d0);
+					HIPCHK(hipGetLastError());
+					rc = solve_gang(S, &out[s0]);
+					if (rc != GF2BV_RETRY_EVENTS) break;
+					for (int k = 0; k < ns; k++) { delete out[s0 + k]; out[s0 + k] = nullptr; }
+					(void)hipStreamSynchronize(W.st);
+				}
+				if (rc == GF2BV_RETRY_EVENTS) return fail(GF2BV_ERR_HIP, "a stream hand-over gate timed out on the device");
+				if (rc != GF2BV_OK) return rc;
+				HIPCHK(hipStreamSynchronize(W.st));          // (the next gang's digits overwrite W.dig)
+			}
+			return GF2BV_OK;
+		};
+		try { rcs[(size_t)t] = run(); }
+		catch (const std::bad_alloc &) { rcs[(size_t)t] = fail(GF2BV_ERR_NOMEM, "out of host memory"); }
+		catch (const std::exception &e) { rcs[(size_t)t] = fail(GF2BV_ERR_HIP, e.what()); }
+		if (rcs[(size_t)t] != GF2BV_OK) { errs[(size_t)t] = g_err; next_gang.store(ngangs); }
+	};
+	{
+		std::vector<std::thread> workers;
+		struct Join { std::vector<std::thread> &w; ~Join() { for (auto &t : w) if (t.joinable()) t.join(); } } joiner{ workers };
+		for (int t = 1; t < NS; t++) workers.emplace_back(worker, t);
+		worker(0);
 	}
+	g_attempt = attempt0;
+	for (int t = 0; t < NS; t++)
+		if (rcs[(size_t)t] != GF2BV_OK) return fail(rcs[(size_t)t], errs[(size_t)t].c_str());
 	return GF2BV_OK;
 	});
 }

@@ -267,9 +267,12 @@ def test_gang_bulk_update_with_a_system_per_xcd(monkeypatch, gang, pin, nt, wgs)
     assert got[0].stats["gang_systems"] == int(gang)
 
 
-def test_batched_list_of_int_boundary(monkeypatch):
-    """m4ri_solve_many / LinearSystem.solve_*_many == the single-system calls, element by element."""
+@pytest.mark.parametrize("threads", ["2", "1", "3"])
+def test_batched_list_of_int_boundary(monkeypatch, threads):
+    """m4ri_solve_many / LinearSystem.solve_*_many == the single-system calls, element by element (gangs of 3 taken by 1 / 2 / 3 host
+    threads, each uploading and packing the digits of the gangs it takes)."""
     monkeypatch.setenv("GF2BV_GANG", "3")
+    monkeypatch.setenv("GF2BV_BATCH_THREADS", threads)
     rng = random.Random(99)
     cols = 130
     systems = [random_system(rng, 200, cols), random_system(rng, 200, cols, .5, 90), random_system(rng, 200, cols, .5, 100, False),

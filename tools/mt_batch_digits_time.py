@@ -34,12 +34,13 @@ for rep in range(3):
     st = [s.stats for s in sols]
     print(f"  call {1e3 * (t1 - t0):.1f} ms ({1e3 * (t1 - t0) / nsys:.1f} per system); per system: gang {st[0]['gang_systems']}, eliminate "
           f"{np.mean([x['ms_eliminate'] for x in st]):.1f} ms, total {np.mean([x['ms_total'] for x in st]):.1f} ms, fast blocks "
-          f"{st[0]['fast_blocks']}, hand-overs {st[0]['search_handovers']}", flush=True)
+          f"{st[0]['fast_blocks']}, hand-overs {st[0]['search_handovers']}, retries {sum(x['handover_retries'] for x in st)}", flush=True)
     t0 = time.perf_counter()
     one = [hip.solve_digits(digits[s * rows * nw:(s + 1) * rows * nw], offsets[:rows + 1], 32, rows, cols, 0) for s in range(nsys)]
     t1 = time.perf_counter()
     print(f"  one by one {1e3 * (t1 - t0):.1f} ms ({1e3 * (t1 - t0) / nsys:.1f} per system), eliminate {np.mean([x.stats['ms_eliminate'] for x in one]):.1f}, total "
-          f"{np.mean([x.stats['ms_total'] for x in one]):.1f}; same answers: {all(a.origin_int() == b.origin_int() for a, b in zip(sols, one))}", flush=True)
+          f"{np.mean([x.stats['ms_total'] for x in one]):.1f}; same answers: {all(a.origin_int() == b.origin_int() for a, b in zip(sols, one))}; fast blocks {[x.stats['fast_blocks'] for x in one]}, "
+          f"eliminate {[round(x.stats['ms_eliminate'], 1) for x in one]}, retries {sum(x.stats['handover_retries'] for x in one)}", flush=True)
 t0 = time.perf_counter()
 many = _internal.m4ri_solve_many(systems, cols, 0)
 t1 = time.perf_counter()
