@@ -382,6 +382,17 @@ __global__ void __launch_bounds__(512) k_probe_hold_bulk(unsigned long long *sta
 	while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 	if (big[(threadIdx.x + 1) & 511] == 0xffffffffu) *stamp = 0;
 }
+// (one workgroup with a panel kernel's footprint that works for `ticks`, then says when it ended -- the chain probe of probe_pair)
+__global__ void __launch_bounds__(256) k_probe_panel_work(unsigned long long *stamp, unsigned long long ticks)
+{
+	__shared__ unsigned mid[23 * 256];
+	mid[threadIdx.x] = threadIdx.x;
+	__syncthreads();
+	const unsigned long long t0 = wall_clock64();
+	while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(4);
+	if (threadIdx.x == 0) *stamp = wall_clock64();
+	if (mid[(threadIdx.x + 1) & 255] == 0xffffffffu) *stamp = 0;
+}
 __global__ void __launch_bounds__(256) k_probe_stamp_panel(unsigned long long *stamp)
 {
 	__shared__ unsigned mid[23 * 256];

@@ -300,40 +300,75 @@ struct Pool {
 	std::map<std::pair<hipStream_t, hipStream_t>, int> pair_ok;           // (panel stream, low-priority stream) -> 1 good, 0 throttled
 	std::map<int, int> low_created;                                       // device -> low-priority streams created so far
 	int pairs_probed = 0, pairs_bad = 0;
+	// The probe: a miniature of a solve's pattern, NB "blocks".  Panel stream: two one-workgroup kernels with a panel kernel's footprint
+	// (256 threads, 23 KiB of LDS) that work 10 us each, then a flag; bulk stream: a gate on that flag, then a chip-filling kernel with the
+	// bulk update's footprint (512 threads and 133 KiB per CU) that holds 40 us.  The panel chain depends on nothing the bulk stream
+	// does: on a good pair it ends after NB x ~24 us (measured 187-192 us for 8 blocks), on a bad one after NB x ~55 us (439-446): each
+	// block's panel kernels wait for the hold before them.  (A first probe -- when does the last of 80 panel-shaped workgroups begin
+	// beside two holds: 3 us or 36 -- saw only some of the bad pairs; this one agreed with the solve on 38 of 38 pairs.)
 	hipError_t probe_pair(hipStream_t a, hipStream_t b, int device, int *ok)
 	{
 		*ok = 1;
-		unsigned long long *d = nullptr, h[4] = { 0, 0, 0, 0 };
-		hipError_t e = alloc((void **)&d, sizeof h, device);
+		constexpr int NB = 6;
+		unsigned long long *q = nullptr, hq[2 * NB + 2];
+		int *fl = nullptr;
+		hipError_t e = alloc((void **)&q, sizeof hq, device);
 		if (e != hipSuccess) return e;
-		struct Free { Pool *p; void *q; ~Free() { p->release(q); } } guard{ this, d };
-		if ((e = hipMemsetAsync(d, 0, sizeof h, a)) != hipSuccess) return e;
+		struct Free { Pool *p; void *q; ~Free() { p->release(q); } } g1{ this, q };
+		if ((e = alloc((void **)&fl, sizeof(int) * 2 * NB, device)) != hipSuccess) return e;
+		Free g2{ this, fl };
+		if ((e = hipMemsetAsync(fl, 0, sizeof(int) * 2 * NB, a)) != hipSuccess) return e;
+		if ((e = hipMemsetAsync(q, 0, sizeof hq, a)) != hipSuccess) return e;
 		if ((e = hipStreamSynchronize(a)) != hipSuccess) return e;
 		if ((e = hipStreamSynchronize(b)) != hipSuccess) return e;
 		int cus = 256;
 		(void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-		for (int k = 0; k < 2; k++) k_probe_hold_bulk<<<dim3((unsigned)cus), dim3(512), 0, b>>>(d + k, 8000ull);       // 2 x 80 us
-		k_probe_stamp_panel<<<dim3(1), dim3(256), 0, a>>>(d + 2);
-		k_probe_stamp_panel<<<dim3(80), dim3(256), 0, a>>>(d + 3);
+		k_probe_stamp_panel<<<dim3(1), dim3(256), 0, a>>>(q + 2 * NB);
+		for (int i = 0; i < NB; i++) {
+			k_probe_panel_work<<<dim3(1), dim3(256), 0, a>>>(q + 2 * i, 1000ull);
+			k_probe_panel_work<<<dim3(1), dim3(256), 0, a>>>(q + 2 * i + 1, 1000ull);
+			k_probe_set<<<dim3(1), dim3(1), 0, a>>>(fl + i);
+			k_probe_wait<<<dim3(1), dim3(1), 0, b>>>(fl + i, fl + NB + i, 200000ull);
+			k_probe_hold_bulk<<<dim3((unsigned)cus), dim3(512), 0, b>>>(q + 2 * NB + 1, 4000ull);
+		}
 		if ((e = hipGetLastError()) != hipSuccess) return e;
 		if ((e = hipStreamSynchronize(a)) != hipSuccess) return e;
 		if ((e = hipStreamSynchronize(b)) != hipSuccess) return e;
-		if ((e = hipMemcpy(h, d, sizeof h, hipMemcpyDeviceToHost)) != hipSuccess) return e;
-		// good pairs: the 80 workgroups begin 3-4 us after the single one; throttled pairs: 35-40 us
-		const double gap_us = ((double)h[3] - (double)h[2]) / 100.0;
-		*ok = gap_us < 15.0;
+		if ((e = hipMemcpy(hq, q, sizeof hq, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+		const double chain_us = ((double)hq[2 * NB - 1] - (double)hq[2 * NB]) / 100.0;
+		*ok = chain_us < 37.0 * NB;
 		if (getenv("GF2BV_TRACE"))
-			fprintf(stderr, "[gf2bv trace] stream pair %p / %p: 80 workgroups began %.1f us after the first kernel (%s)\n", (void *)a, (void *)b, gap_us,
-			        *ok ? "good" : "throttled");
+			fprintf(stderr, "[gf2bv trace] stream pair %p / %p: the panel chain of %d probe blocks took %.1f us (%s)\n", (void *)a, (void *)b, NB, chain_us,
+			        *ok ? "good" : "waits for the bulk stream");
 		return hipSuccess;
 	}
-	hipError_t low_stream_for(hipStream_t a, int device, hipStream_t *out)
+	// cls: the class the stream comes from and goes back to (1, or 3 for a batch call's gangs); also: the panel streams of the solves that
+	// will run beside this one (all idle now) -- the stream has to get on with them as well.
+	hipError_t low_stream_for(hipStream_t a, int device, hipStream_t *out, int cls = 1, const std::vector<hipStream_t> &also = {})
 	{
-		static const bool pairing = !(getenv("GF2BV_STREAM_PAIRS") && atoi(getenv("GF2BV_STREAM_PAIRS")) == 0);
-		if (!pairing || !a) return stream(out, device, true);
+		const bool pairing = !(getenv("GF2BV_STREAM_PAIRS") && atoi(getenv("GF2BV_STREAM_PAIRS")) == 0);
+		if (!pairing || !a) return stream(out, device, cls);
 		std::lock_guard<std::mutex> pl(probe_mu);
+		if (const char *e = getenv("GF2BV_LOW_PICK")) {
+			// (experiment, tools/r05/job40_pick.sh: the k-th low-priority stream ever created on the device, whatever the probe says)
+			static std::map<int, std::vector<hipStream_t>> made;
+			auto &v = made[device];
+			const int k = std::max(0, std::min(atoi(e), 15));
+			while ((int)v.size() <= k) {
+				hipStream_t c = nullptr;
+				int lo = 0, hi = 0, ok = 1;
+				(void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+				hipError_t er = hipStreamCreateWithPriority(&c, hipStreamNonBlocking, lo);
+				if (er != hipSuccess) return er;
+				(void)probe_pair(a, c, device, &ok);
+				v.push_back(c);
+			}
+			*out = v[(size_t)k];
+			return hipSuccess;
+		}
 		std::vector<hipStream_t> rejected, with;
 		with.push_back(a);
+		for (hipStream_t x : also) if (x && x != a) with.push_back(x);
 		hipError_t err = hipSuccess;
 		*out = nullptr;
 		// verdict of candidate c against everything in `with`, as far as known: 1 all good, 0 one throttled, -1 something unknown
@@ -350,7 +385,7 @@ struct Pool {
 			bool known_good = false;
 			{
 				std::lock_guard<std::mutex> lk(mu);
-				auto &v = streams[{device, 1}];
+				auto &v = streams[{device, cls}];
 				for (size_t i = v.size(); i-- > 0 && !c;)
 					if (known(v[i]) == 1) { c = v[i]; v.erase(v.begin() + (ptrdiff_t)i); known_good = true; }
 				for (size_t i = v.size(); i-- > 0 && !c;)
@@ -386,8 +421,8 @@ struct Pool {
 			if (all_ok) *out = c; else rejected.push_back(c);
 		}
 		if (!*out && !rejected.empty()) { *out = rejected.front(); rejected.erase(rejected.begin()); }
-		for (hipStream_t r : rejected) release_stream(r, device, true);
-		if (!*out && err == hipSuccess) return stream(out, device, true);
+		for (hipStream_t r : rejected) release_stream(r, device, cls);
+		if (!*out && err == hipSuccess) return stream(out, device, cls);
 		return err;
 	}
 };
@@ -495,6 +530,7 @@ constexpr int TW = GF2_TW;        // words per column tile
 struct Solver {
 	int device = 0;
 	hipStream_t sA = nullptr, sB = nullptr;      // panel path / bulk path
+	hipStream_t sB_preset = nullptr;             // (batch calls choose every gang's pair before the gangs start: StreamSets)
 	bool own_sA = false, own_sB = false;
 	u64 *M = nullptr;             // tile-major working copy (always owned)
 	const u64 *src = nullptr;     // caller's row-major matrix on the device (stride words per row)
@@ -845,9 +881,12 @@ int solver_alloc(Solver &S)
 		// (round 5: single systems take a stream that is KNOWN to run beside sA, see Pool::low_stream_for.  Gangs take any: two
 		// lock-step gangs side by side ran 16 MT19937 systems in 33 ms on whatever the pool handed out and in 36-41 ms on pairs
 		// chosen this way -- with four busy queues other relations than panel / bulk of ONE solve decide, profiles/r05_stream_pairs.txt)
-		if (S.nsys == 1) HIPCHK(pool().low_stream_for(S.sA, S.device, &S.sB));
-		else HIPCHK(pool().stream(&S.sB, S.device, 3));
-		S.own_sB = true;
+		if (S.sB_preset) { S.sB = S.sB_preset; S.own_sB = false; }
+		else {
+			if (S.nsys == 1) HIPCHK(pool().low_stream_for(S.sA, S.device, &S.sB));
+			else HIPCHK(pool().stream(&S.sB, S.device, 3));
+			S.own_sB = true;
+		}
 	}
 	if (S.flag_sync && S.sB != S.sA) {
 		int ok = 0;
@@ -2044,6 +2083,34 @@ i64 pick_gang(i64 nsys, i64 rows, i64 cols, i64 free_bytes = -1)
 	return gang;
 }
 
+// The stream pairs of the NS gangs a batch call runs side by side, chosen by the calling thread before any of them starts (all streams
+// idle: the probes of Pool::low_stream_for see the pairs alone): every gang's bulk stream has been checked against its own panel stream
+// AND against the panel streams of the other gangs.  OPT-IN (GF2BV_GANG_PAIRS=1): measured twice, with both probes, two gangs of MT19937
+// systems side by side run 36-41 ms on streams chosen this way and 33-34 ms on whatever the pool hands out; bulk-bound gangs do not care
+// (64 / 192 x 32768^2: 300-309 against 304-310 systems/s) -- profiles/r05_stream_pairs.txt.
+struct StreamSets {
+	int device = 0;
+	bool on = false;
+	std::vector<hipStream_t> a, b;
+	int acquire(int dev, int n)
+	{
+		device = dev;
+		on = getenv("GF2BV_GANG_PAIRS") && atoi(getenv("GF2BV_GANG_PAIRS")) != 0;
+		if (!on) return GF2BV_OK;
+		a.assign((size_t)n, nullptr); b.assign((size_t)n, nullptr);
+		for (int t = 0; t < n; t++) HIPCHK(pool().stream(&a[(size_t)t], dev, 2));
+		for (int t = 0; t < n; t++) HIPCHK(pool().low_stream_for(a[(size_t)t], dev, &b[(size_t)t], 3, a));
+		return GF2BV_OK;
+	}
+	hipStream_t panel(int t) const { return on ? a[(size_t)t] : nullptr; }
+	hipStream_t bulk(int t) const { return on ? b[(size_t)t] : nullptr; }
+	~StreamSets()
+	{
+		for (hipStream_t x : a) if (x) { (void)hipStreamSynchronize(x); pool().release_stream(x, device, 2); }
+		for (hipStream_t y : b) if (y) { (void)hipStreamSynchronize(y); pool().release_stream(y, device, 3); }
+	}
+};
+
 int check_shape(i64 rows, i64 cols, int mode)
 {
 	// mirrors gf2bv/_internal.c:372-395
@@ -2324,12 +2391,18 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 	HIPCHK(hipEventRecord(ready.ev, (hipStream_t)stream));
 	std::vector<int> rcs(NS, GF2BV_OK);
 	std::vector<std::string> errs(NS);
+	StreamSets sets;
+	HIPCHK(hipSetDevice(device));
+	rc = sets.acquire(device, NS);
+	if (rc) return rc;
 	std::vector<std::thread> workers;
+	struct Join { std::vector<std::thread> &w; ~Join() { for (auto &t : w) if (t.joinable()) t.join(); } } joiner{ workers };     // (before `sets` goes)
 	for (int t = 0; t < NS; t++) {
 		workers.emplace_back([&, t]() {
 			if (hipSetDevice(device) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipSetDevice"; return; }
-			hipStream_t st = nullptr;
-			if (pool().stream(&st, device, 2) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipStreamCreate"; return; }
+			hipStream_t st = sets.panel(t);
+			const bool own_st = st == nullptr;
+			if (own_st && pool().stream(&st, device, 2) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipStreamCreate"; return; }
 			if (hipStreamWaitEvent(st, ready.ev, 0) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipStreamWaitEvent"; }
 			for (i64 q; (q = next_gang.fetch_add(1)) < ngangs && rcs[t] == GF2BV_OK;) {
 				try {
@@ -2344,6 +2417,7 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 					S.t_begin = std::chrono::steady_clock::now();
 					S.device = device;
 					S.sA = st;
+					S.sB_preset = sets.bulk(t);
 					S.nsys = ns;
 					S.src = (const u64 *)d_aug + s0 * sys_stride_words;
 					S.src_sys_words = sys_stride_words;
@@ -2359,7 +2433,7 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 				} catch (const std::bad_alloc &) { rcs[t] = GF2BV_ERR_NOMEM; errs[t] = "out of host memory"; }
 				(void)hipStreamSynchronize(st);
 			}
-			pool().release_stream(st, device, 2);
+			if (own_st) pool().release_stream(st, device, 2);
 		});
 	}
 	for (auto &w : workers) w.join();
@@ -2470,20 +2544,24 @@ static int batch_digits_on(const uint32_t *digits, const int64_t *digit_off, int
 	std::vector<int> rcs((size_t)NS, GF2BV_OK);
 	std::vector<std::string> errs((size_t)NS);
 	const int attempt0 = g_attempt;                    // (a whole-call retry by guarded() reaches the workers' solvers)
+	StreamSets sets;
+	rc = sets.acquire(device, NS);
+	if (rc) return rc;
 	auto worker = [&](int t) {
 		struct Mine {
-			hipStream_t st = nullptr; uint32_t *dig = nullptr; int device = 0;
+			hipStream_t st = nullptr; uint32_t *dig = nullptr; int device = 0; bool own = true;
 			~Mine()
 			{
 				if (st) (void)hipStreamSynchronize(st);
 				pool().release(dig);
-				if (st) pool().release_stream(st, device, 2);
+				if (st && own) pool().release_stream(st, device, 2);
 			}
 		} W;
 		W.device = device;
 		auto run = [&]() -> int {
 			HIPCHK(hipSetDevice(device));
-			HIPCHK(pool().stream(&W.st, device, 2));
+			if (sets.panel(t)) { W.st = sets.panel(t); W.own = false; }
+			else HIPCHK(pool().stream(&W.st, device, 2));
 			HIPCHK(hipStreamWaitEvent(W.st, G.ready, 0));
 			HIPCHK(pool().alloc((void **)&W.dig, sizeof(uint32_t) * max_dig, device));
 			for (i64 q; (q = next_gang.fetch_add(1)) < ngangs;) {
@@ -2499,6 +2577,7 @@ static int batch_digits_on(const uint32_t *digits, const int64_t *digit_off, int
 					S.t_begin = std::chrono::steady_clock::now();
 					S.device = device;
 					S.sA = W.st;
+					S.sB_preset = sets.bulk(t);
 					S.nsys = ns;
 					S.rows = rows; S.cols = cols; S.mode = mode;
 					S.stride = ntiles * TW;

@@ -136,6 +136,29 @@ def test_sparse_block_search(monkeypatch, sparse):
     assert took > 0 or sparse == "0"           # (GF2BV_SPARSE_FAST=0: the dense search may still take the densest systems' later blocks)
 
 
+@pytest.mark.parametrize("knob,value", [("GF2BV_STREAM_PAIRS", "0"), ("GF2BV_LOW_PICK", "2"), ("GF2BV_GANG_PAIRS", "1"), ("GF2BV_STREAM_PAIRS", "1")])
+def test_stream_pair_knobs_change_nothing_but_speed(monkeypatch, knob, value):
+    """Round 5: a single solve's bulk stream is probed to run beside its panel stream (Pool::low_stream_for; GF2BV_STREAM_PAIRS=0: any idle
+    one, GF2BV_LOW_PICK=k: the k-th ever created, the experiment of profiles/r05_stream_pairs.txt), a batch call's gangs take streams of
+    classes of their own (GF2BV_GANG_PAIRS=1: chosen by the probe against every gang's panel stream).  Whatever the streams: the oracle's
+    answers, single solves before and after a batch call."""
+    monkeypatch.setenv(knob, value)
+    monkeypatch.setenv("GF2BV_GANG", "3")
+    rng = random.Random(2718)
+    rows, cols = 3000, 2900
+    systems = [random_system(rng, rows, cols, d, cap, cons, 0) for cap, d, cons in
+               [(None, .5, True), (None, .004, True), (1500, .5, True), (None, .5, False), (cols - 1, .01, True)]]
+    augs = np.stack([O.eqs_to_aug(e, cols) for e in systems])
+    for mode in (0, 1):
+        want = [O.solve_words(a, rows, cols, mode) for a in augs]
+        for a, w in zip(augs[:2], want[:2]):
+            _same(hip.solve_words(a, rows, cols, mode), w, mode)
+        for g, w in zip(hip.solve_batch_words(augs, rows, cols, mode), want):
+            _same(g, w, mode)
+        for a, w in zip(augs[1:3], want[1:3]):
+            _same(hip.solve_words(a, rows, cols, mode), w, mode)
+
+
 @pytest.mark.parametrize("K,P,L", [(2, 2, 0), (2, 2, 1), (2, 2, 2), (2, 4, 2), (3, 2, 1), (2, 3, 0), (4, 2, 3), (2, 2, -1)])
 def test_three_level_elimination_forced_on_small_systems(monkeypatch, K, P, L):
     """Round 5: super-panels of P outer panels of K blocks (GF2BV_THREE_LEVEL=P with GF2BV_TWO_LEVEL=K) -- inside a super-panel the
