@@ -2953,19 +2953,22 @@ k_outer_prow(int j0, int nblk, const PanelRec *__restrict__ panels, const PanelA
 // lookups per segment with that block's 32 B of multipliers (prefetched two segments ahead).  Rows are loaded once and
 // stored once per nblk blocks, and only rows that are alive after the panel are stored at all: the panel's own pivot
 // rows (final since k_outer_trsm) and older ones have nothing to take.
-template <int SEG>
-__global__ void __launch_bounds__(512)
-k_update16k(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__restrict__ gprow,
-            const u64 *__restrict__ mult, i64 set_words, int set0, int nsets,
-            const int *__restrict__ blk_first, const int *__restrict__ died, int j_end, int tile_begin, int ntiles, SysStride ss,
-            int xcd_map, int j_lim)
+template <int SEG, int NT_, int RB, int NB>
+__device__ __forceinline__ void
+update16k_body(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__restrict__ gprow,
+               const u64 *__restrict__ mult, i64 set_words, int set0, int nsets,
+               const int *__restrict__ blk_first, const int *__restrict__ died, int j_end, int tile_begin, int ntiles, SysStride ss,
+               int xcd_map, int j_lim)
 {
 	// j_lim (round 5, three-level elimination): INT_MAX = the outer pass proper (every row alive behind the panel); otherwise the
 	// REPLAY of an outer panel on the tiles right of its super-panel -- only rows that became pivot sources in a LATER panel of the
 	// same super-panel (j_end <= died < j_lim) take it (the TRSM part of the block-recursive elimination: U12 = L11^-1 A12); items
 	// without such a row end at once
-	constexpr int NT = 512, NW = 8;
+	// NT_ / RB / NB (round 5, late): threads per workgroup, lookups per read batch, batches in rotation; the shapes that ship are
+	// the wrappers behind this body
+	constexpr int NT = NT_, NW = NT_ / 64;
 	static_assert(GF2_KMAX * GF2_GMAX * 64 % 512 == 0, "k_outer_apply: whole pivots per lane");
+	static_assert(RB == 8 || RB == 4 || RB == 2 || RB == 1, "read batches of 8, 4, 2 lookups or single lookups");
 	{       // gang: blockIdx.y = system (wave-uniform rebasing, scalar registers)
 		const i64 ao = blockIdx.y * ss.arena_bytes;
 		M += blockIdx.y * ss.m_words;
@@ -3091,38 +3094,49 @@ k_update16k(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__res
 				const uint4 *mr = mrow + (j < SEG ? j : SEG - 1) * (NW * 64 * 2);      // (scalar) + one lane offset shared by all batches
 				m0[slot] = mr[2 * ulane]; m1[slot] = mr[2 * ulane + 1];
 			};
-			auto issue = [&](u32x4 *v, const uint4 &a0, const uint4 &a1, int r) {
+			// round rr of a segment = RB lookups: panel rr / (8 / RB), bytes (rr % (8 / RB)) * RB ... of its multiplier
+			auto issue = [&](u32x4 *v, const uint4 &a0, const uint4 &a1, int rr) {
 				const unsigned mw[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
+				constexpr int RPP = 8 / RB;                     // rounds per panel
+				const int r = rr / RPP, q0 = (rr % RPP) * RB;
 				const int grp = r >> 1, hf = r & 1;
 #pragma unroll
-				for (int q = 0; q < 8; q++) {
+				for (int qq = 0; qq < RB; qq++) {
+					const int q = q0 + qq;
 					const int s = 8 * hf + q;
 					const unsigned sel = (unsigned)(s % 3) | ((4u + (unsigned)(q & 3)) << 8) | ((grp ? 3u : 12u) << 16) | (12u << 24);
 					const unsigned at = __builtin_amdgcn_perm(mw[2 * (2 * grp + hf) + (q >> 2)], KC[s / 3], sel);
-					v[q] = *(lds_u4_ptr)(size_t)at;
+					v[qq] = *(lds_u4_ptr)(size_t)at;
 				}
 			};
 			auto fold = [&](uint4 &acc, const u32x4 *v) {
 #pragma unroll
-				for (int h = 0; h < 4; h++) {
+				for (int h = 0; h < RB / 2; h++) {
 					acc.x = __builtin_amdgcn_bitop3_b32(acc.x, v[2 * h].x, v[2 * h + 1].x, 0x96);
 					acc.y = __builtin_amdgcn_bitop3_b32(acc.y, v[2 * h].y, v[2 * h + 1].y, 0x96);
 					acc.z = __builtin_amdgcn_bitop3_b32(acc.z, v[2 * h].z, v[2 * h + 1].z, 0x96);
 					acc.w = __builtin_amdgcn_bitop3_b32(acc.w, v[2 * h].w, v[2 * h + 1].w, 0x96);
 				}
 			};
-			u32x4 va[8], vb[8];
+			// NB buffers of RB lookups rotate: round g + NB - 1 (of this or the next segment) is issued before the XORs of round g, so
+			// the LDS always has this wavefront's next (NB - 1) x RB reads queued; a segment's multiplier slot takes the segment
+			// after next as soon as its last round has been issued.  (All indices below are compile-time after unrolling.)
+			constexpr int NR = 32 / RB;                         // rounds per segment
+			static_assert(NB >= 2 && NB - 1 <= NR, "buffers");
+			u32x4 v[NB][RB];
 			loadm(0, 0); loadm(1, 1);
-			issue(va, m0[0], m1[0], 0);
+#pragma unroll
+			for (int pre = 0; pre < NB - 1; pre++) issue(v[pre], m0[0], m1[0], pre);
 #pragma unroll
 			for (int j = 0; j < SEG; j++) {
-				const int c = j & 1;
-				issue(vb, m0[c], m1[c], 1); fold(d[j], va);
-				issue(va, m0[c], m1[c], 2); fold(d[j], vb);
-				issue(vb, m0[c], m1[c], 3); fold(d[j], va);
-				const uint4 n0 = m0[c ^ 1], n1 = m1[c ^ 1];
-				loadm(j + 2, c);                        // (past the end: re-reads the last rows' multipliers, unused)
-				issue(va, n0, n1, 0); fold(d[j], vb);   // (past the end: a harmless extra round)
+#pragma unroll
+				for (int rr = 0; rr < NR; rr++) {
+					const int g = j * NR + rr;
+					const int gi = g + NB - 1, ji = gi / NR, ri = gi % NR, ci = ji & 1;      // (ji == SEG, past the end: a harmless extra round)
+					issue(v[gi % NB], m0[ci], m1[ci], ri);
+					if (ri == NR - 1) loadm(ji + 2, ci);            // (past the end: re-reads the last rows' multipliers, unused)
+					fold(d[j], v[g % NB]);
+				}
 			}
 		}
 		// (Requesting the next item's segments while the last block is applied -- each into the registers of the segment just
@@ -3133,6 +3147,36 @@ k_update16k(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__res
 			if ((alive >> j) & 1) (Mrow + j * (NW * 64))[ulane] = d[j];
 	}
 }
+
+#define GF2_U16K_PARAMS u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__restrict__ gprow, const u64 *__restrict__ mult, i64 set_words, \
+	int set0, int nsets, const int *__restrict__ blk_first, const int *__restrict__ died, int j_end, int tile_begin, int ntiles, SysStride ss, int xcd_map, int j_lim
+#define GF2_U16K_ARGS M, rows, srows, nblk, gprow, mult, set_words, set0, nsets, blk_first, died, j_end, tile_begin, ntiles, ss, xcd_map, j_lim
+// Rounds 3-5: 8 wavefronts x GF2_KSEG segments, read batches of 8 (two in flight), ~200 registers -- two wavefronts per SIMD.  Kept as
+// GF2BV_OUTER_SHAPE=1 (and as the base case the three-level experiments were costed with).
+template <int SEG, int NT_ = 512, int RB = 8, int NB = 2>
+__global__ void __launch_bounds__(NT_)
+k_update16k(GF2_U16K_PARAMS)
+{
+	update16k_body<SEG, NT_, RB, NB>(GF2_U16K_ARGS);
+}
+// The default since late round 5: SIXTEEN wavefronts.  The lookup loop is exactly 1 v_perm + 1 ds_read_b128 + 2 v_bitop3 per
+// lookup, and with two wavefronts per SIMD neither the VALU (0.36 busy) nor the LDS (0.48) was saturated -- the wavefronts sat in
+// s_waitcnt (0.40 of their time) behind the LDS latency.  Four wavefronts per SIMD hide it: an item of GF2_WSEG x 1024 rows, read
+// batches of 2 (two in flight), under a REGISTER BUDGET: amdgpu_num_vgpr counts in PAIRS on gfx90a and later, 60 -> 120 registers,
+// four wavefronts = 480 of a SIMD's 512.  What the budget has to leave is room for the GATES (k_gate: 8 registers) -- at 128 the
+// same kernel makes every hand-over of the panel path wait for a workgroup to retire: 262144^2 1.25 s against 1.13 at 120 -- while the
+// panel kernels proper (64-90 registers) have slack in the regime the outer pass runs in and wait for retiring items: budgets of
+// 104 / 112 that keep them resident were measured SLOWER (1.17 / 1.14 s).  The compiler meets 120 with 32 bytes of scratch per lane
+// outside the lookup loop.  Measured (profiles/r05_outer_shapes.txt): isolated 5.45 -> 6.0 TB/s of sweep-words; 262144^2
+// 1.195-1.26 -> 1.105-1.15 s by box (-7.6 ... -8.4 %), 131072^2 173 -> 164 ms; segments 10 / 11 / 12 / 13 / 14: 1.114 / 1.111 /
+// 1.105 / 1.109 / 1.123 s; read batches of 4: 1.144; three buffers of 2: 1.112.  (An attribute cannot depend on a template
+// argument, hence the macro.)
+#define GF2_WSEG 12
+#define GF2_U16K_WIDE(NAME, SEG, RB, NB, VB) \
+	__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(VB))) NAME(GF2_U16K_PARAMS) { update16k_body<SEG, 1024, RB, NB>(GF2_U16K_ARGS); }
+GF2_U16K_WIDE(k_update16k_wide, GF2_WSEG, 2, 2, 60)
+GF2_U16K_WIDE(k_update16k_wide10, 10, 2, 2, 60)             // (GF2BV_OUTER_SHAPE=2: no scratch at all, 1.114 s)
+GF2_U16K_WIDE(k_update16k_wide_room, GF2_WSEG, 2, 2, 56)    // (GF2BV_OUTER_SHAPE=3: 112 registers, k_block_fast_narrow fits beside it, 1.15 s)
 
 // P = T x S on one column tile: the final pivot rows of an outer panel (all 4 K panels) from its source rows, WITHOUT the
 // chain of k_outer_trsm -- T comes from k_outer_trsm<.., IDENT> once per panel.  One workgroup per tile; the "rows" are the

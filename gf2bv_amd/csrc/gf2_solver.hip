@@ -67,9 +67,9 @@ int guarded(F &&body)
 	} while (0)
 
 inline i64 round_up(i64 v, i64 m) { return (v + m - 1) / m * m; }
-// k_update16k does not clamp its row indices: a tile's last chunk of GF2_KSEG x 512 rows may read that far past the tile
+// k_update16k does not clamp its row indices: a tile's last chunk (an item: up to GF2_WSEG x 1024 rows) may read that far past the tile
 // (never stored); the working matrix and the multiplier sets get this much slack behind them
-constexpr size_t kOuterSlackBytes = (size_t)GF2_KSEG * 512 * 32;
+constexpr size_t kOuterSlackBytes = (size_t)GF2_WSEG * 1024 * 32;   // (the largest item of the outer pass's workgroup shapes: 12288 rows)
 
 struct Trace {
 	bool on = getenv("GF2BV_TRACE") != nullptr;
@@ -592,6 +592,9 @@ struct Solver {
 	u64 *Uwin = nullptr;          // rank x GMAX: pivot rows' words of the following window (k_prio_window -> k_unwind)
 	int *oprow = nullptr;         // k_outer_prow -> k_outer_apply / k_update16k: row lists of the outer panel being applied
 	u64 *Tm = nullptr;            // k_outer_trsm<IDENT> -> k_outer_apply: the panel's pivot rows as combinations of its source rows
+	int outer_shape = 0;          // GF2BV_OUTER_SHAPE: workgroup shape of the outer pass (gf2_kernels.hip.h, behind update16k_body) -- 0 = sixteen
+	                              // wavefronts x 12 segments at 120 registers (k_update16k_wide, the default since late round 5), 1 = the eight
+	                              // wavefronts x 16 segments of rounds 3-5, 2 = sixteen x 10 (no scratch), 3 = sixteen x 12 at 112 registers
 	bool outer_xcd = false;       // GF2BV_OUTER_XCD=1: the outer pass walks its items chunk-major per XCD (k_update16k: xcd_map) -- built and
 	                              // measured in round 4, SLOWER: 262144^2 1.305 -> 1.370 s, 131072^2 185 -> 210 ms (profiles/r04_target_scans.txt)
 	bool outer_chain = false;     // GF2BV_OUTER_CHAIN=1: the chain itself on every word group instead (the first form; tests)
@@ -787,6 +790,7 @@ void plan_two_level(Solver &S)
 	S.tl_K = K; S.tl_bend = bend;
 	if (const char *e = getenv("GF2BV_OUTER_CHAIN"); e && *e) S.outer_chain = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_OUTER_XCD"); e && *e) S.outer_xcd = atoi(e) != 0;
+	if (const char *e = getenv("GF2BV_OUTER_SHAPE"); e && *e) S.outer_shape = std::min(3, std::max(0, atoi(e)));
 	S.nsets = 2 * K;              // the outer pass of panel p reads its K sets while the blocks of panel p + 1 write theirs
 }
 
@@ -1348,13 +1352,25 @@ int enqueue_outer_apply(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, 
 	}
 	// items of a dense system: the kernel derives the true count from the alive bound and loops if there are more
 	const i64 est_lo = std::min<i64>(S.rows, (i64)b0 * 64 * G) & ~(i64)63, R64 = round_up(S.rows, 64);
-	const i64 nch = std::max<i64>(1, (R64 - est_lo + (i64)GF2_KSEG * 512 - 1) / ((i64)GF2_KSEG * 512));
+	static const int shape_rows[4] = { GF2_WSEG * 1024, GF2_KSEG * 512, 10 * 1024, GF2_WSEG * 1024 };
+	const i64 item_rows = shape_rows[S.outer_shape];
+	const i64 nch = std::max<i64>(1, (R64 - est_lo + item_rows - 1) / item_rows);
 	const bool xmap = S.outer_xcd && S.nsys == 1;
 	// (xcd_map: one workgroup per item exactly -- the kernel's own chunk count may be smaller than this estimate, never larger)
 	const i64 wgs = xmap ? 8 * ((nch + 7) / 8) * nt : std::min<i64>(nch * nt, (i64)1 << 30);
-	hipExtLaunchKernelGGL((k_update16k<GF2_KSEG>), dim3((unsigned)wgs, S.nsys), dim3(512), 0, st, S.ext_events ? ka : nullptr, S.ext_events ? kb : nullptr, 0,
-	                      S.M, S.rows, S.srows, b1 - b0, (const int *)gprow, (const u64 *)S.mult,
-	                      set_words, b0 % S.nsets, S.nsets, (const int *)(S.blk_first + b0), (const int *)S.died, b1 * G, (int)t_begin, (int)nt, S.ss(), xmap ? 1 : 0, j_lim);
+#define GF2_LAUNCH_OUTER(KERN, ROWS_, NT_) do { \
+	static_assert((size_t)(ROWS_) * 32 <= kOuterSlackBytes, "the slack behind the matrix covers an item of this shape"); \
+	hipExtLaunchKernelGGL((KERN), dim3((unsigned)wgs, S.nsys), dim3(NT_), 0, st, S.ext_events ? ka : nullptr, S.ext_events ? kb : nullptr, 0, \
+	                      S.M, S.rows, S.srows, b1 - b0, (const int *)gprow, (const u64 *)S.mult, \
+	                      set_words, b0 % S.nsets, S.nsets, (const int *)(S.blk_first + b0), (const int *)S.died, b1 * G, (int)t_begin, (int)nt, S.ss(), xcd_flag, j_lim); } while (0)
+	const int xcd_flag = xmap ? 1 : 0;
+	switch (S.outer_shape) {
+	case 1: { auto kern = k_update16k<GF2_KSEG>; GF2_LAUNCH_OUTER(kern, GF2_KSEG * 512, 512); } break;
+	case 2: GF2_LAUNCH_OUTER(k_update16k_wide10, 10 * 1024, 1024); break;
+	case 3: GF2_LAUNCH_OUTER(k_update16k_wide_room, GF2_WSEG * 1024, 1024); break;
+	default: GF2_LAUNCH_OUTER(k_update16k_wide, GF2_WSEG * 1024, 1024); break;
+	}
+#undef GF2_LAUNCH_OUTER
 	HIPCHK(hipGetLastError());
 	if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, st));
 	if (S.dbg_sync & 2) HIPCHK(hipDeviceSynchronize());
@@ -3119,7 +3135,7 @@ int gf2bv_kernel_resources(int device, int32_t *out, int n)
 	}
 	if (n >= 13) {                 // the outer pass of the two-level elimination: registers, LDS, scratch bytes per lane (must be 0)
 		hipFuncAttributes a{};
-		HIPCHK(hipFuncGetAttributes(&a, (const void *)k_update16k<GF2_KSEG>));
+		HIPCHK(hipFuncGetAttributes(&a, (const void *)k_update16k_wide));       // (the default shape: 16 wavefronts under a budget of 120 registers)
 		out[10] = a.numRegs; out[11] = (int32_t)a.sharedSizeBytes; out[12] = (int32_t)a.localSizeBytes;
 	}
 	if (n >= 15) {                 // search + narrow step in one launch (runs beside the bulk update like the two it replaces)

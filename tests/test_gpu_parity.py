@@ -602,10 +602,12 @@ def test_panel_kernels_fit_beside_the_bulk_update():
     for name in ("block_fast", "narrow_all", "prio_window", "panel_step", "block_fast_narrow", "block_sparse"):
         assert res[name]["vgprs"] <= free_vgprs, (name, res)
         assert res[name]["lds"] <= free_lds, (name, res)
-    # the outer pass of the two-level elimination keeps 16 row segments per lane in registers: it must not spill (a spilled
-    # build ran 30 x slower and still gave the right bits) and two of its wavefronts must fit a SIMD
+    # the outer pass of the two-level elimination (late round 5: sixteen wavefronts, 12 row segments per lane) runs under a budget
+    # of 120 registers -- four wavefronts per SIMD and room for the gates of the panel path beside them; the compiler meets it
+    # with a few spills OUTSIDE the lookup loop (32 bytes per lane).  A build that spills the loop (seen: 3500 bytes per lane,
+    # 30 x slower, still the right bits) fails here
     outer = res["update_outer"]
-    assert outer["scratch"] == 0 and outer["vgprs"] <= 256 and outer["lds"] <= 160 * 1024, outer
+    assert outer["scratch"] <= 64 and outer["vgprs"] <= 120 and outer["lds"] <= 160 * 1024, outer
     prod = res["product"]            # (round 5) the product kernel of the three-level elimination: the same loop, the same budget
     assert prod["scratch"] == 0 and prod["vgprs"] <= 256 and prod["lds"] <= 160 * 1024, prod
 

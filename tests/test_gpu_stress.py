@@ -110,6 +110,47 @@ def test_two_level_elimination_forced_on_small_systems(monkeypatch, K, chain):
     # the default plan (no forcing) on a system large enough to take outer panels is covered by test_target_262144_properties
 
 
+@pytest.mark.parametrize("shape,K", [(0, 3), (1, 4), (2, 12), (3, 2), (0, 12)])
+def test_outer_pass_workgroup_shapes(monkeypatch, shape, K):
+    """Late round 5: the outer pass (update16k_body) ships in several workgroup shapes -- GF2BV_OUTER_SHAPE 0 = sixteen wavefronts x 12
+    segments under a budget of 120 registers (the default), 1 = the eight wavefronts x 16 segments of rounds 3-5, 2 = sixteen x 10,
+    3 = sixteen x 12 at 112 registers.  Items of 8192 / 10240 / 12288 rows against systems of 2600-9000 rows (one ragged item, several
+    items, rows >> cols), rank caps, inconsistent systems, both modes: the oracle's answers under every shape."""
+    monkeypatch.setenv("GF2BV_OUTER_SHAPE", str(shape))
+    monkeypatch.setenv("GF2BV_TWO_LEVEL", str(K))
+    rng = random.Random(500 + 10 * shape + K)
+    shapes = [(3000, 2500, .5, None, True, 0), (13000, 2100, .5, None, True, 0), (26000, 1500, .3, 1100, True, 40),
+              (5000, 4097, .5, 4000, False, 300), (2600, 2600, .5, 2599, True, 0), (12288, 1300, .5, None, True, 0)]
+    for i, (rows, cols, density, cap, cons, zr) in enumerate(shapes):
+        eqs = random_system(rng, rows, cols, density, cap, cons, zr)
+        if i % 2:
+            rng.shuffle(eqs)
+        aug = O.eqs_to_aug(eqs, cols)
+        mode = i % 2
+        _same(hip.solve_words(aug, rows, cols, mode), O.solve_words(aug, rows, cols, mode), mode)
+
+
+@pytest.mark.parametrize("shape,K", [(0, 4), (1, 4), (0, 12)])
+def test_outer_panel_with_pivotless_blocks_in_the_middle(monkeypatch, shape, K):
+    """An outer panel whose MIDDLE blocks have no pivot at all (512 all-zero columns, then columns that do have pivots): the outer
+    pass skips those blocks and must build the next block's tables from THAT block's pivot rows.  Forced two-level plans, both shapes
+    of the lookup loop, against the oracle."""
+    monkeypatch.setenv("GF2BV_OUTER_SHAPE", str(shape))
+    monkeypatch.setenv("GF2BV_TWO_LEVEL", str(K))
+    rng = random.Random(900 + shape + K)
+    rows, cols = 3400, 3000
+    eqs = random_system(rng, rows, cols, .5, None, True, 0)
+    keep = ~(((1 << 512) - 1) << 256)                  # columns 256 .. 767 go; constants from a planted solution again
+    plant = rng.getrandbits(cols)
+    coeffs = [(e >> 1) & keep for e in eqs]
+    eqs = [(a << 1) | (bin(a & plant).count("1") & 1) for a in coeffs]
+    aug = O.eqs_to_aug(eqs, cols)
+    for mode in (0, 1):
+        want = O.solve_words(aug, rows, cols, mode)
+        assert want["rank"] <= cols - 512
+        _same(hip.solve_words(aug, rows, cols, mode), want, mode)
+
+
 @pytest.mark.parametrize("sparse", ["1", "0"])
 def test_sparse_block_search(monkeypatch, sparse):
     """Round 5: systems whose first block the dense one-launch search cannot take go through k_block_sparse -- the pool = alive rows

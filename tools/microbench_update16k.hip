@@ -3,6 +3,19 @@
 // tools/microbench_update16_kloop.hip (the stripped-down form the design was costed with: 5.0-5.7 at the same size).
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/microbench_update16k.hip -o /tmp/mbk2 && /tmp/mbk2 [rows] [tiles] [K]
 #include "../gf2bv_amd/csrc/gf2_kernels.hip.h"
+// variants of the workgroup shape (round 5, late): -DMB_SEG=8 -DMB_NT=1024 -DMB_RB=4 = 16 wavefronts x 8 segments, read batches of 4
+#ifndef MB_SEG
+#define MB_SEG GF2_KSEG
+#endif
+#ifndef MB_NT
+#define MB_NT 512
+#endif
+#ifndef MB_NB
+#define MB_NB 2
+#endif
+#ifndef MB_RB
+#define MB_RB 8
+#endif
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -18,7 +31,7 @@ int main(int argc, char **argv)
 	const i64 R64 = (rows + 63) / 64 * 64, srows = aligned ? R64 : R64 + 2;
 	const int npan = K * GF2_GMAX;
 	u64 *M, *mult; PanelRec *panels; PanelAux *aux; int *died, *blkf;
-	const size_t slack = (size_t)GF2_KSEG * 512 * 32;        // the kernel does not clamp a tile's last chunk (the solver leaves this slack too)
+	const size_t slack = (size_t)MB_SEG * MB_NT * 32;        // the kernel does not clamp a tile's last chunk (the solver leaves this slack too)
 	CK(hipMalloc(&M, (size_t)ntiles * srows * 16 + slack)); CK(hipMemset(M, 0x5a, (size_t)ntiles * srows * 16 + slack));
 	const i64 set_words = (i64)GF2_GMAX * mult_rows(rows);
 	std::vector<u64> hm((size_t)K * set_words);
@@ -34,18 +47,18 @@ int main(int argc, char **argv)
 	CK(hipMalloc(&died, rows * 4)); CK(hipMemcpy(died, hd.data(), rows * 4, hipMemcpyHostToDevice));
 	int first = 0; CK(hipMalloc(&blkf, 4)); CK(hipMemcpy(blkf, &first, 4, hipMemcpyHostToDevice));
 	int *gprow; CK(hipMalloc(&gprow, sizeof(int) * GF2_OUTER_LISTS));
-	k_outer_prow<<<dim3(1), dim3(256)>>>(0, K, panels, aux, gprow);
+	k_outer_prow<<<dim3(1), dim3(256)>>>(0, K, panels, aux, gprow, SysStride{0, 0});
 	hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
 	// default: one workgroup per item (as the solver launches it); MB_WGS=256: persistent workgroups
-	const i64 nitems = (R64 + (i64)GF2_KSEG * 512 - 1) / ((i64)GF2_KSEG * 512) * ntiles;
+	const i64 nitems = (R64 + (i64)MB_SEG * MB_NT - 1) / ((i64)MB_SEG * MB_NT) * ntiles;
 	const int wgs = getenv("MB_WGS") ? atoi(getenv("MB_WGS")) : (int)nitems;
-	auto launch = [&] { k_update16k<GF2_KSEG><<<dim3(wgs), dim3(512)>>>(M, rows, srows, K, gprow, mult, set_words, 0, K, blkf, died, npan, 0, ntiles, SysStride{0, 0}, 0, 0x7fffffff); };
+	auto launch = [&] { k_update16k<MB_SEG, MB_NT, MB_RB, MB_NB><<<dim3(wgs), dim3(MB_NT)>>>(M, rows, srows, K, gprow, mult, set_words, 0, K, blkf, died, npan, 0, ntiles, SysStride{0, 0}, 0, 0x7fffffff); };
 	launch(); launch(); CK(hipDeviceSynchronize());
 	const int reps = 6;
 	CK(hipEventRecord(e0)); for (int r = 0; r < reps; r++) launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
 	float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
 	const double bytes = (double)(rows - 64 * npan) * ntiles * 16;
-	printf("k_update16k<%d> rows %lld tiles %d K %d wgs %d %s: %.3f ms per launch = %.3f ms per GiB and block   %.2f TB/s in 256-pivot sweep-words\n", GF2_KSEG,
+	printf("k_update16k<%d,%d,%d> rows %lld tiles %d K %d wgs %d %s: %.3f ms per launch = %.3f ms per GiB and block   %.2f TB/s in 256-pivot sweep-words\n", MB_SEG, MB_NT, MB_RB,
 	       (long long)rows, ntiles, K, wgs, aligned ? "aligned" : "srows=rows+2", ms, ms / K / (bytes / 1073741824.0), 2.0 * K * bytes / ms / 1e9);
 	return 0;
 }
