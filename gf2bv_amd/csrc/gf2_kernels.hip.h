@@ -3033,14 +3033,20 @@ update16k_body(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__
 	auto item_rows = [&](i64 item) { return rlo + (item % nch) * CH + (i64)wvu * 64; };
 	auto item_tile = [&](i64 item) { return reinterpret_cast<uint4 *>(M) + ((i64)tile_begin + item / nch) * srows; };
 	for (;; it += gridDim.x) {
-		if (xcd_map) {
+		i64 item = it;
+		if (xcd_map == 1) {
 			const i64 chunk = xcd + 8 * (slot / ntiles);
 			if (chunk >= nch) break;
-			it = (slot % ntiles) * nch + chunk;        // (tile-major item index of (tile, chunk), what the lambdas below decode)
+			item = (slot % ntiles) * nch + chunk;      // (tile-major item index of (tile, chunk), what the lambdas below decode)
 			slot += gslots;
-		} else if (it >= items) break;
-		uint4 *Mw = item_tile(it);
-		const i64 rb0 = item_rows(it);
+		} else {
+			if (it >= items) break;
+			// xcd_map == 2 (late round 5): plain CHUNK-major order -- the workgroups in flight share ONE chunk's multipliers (12288 rows x
+			// 32 B per block) instead of every chunk's, whatever XCD they sit on
+			if (xcd_map == 2) item = (it % ntiles) * nch + it / ntiles;
+		}
+		uint4 *Mw = item_tile(item);
+		const i64 rb0 = item_rows(item);
 		uint4 *Mrow = Mw + rb0;
 		uint4 d[SEG];
 #pragma unroll

@@ -595,6 +595,8 @@ struct Solver {
 	int outer_shape = 0;          // GF2BV_OUTER_SHAPE: workgroup shape of the outer pass (gf2_kernels.hip.h, behind update16k_body) -- 0 = sixteen
 	                              // wavefronts x 12 segments at 120 registers (k_update16k_wide, the default since late round 5), 1 = the eight
 	                              // wavefronts x 16 segments of rounds 3-5, 2 = sixteen x 10 (no scratch), 3 = sixteen x 12 at 112 registers
+	int outer_order = 2;          // GF2BV_OUTER_ORDER: 2 = the outer pass walks its items CHUNK-major (the default since late round 5: the workgroups in
+	                              // flight share one chunk's multipliers; 262144^2 1.105 -> 1.040 s), 0 = tile-major (rounds 3-5)
 	bool outer_xcd = false;       // GF2BV_OUTER_XCD=1: the outer pass walks its items chunk-major per XCD (k_update16k: xcd_map) -- built and
 	                              // measured in round 4, SLOWER: 262144^2 1.305 -> 1.370 s, 131072^2 185 -> 210 ms (profiles/r04_target_scans.txt)
 	bool outer_chain = false;     // GF2BV_OUTER_CHAIN=1: the chain itself on every word group instead (the first form; tests)
@@ -791,6 +793,7 @@ void plan_two_level(Solver &S)
 	if (const char *e = getenv("GF2BV_OUTER_CHAIN"); e && *e) S.outer_chain = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_OUTER_XCD"); e && *e) S.outer_xcd = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_OUTER_SHAPE"); e && *e) S.outer_shape = std::min(3, std::max(0, atoi(e)));
+	if (const char *e = getenv("GF2BV_OUTER_ORDER"); e && *e) S.outer_order = atoi(e) == 0 ? 0 : 2;
 	S.nsets = 2 * K;              // the outer pass of panel p reads its K sets while the blocks of panel p + 1 write theirs
 }
 
@@ -1363,7 +1366,7 @@ int enqueue_outer_apply(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, 
 	hipExtLaunchKernelGGL((KERN), dim3((unsigned)wgs, S.nsys), dim3(NT_), 0, st, S.ext_events ? ka : nullptr, S.ext_events ? kb : nullptr, 0, \
 	                      S.M, S.rows, S.srows, b1 - b0, (const int *)gprow, (const u64 *)S.mult, \
 	                      set_words, b0 % S.nsets, S.nsets, (const int *)(S.blk_first + b0), (const int *)S.died, b1 * G, (int)t_begin, (int)nt, S.ss(), xcd_flag, j_lim); } while (0)
-	const int xcd_flag = xmap ? 1 : 0;
+	const int xcd_flag = xmap ? 1 : S.outer_order;
 	switch (S.outer_shape) {
 	case 1: { auto kern = k_update16k<GF2_KSEG>; GF2_LAUNCH_OUTER(kern, GF2_KSEG * 512, 512); } break;
 	case 2: GF2_LAUNCH_OUTER(k_update16k_wide10, 10 * 1024, 1024); break;
