@@ -585,7 +585,11 @@ struct Solver {
 	double sp_add_bytes = 0, sp_mul_words = 0;      // what the products' additions moved / the lookups they did (in sweep-words)
 	std::vector<size_t> sp_kev;   // indices into kev of the event pairs that bracket super-panel products (ms_product)
 	hipStream_t sC = nullptr;     // outer passes: panel p's runs BESIDE the inner elimination of panel p + 1 (sA + sB)
-	hipEvent_t evOuter = nullptr, evPri = nullptr, evPanelDone = nullptr, evSp = nullptr;
+	hipStream_t sD = nullptr;     // (late round 5) the RIGHT part of every outer pass (outer_split percent of its tiles): its P = T x S and its
+	                              // k_update16k run beside the left part's on sC, so that one part's short launches (the next panel's tiles, the
+	                              // two applies: ~0.6 ms of an underused chip per panel) fall under the other part's pass
+	int outer_split = 50;         // GF2BV_OUTER_SPLIT: percent of an outer pass's tiles that go to sD (0: one stream, rounds 3-5)
+	hipEvent_t evOuter = nullptr, evPri = nullptr, evPanelDone = nullptr, evSp = nullptr, evRight = nullptr;
 	bool bulk_waits_outer = false;     // the next bulk launch of the one-level schedule has to wait for the last outer pass
 	bool ends_outer_panel(int b) const { return tl_K > 0 && b < tl_bend && (b + 1) % tl_K == 0; }
 	u64 *Wb = nullptr;            // 2 x rows x GMAX window words (the panel steps ping-pong between the halves)
@@ -670,6 +674,7 @@ struct Solver {
 			return;
 		}
 		// nothing goes back to the pool while work may still be in flight (error paths return early)
+		if (sD) (void)hipStreamSynchronize(sD);
 		if (sC) (void)hipStreamSynchronize(sC);
 		if (sB) (void)hipStreamSynchronize(sB);
 		if (arena || M) (void)hipStreamSynchronize(sA);
@@ -681,9 +686,10 @@ struct Solver {
 		st = nullptr; panels = nullptr; aux = nullptr; fu = nullptr; died = nullptr; pivcol = nullptr;
 		urow = nullptr; blk_first = nullptr; mult = nullptr; Wb = nullptr;
 		for (hipEvent_t *e : { &ev0, &ev1, &ev2, &ev3, &evx }) { P.release_event(*e, true); *e = nullptr; }
-		for (hipEvent_t *e : { &evOuter, &evPri, &evPanelDone, &evSp }) { P.release_event(*e, false); *e = nullptr; }
+		for (hipEvent_t *e : { &evOuter, &evPri, &evPanelDone, &evSp, &evRight }) { P.release_event(*e, false); *e = nullptr; }
 		if (sC) P.release_stream(sC, device, nsys > 1 ? 3 : 1);
-		sC = nullptr;
+		if (sD) P.release_stream(sD, device, 1);
+		sC = nullptr; sD = nullptr;
 		for (hipEvent_t e : kev) P.release_event(e, true);
 		for (hipEvent_t e : evA) P.release_event(e, false);
 		for (hipEvent_t e : evPrio) P.release_event(e, false);
@@ -940,6 +946,11 @@ int solver_alloc(Solver &S)
 	if (S.tl_K) {
 		for (hipEvent_t *e : { &S.evOuter, &S.evPri, &S.evPanelDone }) HIPCHK(pool().event(e, false));
 		if (S.sB != S.sA) { if (S.nsys == 1) HIPCHK(pool().low_stream_for(S.sA, S.device, &S.sC)); else HIPCHK(pool().stream(&S.sC, S.device, 3)); }       // (GF2BV_SERIAL: everything on one stream)
+		if (const char *e = getenv("GF2BV_OUTER_SPLIT"); e && *e) S.outer_split = std::min(90, std::max(0, atoi(e)));
+		if (S.sC && S.nsys == 1 && S.outer_split > 0 && !S.sp_P) {
+			HIPCHK(pool().event(&S.evRight, false));
+			HIPCHK(pool().low_stream_for(S.sA, S.device, &S.sD, 1, { S.sC }));
+		}
 	}
 	S.evA.resize(S.nblocks); S.evPrio.resize(S.nblocks); S.waitPrio.assign(S.nblocks, nullptr);
 	for (int b = 0; b < S.nblocks; b++) {
@@ -1579,6 +1590,7 @@ int enqueue_forward(Solver &S)
 	auto sparse_ok = [&](int blk) { return S.sparse_on && blk != general_only && fast_block_possible(S, block_geom(S, blk)); };
 	// after a poisoned block pb: everything in flight drained, the plan cut back to what has run, the counters rebased
 	auto recover = [&](int pb) -> int {
+		if (S.sD) HIPCHK(hipStreamSynchronize(S.sD));
 		if (S.sC) HIPCHK(hipStreamSynchronize(S.sC));
 		HIPCHK(hipStreamSynchronize(S.sB));
 		// (two-level: the outer panels before the poisoned one are complete; the published blocks of the poisoned panel have been
@@ -1644,6 +1656,7 @@ int enqueue_forward(Solver &S)
 	if (S.tl_K) {
 		const int G = S.impl->G;
 		hipStream_t so = S.sC ? S.sC : S.sB;           // (GF2BV_SERIAL: one stream, everything in order)
+		bool right_running = false;                    // the previous panel's pass was split over so and sD
 		for (int p0 = 0; p0 < S.tl_bend; p0 += S.tl_K) {
 			const int p1 = p0 + S.tl_K;
 			if (p0 > 0) {
@@ -1670,7 +1683,22 @@ int enqueue_forward(Solver &S)
 				if ((rc = enqueue_super_panel_finish(S, so, sp1 - spb, sp1))) return rc;       // (records evPri behind the next panel's tiles)
 			} else {
 				HIPCHK(hipEventRecord(S.evPri, so));
-				if ((rc = enqueue_outer_apply(S, so, p0, p1, t1, t_out))) return rc;
+				const i64 tr = S.sD ? t_out - (t_out - t1) * S.outer_split / 100 : t_out;       // the right part: tiles [tr, t_out) on sD
+				if (S.sD && tr > t1 && t_out - tr >= 32) {
+					// sD is one pass of its own tiles behind at most: its previous pass precedes this one in stream order, and `so` goes on
+					// to the next panel's tiles (behind which that panel's elimination starts and the multiplier sets / row lists of THIS
+					// panel's parity are written again two panels on) only when this pass is complete on both streams -- the hand-over
+					// of rounds 3-5, one event wider.  The first split pass waits for everything `so` has queued before it.
+					HIPCHK(hipStreamWaitEvent(S.sD, right_running ? S.evPanelDone : S.evPri, 0));
+					if ((rc = enqueue_outer_apply(S, S.sD, p0, p1, tr, t_out))) return rc;
+					HIPCHK(hipEventRecord(S.evRight, S.sD));
+					if ((rc = enqueue_outer_apply(S, so, p0, p1, t1, tr))) return rc;
+					HIPCHK(hipStreamWaitEvent(so, S.evRight, 0));
+					right_running = true;
+				} else {
+					if ((rc = enqueue_outer_apply(S, so, p0, p1, t1, t_out))) return rc;
+					right_running = false;
+				}
 			}
 		}
 		HIPCHK(hipEventRecord(S.evOuter, so));

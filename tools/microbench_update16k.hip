@@ -4,6 +4,11 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/microbench_update16k.hip -o /tmp/mbk2 && /tmp/mbk2 [rows] [tiles] [K]
 #include "../gf2bv_amd/csrc/gf2_kernels.hip.h"
 // variants of the workgroup shape (round 5, late): -DMB_SEG=8 -DMB_NT=1024 -DMB_RB=4 = 16 wavefronts x 8 segments, read batches of 4
+#ifdef MB_WIDE        /* -DMB_WIDE: the shipped default kernel, k_update16k_wide */
+#define MB_SEG GF2_WSEG
+#define MB_NT 1024
+#define MB_RB 2
+#endif
 #ifndef MB_SEG
 #define MB_SEG GF2_KSEG
 #endif
@@ -52,7 +57,12 @@ int main(int argc, char **argv)
 	// default: one workgroup per item (as the solver launches it); MB_WGS=256: persistent workgroups
 	const i64 nitems = (R64 + (i64)MB_SEG * MB_NT - 1) / ((i64)MB_SEG * MB_NT) * ntiles;
 	const int wgs = getenv("MB_WGS") ? atoi(getenv("MB_WGS")) : (int)nitems;
-	auto launch = [&] { k_update16k<MB_SEG, MB_NT, MB_RB, MB_NB><<<dim3(wgs), dim3(MB_NT)>>>(M, rows, srows, K, gprow, mult, set_words, 0, K, blkf, died, npan, 0, ntiles, SysStride{0, 0}, 0, 0x7fffffff); };
+	const int order = getenv("MB_ORDER") ? atoi(getenv("MB_ORDER")) : 0;      // 2: chunk-major items (the solver's default since late round 5)
+#ifdef MB_WIDE        /* the shipped default: k_update16k_wide (GF2_WSEG x 1024 rows per item, budget of 120 registers) */
+	auto launch = [&] { k_update16k_wide<<<dim3(wgs), dim3(1024)>>>(M, rows, srows, K, gprow, mult, set_words, 0, K, blkf, died, npan, 0, ntiles, SysStride{0, 0}, order, 0x7fffffff); };
+#else
+	auto launch = [&] { k_update16k<MB_SEG, MB_NT, MB_RB, MB_NB><<<dim3(wgs), dim3(MB_NT)>>>(M, rows, srows, K, gprow, mult, set_words, 0, K, blkf, died, npan, 0, ntiles, SysStride{0, 0}, order, 0x7fffffff); };
+#endif
 	launch(); launch(); CK(hipDeviceSynchronize());
 	const int reps = 6;
 	CK(hipEventRecord(e0)); for (int r = 0; r < reps; r++) launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
