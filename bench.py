@@ -202,8 +202,9 @@ def roofline_block(stats_list, sweep_ms_total: float, n: int, device: int, ceil:
         lds = {"lookup_bytes_total": lds_bytes, "achieved_GBs": lds_rate, "peak_GBs": clk["lds_peak_GBs"],
                "frac": lds_rate / clk["lds_peak_GBs"], "shader_mhz_under_lds_load": clk["shader_mhz"], "cus": clk["cus"],
                "probe_bytes_per_clk_cu": clk["lds_bytes_per_clk_cu"],
-               "note": "table lookups only (the table builds, ~9 % more LDS traffic, are not counted); kernel time = sum of the "
-                       "launches' durations, the next panel's elimination runs beside them"}
+               "note": "table lookups only (the table builds, ~9 % more LDS traffic, are not counted); kernel time = the time during "
+                       "which at least one bulk-update launch runs (launches side by side -- the two halves of an outer pass on "
+                       "their two streams, the next panel's inner updates -- count once)"}
     out = {
         "bound": "lds" if outer_dominant else "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": achieved / HBM_PEAK_GBS, "lds": lds,
@@ -240,9 +241,10 @@ def finish_roofline(roofline: dict, s0: dict, blocks: int):
     roofline["alg_bytes_per_launch"] = roofline["alg_bytes_total"] / nl
     roofline["hbm_bytes_per_launch"] = roofline["hbm_bytes_total"] / nl
     roofline["avg_launch_ms"] = roofline["kernel_ms_total"] / nl
-    # (the bulk kernels of an outer panel -- inner updates on its own tiles -- overlap the previous panel's outer pass on another
-    # stream since round 3: kernel_ms_total is the SUM of launch durations and can exceed the elimination's wall time; `achieved`
-    # is therefore a lower bound there, and elimination_* below is the whole forward elimination, panel path included)
+    # (kernel_ms_total = gf2bv_stats.ms_sweep: launches of one stream add up -- every one-level plan, the headline -- while launches
+    # that run side by side count once: since late round 5 an outer pass of the two-level elimination is two launches on two
+    # streams and the next panel's inner updates run beside them; avg_launch_ms is then the time a launch ACCOUNTS for, not its
+    # own duration.  elimination_* below is the whole forward elimination, panel path included)
 
 
 def timed_single(mat: torch.Tensor, n: int, stride: int, steps: int, warmup: int, device: int, dev, world: int,

@@ -588,7 +588,10 @@ struct Solver {
 	hipStream_t sD = nullptr;     // (late round 5) the RIGHT part of every outer pass (outer_split percent of its tiles): its P = T x S and its
 	                              // k_update16k run beside the left part's on sC, so that one part's short launches (the next panel's tiles, the
 	                              // two applies: ~0.6 ms of an underused chip per panel) fall under the other part's pass
-	int outer_split = 50;         // GF2BV_OUTER_SPLIT: percent of an outer pass's tiles that go to sD (0: one stream, rounds 3-5)
+	int outer_split = 0;          // GF2BV_OUTER_SPLIT: percent of an outer pass's tiles that go to sD (0, the default: one stream).  OPT-IN: 50 takes
+	                              // 131072^2 from 162 to 155 ms and 262144^2 0.8 % down, but the process then owns one more low-priority stream, and
+	                              // batch calls that create THEIR streams after it ran 290 instead of 301 systems/s in the same process (their two gangs
+	                              // no longer overlapped: the stream-pair effect of profiles/r05_stream_pairs.txt, seen from the other side)
 	hipEvent_t evOuter = nullptr, evPri = nullptr, evPanelDone = nullptr, evSp = nullptr, evRight = nullptr;
 	bool bulk_waits_outer = false;     // the next bulk launch of the one-level schedule has to wait for the last outer pass
 	bool ends_outer_panel(int b) const { return tl_K > 0 && b < tl_bend && (b + 1) % tl_K == 0; }
@@ -1991,7 +1994,7 @@ int finish_end(Solver &S, gf2bv_result **out)
 				const i64 out_w = b < S.sp_bend ? std::min<i64>(S.wt, (i64)(b / spb + 1) * spb * G) : S.wt;
 				st.outer_blocks++;
 				if (pend_w > wlo) { st.hbm_words += rows_swept * (double)(std::min<i64>(pend_w, S.wt) - wlo); st.bulk_launches++; }
-				if ((b + 1) % S.tl_K == 0 && out_w > pend_w) { st.hbm_words += rows_swept * (double)(out_w - pend_w); st.bulk_launches += 2; }
+				if ((b + 1) % S.tl_K == 0 && out_w > pend_w) { st.hbm_words += rows_swept * (double)(out_w - pend_w); st.bulk_launches += S.sD && b >= S.sp_bend ? 3 : 2; }      // (the next panel's tiles, then the rest -- in two halves on two streams since late round 5)
 				if (b < S.sp_bend && (b + 1) % spb == 0 && S.wt > out_w) { st.hbm_words += rows_swept * (double)(S.wt - out_w); st.bulk_launches += 2; }
 			} else { st.hbm_words += rows_swept * (double)(S.wt - wlo); st.bulk_launches++; }
 		}
@@ -2001,11 +2004,26 @@ int finish_end(Solver &S, gf2bv_result **out)
 	(void)hipEventElapsedTime(&st.ms_eliminate, S.ev0, S.ev1);
 	(void)hipEventElapsedTime(&st.ms_backsub, S.ev1, S.ev2);
 	(void)hipEventElapsedTime(&st.ms_export, S.ev2, evx);
-	for (size_t i = 0; i + 1 < S.kev.size(); i += 2) {
-		float ms = 0;
-		(void)hipEventElapsedTime(&ms, S.kev[i], S.kev[i + 1]);
-		st.ms_sweep += ms;
-		if (std::find(S.sp_kev.begin(), S.sp_kev.end(), i) != S.sp_kev.end()) st.ms_product += ms;
+	{
+		// ms_sweep = the time during which AT LEAST ONE bulk-update launch was running: launches of one stream add up as before
+		// (every one-level plan), launches that run side by side -- the two halves of an outer pass on their two streams, the next
+		// panel's inner updates beside them -- count once (summed, the split pass of late round 5 would be counted twice)
+		std::vector<std::pair<float, float>> iv;
+		for (size_t i = 0; i + 1 < S.kev.size(); i += 2) {
+			float ms = 0, at = 0;
+			(void)hipEventElapsedTime(&ms, S.kev[i], S.kev[i + 1]);
+			if (hipEventElapsedTime(&at, S.ev0, S.kev[i]) != hipSuccess) { (void)hipGetLastError(); at = iv.empty() ? 0.f : iv.back().second; }
+			iv.push_back({ at, at + ms });
+			if (std::find(S.sp_kev.begin(), S.sp_kev.end(), i) != S.sp_kev.end()) st.ms_product += ms;
+		}
+		std::sort(iv.begin(), iv.end());
+		float lo = 0, hi = -1;
+		for (const auto &v : iv) {
+			if (hi < 0) { lo = v.first; hi = v.second; }
+			else if (v.first <= hi) hi = std::max(hi, v.second);
+			else { st.ms_sweep += hi - lo; lo = v.first; hi = v.second; }
+		}
+		if (hi >= 0) st.ms_sweep += hi - lo;
 	}
 	st.super_panels = S.sp_products;
 	st.strassen_levels = S.sp_levels_used;

@@ -60,7 +60,8 @@ typedef struct gf2bv_stats {
 	double  row_xors;          /* sum over sweeps of rows_swept x T                            */
 	float   ms_pack;           /* digits/words -> device matrix (H2D + pack kernel)            */
 	float   ms_eliminate;      /* forward elimination, all panels (HIP events)                 */
-	float   ms_sweep;          /* time inside the bulk-update kernel (sum over passes, HIP events) */
+	float   ms_sweep;          /* time inside the bulk-update kernels (HIP events): the sum over passes; launches that run side by side
+	                            * (the two halves of an outer pass of the two-level elimination, the inner updates beside them) count once */
 	float   ms_backsub;        /* consistency check + back-substitution + kernel basis         */
 	float   ms_export;         /* D2H of origin / basis                                        */
 	float   ms_total;          /* host wall clock of the whole call                            */
