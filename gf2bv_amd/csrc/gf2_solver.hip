@@ -588,11 +588,12 @@ struct Solver {
 	hipStream_t sD = nullptr;     // (late round 5) the RIGHT part of every outer pass (outer_split percent of its tiles): its P = T x S and its
 	                              // k_update16k run beside the left part's on sC, so that one part's short launches (the next panel's tiles, the
 	                              // two applies: ~0.6 ms of an underused chip per panel) fall under the other part's pass
+	bool outer_side = true;       // GF2BV_OUTER_SIDE=0: the outer step on the next panel's tiles in front of the pass on the outer stream (rounds 3-5)
 	int outer_split = 0;          // GF2BV_OUTER_SPLIT: percent of an outer pass's tiles that go to sD (0, the default: one stream).  OPT-IN: 50 takes
 	                              // 131072^2 from 162 to 155 ms and 262144^2 0.8 % down, but the process then owns one more low-priority stream, and
 	                              // batch calls that create THEIR streams after it ran 290 instead of 301 systems/s in the same process (their two gangs
 	                              // no longer overlapped: the stream-pair effect of profiles/r05_stream_pairs.txt, seen from the other side)
-	hipEvent_t evOuter = nullptr, evPri = nullptr, evPanelDone = nullptr, evSp = nullptr, evRight = nullptr;
+	hipEvent_t evOuter = nullptr, evPri = nullptr, evPanelDone = nullptr, evSp = nullptr, evRight = nullptr, evBig = nullptr;
 	bool bulk_waits_outer = false;     // the next bulk launch of the one-level schedule has to wait for the last outer pass
 	bool ends_outer_panel(int b) const { return tl_K > 0 && b < tl_bend && (b + 1) % tl_K == 0; }
 	u64 *Wb = nullptr;            // 2 x rows x GMAX window words (the panel steps ping-pong between the halves)
@@ -689,7 +690,7 @@ struct Solver {
 		st = nullptr; panels = nullptr; aux = nullptr; fu = nullptr; died = nullptr; pivcol = nullptr;
 		urow = nullptr; blk_first = nullptr; mult = nullptr; Wb = nullptr;
 		for (hipEvent_t *e : { &ev0, &ev1, &ev2, &ev3, &evx }) { P.release_event(*e, true); *e = nullptr; }
-		for (hipEvent_t *e : { &evOuter, &evPri, &evPanelDone, &evSp, &evRight }) { P.release_event(*e, false); *e = nullptr; }
+		for (hipEvent_t *e : { &evOuter, &evPri, &evPanelDone, &evSp, &evRight, &evBig }) { P.release_event(*e, false); *e = nullptr; }
 		if (sC) P.release_stream(sC, device, nsys > 1 ? 3 : 1);
 		if (sD) P.release_stream(sD, device, 1);
 		sC = nullptr; sD = nullptr;
@@ -949,6 +950,8 @@ int solver_alloc(Solver &S)
 	if (S.tl_K) {
 		for (hipEvent_t *e : { &S.evOuter, &S.evPri, &S.evPanelDone }) HIPCHK(pool().event(e, false));
 		if (S.sB != S.sA) { if (S.nsys == 1) HIPCHK(pool().low_stream_for(S.sA, S.device, &S.sC)); else HIPCHK(pool().stream(&S.sC, S.device, 3)); }       // (GF2BV_SERIAL: everything on one stream)
+		HIPCHK(pool().event(&S.evBig, false));
+		if (const char *e = getenv("GF2BV_OUTER_SIDE"); e && *e) S.outer_side = atoi(e) != 0;
 		if (const char *e = getenv("GF2BV_OUTER_SPLIT"); e && *e) S.outer_split = std::min(90, std::max(0, atoi(e)));
 		if (S.sC && S.nsys == 1 && S.outer_split > 0 && !S.sp_P) {
 			HIPCHK(pool().event(&S.evRight, false));
@@ -1660,6 +1663,7 @@ int enqueue_forward(Solver &S)
 		const int G = S.impl->G;
 		hipStream_t so = S.sC ? S.sC : S.sB;           // (GF2BV_SERIAL: one stream, everything in order)
 		bool right_running = false;                    // the previous panel's pass was split over so and sD
+		bool big_recorded = false;                     // evBig holds the end of the previous panel's pass (side launches)
 		for (int p0 = 0; p0 < S.tl_bend; p0 += S.tl_K) {
 			const int p1 = p0 + S.tl_K;
 			if (p0 > 0) {
@@ -1681,6 +1685,22 @@ int enqueue_forward(Solver &S)
 			const int sp1 = in_sp ? (p0 / spb + 1) * spb : 0;
 			const i64 t_out = in_sp ? (i64)sp1 * G / TW : S.ntiles;
 			const i64 t0 = (i64)p1 * G / TW, t1 = std::min<i64>(t_out, t0 + (i64)S.tl_K * G / TW);
+			// (late round 5) the outer step on the NEXT panel's tiles -- a short launch on an underused chip, ~0.3 ms -- goes to the
+			// inner elimination's bulk stream, idle at this point, and runs BESIDE the start of the pass proper instead of before it:
+			// it needs the previous pass complete (evBig; it used to follow it in stream order) and this panel's T; the pass proper
+			// needs T alone (disjoint tiles).  No new stream (cf. GF2BV_OUTER_SPLIT).
+			const bool side = S.outer_side && !in_sp && !S.sD && S.sB != so && S.sB != S.sA;
+			if (side) {
+				HIPCHK(hipStreamWaitEvent(S.sB, S.evPanelDone, 0));
+				if (big_recorded) HIPCHK(hipStreamWaitEvent(S.sB, S.evBig, 0));
+				if ((rc = enqueue_outer_apply(S, S.sB, p0, p1, t0, t1))) return rc;
+				HIPCHK(hipEventRecord(S.evPri, S.sB));
+				if ((rc = enqueue_outer_apply(S, so, p0, p1, t1, t_out))) return rc;
+				HIPCHK(hipEventRecord(S.evBig, so));
+				big_recorded = true;
+				right_running = false;
+				continue;
+			}
 			if ((rc = enqueue_outer_apply(S, so, p0, p1, t0, t1))) return rc;
 			if (in_sp && p1 == sp1) {
 				if ((rc = enqueue_super_panel_finish(S, so, sp1 - spb, sp1))) return rc;       // (records evPri behind the next panel's tiles)
@@ -1703,6 +1723,10 @@ int enqueue_forward(Solver &S)
 					right_running = false;
 				}
 			}
+			// (whatever path this panel took: a side launch of the NEXT panel waits for all of it -- e.g. the first two-level panel
+			// behind a super-panel's product)
+			HIPCHK(hipEventRecord(S.evBig, so));
+			big_recorded = true;
 		}
 		HIPCHK(hipEventRecord(S.evOuter, so));
 		b = S.tl_bend;

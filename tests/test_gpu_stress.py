@@ -110,17 +110,20 @@ def test_two_level_elimination_forced_on_small_systems(monkeypatch, K, chain):
     # the default plan (no forcing) on a system large enough to take outer panels is covered by test_target_262144_properties
 
 
-@pytest.mark.parametrize("shape,K,order,split", [(0, 3, 2, 0), (1, 4, 2, 50), (2, 12, 0, 0), (3, 2, 2, 33), (0, 12, 0, 50), (1, 8, 0, 0), (0, 2, 2, 50)])
-def test_outer_pass_workgroup_shapes(monkeypatch, shape, K, order, split):
+@pytest.mark.parametrize("shape,K,order,split,side", [(0, 3, 2, 0, 1), (1, 4, 2, 50, 1), (2, 12, 0, 0, 0), (3, 2, 2, 33, 1), (0, 12, 0, 50, 0), (1, 8, 0, 0, 1),
+                                                      (0, 2, 2, 50, 1), (0, 4, 2, 0, 0), (0, 12, 2, 0, 1)])
+def test_outer_pass_workgroup_shapes(monkeypatch, shape, K, order, split, side):
     """Late round 5: the outer pass (update16k_body) ships in several workgroup shapes -- GF2BV_OUTER_SHAPE 0 = sixteen wavefronts x 12
     segments under a budget of 120 registers (the default), 1 = the eight wavefronts x 16 segments of rounds 3-5, 2 = sixteen x 10,
     3 = sixteen x 12 at 112 registers.  Items of 8192 / 10240 / 12288 rows against systems of 2600-9000 rows (one ragged item, several
     items, rows >> cols), rank caps, inconsistent systems, both modes: the oracle's answers under every shape, and under both orders the
     items are walked in (GF2BV_OUTER_ORDER 2 = chunk-major, the default; 0 = tile-major), with the pass on one stream (default) and with
-    its right part on a second one (GF2BV_OUTER_SPLIT = percent of the tiles)."""
+    its right part on a second one (GF2BV_OUTER_SPLIT = percent of the tiles), with the outer step on the next panel's tiles beside the
+    pass on the inner bulk stream (GF2BV_OUTER_SIDE=1, default) and in front of it (0)."""
     monkeypatch.setenv("GF2BV_OUTER_SHAPE", str(shape))
     monkeypatch.setenv("GF2BV_OUTER_ORDER", str(order))
     monkeypatch.setenv("GF2BV_OUTER_SPLIT", str(split))
+    monkeypatch.setenv("GF2BV_OUTER_SIDE", str(side))
     monkeypatch.setenv("GF2BV_TWO_LEVEL", str(K))
     rng = random.Random(500 + 10 * shape + K)
     shapes = [(3000, 2500, .5, None, True, 0), (13000, 2100, .5, None, True, 0), (26000, 1500, .3, 1100, True, 40),
