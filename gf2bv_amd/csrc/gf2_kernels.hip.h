@@ -3232,6 +3232,17 @@ k_outer_apply(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__r
 	const uint4 *tbase = reinterpret_cast<const uint4 *>(Tm);
 #pragma unroll 1
 	for (int k = 0; k < nblk; k++) {
+		// (late round 5) this block's T multipliers of all of the lane's pivots are requested HERE, in front of the table build, not
+		// segment by segment in front of their lookups: six exposed L2 round trips per block and wavefront were a third of the
+		// launch (262144^2: 44 ms of P = T x S in front of the passes)
+		const uint4 *mq = tbase + (i64)k * (NQ * 2);           // T's multiplier set of source block k: 32 B per pivot
+		uint4 A0[SEG], A1[SEG];
+#pragma unroll
+		for (int j = 0; j < SEG; j++) {
+			const int i = (j * NW + wv) * 64 + lane;           // pivot index 64 q + k'
+			if (((j * NW + wvu) >> 2) < k) { A0[j] = make_uint4(0, 0, 0, 0); A1[j] = A0[j]; }      // (uniform: nothing to look up, see below)
+			else { A0[j] = mq[i * 2]; A1[j] = mq[i * 2 + 1]; }
+		}
 		__syncthreads();
 		if (threadIdx.x < GF2_GMAX * 64) stage[threadIdx.x] = staged;
 		__syncthreads();
@@ -3256,15 +3267,13 @@ k_outer_apply(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__r
 			staged = sr >= 0 ? Mw[sr] : make_uint4(0, 0, 0, 0);
 		}
 		__syncthreads();
-		const uint4 *mq = tbase + (i64)k * (NQ * 2);           // T's multiplier set of source block k: 32 B per pivot
 #pragma unroll
 		for (int j = 0; j < SEG; j++) {
 			// T is block lower triangular: the pivot rows of block b take nothing from the sources of a LATER block (the chain
 			// forms them in order), so a wavefront whose 64 pivots lie in a block before k has only zeros to look up -- half
 			// of all lookups (no effect on the wall time of a 262144^2 solve, 1.3235 s either way: the kernel is table builds and latency)
 			if (((j * NW + wvu) >> 2) < k) continue;
-			const int i = (j * NW + wv) * 64 + lane;           // pivot index 64 q + k'
-			const uint4 a0 = mq[i * 2], a1 = mq[i * 2 + 1];
+			const uint4 a0 = A0[j], a1 = A1[j];
 			const unsigned mw[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
 #pragma unroll
 			for (int r = 0; r < 4; r++) {
