@@ -805,14 +805,19 @@ def main():
     backend = os.environ.get("GF2BV_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    rank_info = None
     if world > 1:
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        # watchdog + one diagnostic line per rank (device, PCI id, RCCL version, seconds the init took) on stderr BEFORE anything is
+        # allocated; an init that does not return within the limit ends the rank with exit code 3 and the RCCL log -- never a hang
+        rank_info = batch.init_process_group_guarded(backend, dev if backend == "nccl" else None,
+                                                     limit_s=float(os.environ.get("GF2BV_BENCH_INIT_LIMIT_S", "240")))
+    print(f"[gf2bv bench] rank {rank}: libgf2bv_hip.so build {hip.build_id()}", file=sys.stderr, flush=True)
     workload = args.workload if args.workload != "auto" else "single"
     out = {"single": run_single, "batch": run_batch, "sharded": run_sharded}[workload](args, world, rank, local_rank, dev)
     if rank == 0:
+        out["build_id"] = hip.build_id()
+        if rank_info is not None:
+            out["rank0"] = rank_info
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

@@ -10,6 +10,8 @@ Record layout (int64 words): [status, rank, origin word 0 .. origin word cw-1].
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -58,6 +60,70 @@ def gather_records(local: torch.Tensor, nsys: int, group=None) -> torch.Tensor:
         lo, hi = shard_bounds(nsys, world, r)
         out[lo:hi] = parts[r][: hi - lo]
     return out
+
+
+def rank_diagnostics(device_index: int) -> dict:
+    """What a record needs to tell one rank's GPU from another's: device, PCI bus id, name, RCCL version.  Touches the device
+    properties only (no allocation, no stream)."""
+    info = {"rank": int(os.environ.get("RANK", "0")), "local_rank": int(os.environ.get("LOCAL_RANK", "0")),
+            "world": int(os.environ.get("WORLD_SIZE", "1")), "device": device_index, "pid": os.getpid()}
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        info.update(name=p.name, hbm_gib=round(p.total_memory / 2 ** 30, 1), pci_bus_id=getattr(p, "pci_bus_id", None),
+                    pci_device_id=getattr(p, "pci_device_id", None), visible=os.environ.get("HIP_VISIBLE_DEVICES"))
+    except Exception as exc:                                # pragma: no cover - diagnostics must never be what fails
+        info["device_error"] = repr(exc)
+    try:
+        info["rccl"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as exc:                                # pragma: no cover
+        info["rccl"] = repr(exc)
+    return info
+
+
+def init_process_group_guarded(backend: str, device: torch.device | None = None, limit_s: float = 180.0, **kw) -> dict:
+    """`dist.init_process_group` that cannot hang the job: a watchdog thread ends the PROCESS with exit code 3 when the call has not
+    returned after limit_s, after printing this rank's diagnostics, every thread's Python stack and -- if NCCL_DEBUG_FILE is set --
+    the tail of the RCCL log to stderr.  (Round 5: the driver's GPU run waited 240 s inside RCCL's eager single-device connect and
+    could not say where.)  Prints one JSON diagnostic line per rank to stderr BEFORE the call; returns it with `init_seconds`."""
+    import faulthandler
+    import json
+    import sys
+    import threading
+    import time
+
+    idx = device.index if device is not None and device.index is not None else 0
+    info = rank_diagnostics(idx) if backend == "nccl" else {"rank": int(os.environ.get("RANK", "0")), "pid": os.getpid()}
+    info["backend"] = backend
+    print("[gf2bv rank] " + json.dumps(info), file=sys.stderr, flush=True)
+    done = threading.Event()
+
+    def watchdog():
+        if done.wait(limit_s):
+            return
+        print(f"[gf2bv rank] init_process_group({backend!r}) did not return within {limit_s:.0f} s -- giving up: "
+              + json.dumps(info), file=sys.stderr, flush=True)
+        faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+        path = os.environ.get("NCCL_DEBUG_FILE")
+        if path:
+            try:
+                sys.stderr.write("--- RCCL log (tail) ---\n" + open(path, errors="replace").read()[-4000:] + "\n")
+            except OSError:
+                pass
+        sys.stderr.flush()
+        os._exit(3)
+
+    threading.Thread(target=watchdog, name="gf2bv-init-watchdog", daemon=True).start()
+    t0 = time.perf_counter()
+    try:
+        if backend == "nccl" and device is not None:
+            dist.init_process_group(backend, device_id=device, **kw)
+        else:
+            dist.init_process_group(backend, **kw)
+    finally:
+        done.set()
+    info["init_seconds"] = round(time.perf_counter() - t0, 3)
+    print(f"[gf2bv rank] process group up after {info['init_seconds']} s", file=sys.stderr, flush=True)
+    return info
 
 
 def rank_plan(total: int, n: int, world: int, rank: int, hbm_bytes: int = 288 * 10 ** 9) -> dict:

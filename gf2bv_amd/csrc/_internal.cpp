@@ -394,6 +394,15 @@ struct DigitGather {
 	std::vector<const uint32_t *> src;                         // first digit of row r
 	Staging own;
 	uint32_t *digits = nullptr;                                // (gather(): every row, in `own`)
+	// `src` points into the ints' ob_digit arrays.  m4ri_solve gathers before it first drops the GIL, so borrowed pointers do;
+	// m4ri_solve_many gathers chunk k + 1 AFTER it dropped the GIL to wait for chunk k - 1 -- another Python thread may have
+	// emptied the caller's lists by then -- and therefore holds a strong reference to every int until the call ends.
+	bool hold = false;
+	std::vector<PyObject *> held;
+	DigitGather() = default;
+	DigitGather(const DigitGather &) = delete;
+	DigitGather &operator=(const DigitGather &) = delete;
+	~DigitGather() { for (PyObject *o : held) Py_DECREF(o); }     // (destroyed by the Python-facing function, GIL held)
 	bool add(PyObject *list, Py_ssize_t cols)
 	{
 		const Py_ssize_t need = (cols + 1 + PyLong_SHIFT - 1) / PyLong_SHIFT;
@@ -408,6 +417,7 @@ struct DigitGather {
 			const Py_ssize_t nd = GF2_DIGIT_COUNT((PyLongObject *)item);
 			off.push_back(off.back() + (nd < need ? nd : need));
 			src.push_back(reinterpret_cast<const uint32_t *>(GF2_DIGITS((PyLongObject *)item)));
+			if (hold) { Py_INCREF(item); held.push_back(item); }
 		}
 		return true;
 	}
@@ -563,6 +573,7 @@ PyObject *py_m4ri_solve_many(PyObject *, PyObject *const *args, Py_ssize_t nargs
 	if (nsys == 0) return PyList_New(0);
 	Py_ssize_t rows = -1;
 	DigitGather dg;
+	dg.hold = true;                        // later chunks are gathered after the GIL was dropped: own the ints for the whole call
 	for (Py_ssize_t s = 0; s < nsys; s++) {
 		PyObject *list = PyList_GET_ITEM(systems, s);
 		if (!PyList_Check(list)) {
@@ -968,6 +979,13 @@ PyObject *py_set_default_device(PyObject *, PyObject *arg)
 	Py_RETURN_NONE;
 }
 
+// content ids of the two binaries (gf2bv_amd/build.py compiles them in; the marker lets build.py read the shim's without loading it)
+#ifndef GF2BV_SHIM_ID
+#define GF2BV_SHIM_ID "unknown"
+#endif
+const char g_shim_id[] = "GF2BV_SHIM_ID=" GF2BV_SHIM_ID;
+PyObject *py_build_id(PyObject *, PyObject *) { return Py_BuildValue("{s:s,s:s}", "hip", gf2bv_build_id(), "shim", g_shim_id + 14); }
+
 #define FAST(fn) (PyCFunction)(void (*)(void))(fn)
 PyMethodDef module_methods[] = {
 	{"m4ri_solve", FAST(py_m4ri_solve), METH_FASTCALL,
@@ -984,6 +1002,7 @@ PyMethodDef module_methods[] = {
 	 "eqs_to_sage_mat_helper(equations, cols)\n--\n\n(png_bytes, affine): the coefficient matrix as a two-colour PNG (black = 1) for Sage's unpickle_matrix_mod2_dense_v2, and the affine bits."},
 	{"_space_from_ints", FAST(py_space_from_ints), METH_FASTCALL, "test hook: AffineSpace from ints"},
 	{"device_count", py_device_count, METH_NOARGS, "number of visible HIP devices"},
+	{"build_id", py_build_id, METH_NOARGS, "content hashes of the sources libgf2bv_hip.so and this module were compiled from"},
 	{"get_default_device", py_get_default_device, METH_NOARGS, "the device solves run on when no `device` argument is given"},
 	{"set_default_device", py_set_default_device, METH_O, "set_default_device(d)\n--\n\nselect the GPU for solves without a `device` argument"},
 	{nullptr, nullptr, 0, nullptr}};

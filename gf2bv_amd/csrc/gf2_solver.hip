@@ -2390,6 +2390,14 @@ extern "C" {
 
 int gf2bv_version(void) { return 100; }
 
+// sha256 (first 16 hex digits) over gf2_solver.hip + gf2_kernels.hip.h + gf2bv_hip.h, handed in by gf2bv_amd/build.py; the
+// marker in front lets build.py read the id of an existing library without loading it (staleness by content, not by mtime)
+#ifndef GF2BV_BUILD_ID
+#define GF2BV_BUILD_ID "unknown"
+#endif
+static const char g_build_id[] = "GF2BV_BUILD_ID=" GF2BV_BUILD_ID;
+const char *gf2bv_build_id(void) { return g_build_id + 15; }
+
 int gf2bv_device_count(void)
 {
 	int n = 0;

@@ -24,7 +24,7 @@ STATUS_INCONSISTENT = 1
 
 # every symbol include/gf2bv_hip.h declares (checked by tests/test_cabi.py)
 EXPORTS = [
-    "gf2bv_version", "gf2bv_device_count", "gf2bv_last_error",
+    "gf2bv_version", "gf2bv_build_id", "gf2bv_device_count", "gf2bv_last_error",
     "gf2bv_solve_digits", "gf2bv_solve_words", "gf2bv_solve_device", "gf2bv_solve_batch_device",
     "gf2bv_solve_batch_digits", "gf2bv_solve_batch_digits_multi",
     "gf2bv_result_status", "gf2bv_result_rank", "gf2bv_result_dimension", "gf2bv_result_words",
@@ -78,6 +78,7 @@ def lib():
         vp, i64, i32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int
         pp = ctypes.POINTER(ctypes.c_void_p)
         L.gf2bv_last_error.restype = ctypes.c_char_p
+        L.gf2bv_build_id.restype = ctypes.c_char_p
         L.gf2bv_solve_digits.argtypes = [vp, vp, i32, i64, i64, i32, i32, pp]
         L.gf2bv_solve_words.argtypes = [vp, i64, i64, i64, i32, i32, pp]
         L.gf2bv_solve_device.argtypes = [vp, i64, i64, i64, i32, i32, vp, i32, pp]
@@ -147,6 +148,11 @@ def _check(rc: int):
         if rc == 1:
             raise ValueError(msg)
         raise HipError(f"gf2bv_hip error {rc}: {msg}")
+
+
+def build_id() -> str:
+    """Content hash of the sources the loaded libgf2bv_hip.so was compiled from (gf2bv_amd/build.py)."""
+    return lib().gf2bv_build_id().decode()
 
 
 def device_count() -> int:

@@ -91,6 +91,7 @@ typedef struct gf2bv_stats {
 
 /* ---- library / device ------------------------------------------------------------------ */
 int         gf2bv_version(void);
+const char *gf2bv_build_id(void);              /* content hash of the HIP sources this binary was compiled from (build.py) */
 int         gf2bv_device_count(void);          /* 0 when no HIP device is visible */
 const char *gf2bv_last_error(void);            /* thread-local, never NULL */
 

@@ -1,16 +1,12 @@
-"""BASELINE configs[3] on the GPU: the batch workload's real shard functions (gf2bv_amd.batch.synth_shard /
-solve_shard / gather_records -- what `bench.py --gpus N` runs on every rank), one GPU's share of the 512-system job,
-the end-of-job gather over RCCL (backend "nccl", world size 1 on a one-GPU box) and bench.py's batch mode itself."""
-import json
+"""BASELINE configs[3] on the GPU, in-process: the batch workload's real shard functions (gf2bv_amd.batch.synth_shard /
+solve_shard -- what `bench.py --gpus N` runs on every rank) on one GPU's share of the 512-system job, and the pool's behaviour
+under memory pressure.  The end-of-job gather over RCCL and the bench.py launches run in child processes:
+tests/test_gpu_external.py."""
 import os
-import socket
-import subprocess
-import sys
 
 import numpy as np
 import pytest
 import torch
-import torch.distributed as dist
 
 from gf2bv_amd import batch, hip
 from oracle import gf2_oracle as O
@@ -54,126 +50,6 @@ def test_c4_one_gpu_share_64_systems_of_32768():
     mats2 = batch.synth_shard(n, seeds[:16], 0, mats[:16])
     recs2, _ = batch.solve_shard(n, mats2, 0)
     assert torch.equal(recs2, recs[:16])
-
-
-def test_gather_records_over_nccl_world_size_1():
-    """The end-of-job collective with the backend the multi-GPU run uses (RCCL), on this box's one GPU."""
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
-    dev = torch.device("cuda", 0)
-    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
-    try:
-        n, total = 2048, 5
-        lo, hi = batch.shard_bounds(total, 1, 0)
-        seeds = [900 + i for i in range(lo, hi)]
-        mats = batch.synth_shard(n, seeds, 0)
-        recs, sols = batch.solve_shard(n, mats, 0)
-        allrec = batch.gather_records(recs, total)
-        torch.cuda.synchronize()
-        assert allrec.is_cuda and torch.equal(allrec, recs)
-        _check_records(n, seeds, allrec, sols, mats, oracle_diff=(0, 4))
-        # an uneven split as rank 0 of a larger job would see it: padding rows never leak into the table
-        part = batch.gather_records(recs[:3], 3)
-        assert torch.equal(part, recs[:3])
-    finally:
-        dist.destroy_process_group()
-
-
-@pytest.mark.timeout(600)
-def test_bench_batch_mode_end_to_end():
-    """bench.py --workload batch (what --gpus N > 1 runs on every rank), launched through torch.distributed.run."""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
-           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--workload", "batch", "--steps", "2",
-           "--warmup", "1", "--batch-total", "12", "--batch-n", "4096", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=550, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["scaling"] == "strong" and line["n_gpus"] == 1 and line["config"]["systems_total"] == 12
-    assert line["parity_gate"]["all_ranks_ok"] and line["parity_gate"]["residual_rows_rank0"] == 0
-    assert line["parity_gate"]["gathered_records"] == 12
-    assert line["value"] > 0 and line["roofline"]["achieved"] > 0
-
-
-@pytest.mark.timeout(600)
-def test_bench_sharded_mode_single_rank():
-    """bench.py --workload sharded (ONE system, column slabs over the ranks) at world size 1: the schedule end to end."""
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "sharded", "--n", "8192", "--steps", "2", "--warmup", "1"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=550, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["scaling"] == "strong" and line["parity_gate"]["residual_rows"] == 0 and line["parity_gate"]["all_solved"]
-
-
-@pytest.mark.timeout(600)
-def test_bench_two_ranks_sharing_the_gpu():
-    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one process per rank): the default line is
-    the N = 1 workload on every rank (weak scaling: one system per GPU per step) plus the configs[3] job sharded over the
-    ranks as `batch_c4` -- shard bounds, barriers, max-over-ranks timing, the gathers and the JSON line -- with both ranks
-    pinned to this box's one GPU and gloo standing in for RCCL (which cannot put two ranks on one device)."""
-    env = dict(os.environ, GF2BV_BENCH_DEVICE="0", GF2BV_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29547", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--size", "8192", "--batch-total", "9", "--batch-n", "4096"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=550, cwd=ROOT, env=env)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1                                    # rank 0 only
-    line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and "8192x8192" in line["config"]["workload"]
-    assert line["parity_gate"]["all_ranks_ok"] and line["parity_gate"]["residual_rows"] == 0
-    assert "cpu_baseline" not in line and "target_262144" not in line and line["value"] > 0 and line["roofline"]["achieved"] > 0
-    c4 = line["batch_c4"]
-    assert c4["n_gpus"] == 2 and c4["scaling"] == "strong" and c4["config"]["systems_total"] == 9
-    assert c4["parity_gate"]["all_ranks_ok"] and c4["parity_gate"]["gathered_records"] == 9
-    assert c4["systems_per_s"] > 0 and c4["roofline"]["achieved"] > 0
-
-
-@pytest.mark.timeout(1200)
-def test_bench_eight_ranks_sharing_the_gpu():
-    """Multi-GPU readiness without an 8-GPU node (no scaling curve can be taken here: N > 1 is UNMEASURED on hardware):
-    `bench.py --gpus 8` exactly as the driver launches it -- eight ranks under torch.distributed.run -- all pinned to this
-    box's one GPU with gloo standing in for RCCL, at reduced sizes: the shard bounds of configs[3] at world 8 (64 systems
-    -> 8 per rank, what 512 / 8 = 64 per rank exercises), gang sizing for a rank's share, the order of the gathered records,
-    barriers and max-over-ranks timing, one JSON line from rank 0."""
-    env = dict(os.environ, GF2BV_BENCH_DEVICE="0", GF2BV_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
-           "--master-port", "29549", os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1",
-           "--size", "4096", "--batch-total", "64", "--batch-n", "2048"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=1100, cwd=ROOT, env=env)
-    assert out.returncode == 0, out.stderr[-2000:]
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    line = json.loads(lines[0])
-    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["parity_gate"]["all_ranks_ok"]
-    assert "cpu_baseline" not in line and "c3_mt19937" not in line and line["value"] > 0
-    c4 = line["batch_c4"]
-    assert c4["n_gpus"] == 8 and c4["scaling"] == "strong" and c4["config"]["systems_total"] == 64
-    assert c4["config"]["systems_per_gpu"] == 8 and c4["parity_gate"]["all_ranks_ok"] and c4["parity_gate"]["gathered_records"] == 64
-    assert c4["systems_per_s"] > 0
-
-
-@pytest.mark.timeout(600)
-def test_bench_default_line_carries_the_scale_anchor():
-    """N = 1: the same line shape (headline + `batch_c4` with its roofline), here at reduced sizes."""
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--n", "8192", "--batch-total", "6",
-           "--batch-n", "4096", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=550, cwd=ROOT)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
-    assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["parity_gate"]["residual_rows"] == 0
-    c4 = line["batch_c4"]
-    assert c4["n_gpus"] == 1 and c4["config"]["systems_total"] == 6 and c4["parity_gate"]["all_ranks_ok"]
-    assert c4["roofline"]["frac"] > 0 and c4["roofline"]["end_to_end_frac"] > 0
-    # the reference's own example timings ride along at N = 1 (SURVEY 8d): configs[2] x 6 variants, configs[4], host-resident input
-    c3 = line["c3_mt19937"]["variants"]
-    assert [v["bits_per_output"] for v in c3] == [32, 17, 9, 1, 1337, 137]
-    assert all(v["recovered_state_equals_known_answer"] and v["m4ri_solve_ms"]["warm"] > 0 and v["device_ms"]["eliminate"] > 0 for v in c3)
-    c5 = line["c5_xoshiro"]
-    assert c5["recovered_seed_equals_known_answer"] and c5["solutions"] == 1 and c5["solve_all_ms"]["warm_median"] > 0
-    h2d = line["h2d_inclusive"]
-    assert h2d["phases_ms"]["pack_h2d"] > 0 and h2d["ms_per_solve"]["second"] > 0
 
 
 @pytest.mark.timeout(600)

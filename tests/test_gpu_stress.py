@@ -3,7 +3,6 @@
 two-level elimination forced onto small systems, and the "gate timed out -> void solve -> repeat with events" path."""
 import os
 import random
-import subprocess
 import sys
 
 import numpy as np
@@ -11,6 +10,7 @@ import pytest
 
 from gf2bv_amd import hip
 from oracle import gf2_oracle as O
+from tests.child import run_child
 from tests.systems import random_system
 
 pytestmark = pytest.mark.gpu
@@ -260,6 +260,7 @@ def test_back_substitution_with_inverted_diagonal_blocks(monkeypatch, inv):
             _same(hip.solve_words(aug, rows, cols, mode), O.solve_words(aug, rows, cols, mode), mode)
 
 
+@pytest.mark.external
 @pytest.mark.timeout(600)
 def test_soak_many_solves_in_flight():
     """A reduced run of tests/manual/soak_concurrent.py in the automated suite: 2 rounds of 40 solves from 16
@@ -267,9 +268,8 @@ def test_soak_many_solves_in_flight():
     the oracle.  The in-kernel hand-overs are timing-dependent: k_block_fast_narrow's progress counter (sc1 write-through stores
     of the data, vmcnt(0), then the counter; sc1 loads behind the counter on the consumer side: the second visibility recipe of
     MI355X_MICROARCH.md, no L2 write-back / invalidate beside a running bulk update), the stream gates."""
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "manual", "soak_concurrent.py"), "2", "16", "4711"],
-                         capture_output=True, text=True, timeout=560, cwd=ROOT)
-    assert out.returncode == 0 and "SOAK ok" in out.stdout, out.stdout[-1500:] + out.stderr[-1500:]
+    out = run_child([sys.executable, os.path.join(ROOT, "tests", "manual", "soak_concurrent.py"), "2", "16", "4711"], 400)
+    assert out.ok and "SOAK ok" in out.out, out.report()
 
 
 _RETRY_SCRIPT = r"""
@@ -288,6 +288,7 @@ for k in range(2):
 """
 
 
+@pytest.mark.external
 @pytest.mark.timeout(300)
 def test_expired_gate_voids_the_solve_and_it_is_repeated_with_events(tmp_path):
     """GF2BV_FLAG_SYNC=2 skips the concurrency probe; under `rocprofv3 --pmc` kernels of two streams do not execute
@@ -299,8 +300,8 @@ def test_expired_gate_voids_the_solve_and_it_is_repeated_with_events(tmp_path):
     env = dict(os.environ, GF2BV_FLAG_SYNC="2", TMPDIR="/tmp")
     cmd = ["rocprofv3", "--pmc", "SQ_WAVES", "--kernel-trace", "--output-format", "csv", "-d", str(tmp_path / "prof"), "--",
            sys.executable, str(script)]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=280, cwd="/tmp", env=env)
-    lines = [ln.split() for ln in out.stdout.splitlines() if ln.startswith("SOLVE")]
-    assert len(lines) == 2, (out.stdout[-1500:], out.stderr[-1500:])
+    out = run_child(cmd, 200, env=env, cwd="/tmp")
+    lines = [ln.split() for ln in out.out.splitlines() if ln.startswith("SOLVE")]
+    assert len(lines) == 2, out.report()
     assert lines[0][2] == "ok" and lines[1][2] == "ok"
     assert float(lines[0][3]) > 4.0 and float(lines[1][3]) < 2.0, lines          # one expired gate, then events
