@@ -393,22 +393,6 @@ def target_leg(n: int, device: int, dev, ceil: dict) -> dict:
     # packet: the next launch cannot ramp up under the tail of the previous one) -- what a caller of solve_one sees
     plain_elapsed, plain_stats, _ = timed_single(mat, n, stride, steps, 0, device, dev, 1, False)
     bad = hip.residual_device(mat.data_ptr(), n, n, stride, stats[-1].origin, device=device, stream=stream)
-    # (round 5) the opt-in three-level elimination on the same system: super-panels of 10 outer panels, each Schur update ONE product
-    # under Strassen-Winograd levels -- built, bit-exact, slower than the default plan; reported so that the claim has
-    # the driver's clock behind it.  1 warm-up + 1 step; never part of any other figure of this block.
-    three = None
-    if os.environ.get("GF2BV_THREE_LEVEL") is None:
-        os.environ["GF2BV_THREE_LEVEL"] = "10"
-        try:
-            t_el, t_stats, _ = timed_single(mat, n, stride, 1, 1, device, dev, 1, True)
-            ts = t_stats[-1].stats
-            three = {"ms_per_step": t_el * 1e3, "eliminate_ms": float(ts["ms_eliminate"]), "super_panels": int(ts["super_panels"]),
-                     "strassen_levels": int(ts["strassen_levels"]), "ms_in_products": float(ts["ms_product"]),
-                     "product_lookups_vs_classical": (float(ts["product_lookup_words"]) / max(1.0, _classical_product_words(ts, n))),
-                     "addition_GB": float(ts["product_add_bytes"]) / 1e9,
-                     "same_answer_as_default_plan": bool(np.array_equal(t_stats[-1].origin, stats[-1].origin) and t_stats[-1].rank == stats[-1].rank)}
-        finally:
-            del os.environ["GF2BV_THREE_LEVEL"]
     del mat
     s0 = stats[-1].stats
     roofline, launches = roofline_block([s.stats for s in stats], float(sum(s.stats["ms_sweep"] for s in stats)), n, device, ceil)
@@ -427,17 +411,7 @@ def target_leg(n: int, device: int, dev, ceil: dict) -> dict:
             "x_equals_planted": bool(all(np.array_equal(s.origin, hip.planted_solution(n, seed)) for s in stats + plain_stats)),
             "solve_wall_ms": {"eliminate": float(np.mean([s.stats["ms_eliminate"] for s in stats])),
                               "backsub": float(np.mean([s.stats["ms_backsub"] for s in stats]))},
-            "roofline": roofline, "three_level_opt_in": three}
-
-
-def _classical_product_words(ts: dict, n: int) -> float:
-    """sweep-words the super-panel products of a dense n x n solve stand for: rows x trailing words x blocks per super-panel of 10 x 12 blocks"""
-    spb, G = 120, 4
-    tot = 0.0
-    for s in range(int(ts["super_panels"])):
-        done = (s + 1) * spb * 64 * G
-        tot += max(0, n - done) * max(0, (n + 64) // 64 - (s + 1) * spb * G) * spb
-    return tot
+            "roofline": roofline}
 
 
 MT_VARIANTS = ((32, None), (17, None), (9, None), (1, None), (1337, 19968 // 1337 + 10), (137, 19968 // 137 + 60))

@@ -2920,7 +2920,9 @@ k_outer_trsm(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int npan, int gro
 //   out[NQ .. NQ + KMAX) block k has pivots
 //   out[NQ + KMAX .. )  [panel q][slot / pivot k] -> slot_row of the panel, -1 beyond its p: the SOURCE row of slot k (tables
 //                       of k_outer_apply) and at the same time the row pivot k is stored in (its output rows)
-#define GF2_OUTER_LISTS (2 * GF2_KMAX * GF2_GMAX * 64 + GF2_KMAX)
+//   out[2 NQ + KMAX]    the LARGEST source row of the panel (round 6: k_outer_apply ahead of the previous pass's end, see there)
+#define GF2_OUTER_MAXSRC (2 * GF2_KMAX * GF2_GMAX * 64 + GF2_KMAX)
+#define GF2_OUTER_LISTS (2 * GF2_KMAX * GF2_GMAX * 64 + GF2_KMAX + 4)
 __global__ void __launch_bounds__(256)
 k_outer_prow(int j0, int nblk, const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux, int *__restrict__ out, SysStride ss)
 {
@@ -2930,8 +2932,11 @@ k_outer_prow(int j0, int nblk, const PanelRec *__restrict__ panels, const PanelA
 	}
 	constexpr int NQ = GF2_KMAX * GF2_GMAX * 64;
 	__shared__ int anyb[GF2_KMAX];
+	__shared__ int maxsrc;
 	if (threadIdx.x < GF2_KMAX) anyb[threadIdx.x] = 0;
+	if (threadIdx.x == 0) maxsrc = -1;
 	__syncthreads();
+	int mine = -1;
 	for (int t = threadIdx.x; t < NQ; t += blockDim.x) {
 		int pr = -1, sr = -1;
 		if (t < nblk * GF2_GMAX * 64) {
@@ -2942,9 +2947,12 @@ k_outer_prow(int j0, int nblk, const PanelRec *__restrict__ panels, const PanelA
 		}
 		out[t] = pr;
 		out[NQ + GF2_KMAX + t] = sr;
+		mine = max(mine, sr);
 	}
+	atomicMax(&maxsrc, mine);
 	__syncthreads();
 	if (threadIdx.x < GF2_KMAX) out[NQ + threadIdx.x] = anyb[threadIdx.x];
+	if (threadIdx.x == 0) out[GF2_OUTER_MAXSRC] = maxsrc;
 }
 
 // The outer pass: all `nblk` blocks of an outer panel (first panel j0) applied to the column tiles [tile_begin, tile_begin +
@@ -2958,12 +2966,12 @@ __device__ __forceinline__ void
 update16k_body(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__restrict__ gprow,
                const u64 *__restrict__ mult, i64 set_words, int set0, int nsets,
                const int *__restrict__ blk_first, const int *__restrict__ died, int j_end, int tile_begin, int ntiles, SysStride ss,
-               int xcd_map, int j_lim)
+               int xcd_map, i64 item_begin, i64 item_end)
 {
-	// j_lim (round 5, three-level elimination): INT_MAX = the outer pass proper (every row alive behind the panel); otherwise the
-	// REPLAY of an outer panel on the tiles right of its super-panel -- only rows that became pivot sources in a LATER panel of the
-	// same super-panel (j_end <= died < j_lim) take it (the TRSM part of the block-recursive elimination: U12 = L11^-1 A12); items
-	// without such a row end at once
+	// item_begin / item_end (round 6): the launch takes the items [item_begin, min(item_end, all)) of the pass in ITS item order.  The
+	// solver cuts a chunk-major pass (xcd_map == 2) behind its first chunk -- items [0, ntiles): the 12288 rows from the alive bound,
+	// where the NEXT outer panel finds its pivots -- so that the next panel's P = T x S (k_outer_apply) can start when those rows are
+	// final instead of when the whole pass is
 	// NT_ / RB / NB (round 5, late): threads per workgroup, lookups per read batch, batches in rotation; the shapes that ship are
 	// the wrappers behind this body
 	constexpr int NT = NT_, NW = NT_ / 64;
@@ -3010,7 +3018,8 @@ update16k_body(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__
 	const i64 nch = (R64 - rlo + CH - 1) / CH;
 	const i64 items = nch * ntiles;
 	const uint4 *mbase = reinterpret_cast<const uint4 *>(mult);
-	i64 it = blockIdx.x;
+	i64 it = item_begin + blockIdx.x;
+	const i64 item_lim = items < item_end ? items : item_end;
 	// xcd_map (round 4): workgroup b sits on XCD b % 8 (observed placement: speed only).  An item reads nblk x 32 B of multipliers per
 	// row of its chunk -- K x 256 KiB, 3 MiB for K = 12 -- and every tile re-reads them; in tile-major item order an XCD meets
 	// nch / 8 chunks per tile, 12 MiB and more between two uses of the same multipliers: they come from the MALL.  Here XCD c takes
@@ -3021,8 +3030,8 @@ update16k_body(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__
 	// fetch 32 sets of pivot rows per block where tile-major neighbours share them.
 	// (the host sizes the launch from the DENSE estimate of the alive bound; a system with fewer pivots has more chunks: the loop
 	// below then comes round again, gridDim.x / 8 slots further)
-	const i64 xcd = it & 7, gslots = (i64)(gridDim.x >> 3);
-	i64 slot = it >> 3;
+	const i64 xcd = blockIdx.x & 7, gslots = (i64)(gridDim.x >> 3);
+	i64 slot = blockIdx.x >> 3;
 	// Every address below = a wave-uniform 64-bit base (scalar registers) + a 32-BIT lane offset (batch j of a wavefront =
 	// rows base + 512 j + lane): nothing per batch lives in a 64-bit VGPR pair -- with per-lane 64-bit row indices, clamped to
 	// the row range, the compiler kept 16 address pairs per stream across the block loop and spilled up to 1700 registers.
@@ -3040,7 +3049,7 @@ update16k_body(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__
 			item = (slot % ntiles) * nch + chunk;      // (tile-major item index of (tile, chunk), what the lambdas below decode)
 			slot += gslots;
 		} else {
-			if (it >= items) break;
+			if (it >= item_lim) break;
 			// xcd_map == 2 (late round 5): plain CHUNK-major order -- the workgroups in flight share ONE chunk's multipliers (12288 rows x
 			// 32 B per block) instead of every chunk's, whatever XCD they sit on
 			if (xcd_map == 2) item = (it % ntiles) * nch + it / ntiles;
@@ -3057,9 +3066,8 @@ update16k_body(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__
 			const i64 rl = rb0 + j * (NW * 64) + lane;
 			const int dd = died[rl < rows ? rl : rows - 1];
 			// alive BEHIND this panel: never a pivot source, or one of a later panel (the next panel may already be under way)
-			if (rl < rows && dd >= j_end && dd < j_lim) alive |= 1u << j;
+			if (rl < rows && dd >= j_end) alive |= 1u << j;
 		}
-		if (j_lim != 0x7fffffff && !__syncthreads_or(alive != 0)) continue;      // (uniform) replay: nothing to store in this item
 		uint4 staged = make_uint4(0, 0, 0, 0);
 		if (threadIdx.x < GF2_GMAX * 64) { const int pr = gprow[first_blk * 256 + threadIdx.x]; staged = pr >= 0 ? Mw[pr] : make_uint4(0, 0, 0, 0); }
 #pragma unroll 1
@@ -3155,8 +3163,8 @@ update16k_body(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__
 }
 
 #define GF2_U16K_PARAMS u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__restrict__ gprow, const u64 *__restrict__ mult, i64 set_words, \
-	int set0, int nsets, const int *__restrict__ blk_first, const int *__restrict__ died, int j_end, int tile_begin, int ntiles, SysStride ss, int xcd_map, int j_lim
-#define GF2_U16K_ARGS M, rows, srows, nblk, gprow, mult, set_words, set0, nsets, blk_first, died, j_end, tile_begin, ntiles, ss, xcd_map, j_lim
+	int set0, int nsets, const int *__restrict__ blk_first, const int *__restrict__ died, int j_end, int tile_begin, int ntiles, SysStride ss, int xcd_map, i64 item_begin, i64 item_end
+#define GF2_U16K_ARGS M, rows, srows, nblk, gprow, mult, set_words, set0, nsets, blk_first, died, j_end, tile_begin, ntiles, ss, xcd_map, item_begin, item_end
 // Rounds 3-5: 8 wavefronts x GF2_KSEG segments, read batches of 8 (two in flight), ~200 registers -- two wavefronts per SIMD.  Kept as
 // GF2BV_OUTER_SHAPE=1 (and as the base case the three-level experiments were costed with).
 template <int SEG, int NT_ = 512, int RB = 8, int NB = 2>
@@ -3191,12 +3199,24 @@ GF2_U16K_WIDE(k_update16k_wide_room, GF2_WSEG, 2, 2, 56)    // (GF2BV_OUTER_SHAP
 // the very end, into the rows of the same set), the lookups go by the T row's 32 bytes of that block -- the table and lookup
 // code of the bulk update, accumulating from zero.  ~5 us per source block and tile instead of a 0.3 ms chain per word group.
 __global__ void __launch_bounds__(512)
-k_outer_apply(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__restrict__ lists, const u64 *__restrict__ Tm, int tile_begin, SysStride ss)
+k_outer_apply(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__restrict__ lists, const u64 *__restrict__ Tm, int tile_begin, SysStride ss,
+              int when, const int *__restrict__ prev_first, int chunk_rows)
 {
 	{
 		const i64 ao = blockIdx.y * ss.arena_bytes;
 		M += blockIdx.y * ss.m_words;
 		lists = sys_at(lists, ao); Tm = sys_at(Tm, ao);
+		if (when) prev_first = sys_at(prev_first, ao);
+	}
+	// when (round 6): 0 = always.  The source rows of this panel have taken the previous panel's outer pass when that pass has gone over
+	// the rows they sit in; a chunk-major pass finishes its FIRST chunk -- the chunk_rows rows from its row bound *prev_first & ~63 --
+	// in a launch of its own, and a dense panel finds all its pivots there.  The solver therefore enqueues this kernel twice: EARLY
+	// (when = 1) behind that first launch, beside the rest of the previous pass, and LATE (when = 2) in front of this panel's own pass
+	// as before.  Every workgroup of both takes the same decision from the panel's lists: early runs iff every source row lies below
+	// the first chunk's end, late iff not -- exactly one of the two does the work, whatever the system looks like.
+	if (when) {
+		const bool in_first_chunk = lists[GF2_OUTER_MAXSRC] < ((*prev_first) & ~63) + chunk_rows;
+		if (in_first_chunk != (when == 1)) return;
 	}
 	constexpr int NT = 512, NW = 8, SEG = GF2_KMAX * GF2_GMAX * 64 / NT, NQ = GF2_KMAX * GF2_GMAX * 64;      // 4 pivots per lane
 	__shared__ __attribute__((aligned(256))) uint4 tab[2 * 256 * 16];      // 128 KiB at LDS address 0
@@ -3306,190 +3326,6 @@ k_outer_apply(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__r
 	}
 }
 
-
-// ==========================================================================================
-// THREE-LEVEL ELIMINATION (round 5): super-panels, the Schur update as ONE GF(2) matrix product
-// ==========================================================================================
-// M4RI's _mzd_pluq (gf2bv/_internal.c:431-433) is block-recursive: the trailing matrix takes a whole column half at a time as a
-// matrix product (mzd_addmul: Strassen-Winograd over an M4RM base case).  The two-level elimination above sends every outer
-// panel of K <= 12 blocks through the whole trailing matrix: rows make one HBM trip per K blocks, each trip pays its load / store
-// phase, and nothing sub-cubic can be done with an inner dimension of 3072.  Here SP consecutive outer panels form a SUPER-PANEL
-// (D = SP x K x 256 columns, ~30000): inside it the two-level elimination runs unchanged but confined to the super-panel's own
-// column tiles; right of it
-//   (1) the super-panel's D pivot rows are brought up to date panel by panel (the REPLAY: k_outer_apply + k_update16k restricted
-//       to rows that die later in the same super-panel -- the triangular solve U12 = L11^-1 A12, D^2/2 x columns of work),
-//   (2) their segments are gathered into a compact B (k_gather_b), the multipliers of rows that died inside the super-panel are
-//       cleared (k_zero_dead_mults: what is left is exactly L21),
-//   (3) ONE product C ^= A x B updates every alive row: A = the per-row multipliers of the super-panel's blocks as the panel path
-//       stored them, C = the matrix tiles right of the super-panel.  Its base case k_mul16k is the outer pass's table code with the
-//       row segments held in registers through ALL blocks of the product (5.8 TB/s of sweep-words isolated against 4.9 for an
-//       outer pass of 12 blocks inside a solve), and above it the host runs Strassen-Winograd levels (tools/microbench_strassen.hip,
-//       profiles/r05_strassen.txt: 0.87 / 0.82 of the classical time with one / two levels at an inner dimension of 32768).
-// Operand views (uint4 = 16-byte units): C tile t, row r at p[t * ts + r]; A block k, row r at p[k * bs + 2 r .. + 1] (stored
-// multiplier form, midx / mult_stored: quadrant splits keep row offsets at multiples of 64); B block k, tile t, pivot i
-// (= 64 panel + pivot bit) at p[k * bs + 256 t + i].
-struct MulC { uint4 *p; i64 ts; };
-struct MulA { const uint4 *p; i64 bs; };
-struct MulB { const uint4 *p; i64 bs; };
-
-// C (R rows x ntiles) ^= A x B over nb blocks (ZERO: C = A x B, C is not read).  One item = (tile, chunk of SEG x 512 rows); rows
-// past R in the last chunk are read (the buffers carry a chunk of slack) and never stored.
-template <int SEG, bool ZERO>
-__global__ void __launch_bounds__(512)
-k_mul16k(MulC C, i64 R, int ntiles, MulA A, MulB B, int nb)
-{
-	constexpr int NT = 512, NW = 8;
-	__shared__ __attribute__((aligned(256))) uint4 tab[2 * 256 * 16];      // 128 KiB at LDS address 0
-	__shared__ uint4 stage[GF2_GMAX * 64];
-	if ((unsigned)(size_t)tab != 0u) __builtin_trap();
-	const int lane = threadIdx.x & 63;
-	const unsigned ulane = (unsigned)lane;
-	const int wvu = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-	unsigned KC[6];
-	{
-		const int rq_lo = lane & 7, rq_hi = (lane >> 3) & 1;
-#pragma unroll
-		for (int v = 0; v < 6; v++) {
-			unsigned k = 1u << 24;
-#pragma unroll
-			for (int b = 0; b < 3; b++) {
-				const int s = 3 * v + b;
-				if (s < 16) k |= (unsigned)(16 * (8 * ((s >> 3) ^ rq_hi) + (((s & 7) + rq_lo) & 7))) << (8 * b);
-			}
-			asm volatile("" : "+v"(k));
-			KC[v] = k;
-		}
-	}
-	constexpr i64 CH = (i64)SEG * NT;
-	const i64 nch = (R + CH - 1) / CH;
-	const i64 items = nch * ntiles;
-	for (i64 it = blockIdx.x; it < items; it += gridDim.x) {
-		uint4 *Mw = C.p + (it / nch) * C.ts;
-		const i64 rb0 = (it % nch) * CH + (i64)wvu * 64;
-		uint4 *Mrow = Mw + rb0;
-		uint4 d[SEG];
-#pragma unroll
-		for (int j = 0; j < SEG; j++) d[j] = ZERO ? make_uint4(0, 0, 0, 0) : (Mrow + j * (NW * 64))[ulane];
-		const uint4 *Bt = B.p + (it / nch) * 256;
-		uint4 staged = make_uint4(0, 0, 0, 0);
-		if (threadIdx.x < GF2_GMAX * 64) staged = Bt[threadIdx.x];
-#pragma unroll 1
-		for (int k = 0; k < nb; k++) {
-			__syncthreads();
-			if (threadIdx.x < GF2_GMAX * 64) stage[threadIdx.x] = staged;
-			__syncthreads();
-			for (int e = threadIdx.x; e < 2 * 31 * 16; e += NT) {
-				const int sub = e & 15, q = (e >> 4) % 31, grp = (e >> 4) / 31;
-				const int idx = q <= 15 ? q : (q - 15) << 4;
-				const uint4 *st = stage + (2 * grp + (sub >> 3)) * 64 + 8 * (sub & 7);
-				uint4 acc = make_uint4(0, 0, 0, 0);
-				int bits = idx;
-				while (bits) { const int l = __ffs(bits) - 1; bits &= bits - 1; acc = xor4(acc, st[l]); }
-				tab[grp * 4096 + idx * 16 + sub] = acc;
-			}
-			__syncthreads();
-			for (int e = threadIdx.x; e < 2 * 225 * 16; e += NT) {
-				const int sub = e & 15, q = (e >> 4) % 225, grp = (e >> 4) / 225;
-				const int lo = 1 + q % 15, hi = (1 + q / 15) << 4;
-				uint4 *tb = tab + grp * 4096 + sub;
-				tb[(lo | hi) * 16] = xor4(tb[lo * 16], tb[hi * 16]);
-			}
-			if (k + 1 < nb && threadIdx.x < GF2_GMAX * 64) staged = Bt[(i64)(k + 1) * B.bs + threadIdx.x];
-			__syncthreads();
-			uint4 m0[2], m1[2];
-			const uint4 *mrow = A.p + (i64)k * A.bs + rb0 * 2;
-			auto loadm = [&](int j, int slot) {
-				const uint4 *mr = mrow + (j < SEG ? j : SEG - 1) * (NW * 64 * 2);
-				m0[slot] = mr[2 * ulane]; m1[slot] = mr[2 * ulane + 1];
-			};
-			auto issue = [&](u32x4 *v, const uint4 &a0, const uint4 &a1, int r) {
-				const unsigned mw[8] = { a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w };
-				const int grp = r >> 1, hf = r & 1;
-#pragma unroll
-				for (int q = 0; q < 8; q++) {
-					const int s = 8 * hf + q;
-					const unsigned sel = (unsigned)(s % 3) | ((4u + (unsigned)(q & 3)) << 8) | ((grp ? 3u : 12u) << 16) | (12u << 24);
-					const unsigned at = __builtin_amdgcn_perm(mw[2 * (2 * grp + hf) + (q >> 2)], KC[s / 3], sel);
-					v[q] = *(lds_u4_ptr)(size_t)at;
-				}
-			};
-			auto fold = [&](uint4 &acc, const u32x4 *v) {
-#pragma unroll
-				for (int h = 0; h < 4; h++) {
-					acc.x = __builtin_amdgcn_bitop3_b32(acc.x, v[2 * h].x, v[2 * h + 1].x, 0x96);
-					acc.y = __builtin_amdgcn_bitop3_b32(acc.y, v[2 * h].y, v[2 * h + 1].y, 0x96);
-					acc.z = __builtin_amdgcn_bitop3_b32(acc.z, v[2 * h].z, v[2 * h + 1].z, 0x96);
-					acc.w = __builtin_amdgcn_bitop3_b32(acc.w, v[2 * h].w, v[2 * h + 1].w, 0x96);
-				}
-			};
-			u32x4 va[8], vb[8];
-			loadm(0, 0); loadm(1, 1);
-			issue(va, m0[0], m1[0], 0);
-#pragma unroll
-			for (int j = 0; j < SEG; j++) {
-				const int c = j & 1;
-				issue(vb, m0[c], m1[c], 1); fold(d[j], va);
-				issue(va, m0[c], m1[c], 2); fold(d[j], vb);
-				issue(vb, m0[c], m1[c], 3); fold(d[j], va);
-				const uint4 n0 = m0[c ^ 1], n1 = m1[c ^ 1];
-				loadm(j + 2, c);
-				issue(va, n0, n1, 0); fold(d[j], vb);
-			}
-		}
-#pragma unroll
-		for (int j = 0; j < SEG; j++)
-			if (rb0 + j * (NW * 64) + lane < R) (Mrow + j * (NW * 64))[ulane] = d[j];
-	}
-}
-
-// X = Y ^ Z (^ W): the additions of the Strassen-Winograd levels on any operand type, element i of outer slice o at
-// p[o * stride + i] -- ONE 16-byte element per thread with the non-temporal hint, the fastest stream form of this chip
-__global__ void __launch_bounds__(256)
-k_xor16(uint4 *X, i64 xs, const uint4 *Y, i64 ys, const uint4 *Z, i64 zs, const uint4 *W, i64 ws, i64 inner)
-{
-	const i64 i = (i64)blockIdx.x * 256 + threadIdx.x, o = blockIdx.y;
-	if (i >= inner) return;
-	u32x4 a = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Y + o * ys + i));
-	const u32x4 b = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(Z + o * zs + i));
-	a ^= b;
-	if (W) a ^= __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(W + o * ws + i));
-	__builtin_nontemporal_store(a, reinterpret_cast<u32x4 *>(X + o * xs + i));
-}
-__global__ void __launch_bounds__(256)
-k_zero16(uint4 *X, i64 xs, i64 inner)
-{
-	const i64 i = (i64)blockIdx.x * 256 + threadIdx.x, o = blockIdx.y;
-	if (i < inner) X[o * xs + i] = make_uint4(0, 0, 0, 0);
-}
-
-// B of a super-panel: the final pivot rows of its blocks on the tiles [tile_begin, tile_begin + gridDim.x), compact.  lists: the row
-// lists of its outer panels (k_outer_prow), panel pi of the super-panel in list slot (slot0 + pi) % nlist; a block without pivots
-// (or a pivot bit without pivot) gives zeros.  grid (tiles, blocks).
-__global__ void __launch_bounds__(256)
-k_gather_b(const u64 *__restrict__ M, i64 srows, int tile_begin, const int *__restrict__ lists, int slot0, int nlist, int K,
-           uint4 *__restrict__ Bc, i64 bs)
-{
-	const int k = blockIdx.y, pi = k / K, kl = k % K;
-	const int *gprow = lists + (size_t)((slot0 + pi) % nlist) * GF2_OUTER_LISTS;
-	const int pr = gprow[kl * 256 + threadIdx.x];
-	const uint4 *Mw = reinterpret_cast<const uint4 *>(M) + ((i64)tile_begin + blockIdx.x) * srows;
-	Bc[(i64)k * bs + (i64)blockIdx.x * 256 + threadIdx.x] = pr >= 0 ? Mw[pr] : make_uint4(0, 0, 0, 0);
-}
-
-// Rows that became pivot sources inside the super-panel (j_begin <= died < j_end) recorded multipliers for the blocks before their
-// own while they were alive: the replay has used them, the product must not (their rows are final): cleared in all nb sets.
-__global__ void __launch_bounds__(256)
-k_zero_dead_mults(const int *__restrict__ died, i64 rows, i64 row_begin, int j_begin, int j_end, uint4 *__restrict__ mult, i64 bs, int nb)
-{
-	const i64 r = row_begin + (i64)blockIdx.x * 256 + threadIdx.x;
-	if (r >= rows) return;
-	const int d = died[r];
-	if (d < j_begin || d >= j_end) return;
-	for (int k = 0; k < nb; k++) {
-		mult[(i64)k * bs + 2 * r] = make_uint4(0, 0, 0, 0);
-		mult[(i64)k * bs + 2 * r + 1] = make_uint4(0, 0, 0, 0);
-	}
-}
 
 // ==========================================================================================
 // BACK-SUBSTITUTION

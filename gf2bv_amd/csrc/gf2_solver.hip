@@ -99,6 +99,16 @@ inline i64 tiles_for(i64 wt) { return round_up(std::max<i64>(wt, 1), (i64)1 << G
 // microseconds of GPU time) would spend 5+ ms in them.  Buffers up to 64 MiB (512 MiB in total per
 // process), streams and events are therefore recycled across calls.  Thread-safe; everything handed
 // out is idle (a solve releases its resources only after synchronising its streams).
+// GF2BV_PLAIN=1 (round 6): the floor without heuristics on undocumented hardware behaviour -- no stream-pair probing (any idle
+// low-priority stream), no XCD pinning of gangs (the plain (spans, systems) grid), hand-overs between the streams through events instead
+// of counters in memory + k_gate, every block enqueued with both panel paths (no optimistic enqueue).  Same answers (the parity file runs
+// under it), the speed it costs is reported by bench.py as `plain_ms_per_step`.  An explicit knob still wins over it.
+bool plain_mode()
+{
+	const char *e = getenv("GF2BV_PLAIN");
+	return e && atoi(e) != 0;
+}
+
 struct Pool {
 	std::mutex mu;
 	std::unordered_map<void *, std::pair<int, size_t>> live;          // ptr -> (device, bucket bytes)
@@ -346,26 +356,9 @@ struct Pool {
 	// will run beside this one (all idle now) -- the stream has to get on with them as well.
 	hipError_t low_stream_for(hipStream_t a, int device, hipStream_t *out, int cls = 1, const std::vector<hipStream_t> &also = {})
 	{
-		const bool pairing = !(getenv("GF2BV_STREAM_PAIRS") && atoi(getenv("GF2BV_STREAM_PAIRS")) == 0);
+		const bool pairing = !(getenv("GF2BV_STREAM_PAIRS") ? atoi(getenv("GF2BV_STREAM_PAIRS")) == 0 : plain_mode());
 		if (!pairing || !a) return stream(out, device, cls);
 		std::lock_guard<std::mutex> pl(probe_mu);
-		if (const char *e = getenv("GF2BV_LOW_PICK")) {
-			// (experiment, tools/r05/job40_pick.sh: the k-th low-priority stream ever created on the device, whatever the probe says)
-			static std::map<int, std::vector<hipStream_t>> made;
-			auto &v = made[device];
-			const int k = std::max(0, std::min(atoi(e), 15));
-			while ((int)v.size() <= k) {
-				hipStream_t c = nullptr;
-				int lo = 0, hi = 0, ok = 1;
-				(void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-				hipError_t er = hipStreamCreateWithPriority(&c, hipStreamNonBlocking, lo);
-				if (er != hipSuccess) return er;
-				(void)probe_pair(a, c, device, &ok);
-				v.push_back(c);
-			}
-			*out = v[(size_t)k];
-			return hipSuccess;
-		}
 		std::vector<hipStream_t> rejected, with;
 		with.push_back(a);
 		for (hipStream_t x : also) if (x && x != a) with.push_back(x);
@@ -411,10 +404,12 @@ struct Pool {
 				}
 				if (ok < 0) {
 					ok = 1;
-					if (probe_pair(x, c, device, &ok) != hipSuccess) { (void)hipGetLastError(); ok = 1; }      // (a probe that cannot run decides nothing)
-					std::lock_guard<std::mutex> lk(mu);
-					pair_ok[{x, c}] = ok;
-					pairs_probed++; pairs_bad += !ok;
+					if (probe_pair(x, c, device, &ok) != hipSuccess) { (void)hipGetLastError(); ok = 1; }      // (a probe that cannot run decides nothing -- and leaves no verdict: the pair is asked again)
+					else {
+						std::lock_guard<std::mutex> lk(mu);
+						pair_ok[{x, c}] = ok;
+						pairs_probed++; pairs_bad += !ok;
+					}
 				}
 				if (!ok) { all_ok = 0; break; }
 			}
@@ -530,7 +525,6 @@ constexpr int TW = GF2_TW;        // words per column tile
 struct Solver {
 	int device = 0;
 	hipStream_t sA = nullptr, sB = nullptr;      // panel path / bulk path
-	hipStream_t sB_preset = nullptr;             // (batch calls choose every gang's pair before the gangs start: StreamSets)
 	bool own_sA = false, own_sB = false;
 	u64 *M = nullptr;             // tile-major working copy (always owned)
 	const u64 *src = nullptr;     // caller's row-major matrix on the device (stride words per row)
@@ -571,19 +565,7 @@ struct Solver {
 	// two-level elimination (large systems; see k_update16k): blocks [0, tl_bend) go in outer panels of tl_K blocks
 	int tl_K = 0, tl_bend = 0;
 	i64 tile_hi = 0;              // bulk kernels touch tiles < tile_hi (= ntiles; the outer panel's end while it is eliminated)
-	// three-level elimination (round 5; see "THREE-LEVEL ELIMINATION" in gf2_kernels.hip.h): blocks [0, sp_bend) go in super-panels
-	// of sp_P outer panels; right of a super-panel its blocks are applied by ONE matrix product (Strassen-Winograd levels over
-	// k_mul16k) instead of one outer pass per panel
-	int sp_P = 0, sp_bend = 0;
-	int sp_force_levels = -1;     // GF2BV_STRASSEN=L: Strassen-Winograd levels of every product (default: by size)
-	int nlist = 2;                // row lists / T matrices kept: panel parity (two-level), 2 sp_P with super-panels (the replay needs all of a super-panel's)
-	uint4 *spB = nullptr;         // compact pivot rows of the super-panel being applied: [block][tile][256] x 16 B
-	size_t spB_elems = 0;
-	struct SpTemps { uint4 *S = nullptr, *T = nullptr, *U = nullptr, *V = nullptr; size_t ns = 0, nt = 0, nc = 0; };
-	std::vector<SpTemps> sp_t;    // Strassen temporaries by depth: A-quadrant, B-quadrant, two C-quadrants
-	int sp_products = 0, sp_levels_used = 0;
-	double sp_add_bytes = 0, sp_mul_words = 0;      // what the products' additions moved / the lookups they did (in sweep-words)
-	std::vector<size_t> sp_kev;   // indices into kev of the event pairs that bracket super-panel products (ms_product)
+	static constexpr int nlist = 2;      // row lists / T matrices kept: by panel parity (the previous panel's outer pass may still be reading its own)
 	hipStream_t sC = nullptr;     // outer passes: panel p's runs BESIDE the inner elimination of panel p + 1 (sA + sB)
 	hipStream_t sD = nullptr;     // (late round 5) the RIGHT part of every outer pass (outer_split percent of its tiles): its P = T x S and its
 	                              // k_update16k run beside the left part's on sC, so that one part's short launches (the next panel's tiles, the
@@ -594,6 +576,10 @@ struct Solver {
 	                              // batch calls that create THEIR streams after it ran 290 instead of 301 systems/s in the same process (their two gangs
 	                              // no longer overlapped: the stream-pair effect of profiles/r05_stream_pairs.txt, seen from the other side)
 	hipEvent_t evOuter = nullptr, evPri = nullptr, evPanelDone = nullptr, evSp = nullptr, evRight = nullptr, evBig = nullptr;
+	hipEvent_t evChunk0 = nullptr, evEarly = nullptr;
+	bool outer_early = true;      // (round 6) GF2BV_OUTER_EARLY=0: P = T x S of every outer panel in front of its own pass only, as rounds 3-5.  Default: a
+	                              // chunk-major pass is cut behind its first chunk (the rows the next panel takes its pivots from) and the next panel's
+	                              // P = T x S on the tiles of ITS pass starts behind that first launch, beside the rest of the running pass (enqueue_forward)
 	bool bulk_waits_outer = false;     // the next bulk launch of the one-level schedule has to wait for the last outer pass
 	bool ends_outer_panel(int b) const { return tl_K > 0 && b < tl_bend && (b + 1) % tl_K == 0; }
 	u64 *Wb = nullptr;            // 2 x rows x GMAX window words (the panel steps ping-pong between the halves)
@@ -683,14 +669,12 @@ struct Solver {
 		if (sB) (void)hipStreamSynchronize(sB);
 		if (arena || M) (void)hipStreamSynchronize(sA);
 		Pool &P = pool();
-		for (void *p : { arena, (void *)Y, (void *)ycols, (void *)out, (void *)Minv, (void *)(ext_M ? nullptr : M), (void *)tmp_src, (void *)spB }) P.release(p);
-		for (SpTemps &t : sp_t) for (void *p : { (void *)t.S, (void *)t.T, (void *)t.U, (void *)t.V }) P.release(p);
-		sp_t.clear(); spB = nullptr; spB_elems = 0;
+		for (void *p : { arena, (void *)Y, (void *)ycols, (void *)out, (void *)Minv, (void *)(ext_M ? nullptr : M), (void *)tmp_src }) P.release(p);
 		arena = nullptr; Y = nullptr; ycols = nullptr; out = nullptr; Minv = nullptr; M = nullptr; tmp_src = nullptr;
 		st = nullptr; panels = nullptr; aux = nullptr; fu = nullptr; died = nullptr; pivcol = nullptr;
 		urow = nullptr; blk_first = nullptr; mult = nullptr; Wb = nullptr;
 		for (hipEvent_t *e : { &ev0, &ev1, &ev2, &ev3, &evx }) { P.release_event(*e, true); *e = nullptr; }
-		for (hipEvent_t *e : { &evOuter, &evPri, &evPanelDone, &evSp, &evRight, &evBig }) { P.release_event(*e, false); *e = nullptr; }
+		for (hipEvent_t *e : { &evOuter, &evPri, &evPanelDone, &evSp, &evRight, &evBig, &evChunk0, &evEarly }) { P.release_event(*e, false); *e = nullptr; }
 		if (sC) P.release_stream(sC, device, nsys > 1 ? 3 : 1);
 		if (sD) P.release_stream(sD, device, 1);
 		sC = nullptr; sD = nullptr;
@@ -789,7 +773,6 @@ void plan_two_level(Solver &S)
 		min_bytes = 0;
 	}
 	if (const char *e = getenv("GF2BV_TWO_LEVEL_MIN_MIB"); e && *e) min_bytes = 1048576.0 * atof(e);      // (threshold scans)
-	if (const char *e = getenv("GF2BV_OUTER_K"); e && *e) K = std::min(GF2_KMAX, std::max(2, atoi(e)));  // (K scans under the default plan)
 	const int G = S.impl->G;
 	int bend = 0;
 	for (int b0 = 0; b0 + K < S.nblocks; b0 += K) {            // (the last block never ends an outer panel: it may be short)
@@ -805,43 +788,6 @@ void plan_two_level(Solver &S)
 	if (const char *e = getenv("GF2BV_OUTER_SHAPE"); e && *e) S.outer_shape = std::min(3, std::max(0, atoi(e)));
 	if (const char *e = getenv("GF2BV_OUTER_ORDER"); e && *e) S.outer_order = atoi(e) == 0 ? 0 : 2;
 	S.nsets = 2 * K;              // the outer pass of panel p reads its K sets while the blocks of panel p + 1 write theirs
-}
-
-// Three-level elimination: which blocks go in super-panels.  A super-panel = sp_P outer panels (e.g. 10 x 12 blocks = 30720
-// columns): its Schur update is one matrix product with an inner dimension large enough for the rows to stay in registers through
-// 120 table builds (5.8 TB/s of sweep-words in isolation against 4.9 for an outer pass of 12 blocks inside a solve) and for
-// Strassen-Winograd to pay (profiles/r05_strassen.txt: 0.87 / 0.82 of the classical time with one / two levels).
-// OPT-IN (GF2BV_THREE_LEVEL=P, super-panels of P outer panels wherever the two-level plan has that many whole panels and more than
-// GF2BV_THREE_LEVEL_MIN_MIB -- default 1024 -- lie right of the super-panel; tests force it onto small systems together with
-// GF2BV_TWO_LEVEL=K), NOT the default plan: built, bit-exact, and measured SLOWER than the two-level elimination at 262144^2 --
-// 1.31-1.34 s against 1.22-1.27 s on the same boxes (profiles/r05_three_level.txt).  The products do run faster than the outer
-// passes they replace (4.62 TB of sweep-words in 0.78 s = 5.9 TB/s with two Strassen levels against 4.9), but the triangular part
-// the recursion needs -- the replay of every outer panel on the rows that die later in the super-panel -- costs 0.21 s where the
-// ideal D^2 / 2 share is 0.1 s (whole chunks of 8192 rows are looked up for a few thousand dying rows, and every replay launch walks
-// all items of the trailing matrix to find them), and a super-panel exposes ~12 ms of panel path that an outer pass used to hide.
-void plan_three_level(Solver &S)
-{
-	S.sp_P = 0; S.sp_bend = 0; S.nlist = 2;
-	if (!S.tl_K || S.nsys != 1) return;
-	int P = 0;
-	double min_bytes = 1.0 * 1073741824.0;
-	if (const char *e = getenv("GF2BV_THREE_LEVEL"); e && *e) P = std::max(0, std::min(atoi(e), 64));
-	if (P < 2) return;
-	// (a forced two-level plan -- tests on small systems -- takes super-panels wherever it has whole ones)
-	if (getenv("GF2BV_TWO_LEVEL") && *getenv("GF2BV_TWO_LEVEL")) min_bytes = 0;
-	if (const char *e = getenv("GF2BV_THREE_LEVEL_MIN_MIB"); e && *e) min_bytes = 1048576.0 * atof(e);
-	if (const char *e = getenv("GF2BV_STRASSEN"); e && *e) S.sp_force_levels = std::max(0, std::min(atoi(e), 4));
-	const int G = S.impl->G, spb = P * S.tl_K;
-	int bend = 0;
-	for (int b0 = 0; b0 + spb <= S.tl_bend; b0 += spb) {
-		const i64 rows_left = S.rows - (i64)(b0 + spb) * 64 * G, words_left = S.wt - (i64)(b0 + spb) * G;
-		if (rows_left <= 0 || words_left <= 0 || (double)rows_left * (double)words_left * 8.0 < min_bytes) break;
-		bend = b0 + spb;
-	}
-	if (!bend) return;
-	S.sp_P = P; S.sp_bend = bend;
-	S.nlist = 2 * P;
-	S.nsets = 2 * spb;            // a super-panel's multipliers stay until its product has run, beside the next super-panel's
 }
 
 int solver_alloc(Solver &S)
@@ -863,11 +809,12 @@ int solver_alloc(Solver &S)
 	S.nblocks = (S.npanels + G - 1) / G;
 	S.tile_hi = S.ntiles;
 	plan_two_level(S);
-	plan_three_level(S);
 	S.units = (int)std::min<i64>(256, std::max<i64>(1, (S.rows + 255) / 256));
 	if (const char *e = getenv("GF2BV_DEBUG_SYNC")) S.dbg_sync = atoi(e);
 	if (const char *e = getenv("GF2BV_FAST")) S.fast_blocks = atoi(e) != 0;
-	S.flag_sync = S.world == 1;           // (a column-slab solve hands over through the host between the pieces: events)
+	const bool plain = plain_mode();
+	S.flag_sync = S.world == 1 && !plain; // (a column-slab solve hands over through the host between the pieces: events)
+	S.optimistic = !plain;
 	if (const char *e = getenv("GF2BV_FLAG_SYNC")) S.flag_sync = S.flag_sync && atoi(e) != 0;
 	if (getenv("GF2BV_SERIAL")) S.flag_sync = false;      // (one stream: the panel gate would wait for a gate queued behind it)
 	if (const char *e = getenv("GF2BV_OPTIMISTIC")) S.optimistic = atoi(e) != 0;
@@ -875,6 +822,7 @@ int solver_alloc(Solver &S)
 	if (const char *e = getenv("GF2BV_SPARSE_FAST")) S.sparse_fast = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_PC")) S.use_pc = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_XCD_PIN")) S.xcd_pin = atoi(e) != 0;
+	else if (plain) S.xcd_pin = false;
 	else if (S.nsys >= 8 && S.nsys % 8 == 0) {           // a gang that would be pinned: is the dispatch order what the pinning assumes?
 		int ok = 0;
 		int rc = xcd_dispatch_is_round_robin(S.device, S.sA, &ok);
@@ -883,9 +831,7 @@ int solver_alloc(Solver &S)
 	}
 	if (const char *e = getenv("GF2BV_XCD_WGS")) S.xcd_wgs = std::min(256, std::max(1, atoi(e)));
 	if (const char *e = getenv("GF2BV_GANG_NT")) S.nt_gang = atoi(e) != 0;
-	if (const char *e = getenv("GF2BV_SINGLE_NT")) S.nt_single = atoi(e) != 0;
 	if (const char *e = getenv("GF2BV_GANG_BS")) S.gang_bs = atoi(e) != 0;
-	if (const char *e = getenv("GF2BV_FUSED_RPT")) S.fused_rpt = atoi(e);
 	// narrow workgroups: as many rows each as keeps ~256 of them (all systems of a gang together) busy, at most 8 blocks
 	{
 		const i64 blocks = (S.rows + 255) / 256 * std::max(1, S.nsys);
@@ -898,12 +844,9 @@ int solver_alloc(Solver &S)
 		// (round 5: single systems take a stream that is KNOWN to run beside sA, see Pool::low_stream_for.  Gangs take any: two
 		// lock-step gangs side by side ran 16 MT19937 systems in 33 ms on whatever the pool handed out and in 36-41 ms on pairs
 		// chosen this way -- with four busy queues other relations than panel / bulk of ONE solve decide, profiles/r05_stream_pairs.txt)
-		if (S.sB_preset) { S.sB = S.sB_preset; S.own_sB = false; }
-		else {
-			if (S.nsys == 1) HIPCHK(pool().low_stream_for(S.sA, S.device, &S.sB));
-			else HIPCHK(pool().stream(&S.sB, S.device, 3));
-			S.own_sB = true;
-		}
+		if (S.nsys == 1) HIPCHK(pool().low_stream_for(S.sA, S.device, &S.sB));
+		else HIPCHK(pool().stream(&S.sB, S.device, 3));
+		S.own_sB = true;
 	}
 	if (S.flag_sync && S.sB != S.sA) {
 		int ok = 0;
@@ -951,9 +894,12 @@ int solver_alloc(Solver &S)
 		for (hipEvent_t *e : { &S.evOuter, &S.evPri, &S.evPanelDone }) HIPCHK(pool().event(e, false));
 		if (S.sB != S.sA) { if (S.nsys == 1) HIPCHK(pool().low_stream_for(S.sA, S.device, &S.sC)); else HIPCHK(pool().stream(&S.sC, S.device, 3)); }       // (GF2BV_SERIAL: everything on one stream)
 		HIPCHK(pool().event(&S.evBig, false));
+		HIPCHK(pool().event(&S.evChunk0, false));
+		HIPCHK(pool().event(&S.evEarly, false));
 		if (const char *e = getenv("GF2BV_OUTER_SIDE"); e && *e) S.outer_side = atoi(e) != 0;
+		if (const char *e = getenv("GF2BV_OUTER_EARLY"); e && *e) S.outer_early = atoi(e) != 0;
 		if (const char *e = getenv("GF2BV_OUTER_SPLIT"); e && *e) S.outer_split = std::min(90, std::max(0, atoi(e)));
-		if (S.sC && S.nsys == 1 && S.outer_split > 0 && !S.sp_P) {
+		if (S.sC && S.nsys == 1 && S.outer_split > 0) {
 			HIPCHK(pool().event(&S.evRight, false));
 			HIPCHK(pool().low_stream_for(S.sA, S.device, &S.sD, 1, { S.sC }));
 		}
@@ -1346,13 +1292,21 @@ int enqueue_outer_prepare(Solver &S, hipStream_t st, int b0, int b1)
 	return GF2BV_OK;
 }
 
-// j_lim < INT_MAX: the REPLAY of the panel right of its super-panel (three-level elimination) -- only rows that became pivot sources
-// in later panels of the super-panel (panels [b1 G, j_lim)) take it
-int enqueue_outer_apply(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, i64 t_end, int j_lim = 0x7fffffff)
+// rows of one item of the outer pass by workgroup shape (GF2BV_OUTER_SHAPE)
+i64 outer_item_rows(const Solver &S)
 {
-	const int G = S.impl->G;
+	static const int shape_rows[4] = { GF2_WSEG * 1024, GF2_KSEG * 512, 10 * 1024, GF2_WSEG * 1024 };
+	return shape_rows[S.outer_shape];
+}
+
+// P = T x S of the panel of blocks [b0, b1) on the tiles [t_begin, t_end).  when = 0: unconditionally; 1 / 2: the EARLY / LATE launch of
+// a pair of which exactly one does the work (k_outer_apply: early iff every source row of the panel lies in the first chunk of the
+// PREVIOUS panel's pass, whose row bound is blk_first[b0 - K])
+int enqueue_outer_pivots(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, i64 t_end, int when)
+{
 	const i64 nt = t_end - t_begin;
 	if (nt <= 0) return GF2BV_OK;
+	const int G = S.impl->G;
 	const i64 set_words = (i64)G * mult_rows(S.rows);
 	int *gprow = S.oprow + (size_t)((b0 / S.tl_K) % S.nlist) * GF2_OUTER_LISTS;
 	const int npan = (b1 - b0) * G;
@@ -1362,202 +1316,65 @@ int enqueue_outer_apply(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, 
 		                                                                          S.mult, set_words, b0 % S.nsets, S.nsets, S.impl->T, (u64 *)nullptr, S.ss());
 	} else
 		k_outer_apply<<<dim3((unsigned)nt, S.nsys), dim3(512), 0, st>>>(S.M, S.rows, S.srows, b1 - b0, (const int *)gprow,
-		                                                                (const u64 *)(S.Tm + (size_t)((b0 / S.tl_K) % S.nlist) * ((size_t)GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX)), (int)t_begin, S.ss());
+		                                                                (const u64 *)(S.Tm + (size_t)((b0 / S.tl_K) % S.nlist) * ((size_t)GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX)), (int)t_begin, S.ss(),
+		                                                                when, (const int *)(S.blk_first + std::max(0, b0 - S.tl_K)), (int)outer_item_rows(S));
 	HIPCHK(hipGetLastError());
-	hipEvent_t ka = nullptr, kb = nullptr;
-	if (S.time_kernels) {
-		HIPCHK(pool().event(&ka, true)); HIPCHK(pool().event(&kb, true));
-		S.kev.push_back(ka); S.kev.push_back(kb);
-		if (!S.ext_events) HIPCHK(hipEventRecord(ka, st));
-	}
+	return GF2BV_OK;
+}
+
+// The outer step of the panel of blocks [b0, b1) on the tiles [t_begin, t_end): the pivot rows (pivots_when: see enqueue_outer_pivots; -1 =
+// the caller has them in place), then the pass.  cut: a chunk-major pass goes as TWO launches -- its first chunk (the item_rows rows from the
+// alive bound: items [0, tiles)), S.evChunk0 recorded behind it, then the rest.
+int enqueue_outer_apply(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, i64 t_end, int pivots_when = 0, bool cut = false)
+{
+	const int G = S.impl->G;
+	const i64 nt = t_end - t_begin;
+	if (nt <= 0) { if (cut) HIPCHK(hipEventRecord(S.evChunk0, st)); return GF2BV_OK; }
+	const i64 set_words = (i64)G * mult_rows(S.rows);
+	int *gprow = S.oprow + (size_t)((b0 / S.tl_K) % S.nlist) * GF2_OUTER_LISTS;
+	if (pivots_when >= 0) { int rc = enqueue_outer_pivots(S, st, b0, b1, t_begin, t_end, pivots_when); if (rc) return rc; }
 	// items of a dense system: the kernel derives the true count from the alive bound and loops if there are more
 	const i64 est_lo = std::min<i64>(S.rows, (i64)b0 * 64 * G) & ~(i64)63, R64 = round_up(S.rows, 64);
-	static const int shape_rows[4] = { GF2_WSEG * 1024, GF2_KSEG * 512, 10 * 1024, GF2_WSEG * 1024 };
-	const i64 item_rows = shape_rows[S.outer_shape];
+	const i64 item_rows = outer_item_rows(S);
 	const i64 nch = std::max<i64>(1, (R64 - est_lo + item_rows - 1) / item_rows);
 	const bool xmap = S.outer_xcd && S.nsys == 1;
-	// (xcd_map: one workgroup per item exactly -- the kernel's own chunk count may be smaller than this estimate, never larger)
-	const i64 wgs = xmap ? 8 * ((nch + 7) / 8) * nt : std::min<i64>(nch * nt, (i64)1 << 30);
+	const int xcd_flag = xmap ? 1 : S.outer_order;
+	cut = cut && xcd_flag == 2;
+	const int nparts = cut ? 2 : 1;
+	for (int part = 0; part < nparts; part++) {
+		// (cut) part 0 = items [0, nt), part 1 = items [nt, all); otherwise everything in one launch
+		const i64 it0 = cut && part == 1 ? nt : 0, it1 = cut && part == 0 ? nt : (i64)1 << 62;
+		const i64 est_items = cut ? (part == 0 ? nt : (nch - 1) * nt) : nch * nt;
+		if (est_items > 0) {
+			hipEvent_t ka = nullptr, kb = nullptr;
+			if (S.time_kernels) {
+				HIPCHK(pool().event(&ka, true)); HIPCHK(pool().event(&kb, true));
+				S.kev.push_back(ka); S.kev.push_back(kb);
+				if (!S.ext_events) HIPCHK(hipEventRecord(ka, st));
+			}
+			// (xcd_map: one workgroup per item exactly -- the kernel's own chunk count may be smaller than this estimate, never larger)
+			const i64 wgs = xmap ? 8 * ((nch + 7) / 8) * nt : std::min<i64>(est_items, (i64)1 << 30);
 #define GF2_LAUNCH_OUTER(KERN, ROWS_, NT_) do { \
 	static_assert((size_t)(ROWS_) * 32 <= kOuterSlackBytes, "the slack behind the matrix covers an item of this shape"); \
 	hipExtLaunchKernelGGL((KERN), dim3((unsigned)wgs, S.nsys), dim3(NT_), 0, st, S.ext_events ? ka : nullptr, S.ext_events ? kb : nullptr, 0, \
 	                      S.M, S.rows, S.srows, b1 - b0, (const int *)gprow, (const u64 *)S.mult, \
-	                      set_words, b0 % S.nsets, S.nsets, (const int *)(S.blk_first + b0), (const int *)S.died, b1 * G, (int)t_begin, (int)nt, S.ss(), xcd_flag, j_lim); } while (0)
-	const int xcd_flag = xmap ? 1 : S.outer_order;
-	switch (S.outer_shape) {
-	case 1: { auto kern = k_update16k<GF2_KSEG>; GF2_LAUNCH_OUTER(kern, GF2_KSEG * 512, 512); } break;
-	case 2: GF2_LAUNCH_OUTER(k_update16k_wide10, 10 * 1024, 1024); break;
-	case 3: GF2_LAUNCH_OUTER(k_update16k_wide_room, GF2_WSEG * 1024, 1024); break;
-	default: GF2_LAUNCH_OUTER(k_update16k_wide, GF2_WSEG * 1024, 1024); break;
-	}
+	                      set_words, b0 % S.nsets, S.nsets, (const int *)(S.blk_first + b0), (const int *)S.died, b1 * G, (int)t_begin, (int)nt, S.ss(), xcd_flag, it0, it1); } while (0)
+			switch (S.outer_shape) {
+			case 1: { auto kern = k_update16k<GF2_KSEG>; GF2_LAUNCH_OUTER(kern, GF2_KSEG * 512, 512); } break;
+			case 2: GF2_LAUNCH_OUTER(k_update16k_wide10, 10 * 1024, 1024); break;
+			case 3: GF2_LAUNCH_OUTER(k_update16k_wide_room, GF2_WSEG * 1024, 1024); break;
+			default: GF2_LAUNCH_OUTER(k_update16k_wide, GF2_WSEG * 1024, 1024); break;
+			}
 #undef GF2_LAUNCH_OUTER
-	HIPCHK(hipGetLastError());
-	if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, st));
+			HIPCHK(hipGetLastError());
+			if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, st));
+		}
+		if (cut && part == 0) HIPCHK(hipEventRecord(S.evChunk0, st));
+	}
 	if (S.dbg_sync & 2) HIPCHK(hipDeviceSynchronize());
 	return GF2BV_OK;
 }
 
-// ---- three-level elimination: the Schur update of a super-panel as one matrix product ------------------------------------
-// C ^= A x B (zero: C = A x B) with `level` Strassen-Winograd levels over the base case k_mul16k.  R: rows of the views (a multiple
-// of 64 << level), T tiles and nb blocks (multiples of 1 << level).  Winograd's form, signs dropped (GF(2)):
-//   S1 = A21 + A22, S2 = S1 + A11, S3 = A11 + A21, S4 = A12 + S2;  T1 = B12 + B11, T2 = B22 + T1, T3 = B22 + B12, T4 = T2 + B21
-//   P1 = A11 B11, P2 = A12 B21, P3 = S4 B22, P4 = A22 T4, P5 = S1 T1, P6 = S2 T2, P7 = S3 T3
-//   C11 += P1 + P2, C12 += P1 + P6 + P5 + P3, C21 += P1 + P6 + P7 + P4, C22 += P1 + P6 + P7 + P5
-// scheduled with one A-quadrant, one B-quadrant and two C-quadrant temporaries per level; every product accumulates straight into
-// its target where it can (P2, P3, P4), so the additions move 22 C-quadrants + 12 A-quadrants + 12 B-quadrants per level.
-int sp_mul(Solver &S, hipStream_t st, MulC C, i64 R, int T, MulA A, MulB B, int nb, int level, bool zero, int depth)
-{
-	if (level == 0) {
-		constexpr i64 CH = (i64)GF2_KSEG * 512;
-		const i64 items = (R + CH - 1) / CH * T;
-		const unsigned wgs = (unsigned)std::min<i64>(items, (i64)1 << 30);
-		if (zero) hipLaunchKernelGGL((k_mul16k<GF2_KSEG, true>), dim3(wgs), dim3(512), 0, st, C, R, T, A, B, nb);
-		else hipLaunchKernelGGL((k_mul16k<GF2_KSEG, false>), dim3(wgs), dim3(512), 0, st, C, R, T, A, B, nb);
-		HIPCHK(hipGetLastError());
-		S.sp_mul_words += (double)R * T * 2 * nb;
-		return GF2BV_OK;
-	}
-	const Solver::SpTemps &t = S.sp_t[depth];
-	const i64 R2 = R / 2; const int T2 = T / 2, n2 = nb / 2;
-	const MulC C11{ C.p, C.ts }, C12{ C.p + (i64)T2 * C.ts, C.ts }, C21{ C.p + R2, C.ts }, C22{ C.p + (i64)T2 * C.ts + R2, C.ts };
-	const MulA A11{ A.p, A.bs }, A12{ A.p + (i64)n2 * A.bs, A.bs }, A21{ A.p + R2 * 2, A.bs }, A22{ A.p + (i64)n2 * A.bs + R2 * 2, A.bs };
-	const MulB B11{ B.p, B.bs }, B12{ B.p + (i64)T2 * 256, B.bs }, B21{ B.p + (i64)n2 * B.bs, B.bs }, B22{ B.p + (i64)n2 * B.bs + (i64)T2 * 256, B.bs };
-	const MulA Sq{ t.S, R2 * 2 }; const MulB Tq{ t.T, (i64)T2 * 256 }; const MulC U{ t.U, R2 }, V{ t.V, R2 };
-	auto xr = [&](uint4 *X, i64 xs, const uint4 *Y, i64 ys, const uint4 *Z, i64 zs, const uint4 *W, i64 ws, i64 inner, i64 outer) {
-		k_xor16<<<dim3((unsigned)((inner + 255) / 256), (unsigned)outer), dim3(256), 0, st>>>(X, xs, Y, ys, Z, zs, W, ws, inner);
-		S.sp_add_bytes += (double)inner * outer * 16 * (W ? 4 : 3);
-	};
-	auto xa = [&](const MulA &y, const MulA &z) { xr(t.S, Sq.bs, y.p, y.bs, z.p, z.bs, nullptr, 0, R2 * 2, n2); };
-	auto xb = [&](const MulB &y, const MulB &z) { xr(t.T, Tq.bs, y.p, y.bs, z.p, z.bs, nullptr, 0, (i64)T2 * 256, n2); };
-	auto xc = [&](const MulC &x, const MulC &u, const MulC *v) { xr(x.p, x.ts, x.p, x.ts, u.p, u.ts, v ? v->p : nullptr, v ? v->ts : 0, R2, T2); };
-	int rc;
-#define SPM(...) do { if ((rc = sp_mul(S, st, __VA_ARGS__))) return rc; } while (0)
-	if (zero) {       // (an overwriting product at an inner level: cleared, then accumulated into)
-		k_zero16<<<dim3((unsigned)((R + 255) / 256), (unsigned)T), dim3(256), 0, st>>>(C.p, C.ts, R);
-		S.sp_add_bytes += (double)R * T * 16;
-	}
-	xa(A21, A22); xb(B12, B11);                                    // S1, T1
-	SPM(V, R2, T2, Sq, Tq, n2, level - 1, true, depth + 1);        // V = P5
-	xa(Sq, A11); xb(B22, Tq);                                      // S2, T2
-	SPM(U, R2, T2, A11, B11, n2, level - 1, true, depth + 1);      // U = P1
-	xc(C11, U, nullptr);                                           // C11 += P1
-	SPM(C11, R2, T2, A12, B21, n2, level - 1, false, depth + 1);   // C11 += P2
-	SPM(U, R2, T2, Sq, Tq, n2, level - 1, false, depth + 1);       // U = P1 + P6
-	xc(C12, U, &V);                                                // C12 += P1 + P6 + P5
-	xa(A12, Sq);                                                   // S4
-	SPM(C12, R2, T2, Sq, B22, n2, level - 1, false, depth + 1);    // C12 += P3
-	xb(Tq, B21);                                                   // T4
-	SPM(C21, R2, T2, A22, Tq, n2, level - 1, false, depth + 1);    // C21 += P4
-	xa(A11, A21); xb(B22, B12);                                    // S3, T3
-	SPM(U, R2, T2, Sq, Tq, n2, level - 1, false, depth + 1);       // U = P1 + P6 + P7
-	xc(C21, U, nullptr);                                           // C21 += P1 + P6 + P7
-	xc(C22, U, &V);                                                // C22 += P1 + P6 + P7 + P5
-#undef SPM
-	HIPCHK(hipGetLastError());
-	return GF2BV_OK;
-}
-
-// The end of the super-panel of blocks [B0, B1): everything right of it (tiles [t_hi, ntiles)) takes the super-panel in three steps
-// on the outer stream -- the replay of its outer panels on the rows that died inside it (U12), B gathered / the dead rows'
-// multipliers cleared, the product -- with the tiles of the NEXT outer panel first (evPri: its elimination starts behind them).
-// The host has to know the alive bound (the product's row range): it waits for the panel stream here, once per super-panel.
-int enqueue_super_panel_finish(Solver &S, hipStream_t so, int B0, int B1)
-{
-	const int G = S.impl->G, K = S.tl_K, nb = B1 - B0;
-	const i64 t_hi = (i64)B1 * G / TW, T_all = S.ntiles - t_hi;
-	if (T_all <= 0) return GF2BV_OK;
-	int h_first = 0;
-	HIPCHK(hipMemcpyAsync(&h_first, S.blk_first + (B1 - 1), sizeof(int), hipMemcpyDeviceToHost, S.sA));
-	HIPCHK(hipStreamSynchronize(S.sA));
-	const i64 R64 = mult_rows(S.rows);
-	const i64 first64 = std::min<i64>(std::max(0, h_first), R64 - 64) & ~(i64)63;
-	// Strassen-Winograd levels by size (profiles/r05_strassen.txt: inner dimension 30720 -- two levels pay from ~100000 rows and
-	// columns, one from ~30000), bounded by what the shapes divide by
-	const i64 Tp_min = std::min<i64>(T_all, (i64)K * G / TW);       // the next outer panel's tiles: first, classically
-	int L = (R64 - first64 >= 98304 && T_all - Tp_min >= 768) ? 2 : (R64 - first64 >= 32768 && T_all - Tp_min >= 256) ? 1 : 0;
-	if (S.sp_force_levels >= 0) L = S.sp_force_levels;
-	while (L > 0 && (nb % (1 << L) || (T_all - Tp_min) < (2 << L) || R64 < ((i64)64 << L))) L--;
-	i64 lo = first64, R = R64 - first64;
-	if (L > 0) {
-		const i64 al = (i64)64 << L;
-		R = (R64 - first64 + al - 1) / al * al;
-		lo = R64 - R;
-		while (lo < 0) { L--; const i64 a2 = (i64)64 << L; R = (R64 - first64 + a2 - 1) / a2 * a2; lo = R64 - R; }
-	}
-	const i64 Ts = L > 0 ? (T_all - Tp_min) / (1 << L) * (1 << L) : T_all - Tp_min, Tp = T_all - Ts;
-	// buffers: B, and the temporaries of the levels (the first super-panel is the largest)
-	const size_t slack = kOuterSlackBytes / 16;
-	const size_t needB = (size_t)nb * T_all * 256;
-	// (buffers only ever grow at the first super-panel -- shapes shrink from there -- but nothing is handed back under a running product)
-	bool grow = S.spB_elems < needB || (int)S.sp_t.size() < L;
-	{
-		i64 r = R; i64 t = Ts; int n = nb;
-		for (int d = 0; d < L && d < (int)S.sp_t.size(); d++) {
-			r /= 2; t /= 2; n /= 2;
-			const Solver::SpTemps &q = S.sp_t[d];
-			grow = grow || q.ns < (size_t)n * r * 2 || q.nt < (size_t)n * t * 256 || q.nc < (size_t)r * t;
-		}
-	}
-	if (grow && S.sp_products > 0) HIPCHK(hipStreamSynchronize(so));
-	if (S.spB_elems < needB) {
-		pool().release(S.spB); S.spB = nullptr; S.spB_elems = 0;
-		HIPCHK(pool().alloc((void **)&S.spB, needB * 16 + kOuterSlackBytes, S.device));
-		S.spB_elems = needB;
-	}
-	if ((int)S.sp_t.size() < L) S.sp_t.resize(L);
-	{
-		i64 r = R; i64 t = Ts; int n = nb;
-		for (int d = 0; d < L; d++) {
-			r /= 2; t /= 2; n /= 2;
-			Solver::SpTemps &q = S.sp_t[d];
-			const size_t ns = (size_t)n * r * 2, nt = (size_t)n * t * 256, nc = (size_t)r * t;
-			if (q.ns < ns) { pool().release(q.S); q.S = nullptr; HIPCHK(pool().alloc((void **)&q.S, (ns + slack) * 16, S.device)); q.ns = ns; }
-			if (q.nt < nt) { pool().release(q.T); q.T = nullptr; HIPCHK(pool().alloc((void **)&q.T, (nt + slack) * 16, S.device)); q.nt = nt; }
-			if (q.nc < nc) {
-				pool().release(q.U); pool().release(q.V); q.U = q.V = nullptr;
-				HIPCHK(pool().alloc((void **)&q.U, (nc + slack) * 16, S.device)); HIPCHK(pool().alloc((void **)&q.V, (nc + slack) * 16, S.device));
-				q.nc = nc;
-			}
-		}
-	}
-	hipEvent_t ka = nullptr, kb = nullptr;
-	if (S.time_kernels) {
-		HIPCHK(pool().event(&ka, true)); HIPCHK(pool().event(&kb, true));
-		S.sp_kev.push_back(S.kev.size());
-		S.kev.push_back(ka); S.kev.push_back(kb);
-	}
-	int rc;
-	// (1) replay: panel by panel, the rows that die later in this super-panel
-	for (int p0 = B0; p0 < B1; p0 += K)
-		if ((rc = enqueue_outer_apply(S, so, p0, p0 + K, t_hi, S.ntiles, B1 * G))) return rc;
-	if (ka) HIPCHK(hipEventRecord(ka, so));
-	// (2) B, and the multipliers of the rows that died inside the super-panel.  The bulk stream's last one-level launches of this
-	// super-panel still READ those multipliers (a dying row is an ordinary alive row to the blocks before its own): the clearing waits for them
-	if (S.sB != so) {
-		if (!S.evSp) HIPCHK(pool().event(&S.evSp, false));
-		HIPCHK(hipEventRecord(S.evSp, S.sB));
-		HIPCHK(hipStreamWaitEvent(so, S.evSp, 0));
-	}
-	const i64 set_u4 = (i64)G * mult_rows(S.rows) / 2;
-	uint4 *Aset = reinterpret_cast<uint4 *>(S.mult) + (i64)(B0 % S.nsets) * set_u4;
-	k_gather_b<<<dim3((unsigned)T_all, (unsigned)nb), dim3(256), 0, so>>>((const u64 *)S.M, S.srows, (int)t_hi, (const int *)S.oprow, (B0 / K) % S.nlist, S.nlist, K,
-	                                                                     S.spB, T_all * 256);
-	k_zero_dead_mults<<<dim3((unsigned)((S.rows + 255) / 256)), dim3(256), 0, so>>>((const int *)S.died, S.rows, 0, B0 * G, B1 * G, Aset, set_u4, nb);
-	HIPCHK(hipGetLastError());
-	// (3) the product: the next outer panel's tiles (and what the levels' shapes leave over) first
-	uint4 *Cb = reinterpret_cast<uint4 *>(S.M) + t_hi * S.srows + lo;
-	const MulA A{ Aset + lo * 2, set_u4 };
-	if (Tp > 0 && (rc = sp_mul(S, so, MulC{ Cb, S.srows }, R, (int)Tp, A, MulB{ S.spB, T_all * 256 }, nb, 0, false, 0))) return rc;
-	HIPCHK(hipEventRecord(S.evPri, so));
-	if (Ts > 0 && (rc = sp_mul(S, so, MulC{ Cb + Tp * S.srows, S.srows }, R, (int)Ts, A, MulB{ S.spB + Tp * 256, T_all * 256 }, nb, L, false, 0))) return rc;
-	if (kb) HIPCHK(hipEventRecord(kb, so));
-	S.sp_products++;
-	S.sp_levels_used = std::max(S.sp_levels_used, L);
-	return GF2BV_OK;
-}
-
-// panel stream: the window of block b straight from the matrix (block 0; the first block behind an outer pass, which has
-// brought that window up to date like every other tile)
 int enqueue_window_gather(Solver &S, int b)
 {
 	const BlockGeom g = block_geom(S, b);
@@ -1603,7 +1420,6 @@ int enqueue_forward(Solver &S)
 		// applied to its own tiles by the bulk kernels and to everything right of it by its outer pass -- every tile has seen
 		// exactly the blocks before pb -- so the rest runs as a one-level schedule)
 		if (S.tl_K && pb < S.tl_bend) S.tl_bend = pb / S.tl_K * S.tl_K;
-		if (S.sp_bend > S.tl_bend) S.sp_bend = S.tl_bend;       // (never entered again: the resumed blocks run one level)
 		S.bulk_waits_outer = false;
 		HIPCHK(hipMemsetAsync(&S.st->poison, 0, sizeof(int), S.sA));
 		S.sync_base += S.nblocks + 1;
@@ -1664,6 +1480,7 @@ int enqueue_forward(Solver &S)
 		hipStream_t so = S.sC ? S.sC : S.sB;           // (GF2BV_SERIAL: one stream, everything in order)
 		bool right_running = false;                    // the previous panel's pass was split over so and sD
 		bool big_recorded = false;                     // evBig holds the end of the previous panel's pass (side launches)
+		bool chunk0_recorded = false;                  // evChunk0 holds the end of the first chunk of the previous panel's pass
 		for (int p0 = 0; p0 < S.tl_bend; p0 += S.tl_K) {
 			const int p1 = p0 + S.tl_K;
 			if (p0 > 0) {
@@ -1678,33 +1495,38 @@ int enqueue_forward(Solver &S)
 			if ((rc = enqueue_outer_prepare(S, S.sA, p0, p1))) return rc;
 			HIPCHK(hipEventRecord(S.evPanelDone, S.sA));
 			HIPCHK(hipStreamWaitEvent(so, S.evPanelDone, 0));
-			// three-level: inside a super-panel the outer pass stops at the super-panel's last tile; right of it the whole
-			// super-panel is applied at its end (replay + product)
-			const int spb = S.sp_P * S.tl_K;
-			const bool in_sp = p0 < S.sp_bend;
-			const int sp1 = in_sp ? (p0 / spb + 1) * spb : 0;
-			const i64 t_out = in_sp ? (i64)sp1 * G / TW : S.ntiles;
+			const i64 t_out = S.ntiles;
 			const i64 t0 = (i64)p1 * G / TW, t1 = std::min<i64>(t_out, t0 + (i64)S.tl_K * G / TW);
 			// (late round 5) the outer step on the NEXT panel's tiles -- a short launch on an underused chip, ~0.3 ms -- goes to the
 			// inner elimination's bulk stream, idle at this point, and runs BESIDE the start of the pass proper instead of before it:
 			// it needs the previous pass complete (evBig; it used to follow it in stream order) and this panel's T; the pass proper
 			// needs T alone (disjoint tiles).  No new stream (cf. GF2BV_OUTER_SPLIT).
-			const bool side = S.outer_side && !in_sp && !S.sD && S.sB != so && S.sB != S.sA;
+			const bool side = S.outer_side && !S.sD && S.sB != so && S.sB != S.sA;
 			if (side) {
+				// (round 6) P = T x S on the tiles of the pass proper -- 0.3-0.9 ms in front of every pass, 44 ms of a 262144^2 solve, "the
+				// largest serial term left" of round 5 -- starts when the FIRST CHUNK of the previous pass is done (evChunk0: the rows this
+				// panel took its pivots from), on the inner bulk stream, and runs beside the rest of that pass; the launch in front of this
+				// panel's own pass stays and does the work only where a source row lay outside that chunk (k_outer_apply: when)
+				const bool early = S.outer_early && chunk0_recorded && !S.outer_chain && S.outer_order == 2 && !(S.outer_xcd && S.nsys == 1);
 				HIPCHK(hipStreamWaitEvent(S.sB, S.evPanelDone, 0));
+				if (early) {
+					HIPCHK(hipStreamWaitEvent(S.sB, S.evChunk0, 0));
+					if ((rc = enqueue_outer_pivots(S, S.sB, p0, p1, t1, t_out, 1))) return rc;
+					HIPCHK(hipEventRecord(S.evEarly, S.sB));
+				}
 				if (big_recorded) HIPCHK(hipStreamWaitEvent(S.sB, S.evBig, 0));
 				if ((rc = enqueue_outer_apply(S, S.sB, p0, p1, t0, t1))) return rc;
 				HIPCHK(hipEventRecord(S.evPri, S.sB));
-				if ((rc = enqueue_outer_apply(S, so, p0, p1, t1, t_out))) return rc;
+				if (early) HIPCHK(hipStreamWaitEvent(so, S.evEarly, 0));
+				if ((rc = enqueue_outer_apply(S, so, p0, p1, t1, t_out, early ? 2 : 0, S.outer_early))) return rc;
+				chunk0_recorded = S.outer_early;
 				HIPCHK(hipEventRecord(S.evBig, so));
 				big_recorded = true;
 				right_running = false;
 				continue;
 			}
 			if ((rc = enqueue_outer_apply(S, so, p0, p1, t0, t1))) return rc;
-			if (in_sp && p1 == sp1) {
-				if ((rc = enqueue_super_panel_finish(S, so, sp1 - spb, sp1))) return rc;       // (records evPri behind the next panel's tiles)
-			} else {
+			{
 				HIPCHK(hipEventRecord(S.evPri, so));
 				const i64 tr = S.sD ? t_out - (t_out - t1) * S.outer_split / 100 : t_out;       // the right part: tiles [tr, t_out) on sD
 				if (S.sD && tr > t1 && t_out - tr >= 32) {
@@ -2012,14 +1834,10 @@ int finish_end(Solver &S, gf2bv_result **out)
 			// rest of the row takes the whole panel in one outer pass (counted at the panel's last block, two launches)
 			if (S.tl_K && b < S.tl_bend) {
 				const int pend_w = (b / S.tl_K + 1) * S.tl_K * G;
-				// three-level: the outer pass of a panel inside a super-panel stops at the super-panel's end; right of it the rows make
-				// one trip per super-panel (the product; its Strassen additions are reported apart: product_add_bytes)
-				const int spb = S.sp_P * S.tl_K;
-				const i64 out_w = b < S.sp_bend ? std::min<i64>(S.wt, (i64)(b / spb + 1) * spb * G) : S.wt;
+				const i64 out_w = S.wt;
 				st.outer_blocks++;
 				if (pend_w > wlo) { st.hbm_words += rows_swept * (double)(std::min<i64>(pend_w, S.wt) - wlo); st.bulk_launches++; }
-				if ((b + 1) % S.tl_K == 0 && out_w > pend_w) { st.hbm_words += rows_swept * (double)(out_w - pend_w); st.bulk_launches += S.sD && b >= S.sp_bend ? 3 : 2; }      // (the next panel's tiles, then the rest -- in two halves on two streams since late round 5)
-				if (b < S.sp_bend && (b + 1) % spb == 0 && S.wt > out_w) { st.hbm_words += rows_swept * (double)(S.wt - out_w); st.bulk_launches += 2; }
+				if ((b + 1) % S.tl_K == 0 && out_w > pend_w) { st.hbm_words += rows_swept * (double)(out_w - pend_w); st.bulk_launches += (S.sD || (S.outer_early && S.outer_side && S.outer_order == 2 && S.sC)) ? 3 : 2; }      // (the next panel's tiles, then the rest -- in two halves on two streams since late round 5)
 			} else { st.hbm_words += rows_swept * (double)(S.wt - wlo); st.bulk_launches++; }
 		}
 	}
@@ -2038,7 +1856,6 @@ int finish_end(Solver &S, gf2bv_result **out)
 			(void)hipEventElapsedTime(&ms, S.kev[i], S.kev[i + 1]);
 			if (hipEventElapsedTime(&at, S.ev0, S.kev[i]) != hipSuccess) { (void)hipGetLastError(); at = iv.empty() ? 0.f : iv.back().second; }
 			iv.push_back({ at, at + ms });
-			if (std::find(S.sp_kev.begin(), S.sp_kev.end(), i) != S.sp_kev.end()) st.ms_product += ms;
 		}
 		std::sort(iv.begin(), iv.end());
 		float lo = 0, hi = -1;
@@ -2049,10 +1866,6 @@ int finish_end(Solver &S, gf2bv_result **out)
 		}
 		if (hi >= 0) st.ms_sweep += hi - lo;
 	}
-	st.super_panels = S.sp_products;
-	st.strassen_levels = S.sp_levels_used;
-	st.product_add_bytes = S.sp_add_bytes;
-	st.product_lookup_words = S.sp_mul_words;
 	st.ms_total = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - S.t_begin).count();
 	tr.mark("finish: result");
 	*out = R;
@@ -2171,34 +1984,6 @@ i64 pick_gang(i64 nsys, i64 rows, i64 cols, i64 free_bytes = -1)
 	}
 	return gang;
 }
-
-// The stream pairs of the NS gangs a batch call runs side by side, chosen by the calling thread before any of them starts (all streams
-// idle: the probes of Pool::low_stream_for see the pairs alone): every gang's bulk stream has been checked against its own panel stream
-// AND against the panel streams of the other gangs.  OPT-IN (GF2BV_GANG_PAIRS=1): measured twice, with both probes, two gangs of MT19937
-// systems side by side run 36-41 ms on streams chosen this way and 33-34 ms on whatever the pool hands out; bulk-bound gangs do not care
-// (64 / 192 x 32768^2: 300-309 against 304-310 systems/s) -- profiles/r05_stream_pairs.txt.
-struct StreamSets {
-	int device = 0;
-	bool on = false;
-	std::vector<hipStream_t> a, b;
-	int acquire(int dev, int n)
-	{
-		device = dev;
-		on = getenv("GF2BV_GANG_PAIRS") && atoi(getenv("GF2BV_GANG_PAIRS")) != 0;
-		if (!on) return GF2BV_OK;
-		a.assign((size_t)n, nullptr); b.assign((size_t)n, nullptr);
-		for (int t = 0; t < n; t++) HIPCHK(pool().stream(&a[(size_t)t], dev, 2));
-		for (int t = 0; t < n; t++) HIPCHK(pool().low_stream_for(a[(size_t)t], dev, &b[(size_t)t], 3, a));
-		return GF2BV_OK;
-	}
-	hipStream_t panel(int t) const { return on ? a[(size_t)t] : nullptr; }
-	hipStream_t bulk(int t) const { return on ? b[(size_t)t] : nullptr; }
-	~StreamSets()
-	{
-		for (hipStream_t x : a) if (x) { (void)hipStreamSynchronize(x); pool().release_stream(x, device, 2); }
-		for (hipStream_t y : b) if (y) { (void)hipStreamSynchronize(y); pool().release_stream(y, device, 3); }
-	}
-};
 
 int check_shape(i64 rows, i64 cols, int mode)
 {
@@ -2457,7 +2242,7 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 	const i64 gang = pick_gang(nsys, rows, cols);
 	// Gangs in flight: NS host threads, each with its own stream pair, take the next gang off a shared list.  Two threads that
 	// start together stay in phase for the whole job -- both gangs bulk-bound at once, both in their tails at once.  Starting them
-	// apart (GF2BV_STAGGER=1: the list begins with part gangs, thread t's first gang (t + 1) / NS of a full one) was built and
+	// apart (the list beginning with part gangs, thread t's first gang (t + 1) / NS of a full one) was built and
 	// measured in round 4: 3.56 ms per system against 3.42 in phase on 192 x 32768^2 (profiles/r04_batch_scans.txt) -- the bulk
 	// update runs throughout a gang's elimination (its launches are in flight 89 % of the wall time), there is no idle tail to
 	// fill, and part gangs only make smaller launches.  Not the default.
@@ -2465,13 +2250,7 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 	int NS = 2;
 	if (const char *e = getenv("GF2BV_BATCH_THREADS")) { int v = atoi(e); if (v >= 1) NS = std::min(v, 16); }
 	{
-		const bool stagger = getenv("GF2BV_STAGGER") && atoi(getenv("GF2BV_STAGGER")) != 0;
 		i64 s0 = 0;
-		if (stagger && gang >= 2 * NS && nsys > gang * NS)
-			for (int t = 0; t + 1 < NS && s0 < nsys; t++) {
-				const i64 ns = std::min<i64>(nsys - s0, std::max<i64>(1, gang * (t + 1) / NS));
-				ranges.emplace_back(s0, (int)ns); s0 += ns;
-			}
 		while (s0 < nsys) { const i64 ns = std::min<i64>(gang, nsys - s0); ranges.emplace_back(s0, (int)ns); s0 += ns; }
 	}
 	const i64 ngangs = (i64)ranges.size();
@@ -2488,18 +2267,15 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 	HIPCHK(hipEventRecord(ready.ev, (hipStream_t)stream));
 	std::vector<int> rcs(NS, GF2BV_OK);
 	std::vector<std::string> errs(NS);
-	StreamSets sets;
 	HIPCHK(hipSetDevice(device));
-	rc = sets.acquire(device, NS);
-	if (rc) return rc;
 	std::vector<std::thread> workers;
-	struct Join { std::vector<std::thread> &w; ~Join() { for (auto &t : w) if (t.joinable()) t.join(); } } joiner{ workers };     // (before `sets` goes)
+	struct Join { std::vector<std::thread> &w; ~Join() { for (auto &t : w) if (t.joinable()) t.join(); } } joiner{ workers };
 	for (int t = 0; t < NS; t++) {
 		workers.emplace_back([&, t]() {
 			if (hipSetDevice(device) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipSetDevice"; return; }
-			hipStream_t st = sets.panel(t);
-			const bool own_st = st == nullptr;
-			if (own_st && pool().stream(&st, device, 2) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipStreamCreate"; return; }
+			hipStream_t st = nullptr;
+			const bool own_st = true;
+			if (pool().stream(&st, device, 2) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipStreamCreate"; return; }
 			if (hipStreamWaitEvent(st, ready.ev, 0) != hipSuccess) { rcs[t] = GF2BV_ERR_HIP; errs[t] = "hipStreamWaitEvent"; }
 			for (i64 q; (q = next_gang.fetch_add(1)) < ngangs && rcs[t] == GF2BV_OK;) {
 				try {
@@ -2514,7 +2290,6 @@ int gf2bv_solve_batch_device(void *d_aug, int64_t nsys, int64_t sys_stride_words
 					S.t_begin = std::chrono::steady_clock::now();
 					S.device = device;
 					S.sA = st;
-					S.sB_preset = sets.bulk(t);
 					S.nsys = ns;
 					S.src = (const u64 *)d_aug + s0 * sys_stride_words;
 					S.src_sys_words = sys_stride_words;
@@ -2641,9 +2416,6 @@ static int batch_digits_on(const uint32_t *digits, const int64_t *digit_off, int
 	std::vector<int> rcs((size_t)NS, GF2BV_OK);
 	std::vector<std::string> errs((size_t)NS);
 	const int attempt0 = g_attempt;                    // (a whole-call retry by guarded() reaches the workers' solvers)
-	StreamSets sets;
-	rc = sets.acquire(device, NS);
-	if (rc) return rc;
 	auto worker = [&](int t) {
 		struct Mine {
 			hipStream_t st = nullptr; uint32_t *dig = nullptr; int device = 0; bool own = true;
@@ -2657,8 +2429,7 @@ static int batch_digits_on(const uint32_t *digits, const int64_t *digit_off, int
 		W.device = device;
 		auto run = [&]() -> int {
 			HIPCHK(hipSetDevice(device));
-			if (sets.panel(t)) { W.st = sets.panel(t); W.own = false; }
-			else HIPCHK(pool().stream(&W.st, device, 2));
+			HIPCHK(pool().stream(&W.st, device, 2));
 			HIPCHK(hipStreamWaitEvent(W.st, G.ready, 0));
 			HIPCHK(pool().alloc((void **)&W.dig, sizeof(uint32_t) * max_dig, device));
 			for (i64 q; (q = next_gang.fetch_add(1)) < ngangs;) {
@@ -2674,7 +2445,6 @@ static int batch_digits_on(const uint32_t *digits, const int64_t *digit_off, int
 					S.t_begin = std::chrono::steady_clock::now();
 					S.device = device;
 					S.sA = W.st;
-					S.sB_preset = sets.bulk(t);
 					S.nsys = ns;
 					S.rows = rows; S.cols = cols; S.mode = mode;
 					S.stride = ntiles * TW;
@@ -3224,12 +2994,10 @@ int gf2bv_kernel_resources(int device, int32_t *out, int n)
 		HIPCHK(hipFuncGetAttributes(&a, (const void *)k_block_fast_narrow));
 		out[13] = a.numRegs; out[14] = (int32_t)a.sharedSizeBytes;
 	}
-	if (n >= 20) {                 // round 5: the sparse block search (first pool size: beside the bulk update), the product kernel of the
-		hipFuncAttributes a{};     // three-level elimination (registers, LDS, scratch: must not spill)
+	if (n >= 17) {                 // round 5: the sparse block search (first pool size: beside the bulk update)
+		hipFuncAttributes a{};
 		HIPCHK(hipFuncGetAttributes(&a, (const void *)k_block_sparse<256, 4>));
 		out[15] = a.numRegs; out[16] = (int32_t)a.sharedSizeBytes;
-		HIPCHK(hipFuncGetAttributes(&a, (const void *)k_mul16k<GF2_KSEG, false>));
-		out[17] = a.numRegs; out[18] = (int32_t)a.sharedSizeBytes; out[19] = (int32_t)a.localSizeBytes;
 	}
 	return GF2BV_OK;
 	});

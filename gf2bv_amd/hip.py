@@ -54,8 +54,6 @@ class Stats(ctypes.Structure):
         ("search_handovers", ctypes.c_int32), ("fast_blocks", ctypes.c_int32),
         ("hbm_words", ctypes.c_double), ("bulk_launches", ctypes.c_int32), ("outer_blocks", ctypes.c_int32),
         ("handover_retries", ctypes.c_int32), ("small_path", ctypes.c_int32),
-        ("super_panels", ctypes.c_int32), ("strassen_levels", ctypes.c_int32), ("ms_product", ctypes.c_float), ("reserved0", ctypes.c_float),
-        ("product_add_bytes", ctypes.c_double), ("product_lookup_words", ctypes.c_double),
     ]
 
     def as_dict(self) -> dict:
@@ -356,7 +354,6 @@ def kernel_resources(device: int = 0) -> dict:
     res["update_outer"] = {"vgprs": int(out[10]), "lds": int(out[11]), "scratch": int(out[12])}      # k_update16k (two-level)
     res["block_fast_narrow"] = {"vgprs": int(out[13]), "lds": int(out[14])}                          # search + narrow step in one launch
     res["block_sparse"] = {"vgprs": int(out[15]), "lds": int(out[16])}                               # k_block_sparse<256, 4> (round 5)
-    res["product"] = {"vgprs": int(out[17]), "lds": int(out[18]), "scratch": int(out[19])}           # k_mul16k (three-level, round 5)
     return res
 
 

@@ -78,15 +78,6 @@ typedef struct gf2bv_stats {
 	                              made with events (the device stays on events for this process); 0 normally        */
 	int32_t small_path;        /* 1: solved by the one-launch kernel for systems that fit the LDS of one workgroup (k_small_solve; the
 	                              phase times and sweep counters above are then 0 except ms_total); GF2BV_SMALL=0 disables that path */
-	/* round 5 (three-level elimination): super-panels whose Schur update ran as ONE matrix product, the Strassen-Winograd levels
-	 * of the largest of them, the time inside the products (part of ms_sweep when `time_kernels` is set), what their additions
-	 * moved through HBM, and the table lookups they did in sweep-words (less than the sweep_words they stand for) */
-	int32_t super_panels;
-	int32_t strassen_levels;
-	float   ms_product;
-	float   reserved0;
-	double  product_add_bytes;
-	double  product_lookup_words;
 } gf2bv_stats;
 
 /* ---- library / device ------------------------------------------------------------------ */
@@ -257,9 +248,9 @@ int gf2bv_lds_clock_device(int device, double *shader_mhz, double *lds_bytes_per
  * instance, then k_block_fast, k_narrow_all, k_prio_window, k_panel_step (registers, LDS each; n >= 10).  A test holds the
  * budget: registers <= 512 - 2 x round_up(update's, 8), LDS <= 160 KiB - update's.  With n >= 13: out[10..12] = registers,
  * LDS and SCRATCH bytes per lane of k_update16k, the outer pass of the two-level elimination (it keeps 16 row segments per
- * lane in registers: scratch must be 0).  With n >= 15: out[13..14] = registers, LDS of k_block_fast_narrow.  With n >= 20:
+ * lane in registers: scratch must be 0).  With n >= 15: out[13..14] = registers, LDS of k_block_fast_narrow.  With n >= 17:
  * out[15..16] = registers, LDS of k_block_sparse<256, 4> (the sparse block search, first pool size: beside the bulk update like
- * every panel kernel), out[17..19] = registers, LDS, scratch of k_mul16k (the product of the three-level elimination). */
+ * every panel kernel). */
 int gf2bv_kernel_resources(int device, int32_t *out, int n);
 
 /* plain device buffer helpers so a host language without a HIP binding can stage data.  gf2bv_device_alloc: when the device

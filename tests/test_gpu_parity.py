@@ -608,8 +608,6 @@ def test_panel_kernels_fit_beside_the_bulk_update():
     # 30 x slower, still the right bits) fails here
     outer = res["update_outer"]
     assert outer["scratch"] <= 64 and outer["vgprs"] <= 120 and outer["lds"] <= 160 * 1024, outer
-    prod = res["product"]            # (round 5) the product kernel of the three-level elimination: the same loop, the same budget
-    assert prod["scratch"] == 0 and prod["vgprs"] <= 256 and prod["lds"] <= 160 * 1024, prod
 
 
 def test_stream_ceiling_reports_sane_rates():

@@ -207,39 +207,6 @@ def test_stream_pair_knobs_change_nothing_but_speed(monkeypatch, knob, value):
             _same(hip.solve_words(a, rows, cols, mode), w, mode)
 
 
-@pytest.mark.parametrize("K,P,L", [(2, 2, 0), (2, 2, 1), (2, 2, 2), (2, 4, 2), (3, 2, 1), (2, 3, 0), (4, 2, 3), (2, 2, -1)])
-def test_three_level_elimination_forced_on_small_systems(monkeypatch, K, P, L):
-    """Round 5: super-panels of P outer panels of K blocks (GF2BV_THREE_LEVEL=P with GF2BV_TWO_LEVEL=K) -- inside a super-panel the
-    outer passes stop at its last tile; right of it the super-panel's pivot rows are brought up to date by the REPLAY of its outer
-    panels on the rows that died inside it (k_update16k with the died-in-range filter), gathered into B (k_gather_b), the dead rows'
-    multipliers cleared, and every alive row takes ONE product C ^= A x B with L Strassen-Winograd levels (GF2BV_STRASSEN=L; -1: by
-    size) over k_mul16k.  Shapes where the alive bound stays low (shuffled / sparse: dead rows everywhere inside the product's row
-    range), rank caps inside and at the edge of a super-panel, rows >> cols, inconsistent systems, both modes, against the oracle."""
-    monkeypatch.setenv("GF2BV_TWO_LEVEL", str(K))
-    monkeypatch.setenv("GF2BV_THREE_LEVEL", str(P))
-    if L >= 0:
-        monkeypatch.setenv("GF2BV_STRASSEN", str(L))
-    rng = random.Random(900 + 10 * K + P)
-    spc = 256 * K * P                       # columns of a super-panel
-    shapes = [(4200, 4100, .5, None, True, 0), (4200, 4100, .5, spc, True, 0), (4200, 4100, .5, spc + 70, False, 0),
-              (4200, 4100, .5, 2 * spc - 1, True, 0), (9000, 4097, .5, 4000, True, 300), (12000, 3073, .004, None, True, 0),
-              (5300, 5200, .5, 5199, True, 0), (6000, 4100, .1, 2900, True, 50), (4200, 4100, .02, None, True, 0)]
-    took = 0
-    for i, (rows, cols, density, cap, cons, zr) in enumerate(shapes):
-        eqs = random_system(rng, rows, cols, density, cap, cons, zr)
-        if i % 2:
-            rng.shuffle(eqs)
-        aug = O.eqs_to_aug(eqs, cols)
-        monkeypatch.setenv("GF2BV_FLAG_SYNC", "0" if i % 3 == 2 else "1")
-        for mode in ((0, 1) if i < 4 else (i % 2,)):
-            got = hip.solve_words(aug, rows, cols, mode)
-            _same(got, O.solve_words(aug, rows, cols, mode), mode)
-            took += got.stats["super_panels"]
-            if L > 0 and got.stats["super_panels"]:
-                assert got.stats["strassen_levels"] >= 1
-    assert took > 0                           # the plan was taken
-
-
 @pytest.mark.parametrize("inv", ["1", "0"])
 def test_back_substitution_with_inverted_diagonal_blocks(monkeypatch, inv):
     """Round 4: from four groups of 16 panels up the back-substitution inverts the diagonal blocks up front (k_bs_inv) and a link

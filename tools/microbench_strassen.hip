@@ -11,6 +11,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/microbench_strassen.hip -o /tmp/mbs && /tmp/mbs [R] [tiles] [nb] [max level]
 // defaults: R = 262144 rows, 1024 tiles (131072 columns), nb = 512 blocks (131072 pivots): C(N x N/2) ^= A(N x N/2) . B(N/2 x N/2), N = 262144
 #include "../gf2bv_amd/csrc/gf2_kernels.hip.h"
+#include "three_level/gf2_three_level.hip.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>

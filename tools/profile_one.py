@@ -15,6 +15,6 @@ for r in range(reps):
     s = sol.stats
     res = hip.residual_device(buf.ptr, n, n, stride, sol.origin) if os.environ.get("RESIDUAL", "1") == "1" else -1
     print(f"N={n} rank={sol.rank} wall={dt*1e3:.1f}ms elim={s['ms_eliminate']:.1f} sweep={s['ms_sweep']:.1f} back={s['ms_backsub']:.1f} total={s['ms_total']:.1f} fast_blocks={s['fast_blocks']} handovers={s['search_handovers']}"
-          f" outer_blocks={s['outer_blocks']} super_panels={s['super_panels']} strassen={s['strassen_levels']} product_ms={s['ms_product']:.1f} add_GB={s['product_add_bytes'] / 1e9:.1f}"
+          f" outer_blocks={s['outer_blocks']}"
           f" elim_TBs={s['sweep_words'] * 16 / max(s['ms_eliminate'], 1e-9) / 1e9:.3f} residual_rows={res}", flush=True)
 buf.free()
