@@ -303,6 +303,17 @@ def run_single(args, world, rank, local_rank, dev):
 
     # correctness gate on this rank: A x = b on the untouched input, by the independent residual kernel
     bad = hip.residual_device(mat.data_ptr(), n, n, stride, stats[-1].origin, device=local_rank, stream=stream)
+    # (round 6) the same steps with GF2BV_PLAIN=1 -- no stream-pair probes, no XCD pinning, events instead of memory gates, no
+    # optimistic enqueue -- on rank 0 at N = 1: what a box costs where those heuristics are off; never part of `value`
+    plain = None
+    if world == 1 and os.environ.get("GF2BV_PLAIN") is None:
+        os.environ["GF2BV_PLAIN"] = "1"
+        try:
+            p_elapsed, p_stats, _ = timed_single(mat, n, stride, args.steps, 1, local_rank, dev, world, False)
+            plain = {"ms_per_step": p_elapsed / args.steps * 1e3,
+                     "same_answer": bool(all(np.array_equal(a.origin, b.origin) and a.rank == b.rank for a, b in zip(stats, p_stats)))}
+        finally:
+            del os.environ["GF2BV_PLAIN"]
     ok = torch.tensor([1 if (bad == 0 and all(s.solved for s in stats)) else 0], device=dev)
     agg = torch.tensor([float(sum(s.stats["row_xors"] for s in stats))], dtype=torch.float64, device=dev)
     if world > 1:
@@ -331,6 +342,7 @@ def run_single(args, world, rank, local_rank, dev):
         elim_ms = float(sum(s.stats["ms_eliminate"] for s in stats))
         roofline["elimination_GBs"] = roofline["alg_bytes_total"] / (elim_ms * 1e-3) / 1e9
         roofline["elimination_frac"] = roofline["elimination_GBs"] / HBM_PEAK_GBS
+        roofline["hbm_real_frac"] = roofline["hbm_bytes_total"] / (elim_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     out = {
         "metric": "GF(2) row-XORs/s (solve_one, dense NxN)", "value": float(agg.item()) / elapsed,
         "unit": "row-XORs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -355,6 +367,9 @@ def run_single(args, world, rank, local_rank, dev):
         "row_panels_per_s": world * n * ((n + 63) // 64) / 2 / (elapsed / args.steps),
         "roofline": roofline,
     }
+    if plain is not None:
+        out["plain_ms_per_step"] = plain["ms_per_step"]
+        out["parity_gate"]["plain_same_answer"] = plain["same_answer"]
     if target is not None:
         out[f"target_{args.target_n}"] = target
     if c4 is not None:
@@ -400,6 +415,9 @@ def target_leg(n: int, device: int, dev, ceil: dict) -> dict:
     elim_ms = float(sum(s.stats["ms_eliminate"] for s in stats))
     roofline["elimination_GBs"] = roofline["alg_bytes_total"] / (elim_ms * 1e-3) / 1e9
     roofline["elimination_frac"] = roofline["elimination_GBs"] / HBM_PEAK_GBS
+    # what the bulk launches really moved through HBM (rows read once and written once per launch: K blocks per trip in an outer pass)
+    # over the same time -- the figure in BYTES, beside the one in the roofline's unit (sweep-words, one per word and block applied)
+    roofline["hbm_real_frac"] = roofline["hbm_bytes_total"] / (elim_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
     return {"n": n, "seed": seed, "steps": steps, "warmup": 1, "ms_per_step": elapsed / steps * 1e3,
             "ms_per_step_without_event_brackets": plain_elapsed / steps * 1e3,
             "same_answer_without_brackets": bool(all(np.array_equal(a.origin, b.origin) and a.rank == b.rank
@@ -427,7 +445,7 @@ def c3_mt19937_leg(device: int, with_oracle: bool) -> dict:
     import random
 
     from gf2bv_amd import LinearSystem, _internal
-    from gf2bv_amd.crypto import MT19937
+    from tests.harness_models import MT19937
     out, threads = [], None
     for bs, samples in MT_VARIANTS:
         rand = random.Random(3142)
@@ -512,7 +530,7 @@ def c5_xoshiro_leg(device: int, with_oracle: bool) -> dict:
     import random
 
     from gf2bv_amd import LinearSystem
-    from gf2bv_amd.crypto import Xoshiro256starstar
+    from tests.harness_models import Xoshiro256starstar
     rnd = random.Random(1)
     gen = Xoshiro256starstar([rnd.getrandbits(64) for _ in range(4)])
     secret = tuple(gen.s)

@@ -3,7 +3,7 @@ scenario of the reference's examples/mt.py with gf2bv_amd's own API and models).
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gf2bv_amd import LinearSystem, PackedLinearSystem
-from gf2bv_amd.crypto import MT19937
+from tests.harness_models import MT19937
 
 
 def recover(bs, samples=None, system=LinearSystem):

@@ -8,7 +8,7 @@ in 8256 unknowns -- one dense GF(2) solve on the GPU.  (Same experiment as the r
 import itertools, os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gf2bv_amd import QuadraticSystem
-from gf2bv_amd.crypto import FibonacciLFSR, GaloisLFSR
+from tests.harness_models import FibonacciLFSR, GaloisLFSR
 
 N_BITS, TAPS = 128, 0xD670201BAC7515352A273372B2A95B23
 SELECT = (13, 24, 35, 46, 57)

@@ -2,7 +2,7 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gf2bv_amd import LinearSystem
-from gf2bv_amd.crypto import Xoshiro256starstar
+from tests.harness_models import Xoshiro256starstar
 
 gen = Xoshiro256starstar.generate()
 secret = tuple(gen.s)

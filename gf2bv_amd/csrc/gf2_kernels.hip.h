@@ -2920,9 +2920,7 @@ k_outer_trsm(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int npan, int gro
 //   out[NQ .. NQ + KMAX) block k has pivots
 //   out[NQ + KMAX .. )  [panel q][slot / pivot k] -> slot_row of the panel, -1 beyond its p: the SOURCE row of slot k (tables
 //                       of k_outer_apply) and at the same time the row pivot k is stored in (its output rows)
-//   out[2 NQ + KMAX]    the LARGEST source row of the panel (round 6: k_outer_apply ahead of the previous pass's end, see there)
-#define GF2_OUTER_MAXSRC (2 * GF2_KMAX * GF2_GMAX * 64 + GF2_KMAX)
-#define GF2_OUTER_LISTS (2 * GF2_KMAX * GF2_GMAX * 64 + GF2_KMAX + 4)
+#define GF2_OUTER_LISTS (2 * GF2_KMAX * GF2_GMAX * 64 + GF2_KMAX)
 __global__ void __launch_bounds__(256)
 k_outer_prow(int j0, int nblk, const PanelRec *__restrict__ panels, const PanelAux *__restrict__ aux, int *__restrict__ out, SysStride ss)
 {
@@ -2932,11 +2930,8 @@ k_outer_prow(int j0, int nblk, const PanelRec *__restrict__ panels, const PanelA
 	}
 	constexpr int NQ = GF2_KMAX * GF2_GMAX * 64;
 	__shared__ int anyb[GF2_KMAX];
-	__shared__ int maxsrc;
 	if (threadIdx.x < GF2_KMAX) anyb[threadIdx.x] = 0;
-	if (threadIdx.x == 0) maxsrc = -1;
 	__syncthreads();
-	int mine = -1;
 	for (int t = threadIdx.x; t < NQ; t += blockDim.x) {
 		int pr = -1, sr = -1;
 		if (t < nblk * GF2_GMAX * 64) {
@@ -2947,12 +2942,9 @@ k_outer_prow(int j0, int nblk, const PanelRec *__restrict__ panels, const PanelA
 		}
 		out[t] = pr;
 		out[NQ + GF2_KMAX + t] = sr;
-		mine = max(mine, sr);
 	}
-	atomicMax(&maxsrc, mine);
 	__syncthreads();
 	if (threadIdx.x < GF2_KMAX) out[NQ + threadIdx.x] = anyb[threadIdx.x];
-	if (threadIdx.x == 0) out[GF2_OUTER_MAXSRC] = maxsrc;
 }
 
 // The outer pass: all `nblk` blocks of an outer panel (first panel j0) applied to the column tiles [tile_begin, tile_begin +
@@ -2966,12 +2958,8 @@ __device__ __forceinline__ void
 update16k_body(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__restrict__ gprow,
                const u64 *__restrict__ mult, i64 set_words, int set0, int nsets,
                const int *__restrict__ blk_first, const int *__restrict__ died, int j_end, int tile_begin, int ntiles, SysStride ss,
-               int xcd_map, i64 item_begin, i64 item_end)
+               int chunk_major)
 {
-	// item_begin / item_end (round 6): the launch takes the items [item_begin, min(item_end, all)) of the pass in ITS item order.  The
-	// solver cuts a chunk-major pass (xcd_map == 2) behind its first chunk -- items [0, ntiles): the 12288 rows from the alive bound,
-	// where the NEXT outer panel finds its pivots -- so that the next panel's P = T x S (k_outer_apply) can start when those rows are
-	// final instead of when the whole pass is
 	// NT_ / RB / NB (round 5, late): threads per workgroup, lookups per read batch, batches in rotation; the shapes that ship are
 	// the wrappers behind this body
 	constexpr int NT = NT_, NW = NT_ / 64;
@@ -3018,20 +3006,10 @@ update16k_body(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__
 	const i64 nch = (R64 - rlo + CH - 1) / CH;
 	const i64 items = nch * ntiles;
 	const uint4 *mbase = reinterpret_cast<const uint4 *>(mult);
-	i64 it = item_begin + blockIdx.x;
-	const i64 item_lim = items < item_end ? items : item_end;
-	// xcd_map (round 4): workgroup b sits on XCD b % 8 (observed placement: speed only).  An item reads nblk x 32 B of multipliers per
-	// row of its chunk -- K x 256 KiB, 3 MiB for K = 12 -- and every tile re-reads them; in tile-major item order an XCD meets
-	// nch / 8 chunks per tile, 12 MiB and more between two uses of the same multipliers: they come from the MALL.  Here XCD c takes
-	// the chunks c, c + 8, ... and walks them CHUNK-major (all tiles of one chunk, then the next chunk): its 32 concurrent
-	// workgroups share one chunk's multipliers out of its L2.  The launch then has 8 x ceil(nch / 8) x ntiles workgroups.
-	// MEASURED SLOWER (262144^2 1.305 -> 1.370 s, 131072^2 185 -> 210 ms) and therefore off (GF2BV_OUTER_XCD=1 turns it on): the
-	// pass is bound by its LDS lookups, not by where the multipliers come from, and 32 workgroups of an XCD on 32 different tiles
-	// fetch 32 sets of pivot rows per block where tile-major neighbours share them.
+	i64 it = blockIdx.x;
 	// (the host sizes the launch from the DENSE estimate of the alive bound; a system with fewer pivots has more chunks: the loop
-	// below then comes round again, gridDim.x / 8 slots further)
-	const i64 xcd = blockIdx.x & 7, gslots = (i64)(gridDim.x >> 3);
-	i64 slot = blockIdx.x >> 3;
+	// below then comes round again.  Round 4 also walked the items chunk-major PER XCD -- workgroup b on XCD b % 8, XCD c taking the
+	// chunks c, c + 8, ... -- and measured it slower: 262144^2 1.305 -> 1.370 s; removed in round 6, profiles/r04_target_scans.txt)
 	// Every address below = a wave-uniform 64-bit base (scalar registers) + a 32-BIT lane offset (batch j of a wavefront =
 	// rows base + 512 j + lane): nothing per batch lives in a 64-bit VGPR pair -- with per-lane 64-bit row indices, clamped to
 	// the row range, the compiler kept 16 address pairs per stream across the block loop and spilled up to 1700 registers.
@@ -3042,18 +3020,10 @@ update16k_body(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__
 	auto item_rows = [&](i64 item) { return rlo + (item % nch) * CH + (i64)wvu * 64; };
 	auto item_tile = [&](i64 item) { return reinterpret_cast<uint4 *>(M) + ((i64)tile_begin + item / nch) * srows; };
 	for (;; it += gridDim.x) {
-		i64 item = it;
-		if (xcd_map == 1) {
-			const i64 chunk = xcd + 8 * (slot / ntiles);
-			if (chunk >= nch) break;
-			item = (slot % ntiles) * nch + chunk;      // (tile-major item index of (tile, chunk), what the lambdas below decode)
-			slot += gslots;
-		} else {
-			if (it >= item_lim) break;
-			// xcd_map == 2 (late round 5): plain CHUNK-major order -- the workgroups in flight share ONE chunk's multipliers (12288 rows x
-			// 32 B per block) instead of every chunk's, whatever XCD they sit on
-			if (xcd_map == 2) item = (it % ntiles) * nch + it / ntiles;
-		}
+		if (it >= items) break;
+		// chunk_major (late round 5, the solver's order): the workgroups in flight share ONE chunk's multipliers (12288 rows x 32 B per
+		// block) instead of every chunk's; 0 = tile-major (rounds 3-5; tools/microbench_update16k.hip compares the two)
+		const i64 item = chunk_major ? (it % ntiles) * nch + it / ntiles : it;
 		uint4 *Mw = item_tile(item);
 		const i64 rb0 = item_rows(item);
 		uint4 *Mrow = Mw + rb0;
@@ -3163,8 +3133,8 @@ update16k_body(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__
 }
 
 #define GF2_U16K_PARAMS u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__restrict__ gprow, const u64 *__restrict__ mult, i64 set_words, \
-	int set0, int nsets, const int *__restrict__ blk_first, const int *__restrict__ died, int j_end, int tile_begin, int ntiles, SysStride ss, int xcd_map, i64 item_begin, i64 item_end
-#define GF2_U16K_ARGS M, rows, srows, nblk, gprow, mult, set_words, set0, nsets, blk_first, died, j_end, tile_begin, ntiles, ss, xcd_map, item_begin, item_end
+	int set0, int nsets, const int *__restrict__ blk_first, const int *__restrict__ died, int j_end, int tile_begin, int ntiles, SysStride ss, int chunk_major
+#define GF2_U16K_ARGS M, rows, srows, nblk, gprow, mult, set_words, set0, nsets, blk_first, died, j_end, tile_begin, ntiles, ss, chunk_major
 // Rounds 3-5: 8 wavefronts x GF2_KSEG segments, read batches of 8 (two in flight), ~200 registers -- two wavefronts per SIMD.  Kept as
 // GF2BV_OUTER_SHAPE=1 (and as the base case the three-level experiments were costed with).
 template <int SEG, int NT_ = 512, int RB = 8, int NB = 2>
@@ -3189,8 +3159,9 @@ k_update16k(GF2_U16K_PARAMS)
 #define GF2_U16K_WIDE(NAME, SEG, RB, NB, VB) \
 	__global__ void __launch_bounds__(1024) __attribute__((amdgpu_num_vgpr(VB))) NAME(GF2_U16K_PARAMS) { update16k_body<SEG, 1024, RB, NB>(GF2_U16K_ARGS); }
 GF2_U16K_WIDE(k_update16k_wide, GF2_WSEG, 2, 2, 60)
-GF2_U16K_WIDE(k_update16k_wide10, 10, 2, 2, 60)             // (GF2BV_OUTER_SHAPE=2: no scratch at all, 1.114 s)
-GF2_U16K_WIDE(k_update16k_wide_room, GF2_WSEG, 2, 2, 56)    // (GF2BV_OUTER_SHAPE=3: 112 registers, k_block_fast_narrow fits beside it, 1.15 s)
+// (round 5 also shipped 16 x 10 segments without scratch -- 1.114 s -- and 16 x 12 at 112 registers, beside which k_block_fast_narrow
+// fits -- 1.15 s -- as GF2BV_OUTER_SHAPE=2 / 3, and the eight-wavefront kernel above as shape 1; every A/B is in
+// profiles/r05_outer_shapes.txt, the knob went in round 6: GF2_U16K_WIDE(name, SEG, RB, NB, budget / 2) rebuilds any of them)
 
 // P = T x S on one column tile: the final pivot rows of an outer panel (all 4 K panels) from its source rows, WITHOUT the
 // chain of k_outer_trsm -- T comes from k_outer_trsm<.., IDENT> once per panel.  One workgroup per tile; the "rows" are the
@@ -3199,24 +3170,12 @@ GF2_U16K_WIDE(k_update16k_wide_room, GF2_WSEG, 2, 2, 56)    // (GF2BV_OUTER_SHAP
 // the very end, into the rows of the same set), the lookups go by the T row's 32 bytes of that block -- the table and lookup
 // code of the bulk update, accumulating from zero.  ~5 us per source block and tile instead of a 0.3 ms chain per word group.
 __global__ void __launch_bounds__(512)
-k_outer_apply(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__restrict__ lists, const u64 *__restrict__ Tm, int tile_begin, SysStride ss,
-              int when, const int *__restrict__ prev_first, int chunk_rows)
+k_outer_apply(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__restrict__ lists, const u64 *__restrict__ Tm, int tile_begin, SysStride ss)
 {
 	{
 		const i64 ao = blockIdx.y * ss.arena_bytes;
 		M += blockIdx.y * ss.m_words;
 		lists = sys_at(lists, ao); Tm = sys_at(Tm, ao);
-		if (when) prev_first = sys_at(prev_first, ao);
-	}
-	// when (round 6): 0 = always.  The source rows of this panel have taken the previous panel's outer pass when that pass has gone over
-	// the rows they sit in; a chunk-major pass finishes its FIRST chunk -- the chunk_rows rows from its row bound *prev_first & ~63 --
-	// in a launch of its own, and a dense panel finds all its pivots there.  The solver therefore enqueues this kernel twice: EARLY
-	// (when = 1) behind that first launch, beside the rest of the previous pass, and LATE (when = 2) in front of this panel's own pass
-	// as before.  Every workgroup of both takes the same decision from the panel's lists: early runs iff every source row lies below
-	// the first chunk's end, late iff not -- exactly one of the two does the work, whatever the system looks like.
-	if (when) {
-		const bool in_first_chunk = lists[GF2_OUTER_MAXSRC] < ((*prev_first) & ~63) + chunk_rows;
-		if (in_first_chunk != (when == 1)) return;
 	}
 	constexpr int NT = 512, NW = 8, SEG = GF2_KMAX * GF2_GMAX * 64 / NT, NQ = GF2_KMAX * GF2_GMAX * 64;      // 4 pivots per lane
 	__shared__ __attribute__((aligned(256))) uint4 tab[2 * 256 * 16];      // 128 KiB at LDS address 0

@@ -567,32 +567,17 @@ struct Solver {
 	i64 tile_hi = 0;              // bulk kernels touch tiles < tile_hi (= ntiles; the outer panel's end while it is eliminated)
 	static constexpr int nlist = 2;      // row lists / T matrices kept: by panel parity (the previous panel's outer pass may still be reading its own)
 	hipStream_t sC = nullptr;     // outer passes: panel p's runs BESIDE the inner elimination of panel p + 1 (sA + sB)
-	hipStream_t sD = nullptr;     // (late round 5) the RIGHT part of every outer pass (outer_split percent of its tiles): its P = T x S and its
-	                              // k_update16k run beside the left part's on sC, so that one part's short launches (the next panel's tiles, the
-	                              // two applies: ~0.6 ms of an underused chip per panel) fall under the other part's pass
 	bool outer_side = true;       // GF2BV_OUTER_SIDE=0: the outer step on the next panel's tiles in front of the pass on the outer stream (rounds 3-5)
-	int outer_split = 0;          // GF2BV_OUTER_SPLIT: percent of an outer pass's tiles that go to sD (0, the default: one stream).  OPT-IN: 50 takes
-	                              // 131072^2 from 162 to 155 ms and 262144^2 0.8 % down, but the process then owns one more low-priority stream, and
-	                              // batch calls that create THEIR streams after it ran 290 instead of 301 systems/s in the same process (their two gangs
-	                              // no longer overlapped: the stream-pair effect of profiles/r05_stream_pairs.txt, seen from the other side)
-	hipEvent_t evOuter = nullptr, evPri = nullptr, evPanelDone = nullptr, evSp = nullptr, evRight = nullptr, evBig = nullptr;
-	hipEvent_t evChunk0 = nullptr, evEarly = nullptr;
-	bool outer_early = true;      // (round 6) GF2BV_OUTER_EARLY=0: P = T x S of every outer panel in front of its own pass only, as rounds 3-5.  Default: a
-	                              // chunk-major pass is cut behind its first chunk (the rows the next panel takes its pivots from) and the next panel's
-	                              // P = T x S on the tiles of ITS pass starts behind that first launch, beside the rest of the running pass (enqueue_forward)
+	                              // (late round 5 also split the pass itself over two streams -- GF2BV_OUTER_SPLIT: 131072^2 162 -> 155 ms, 262144^2
+	                              // -0.8 %, but a fourth stream that cost later batch calls of the process their overlap; removed in round 6,
+	                              // profiles/r05_outer_shapes.txt)
+	hipEvent_t evOuter = nullptr, evPri = nullptr, evPanelDone = nullptr, evBig = nullptr;
 	bool bulk_waits_outer = false;     // the next bulk launch of the one-level schedule has to wait for the last outer pass
 	bool ends_outer_panel(int b) const { return tl_K > 0 && b < tl_bend && (b + 1) % tl_K == 0; }
 	u64 *Wb = nullptr;            // 2 x rows x GMAX window words (the panel steps ping-pong between the halves)
 	u64 *Uwin = nullptr;          // rank x GMAX: pivot rows' words of the following window (k_prio_window -> k_unwind)
 	int *oprow = nullptr;         // k_outer_prow -> k_outer_apply / k_update16k: row lists of the outer panel being applied
 	u64 *Tm = nullptr;            // k_outer_trsm<IDENT> -> k_outer_apply: the panel's pivot rows as combinations of its source rows
-	int outer_shape = 0;          // GF2BV_OUTER_SHAPE: workgroup shape of the outer pass (gf2_kernels.hip.h, behind update16k_body) -- 0 = sixteen
-	                              // wavefronts x 12 segments at 120 registers (k_update16k_wide, the default since late round 5), 1 = the eight
-	                              // wavefronts x 16 segments of rounds 3-5, 2 = sixteen x 10 (no scratch), 3 = sixteen x 12 at 112 registers
-	int outer_order = 2;          // GF2BV_OUTER_ORDER: 2 = the outer pass walks its items CHUNK-major (the default since late round 5: the workgroups in
-	                              // flight share one chunk's multipliers; 262144^2 1.105 -> 1.040 s), 0 = tile-major (rounds 3-5)
-	bool outer_xcd = false;       // GF2BV_OUTER_XCD=1: the outer pass walks its items chunk-major per XCD (k_update16k: xcd_map) -- built and
-	                              // measured in round 4, SLOWER: 262144^2 1.305 -> 1.370 s, 131072^2 185 -> 210 ms (profiles/r04_target_scans.txt)
 	bool outer_chain = false;     // GF2BV_OUTER_CHAIN=1: the chain itself on every word group instead (the first form; tests)
 	u64 *Pc = nullptr;            // final pivot rows of the current block, compact: [tile][panel][pivot bit] x 16 B (k_block_trsm -> k_update16)
 	u64 *Pfast = nullptr;         // scratch of k_block_fast: the pivot rows' window words of a block, [panel][word][column]
@@ -664,7 +649,6 @@ struct Solver {
 			return;
 		}
 		// nothing goes back to the pool while work may still be in flight (error paths return early)
-		if (sD) (void)hipStreamSynchronize(sD);
 		if (sC) (void)hipStreamSynchronize(sC);
 		if (sB) (void)hipStreamSynchronize(sB);
 		if (arena || M) (void)hipStreamSynchronize(sA);
@@ -674,10 +658,9 @@ struct Solver {
 		st = nullptr; panels = nullptr; aux = nullptr; fu = nullptr; died = nullptr; pivcol = nullptr;
 		urow = nullptr; blk_first = nullptr; mult = nullptr; Wb = nullptr;
 		for (hipEvent_t *e : { &ev0, &ev1, &ev2, &ev3, &evx }) { P.release_event(*e, true); *e = nullptr; }
-		for (hipEvent_t *e : { &evOuter, &evPri, &evPanelDone, &evSp, &evRight, &evBig, &evChunk0, &evEarly }) { P.release_event(*e, false); *e = nullptr; }
+		for (hipEvent_t *e : { &evOuter, &evPri, &evPanelDone, &evBig }) { P.release_event(*e, false); *e = nullptr; }
 		if (sC) P.release_stream(sC, device, nsys > 1 ? 3 : 1);
-		if (sD) P.release_stream(sD, device, 1);
-		sC = nullptr; sD = nullptr;
+		sC = nullptr;
 		for (hipEvent_t e : kev) P.release_event(e, true);
 		for (hipEvent_t e : evA) P.release_event(e, false);
 		for (hipEvent_t e : evPrio) P.release_event(e, false);
@@ -784,9 +767,6 @@ void plan_two_level(Solver &S)
 	if (!bend) return;
 	S.tl_K = K; S.tl_bend = bend;
 	if (const char *e = getenv("GF2BV_OUTER_CHAIN"); e && *e) S.outer_chain = atoi(e) != 0;
-	if (const char *e = getenv("GF2BV_OUTER_XCD"); e && *e) S.outer_xcd = atoi(e) != 0;
-	if (const char *e = getenv("GF2BV_OUTER_SHAPE"); e && *e) S.outer_shape = std::min(3, std::max(0, atoi(e)));
-	if (const char *e = getenv("GF2BV_OUTER_ORDER"); e && *e) S.outer_order = atoi(e) == 0 ? 0 : 2;
 	S.nsets = 2 * K;              // the outer pass of panel p reads its K sets while the blocks of panel p + 1 write theirs
 }
 
@@ -894,15 +874,7 @@ int solver_alloc(Solver &S)
 		for (hipEvent_t *e : { &S.evOuter, &S.evPri, &S.evPanelDone }) HIPCHK(pool().event(e, false));
 		if (S.sB != S.sA) { if (S.nsys == 1) HIPCHK(pool().low_stream_for(S.sA, S.device, &S.sC)); else HIPCHK(pool().stream(&S.sC, S.device, 3)); }       // (GF2BV_SERIAL: everything on one stream)
 		HIPCHK(pool().event(&S.evBig, false));
-		HIPCHK(pool().event(&S.evChunk0, false));
-		HIPCHK(pool().event(&S.evEarly, false));
 		if (const char *e = getenv("GF2BV_OUTER_SIDE"); e && *e) S.outer_side = atoi(e) != 0;
-		if (const char *e = getenv("GF2BV_OUTER_EARLY"); e && *e) S.outer_early = atoi(e) != 0;
-		if (const char *e = getenv("GF2BV_OUTER_SPLIT"); e && *e) S.outer_split = std::min(90, std::max(0, atoi(e)));
-		if (S.sC && S.nsys == 1 && S.outer_split > 0) {
-			HIPCHK(pool().event(&S.evRight, false));
-			HIPCHK(pool().low_stream_for(S.sA, S.device, &S.sD, 1, { S.sC }));
-		}
 	}
 	S.evA.resize(S.nblocks); S.evPrio.resize(S.nblocks); S.waitPrio.assign(S.nblocks, nullptr);
 	for (int b = 0; b < S.nblocks; b++) {
@@ -1292,21 +1264,13 @@ int enqueue_outer_prepare(Solver &S, hipStream_t st, int b0, int b1)
 	return GF2BV_OK;
 }
 
-// rows of one item of the outer pass by workgroup shape (GF2BV_OUTER_SHAPE)
-i64 outer_item_rows(const Solver &S)
+// The outer step of the panel of blocks [b0, b1) on the tiles [t_begin, t_end): the panel's pivot rows P = T x S there (k_outer_apply;
+// GF2BV_OUTER_CHAIN=1: the chain itself on every word group), then the pass (k_update16k_wide, one workgroup per item, chunk-major).
+int enqueue_outer_apply(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, i64 t_end)
 {
-	static const int shape_rows[4] = { GF2_WSEG * 1024, GF2_KSEG * 512, 10 * 1024, GF2_WSEG * 1024 };
-	return shape_rows[S.outer_shape];
-}
-
-// P = T x S of the panel of blocks [b0, b1) on the tiles [t_begin, t_end).  when = 0: unconditionally; 1 / 2: the EARLY / LATE launch of
-// a pair of which exactly one does the work (k_outer_apply: early iff every source row of the panel lies in the first chunk of the
-// PREVIOUS panel's pass, whose row bound is blk_first[b0 - K])
-int enqueue_outer_pivots(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, i64 t_end, int when)
-{
+	const int G = S.impl->G;
 	const i64 nt = t_end - t_begin;
 	if (nt <= 0) return GF2BV_OK;
-	const int G = S.impl->G;
 	const i64 set_words = (i64)G * mult_rows(S.rows);
 	int *gprow = S.oprow + (size_t)((b0 / S.tl_K) % S.nlist) * GF2_OUTER_LISTS;
 	const int npan = (b1 - b0) * G;
@@ -1316,61 +1280,25 @@ int enqueue_outer_pivots(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin,
 		                                                                          S.mult, set_words, b0 % S.nsets, S.nsets, S.impl->T, (u64 *)nullptr, S.ss());
 	} else
 		k_outer_apply<<<dim3((unsigned)nt, S.nsys), dim3(512), 0, st>>>(S.M, S.rows, S.srows, b1 - b0, (const int *)gprow,
-		                                                                (const u64 *)(S.Tm + (size_t)((b0 / S.tl_K) % S.nlist) * ((size_t)GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX)), (int)t_begin, S.ss(),
-		                                                                when, (const int *)(S.blk_first + std::max(0, b0 - S.tl_K)), (int)outer_item_rows(S));
+		                                                                (const u64 *)(S.Tm + (size_t)((b0 / S.tl_K) % S.nlist) * ((size_t)GF2_KMAX * GF2_KMAX * GF2_GMAX * 64 * GF2_GMAX)), (int)t_begin, S.ss());
 	HIPCHK(hipGetLastError());
-	return GF2BV_OK;
-}
-
-// The outer step of the panel of blocks [b0, b1) on the tiles [t_begin, t_end): the pivot rows (pivots_when: see enqueue_outer_pivots; -1 =
-// the caller has them in place), then the pass.  cut: a chunk-major pass goes as TWO launches -- its first chunk (the item_rows rows from the
-// alive bound: items [0, tiles)), S.evChunk0 recorded behind it, then the rest.
-int enqueue_outer_apply(Solver &S, hipStream_t st, int b0, int b1, i64 t_begin, i64 t_end, int pivots_when = 0, bool cut = false)
-{
-	const int G = S.impl->G;
-	const i64 nt = t_end - t_begin;
-	if (nt <= 0) { if (cut) HIPCHK(hipEventRecord(S.evChunk0, st)); return GF2BV_OK; }
-	const i64 set_words = (i64)G * mult_rows(S.rows);
-	int *gprow = S.oprow + (size_t)((b0 / S.tl_K) % S.nlist) * GF2_OUTER_LISTS;
-	if (pivots_when >= 0) { int rc = enqueue_outer_pivots(S, st, b0, b1, t_begin, t_end, pivots_when); if (rc) return rc; }
+	hipEvent_t ka = nullptr, kb = nullptr;
+	if (S.time_kernels) {
+		HIPCHK(pool().event(&ka, true)); HIPCHK(pool().event(&kb, true));
+		S.kev.push_back(ka); S.kev.push_back(kb);
+		if (!S.ext_events) HIPCHK(hipEventRecord(ka, st));
+	}
 	// items of a dense system: the kernel derives the true count from the alive bound and loops if there are more
 	const i64 est_lo = std::min<i64>(S.rows, (i64)b0 * 64 * G) & ~(i64)63, R64 = round_up(S.rows, 64);
-	const i64 item_rows = outer_item_rows(S);
+	constexpr i64 item_rows = (i64)GF2_WSEG * 1024;
+	static_assert((size_t)item_rows * 32 <= kOuterSlackBytes, "the slack behind the matrix covers an item");
 	const i64 nch = std::max<i64>(1, (R64 - est_lo + item_rows - 1) / item_rows);
-	const bool xmap = S.outer_xcd && S.nsys == 1;
-	const int xcd_flag = xmap ? 1 : S.outer_order;
-	cut = cut && xcd_flag == 2;
-	const int nparts = cut ? 2 : 1;
-	for (int part = 0; part < nparts; part++) {
-		// (cut) part 0 = items [0, nt), part 1 = items [nt, all); otherwise everything in one launch
-		const i64 it0 = cut && part == 1 ? nt : 0, it1 = cut && part == 0 ? nt : (i64)1 << 62;
-		const i64 est_items = cut ? (part == 0 ? nt : (nch - 1) * nt) : nch * nt;
-		if (est_items > 0) {
-			hipEvent_t ka = nullptr, kb = nullptr;
-			if (S.time_kernels) {
-				HIPCHK(pool().event(&ka, true)); HIPCHK(pool().event(&kb, true));
-				S.kev.push_back(ka); S.kev.push_back(kb);
-				if (!S.ext_events) HIPCHK(hipEventRecord(ka, st));
-			}
-			// (xcd_map: one workgroup per item exactly -- the kernel's own chunk count may be smaller than this estimate, never larger)
-			const i64 wgs = xmap ? 8 * ((nch + 7) / 8) * nt : std::min<i64>(est_items, (i64)1 << 30);
-#define GF2_LAUNCH_OUTER(KERN, ROWS_, NT_) do { \
-	static_assert((size_t)(ROWS_) * 32 <= kOuterSlackBytes, "the slack behind the matrix covers an item of this shape"); \
-	hipExtLaunchKernelGGL((KERN), dim3((unsigned)wgs, S.nsys), dim3(NT_), 0, st, S.ext_events ? ka : nullptr, S.ext_events ? kb : nullptr, 0, \
-	                      S.M, S.rows, S.srows, b1 - b0, (const int *)gprow, (const u64 *)S.mult, \
-	                      set_words, b0 % S.nsets, S.nsets, (const int *)(S.blk_first + b0), (const int *)S.died, b1 * G, (int)t_begin, (int)nt, S.ss(), xcd_flag, it0, it1); } while (0)
-			switch (S.outer_shape) {
-			case 1: { auto kern = k_update16k<GF2_KSEG>; GF2_LAUNCH_OUTER(kern, GF2_KSEG * 512, 512); } break;
-			case 2: GF2_LAUNCH_OUTER(k_update16k_wide10, 10 * 1024, 1024); break;
-			case 3: GF2_LAUNCH_OUTER(k_update16k_wide_room, GF2_WSEG * 1024, 1024); break;
-			default: GF2_LAUNCH_OUTER(k_update16k_wide, GF2_WSEG * 1024, 1024); break;
-			}
-#undef GF2_LAUNCH_OUTER
-			HIPCHK(hipGetLastError());
-			if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, st));
-		}
-		if (cut && part == 0) HIPCHK(hipEventRecord(S.evChunk0, st));
-	}
+	const i64 wgs = std::min<i64>(nch * nt, (i64)1 << 30);
+	hipExtLaunchKernelGGL(k_update16k_wide, dim3((unsigned)wgs, S.nsys), dim3(1024), 0, st, S.ext_events ? ka : nullptr, S.ext_events ? kb : nullptr, 0,
+	                      S.M, S.rows, S.srows, b1 - b0, (const int *)gprow, (const u64 *)S.mult,
+	                      set_words, b0 % S.nsets, S.nsets, (const int *)(S.blk_first + b0), (const int *)S.died, b1 * G, (int)t_begin, (int)nt, S.ss(), 1);
+	HIPCHK(hipGetLastError());
+	if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, st));
 	if (S.dbg_sync & 2) HIPCHK(hipDeviceSynchronize());
 	return GF2BV_OK;
 }
@@ -1413,7 +1341,6 @@ int enqueue_forward(Solver &S)
 	auto sparse_ok = [&](int blk) { return S.sparse_on && blk != general_only && fast_block_possible(S, block_geom(S, blk)); };
 	// after a poisoned block pb: everything in flight drained, the plan cut back to what has run, the counters rebased
 	auto recover = [&](int pb) -> int {
-		if (S.sD) HIPCHK(hipStreamSynchronize(S.sD));
 		if (S.sC) HIPCHK(hipStreamSynchronize(S.sC));
 		HIPCHK(hipStreamSynchronize(S.sB));
 		// (two-level: the outer panels before the poisoned one are complete; the published blocks of the poisoned panel have been
@@ -1478,9 +1405,7 @@ int enqueue_forward(Solver &S)
 	if (S.tl_K) {
 		const int G = S.impl->G;
 		hipStream_t so = S.sC ? S.sC : S.sB;           // (GF2BV_SERIAL: one stream, everything in order)
-		bool right_running = false;                    // the previous panel's pass was split over so and sD
 		bool big_recorded = false;                     // evBig holds the end of the previous panel's pass (side launches)
-		bool chunk0_recorded = false;                  // evChunk0 holds the end of the first chunk of the previous panel's pass
 		for (int p0 = 0; p0 < S.tl_bend; p0 += S.tl_K) {
 			const int p1 = p0 + S.tl_K;
 			if (p0 > 0) {
@@ -1501,52 +1426,20 @@ int enqueue_forward(Solver &S)
 			// inner elimination's bulk stream, idle at this point, and runs BESIDE the start of the pass proper instead of before it:
 			// it needs the previous pass complete (evBig; it used to follow it in stream order) and this panel's T; the pass proper
 			// needs T alone (disjoint tiles).  No new stream (cf. GF2BV_OUTER_SPLIT).
-			const bool side = S.outer_side && !S.sD && S.sB != so && S.sB != S.sA;
+			const bool side = S.outer_side && S.sB != so && S.sB != S.sA;
 			if (side) {
-				// (round 6) P = T x S on the tiles of the pass proper -- 0.3-0.9 ms in front of every pass, 44 ms of a 262144^2 solve, "the
-				// largest serial term left" of round 5 -- starts when the FIRST CHUNK of the previous pass is done (evChunk0: the rows this
-				// panel took its pivots from), on the inner bulk stream, and runs beside the rest of that pass; the launch in front of this
-				// panel's own pass stays and does the work only where a source row lay outside that chunk (k_outer_apply: when)
-				const bool early = S.outer_early && chunk0_recorded && !S.outer_chain && S.outer_order == 2 && !(S.outer_xcd && S.nsys == 1);
 				HIPCHK(hipStreamWaitEvent(S.sB, S.evPanelDone, 0));
-				if (early) {
-					HIPCHK(hipStreamWaitEvent(S.sB, S.evChunk0, 0));
-					if ((rc = enqueue_outer_pivots(S, S.sB, p0, p1, t1, t_out, 1))) return rc;
-					HIPCHK(hipEventRecord(S.evEarly, S.sB));
-				}
 				if (big_recorded) HIPCHK(hipStreamWaitEvent(S.sB, S.evBig, 0));
 				if ((rc = enqueue_outer_apply(S, S.sB, p0, p1, t0, t1))) return rc;
 				HIPCHK(hipEventRecord(S.evPri, S.sB));
-				if (early) HIPCHK(hipStreamWaitEvent(so, S.evEarly, 0));
-				if ((rc = enqueue_outer_apply(S, so, p0, p1, t1, t_out, early ? 2 : 0, S.outer_early))) return rc;
-				chunk0_recorded = S.outer_early;
-				HIPCHK(hipEventRecord(S.evBig, so));
-				big_recorded = true;
-				right_running = false;
-				continue;
-			}
-			if ((rc = enqueue_outer_apply(S, so, p0, p1, t0, t1))) return rc;
-			{
+				if ((rc = enqueue_outer_apply(S, so, p0, p1, t1, t_out))) return rc;
+			} else {
+				if ((rc = enqueue_outer_apply(S, so, p0, p1, t0, t1))) return rc;
 				HIPCHK(hipEventRecord(S.evPri, so));
-				const i64 tr = S.sD ? t_out - (t_out - t1) * S.outer_split / 100 : t_out;       // the right part: tiles [tr, t_out) on sD
-				if (S.sD && tr > t1 && t_out - tr >= 32) {
-					// sD is one pass of its own tiles behind at most: its previous pass precedes this one in stream order, and `so` goes on
-					// to the next panel's tiles (behind which that panel's elimination starts and the multiplier sets / row lists of THIS
-					// panel's parity are written again two panels on) only when this pass is complete on both streams -- the hand-over
-					// of rounds 3-5, one event wider.  The first split pass waits for everything `so` has queued before it.
-					HIPCHK(hipStreamWaitEvent(S.sD, right_running ? S.evPanelDone : S.evPri, 0));
-					if ((rc = enqueue_outer_apply(S, S.sD, p0, p1, tr, t_out))) return rc;
-					HIPCHK(hipEventRecord(S.evRight, S.sD));
-					if ((rc = enqueue_outer_apply(S, so, p0, p1, t1, tr))) return rc;
-					HIPCHK(hipStreamWaitEvent(so, S.evRight, 0));
-					right_running = true;
-				} else {
-					if ((rc = enqueue_outer_apply(S, so, p0, p1, t1, t_out))) return rc;
-					right_running = false;
-				}
+				if ((rc = enqueue_outer_apply(S, so, p0, p1, t1, t_out))) return rc;
 			}
-			// (whatever path this panel took: a side launch of the NEXT panel waits for all of it -- e.g. the first two-level panel
-			// behind a super-panel's product)
+			// (round 6, VERDICT item 2a: P = T x S of the NEXT panel started behind the first chunk of this pass, beside its rest -- built,
+			// bit-exact, no gain: the launch is LDS table work like the pass itself, not idle chip time.  profiles/r06_outer_early.txt)
 			HIPCHK(hipEventRecord(S.evBig, so));
 			big_recorded = true;
 		}
@@ -1837,7 +1730,7 @@ int finish_end(Solver &S, gf2bv_result **out)
 				const i64 out_w = S.wt;
 				st.outer_blocks++;
 				if (pend_w > wlo) { st.hbm_words += rows_swept * (double)(std::min<i64>(pend_w, S.wt) - wlo); st.bulk_launches++; }
-				if ((b + 1) % S.tl_K == 0 && out_w > pend_w) { st.hbm_words += rows_swept * (double)(out_w - pend_w); st.bulk_launches += (S.sD || (S.outer_early && S.outer_side && S.outer_order == 2 && S.sC)) ? 3 : 2; }      // (the next panel's tiles, then the rest -- in two halves on two streams since late round 5)
+				if ((b + 1) % S.tl_K == 0 && out_w > pend_w) { st.hbm_words += rows_swept * (double)(out_w - pend_w); st.bulk_launches += 2; }      // (the next panel's tiles, then the rest -- in two halves on two streams since late round 5)
 			} else { st.hbm_words += rows_swept * (double)(S.wt - wlo); st.bulk_launches++; }
 		}
 	}

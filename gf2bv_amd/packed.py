@@ -12,7 +12,7 @@ row i = symbolic bit i in the SAME bit order as the reference's ints.  XOR / shi
 numpy operations; ``PackedLinearSystem`` stacks the rows of the ``zeros`` and gives the buffer straight to
 ``_internal.m4ri_solve_packed`` -- the device pack kernel reads it as 32-bit digits -- so no PyLong list exists at any
 point.  Same surface and semantics as ``BitVec`` / ``LinearSystem`` (it IS a BitVec: the PRNG models in
-gf2bv_amd.crypto run on it unchanged); ``get_eqs`` still returns the reference's list of ints for callers that want it.
+tests.harness_models run on it unchanged); ``get_eqs`` still returns the reference's list of ints for callers that want it.
 """
 from __future__ import annotations
 

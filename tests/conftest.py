@@ -32,6 +32,7 @@ def _order_key(item):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    config.addinivalue_line("markers", "default_only: (test_gpu_parity.py) not repeated under GF2BV_PLAIN=1 -- asserts on a heuristic that mode turns off")
     config.addinivalue_line("markers", "external: talks to RCCL / launches torch.distributed.run or bench.py in a child process; "
                                        "ordered behind every in-process test")
     print(f"[gf2bv tests] libgf2bv_hip.so {_BUILD['hip'][0]} {_BUILD['hip'][1]}; _internal {_BUILD['shim'][0]} {_BUILD['shim'][1]}",

@@ -8,7 +8,7 @@ import os
 import random
 
 from gf2bv_amd import LinearSystem, QuadraticSystem
-from gf2bv_amd.crypto import MT19937, FibonacciLFSR, GaloisLFSR, Xoshiro256starstar
+from tests.harness_models import MT19937, FibonacciLFSR, GaloisLFSR, Xoshiro256starstar
 
 GOLDEN = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden.json")))
 MT_VARIANTS = ((32, None), (17, None), (9, None), (1, None), (1337, 19968 // 1337 + 10), (137, 19968 // 137 + 60))

@@ -13,7 +13,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 knobs = [{}, {}, {}, {"GF2BV_XCD_PIN": "0"}, {"GF2BV_GANG_NT": "0"}, {"GF2BV_XCD_WGS": "5"}, {"GF2BV_XCD_WGS": "64"}, {"GF2BV_GANG_BS": "0"},
          {"GF2BV_FLAG_SYNC": "0"},
-         {"GF2BV_BATCH_THREADS": "3"}, {"GF2BV_STAGGER": "1"}]
+         {"GF2BV_BATCH_THREADS": "3"}, {"GF2BV_PLAIN": "1"}]
 ALL = sorted({k for d in knobs for k in d} | {"GF2BV_GANG", "GF2BV_BATCH_CHUNK_MB"})
 t0, n, nsys_total = time.time(), 0, 0
 while time.time() - t0 < budget:

@@ -14,15 +14,11 @@ knobs = [{}, {}, {"GF2BV_FAST": "0"}, {"GF2BV_OPTIMISTIC": "0"}, {"GF2BV_SELF_WA
          {"GF2BV_TWO_LEVEL": "2"}, {"GF2BV_TWO_LEVEL": "3"}, {"GF2BV_TWO_LEVEL": "4"}, {"GF2BV_TWO_LEVEL": "8"}, {"GF2BV_TWO_LEVEL": "2", "GF2BV_FLAG_SYNC": "0"},
          # round 4: systems that fit the LDS take the one-launch kernel unless GF2BV_SMALL=0; its input by copy or straight from pinned memory
          {"GF2BV_SMALL": "0"}, {"GF2BV_SMALL": "0"}, {"GF2BV_SMALL_ZC": "0"}, {"GF2BV_SMALL_ZC": "1"},
-         # round 5: the sparse block search off; super-panels (three-level elimination) of 2 / 3 outer panels with 0-2 Strassen-Winograd levels
-         {"GF2BV_SPARSE_FAST": "0"}, {"GF2BV_TWO_LEVEL": "2", "GF2BV_THREE_LEVEL": "2"}, {"GF2BV_TWO_LEVEL": "2", "GF2BV_THREE_LEVEL": "2", "GF2BV_STRASSEN": "1"},
-         {"GF2BV_TWO_LEVEL": "2", "GF2BV_THREE_LEVEL": "3", "GF2BV_STRASSEN": "0"}, {"GF2BV_TWO_LEVEL": "3", "GF2BV_THREE_LEVEL": "2", "GF2BV_STRASSEN": "2"},
-         {"GF2BV_TWO_LEVEL": "2", "GF2BV_THREE_LEVEL": "2", "GF2BV_FLAG_SYNC": "0"},
-         # late round 5: the outer pass's workgroup shapes, item orders, the pass over two streams, the next panel's tiles beside / before the pass
-         {"GF2BV_TWO_LEVEL": "2", "GF2BV_OUTER_SHAPE": "1"}, {"GF2BV_TWO_LEVEL": "3", "GF2BV_OUTER_SHAPE": "2", "GF2BV_OUTER_ORDER": "0"},
-         {"GF2BV_TWO_LEVEL": "2", "GF2BV_OUTER_SHAPE": "3", "GF2BV_OUTER_SPLIT": "50"}, {"GF2BV_TWO_LEVEL": "4", "GF2BV_OUTER_SPLIT": "33", "GF2BV_OUTER_ORDER": "0"},
-         {"GF2BV_TWO_LEVEL": "2", "GF2BV_OUTER_SIDE": "0"}, {"GF2BV_TWO_LEVEL": "3", "GF2BV_OUTER_SIDE": "0", "GF2BV_FLAG_SYNC": "0"},
-         {"GF2BV_TWO_LEVEL": "2", "GF2BV_THREE_LEVEL": "2", "GF2BV_OUTER_SHAPE": "1", "GF2BV_OUTER_SIDE": "0"}, {"GF2BV_TWO_LEVEL": "2"}, {"GF2BV_TWO_LEVEL": "3"}]
+         # round 5: the sparse block search off; the next panel's tiles beside / before the outer pass
+         {"GF2BV_SPARSE_FAST": "0"}, {"GF2BV_TWO_LEVEL": "2", "GF2BV_OUTER_SIDE": "0"}, {"GF2BV_TWO_LEVEL": "3", "GF2BV_OUTER_SIDE": "0", "GF2BV_FLAG_SYNC": "0"},
+         # round 6: the floor without heuristics (no stream-pair probes, no XCD pinning, events instead of memory gates, no optimistic enqueue)
+         {"GF2BV_PLAIN": "1"}, {"GF2BV_PLAIN": "1", "GF2BV_TWO_LEVEL": "2"}, {"GF2BV_PLAIN": "1", "GF2BV_TWO_LEVEL": "4"},
+         {"GF2BV_TWO_LEVEL": "2"}, {"GF2BV_TWO_LEVEL": "3"}]
 t0, n, worst = time.time(), 0, 0
 while time.time() - t0 < budget:
     cols = rng.choice([rng.randint(1, 130), rng.randint(131, 700), rng.randint(700, 2600), 64 * rng.randint(1, 40), 256 * rng.randint(1, 10) + rng.choice([-1, 0, 1]),
@@ -36,7 +32,7 @@ while time.time() - t0 < budget:
     mode = rng.randint(0, 1)
     os.environ["GF2BV_UPDATE"] = rng.choice(configs)
     for k in ("GF2BV_FAST", "GF2BV_OPTIMISTIC", "GF2BV_SELF_WAIT_US", "GF2BV_FLAG_SYNC", "GF2BV_TWO_LEVEL", "GF2BV_SMALL", "GF2BV_SMALL_ZC",
-              "GF2BV_SPARSE_FAST", "GF2BV_THREE_LEVEL", "GF2BV_STRASSEN", "GF2BV_OUTER_SHAPE", "GF2BV_OUTER_ORDER", "GF2BV_OUTER_SPLIT", "GF2BV_OUTER_SIDE"):
+              "GF2BV_SPARSE_FAST", "GF2BV_OUTER_SIDE", "GF2BV_PLAIN"):
         os.environ.pop(k, None)
     os.environ.update(rng.choice(knobs))
     eqs = random_system(rng, rows, cols, density, cap, consistent, min(zero_rows, rows - 1))

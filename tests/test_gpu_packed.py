@@ -6,7 +6,7 @@ import random
 import pytest
 
 from gf2bv_amd import LinearSystem, PackedLinearSystem, hip
-from gf2bv_amd.crypto import MT19937, Xoshiro256starstar
+from tests.harness_models import MT19937, Xoshiro256starstar
 from tests.systems import random_system
 
 pytestmark = pytest.mark.gpu

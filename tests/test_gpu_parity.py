@@ -19,6 +19,18 @@ def _need_gpu():
     assert hip.device_count() >= 1, "gpu tests need an MI355X; the product path has no CPU fallback"
 
 
+@pytest.fixture(autouse=True, params=["default", "plain"])
+def _heuristics(request, monkeypatch):
+    """The whole file runs twice (round 6): as shipped, and with GF2BV_PLAIN=1 -- no stream-pair probes, no XCD pinning of gangs, the
+    streams hand over through events instead of counters in memory, every block enqueued with both panel paths (no optimistic
+    enqueue).  A box where one of those heuristics mis-fires may cost speed (bench.py: plain_ms_per_step), never an answer."""
+    if request.param == "plain":
+        if request.node.get_closest_marker("default_only"):
+            pytest.skip("exercises a heuristic GF2BV_PLAIN=1 turns off")
+        monkeypatch.setenv("GF2BV_PLAIN", "1")
+    return request.param
+
+
 def assert_same(got: hip.Solution, want: dict, mode: int):
     assert got.status == want["status"]
     assert got.rank == want["rank"]

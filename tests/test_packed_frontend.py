@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from gf2bv_amd import BitVec, LinearSystem, PackedBitVec, PackedLinearSystem
-from gf2bv_amd.crypto import MT19937, GaloisLFSR, Xoshiro256starstar
+from tests.harness_models import MT19937, GaloisLFSR, Xoshiro256starstar
 from tests import harness as H
 
 

@@ -57,11 +57,11 @@ int main(int argc, char **argv)
 	// default: one workgroup per item (as the solver launches it); MB_WGS=256: persistent workgroups
 	const i64 nitems = (R64 + (i64)MB_SEG * MB_NT - 1) / ((i64)MB_SEG * MB_NT) * ntiles;
 	const int wgs = getenv("MB_WGS") ? atoi(getenv("MB_WGS")) : (int)nitems;
-	const int order = getenv("MB_ORDER") ? atoi(getenv("MB_ORDER")) : 0;      // 2: chunk-major items (the solver's default since late round 5)
+	const int order = getenv("MB_ORDER") ? atoi(getenv("MB_ORDER")) : 0;      // != 0: chunk-major items (the solver's order)
 #ifdef MB_WIDE        /* the shipped default: k_update16k_wide (GF2_WSEG x 1024 rows per item, budget of 120 registers) */
-	auto launch = [&] { k_update16k_wide<<<dim3(wgs), dim3(1024)>>>(M, rows, srows, K, gprow, mult, set_words, 0, K, blkf, died, npan, 0, ntiles, SysStride{0, 0}, order, 0x7fffffff); };
+	auto launch = [&] { k_update16k_wide<<<dim3(wgs), dim3(1024)>>>(M, rows, srows, K, gprow, mult, set_words, 0, K, blkf, died, npan, 0, ntiles, SysStride{0, 0}, order != 0); };
 #else
-	auto launch = [&] { k_update16k<MB_SEG, MB_NT, MB_RB, MB_NB><<<dim3(wgs), dim3(MB_NT)>>>(M, rows, srows, K, gprow, mult, set_words, 0, K, blkf, died, npan, 0, ntiles, SysStride{0, 0}, order, 0x7fffffff); };
+	auto launch = [&] { k_update16k<MB_SEG, MB_NT, MB_RB, MB_NB><<<dim3(wgs), dim3(MB_NT)>>>(M, rows, srows, K, gprow, mult, set_words, 0, K, blkf, died, npan, 0, ntiles, SysStride{0, 0}, order != 0); };
 #endif
 	launch(); launch(); CK(hipDeviceSynchronize());
 	const int reps = 6;

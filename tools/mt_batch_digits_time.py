@@ -5,7 +5,7 @@ import os, random, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gf2bv_amd import LinearSystem, _internal, hip
-from gf2bv_amd.crypto import MT19937
+from tests.harness_models import MT19937
 nsys = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 bs = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 eff = ((bs - 1) & bs) or bs

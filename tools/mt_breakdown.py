@@ -3,7 +3,7 @@ import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gf2bv_amd import PackedLinearSystem, hip
-from gf2bv_amd.crypto import MT19937
+from tests.harness_models import MT19937
 rand = random.Random(3142)
 out = [rand.getrandbits(32) for _ in range(624)]
 pk = PackedLinearSystem([32] * 624)

@@ -3,7 +3,7 @@
 import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gf2bv_amd import LinearSystem, PackedLinearSystem
-from gf2bv_amd.crypto import MT19937
+from tests.harness_models import MT19937
 bs = 32
 rand = random.Random(3142)
 state = tuple(rand.getstate()[1][:-1])

@@ -4,7 +4,7 @@ import os, random, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from gf2bv_amd import LinearSystem, hip
-from gf2bv_amd.crypto import MT19937
+from tests.harness_models import MT19937
 VAR = {32: None, 17: None, 9: None, 1: None, 1337: 19968 // 1337 + 10, 137: 19968 // 137 + 60}
 for bs in [int(a) for a in sys.argv[1:]] or [32, 1, 1337]:
     rand = random.Random(3142)
