@@ -3064,7 +3064,8 @@ update16k_body(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__
 				tb[(lo | hi) * 16] = xor4(tb[lo * 16], tb[hi * 16]);
 			}
 			{
-				const int kn = k + 1;                       // (a block without pivots stages zeros and is skipped)
+				int kn = k + 1;                             // the next block that HAS pivots (one without is skipped by the loop above)
+				while (kn <= last_blk && !anyb[kn]) kn++;   // (uniform)
 				if (kn <= last_blk && threadIdx.x < GF2_GMAX * 64) {
 					const int pr = gprow[kn * 256 + threadIdx.x];
 					staged = pr >= 0 ? Mw[pr] : make_uint4(0, 0, 0, 0);
