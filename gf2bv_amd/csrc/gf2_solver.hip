@@ -436,7 +436,7 @@ void forget_concurrency(int device);
 struct UpdateImpl {
 	int G, T, lds_bytes, threads;
 	hipError_t (*update)(dim3, hipStream_t, u64 *, i64, i64, int, int, int, const PanelRec *, const PanelAux *,
-	                     const u64 *, const int *, int, int, int, int, int, int, const uint4 *, SysStride, hipEvent_t, hipEvent_t, int);
+	                     const u64 *, const int *, int, int, int, int, int, bool, const uint4 *, SysStride, hipEvent_t, hipEvent_t, int);
 };
 
 // 16-byte tiles: G = 4 panels, T = 8 byte fields per panel.  nw_lo < 0 selects the HALF instance (only the tile's second
@@ -444,16 +444,14 @@ struct UpdateImpl {
 template <int NT, int DEPTH, bool PIPE, int LB>
 hipError_t launch_update16(dim3 grid, hipStream_t s, u64 *M, i64 rows, i64 srows, int j0, int gb, int wlo,
                            const PanelRec *panels, const PanelAux *aux, const u64 *multset, const int *blk_first,
-                           int tile_begin, int ntiles, int world, int wrank, int nw_lo, int nw_hi, const uint4 *Pc, SysStride ss,
+                           int tile_begin, int ntiles, int world, int wrank, int nw_lo, bool stream_rows, const uint4 *Pc, SysStride ss,
                            hipEvent_t begun, hipEvent_t done, int xcd_nsys)
 {
 	if (xcd_nsys > 0) grid = dim3(grid.x * grid.y);          // one line of workgroups, decoded in the kernel (a system per XCD)
 	{
-		// streaming row accesses (Solver::nt_rows, read from the environment once per solve): pinned gangs (GF2BV_GANG_NT=0: plain);
-		// single systems only as an experiment (GF2BV_SINGLE_NT=1).  The streaming form exists for the default instance only: with
-		// GF2BV_UPDATE != 0 the selected instance runs with plain accesses.
-		const bool stream = nw_hi != 0;
-		if (stream && NT == 512 && DEPTH == 3 && PIPE && LB == 512) {
+		// stream_rows: streaming (non-temporal) row accesses -- pinned gangs (GF2BV_GANG_NT=0: plain).  The streaming form exists for the
+		// default instance only: with GF2BV_UPDATE != 0 the selected instance runs with plain accesses.
+		if (stream_rows && NT == 512 && DEPTH == 3 && PIPE && LB == 512) {
 			if (nw_lo < 0)
 				hipExtLaunchKernelGGL((k_update16<512, true, 3, true, 512, true>), grid, dim3(512), 0, s, begun, done, 0, M, rows, srows, j0, gb, wlo,
 				                      panels, aux, multset, blk_first, tile_begin, ntiles, world, wrank, Pc, ss, xcd_nsys);
@@ -595,7 +593,7 @@ struct Solver {
 	bool xcd_pin = true;          // gangs of a multiple of 8 systems: every system's bulk-update workgroups on ONE XCD, one system after the
 	                              // other there, xcd_wgs workgroups each (GF2BV_XCD_WGS); GF2BV_XCD_PIN=0: the plain (spans, systems) grid
 	int xcd_wgs = 32;
-	bool nt_gang = true, nt_single = false;     // streaming (non-temporal) row accesses of the bulk update: pinned gangs (GF2BV_GANG_NT=0: plain) /
+	bool nt_gang = true;     // streaming (non-temporal) row accesses of the bulk update: pinned gangs (GF2BV_GANG_NT=0: plain) /
 	                                            // single systems (GF2BV_SINGLE_NT=1, an experiment: <= 1 %)
 	bool gang_bs = true;          // GF2BV_GANG_BS=0: one back-substitution chain per system of a gang, as rounds 1-3
 	// sparse systems (round 5): blocks the dense one-launch search cannot take go through k_block_sparse -- candidates = the alive rows
@@ -992,7 +990,7 @@ int launch_trsm(Solver &S, hipStream_t st, int j0, int gb, int wlo, int nw_lo, i
 // One bulk-update launch of block b on the `ntiles` owned tiles from tile_begin on; `last`: it carries the hand-off
 // ("bulk of block b complete") and *handoff receives that event.
 int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wlo, u64 *mset, int tile_begin, int ntiles,
-                        int nw_lo, int nw_hi, bool last, hipEvent_t *handoff)
+                        int nw_lo, bool last, hipEvent_t *handoff)
 {
 	hipEvent_t ka = nullptr, kb = nullptr;
 	if (S.time_kernels) {
@@ -1005,9 +1003,8 @@ int launch_update_timed(Solver &S, hipStream_t st, int b, int j0, int gb, int wl
 	const int wgs = pick_update_wgs(est_rows, ntiles, S.nsys, pin ? S.xcd_wgs : 0);
 	hipEvent_t begun = nullptr, done = nullptr;
 	if (S.ext_events) { begun = ka; done = S.time_kernels ? kb : (last && !S.flag_sync ? S.evPrio[b] : nullptr); }
-	(void)nw_hi;                     // (the launcher's slot of that name carries the streaming-access flag since round 5)
 	HIPCHK(S.impl->update(dim3((unsigned)wgs, S.nsys), st, S.M, S.rows, S.srows, j0, gb, wlo, S.panels, S.aux, mset,
-	                      S.blk_first + b, tile_begin, ntiles, S.world, S.wrank, nw_lo, (pin ? S.nt_gang : S.nt_single) ? 1 : 0,
+	                      S.blk_first + b, tile_begin, ntiles, S.world, S.wrank, nw_lo, pin && S.nt_gang,
 	                      (const uint4 *)S.Pc, S.ss(), begun, done, pin ? S.nsys : 0));
 	if (S.time_kernels && !S.ext_events) HIPCHK(hipEventRecord(kb, st));
 	if (!last || S.flag_sync) return GF2BV_OK;
@@ -1168,12 +1165,12 @@ int enqueue_block_bulk(Solver &S, int b)
 		const int tfull = g.gnext > 0 ? (wend + 1) / 2 : g.wlo / 2;      // first tile with no window word
 		const i64 nfull = owned_count(tfull, S.tile_hi, GF2_OWN_LOG - 1, S.world, S.wrank);
 		if ((wend & 1) && g.gnext > 0 && owned_count(wend / 2, wend / 2 + 1, GF2_OWN_LOG - 1, S.world, S.wrank) > 0) {
-			rc = launch_update_timed(S, S.sB, b, g.j0, g.gb, g.wlo, g.mset, wend / 2, 1, -1, 0, nfull <= 0, &S.waitPrio[b]);
+			rc = launch_update_timed(S, S.sB, b, g.j0, g.gb, g.wlo, g.mset, wend / 2, 1, -1, nfull <= 0, &S.waitPrio[b]);
 			if (rc) return rc;
 			launched = nfull <= 0;
 		}
 		if (nfull > 0) {
-			rc = launch_update_timed(S, S.sB, b, g.j0, g.gb, g.wlo, g.mset, tfull, (int)nfull, 0, 0, true, &S.waitPrio[b]);
+			rc = launch_update_timed(S, S.sB, b, g.j0, g.gb, g.wlo, g.mset, tfull, (int)nfull, 0, true, &S.waitPrio[b]);
 			if (rc) return rc;
 			launched = true;
 		}
