@@ -3137,7 +3137,7 @@ update16k_body(u64 *__restrict__ M, i64 rows, i64 srows, int nblk, const int *__
 	int set0, int nsets, const int *__restrict__ blk_first, const int *__restrict__ died, int j_end, int tile_begin, int ntiles, SysStride ss, int chunk_major
 #define GF2_U16K_ARGS M, rows, srows, nblk, gprow, mult, set_words, set0, nsets, blk_first, died, j_end, tile_begin, ntiles, ss, chunk_major
 // Rounds 3-5: 8 wavefronts x GF2_KSEG segments, read batches of 8 (two in flight), ~200 registers -- two wavefronts per SIMD.  Kept as
-// GF2BV_OUTER_SHAPE=1 (and as the base case the three-level experiments were costed with).
+// the template the microbenchmarks instantiate (tools/microbench_update16k.hip, tools/three_level/): the solver launches k_update16k_wide.
 template <int SEG, int NT_ = 512, int RB = 8, int NB = 2>
 __global__ void __launch_bounds__(NT_)
 k_update16k(GF2_U16K_PARAMS)

@@ -588,13 +588,13 @@ struct Solver {
 	bool ext_events = true;       // hand-off and timing events ride on kernel start / completion signals (hipExtLaunchKernel)
 	                              // instead of marker packets: ~1 % at every size; GF2BV_EXT_EVENTS=0 restores hipEventRecord
 	int sparse_mode = 2;          // search skips absent columns: 0 never, 1 always, 2 per chunk by density (GF2BV_SPARSE)
-	int fused_rpt = 0;            // GF2BV_FUSED_RPT: row blocks of 256 per narrowing workgroup of k_block_fast_narrow (0 = by size)
+	int fused_rpt = 0;            // row blocks of 256 per narrowing workgroup of k_block_fast_narrow (0 = by size)
 	bool use_pc = true;           // GF2BV_PC=0: the bulk update fetches the pivot rows through the panel records, as before round 3
 	bool xcd_pin = true;          // gangs of a multiple of 8 systems: every system's bulk-update workgroups on ONE XCD, one system after the
 	                              // other there, xcd_wgs workgroups each (GF2BV_XCD_WGS); GF2BV_XCD_PIN=0: the plain (spans, systems) grid
 	int xcd_wgs = 32;
-	bool nt_gang = true;     // streaming (non-temporal) row accesses of the bulk update: pinned gangs (GF2BV_GANG_NT=0: plain) /
-	                                            // single systems (GF2BV_SINGLE_NT=1, an experiment: <= 1 %)
+	bool nt_gang = true;          // streaming (non-temporal) row accesses of the bulk update of pinned gangs (GF2BV_GANG_NT=0: plain); single systems
+	                              // keep plain accesses (measured <= 1 % either way in round 4)
 	bool gang_bs = true;          // GF2BV_GANG_BS=0: one back-substitution chain per system of a gang, as rounds 1-3
 	// sparse systems (round 5): blocks the dense one-launch search cannot take go through k_block_sparse -- candidates = the alive rows
 	// with a non-zero window, from the bit masks the look-ahead leaves in wmask (GF2BV_SPARSE_FAST=0: the general panel steps)
@@ -1422,7 +1422,7 @@ int enqueue_forward(Solver &S)
 			// (late round 5) the outer step on the NEXT panel's tiles -- a short launch on an underused chip, ~0.3 ms -- goes to the
 			// inner elimination's bulk stream, idle at this point, and runs BESIDE the start of the pass proper instead of before it:
 			// it needs the previous pass complete (evBig; it used to follow it in stream order) and this panel's T; the pass proper
-			// needs T alone (disjoint tiles).  No new stream (cf. GF2BV_OUTER_SPLIT).
+			// needs T alone (disjoint tiles).  No new stream.
 			const bool side = S.outer_side && S.sB != so && S.sB != S.sA;
 			if (side) {
 				HIPCHK(hipStreamWaitEvent(S.sB, S.evPanelDone, 0));
