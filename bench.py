@@ -65,6 +65,7 @@ def parse():
                     help="single: system size N (rows = cols); spell it --size under torch.distributed.run, whose own parser "
                          "takes a bare --n for an abbreviation of its options")
     ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--no-plain-leg", action="store_true", help="skip the repeat of the timed steps under GF2BV_PLAIN=1 (profiling runs: keeps the kernel statistics to the default path)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-n", type=int, default=None, help="size of the bounded CPU-baseline sample (default: 65536 single / 32768 batch)")
     ap.add_argument("--batch-total", type=int, default=512, help="batch: systems in the whole job (sharded over the ranks)")
@@ -306,7 +307,7 @@ def run_single(args, world, rank, local_rank, dev):
     # (round 6) the same steps with GF2BV_PLAIN=1 -- no stream-pair probes, no XCD pinning, events instead of memory gates, no
     # optimistic enqueue -- on rank 0 at N = 1: what a box costs where those heuristics are off; never part of `value`
     plain = None
-    if world == 1 and os.environ.get("GF2BV_PLAIN") is None:
+    if world == 1 and os.environ.get("GF2BV_PLAIN") is None and not args.no_plain_leg:
         os.environ["GF2BV_PLAIN"] = "1"
         try:
             p_elapsed, p_stats, _ = timed_single(mat, n, stride, args.steps, 1, local_rank, dev, world, False)

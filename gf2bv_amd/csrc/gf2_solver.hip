@@ -316,7 +316,7 @@ struct Pool {
 	// does: on a good pair it ends after NB x ~24 us (measured 187-192 us for 8 blocks), on a bad one after NB x ~55 us (439-446): each
 	// block's panel kernels wait for the hold before them.  (A first probe -- when does the last of 80 panel-shaped workgroups begin
 	// beside two holds: 3 us or 36 -- saw only some of the bad pairs; this one agreed with the solve on 38 of 38 pairs.)
-	hipError_t probe_pair(hipStream_t a, hipStream_t b, int device, int *ok)
+	hipError_t probe_pair(hipStream_t a, hipStream_t b, int device, int *ok, int depth = 0)
 	{
 		*ok = 1;
 		constexpr int NB = 6;
@@ -347,6 +347,13 @@ struct Pool {
 		if ((e = hipMemcpy(hq, q, sizeof hq, hipMemcpyDeviceToHost)) != hipSuccess) return e;
 		const double chain_us = ((double)hq[2 * NB - 1] - (double)hq[2 * NB]) / 100.0;
 		*ok = chain_us < 37.0 * NB;
+		// a verdict near the threshold (good pairs measure ~24 us per probe block, bad ones ~55: other work on the device can push a
+		// probe either way) is not kept on one sample: the pair is measured again, twice at most, and the FASTER run decides -- a
+		// neighbour can only slow a probe down
+		if (depth < 2 && chain_us > 0.75 * 37.0 * NB && chain_us < 1.5 * 37.0 * NB) {
+			int again = 1;
+			if (probe_pair(a, b, device, &again, depth + 1) == hipSuccess) *ok = *ok || again;
+		}
 		if (getenv("GF2BV_TRACE"))
 			fprintf(stderr, "[gf2bv trace] stream pair %p / %p: the panel chain of %d probe blocks took %.1f us (%s)\n", (void *)a, (void *)b, NB, chain_us,
 			        *ok ? "good" : "waits for the bulk stream");

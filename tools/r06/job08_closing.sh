@@ -6,7 +6,7 @@ python tools/r06/rccl_init_ab.py "lease $(date +%H%M)" >> $O/r06_rccl_init.txt 2
 ( time timeout 1500 python -m pytest tests/ -x -q -m gpu --durations=8 ) > $O/r06z_pytest.log 2>&1; echo "full suite rc=$?" > $O/r06z.summary
 python -c "import __graft_entry__ as g; g.build(); g.smoke(); print('smoke ok')" > $O/r06z_smoke.log 2>&1; echo "smoke rc=$?" >> $O/r06z.summary
 python bench.py > $O/r06z_bench_default.json 2> $O/r06z_bench_default.err; echo "bench rc=$?" >> $O/r06z.summary
-bash tools/jobs/kernel_stats.sh r06z_bench python bench.py --no-cpu-baseline --no-batch-c4 --no-extra-legs --target-n 0
+bash tools/jobs/kernel_stats.sh r06z_bench python bench.py --no-cpu-baseline --no-batch-c4 --no-extra-legs --no-plain-leg --target-n 0
 SEED=1242 bash tools/jobs/kernel_stats.sh r06z_262144 python tools/profile_one.py 262144 1
 bash tools/jobs/kernel_stats.sh r06z_batch python tools/profile_batch.py 32768 64 1
 bash tools/jobs/pmc_traffic.sh r06z_65536 "k_update16<" -- python tools/profile_one.py 65536 1
