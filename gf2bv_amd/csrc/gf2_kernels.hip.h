@@ -1448,6 +1448,7 @@ struct SparseLds {
 	int srow_all[GF2_GMAX][64];              // [panel][index into srcw] -> row
 	u64 have;
 	int wsum[16], min_free, min_zero, ok, chunk_ok;
+	int cnts[129];                           // compaction of a panel's entries: [slot][wavefront] counts -> offsets, [128] = their sum
 	unsigned char colof[GF2_SP_NE];           // compacted entry -> basis column + 1 it supplies (selection on wavefront 0)
 };
 #ifdef GF2_SPARSE_DEBUG
@@ -1553,29 +1554,60 @@ k_block_sparse(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fas
 		// the panel before (st->sp_chunk: 0 = try)
 		bool done = false;
 		// compaction of the candidates that have a bit in the panel, in pool order: pos[k] of this thread's candidates, basec of them in
-		// all; the words of the first GF2_SP_NE go to LDS for the selection on wavefront 0
+		// all; the words of the first GF2_SP_NE go to LDS for the selection on wavefront 0.  Only (A) reads it: while the first-64
+		// attempt is switched off (seven of eight blocks after a miss) the 2 x CPT barriers per panel are not paid -- MT19937 with one
+		// bit per output: ~25 us per block (round 6; a panel with fewer than 64 rows that have a bit ends in the rounds' own give-up)
 		int pos[CPT];
 		int basec = 0;
 		u64 *const selw = L.Tn;                               // (the nibble tables' space is free until the pivot rows are formed)
-		if (t < GF2_SP_NE / 4) reinterpret_cast<unsigned *>(F.colof)[t] = 0;
+		if (try_chunk) {
+			// (round 6) the ballots of all CPT candidate slots first (wave-local, no barrier), the CPT x NWV counts to LDS, ONE wavefront
+			// scans them in pool order (slot-major: candidate c = t + NT k), everybody reads its offsets back: 3 barriers per panel
+			// instead of 2 x CPT.  (Entries in THREAD-major order -- a sample across the pool's depth in front -- were measured too: one bit
+			// per output 12.5 -> 12.0 ms, every run-structured variant 10-30 % slower.  Pool order stays.)
+			if (t < GF2_SP_NE / 4) reinterpret_cast<unsigned *>(F.colof)[t] = 0;
+			u64 bal[CPT];
 #pragma unroll
-		for (int k = 0; k < CPT; k++) {
-			u64 w = 0;
+			for (int k = 0; k < CPT; k++) {
+				u64 w = 0;
 #pragma unroll
-			for (int e = 0; e < GF2_GMAX; e++) if (e == g) w = cw[k][e];
-			const bool nzc = (((validk & ~usedk) >> k) & 1) && w != 0;
-			const u64 bal = __ballot(nzc);
+				for (int e = 0; e < GF2_GMAX; e++) if (e == g) w = cw[k][e];
+				bal[k] = __ballot((((validk & ~usedk) >> k) & 1) && w != 0);
+			}
+			__syncthreads();                                  // (earlier readers of cnts are through)
+			if (lane < CPT) {
+				u64 b = 0;
+#pragma unroll
+				for (int k = 0; k < CPT; k++) if (k == lane) b = bal[k];
+				F.cnts[lane * NWV + wv] = __popcll(b);
+			}
 			__syncthreads();
-			if (lane == 0) F.wsum[wv] = __popcll(bal);
-			__syncthreads();
-			int c = basec, tot = 0;
+			if (wv == 0) {                                    // exclusive scan of the CPT x NWV <= 128 counts, two per lane
+				constexpr int NCNT = CPT * NWV;
+				const int i0 = 2 * lane, i1 = 2 * lane + 1;
+				const int a0 = i0 < NCNT ? F.cnts[i0] : 0, a1 = i1 < NCNT ? F.cnts[i1] : 0;
+				int inc = a0 + a1;
 #pragma unroll
-			for (int v = 0; v < NWV; v++) { if (v < wv) c += F.wsum[v]; tot += F.wsum[v]; }
-			pos[k] = nzc ? c + __popcll(bal & lanemask_lt(lane)) : 0x7fffffff;
-			if (pos[k] < GF2_SP_NE) selw[pos[k]] = w;
-			basec += tot;
-		}
+				for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(inc, d); if (lane >= d) inc += o; }
+				if (i0 < NCNT) F.cnts[i0] = inc - a0 - a1;
+				if (i1 < NCNT) F.cnts[i1] = inc - a1;
+				if (lane == 63) F.cnts[128] = inc;
+			}
+			__syncthreads();
+			basec = F.cnts[128];
+#pragma unroll
+			for (int k = 0; k < CPT; k++) {
+				const bool nzc = (bal[k] >> lane) & 1;
+				pos[k] = nzc ? F.cnts[k * NWV + wv] + __popcll(bal[k] & lanemask_lt(lane)) : 0x7fffffff;
+				if (pos[k] < GF2_SP_NE) {
+					u64 w = 0;
+#pragma unroll
+					for (int e = 0; e < GF2_GMAX; e++) if (e == g) w = cw[k][e];
+					selw[pos[k]] = w;
+				}
+			}
 		if (basec < 64) { give_up(5, basec); return; }       // (uniform) fewer rows with a bit in the panel than it has columns
+		}
 		// (A) wavefront 0: the first 64 entries through gj_columns (column-wise, ~3.7 us: complete for systems whose rows come in runs
 		// that determine a panel and for anything dense), then the following chunks of 64 entries through the TARGETED completion of
 		// find_absorb (only the missing columns are looked at: a candidate's reduced bit at a missing column is w[c] ^ parity(w & z_c)
