@@ -11,6 +11,6 @@ SEED=1242 bash tools/jobs/kernel_stats.sh r06z_262144 python tools/profile_one.p
 bash tools/jobs/kernel_stats.sh r06z_batch python tools/profile_batch.py 32768 64 1
 bash tools/jobs/pmc_traffic.sh r06z_65536 "k_update16<" -- python tools/profile_one.py 65536 1
 SEED=1242 bash tools/jobs/pmc_traffic.sh r06z_262144_k16k "k_update16k" --range "[1-6]" -- python tools/profile_one.py 262144 1
-timeout 700 python tests/manual/stress_parity.py 600 6006 > $O/r06z_stress_parity.log 2>&1; echo "stress_parity rc=$?" >> $O/r06z.summary
-timeout 300 python tests/manual/stress_gangs.py 200 606 > $O/r06z_stress_gangs.log 2>&1; echo "stress_gangs rc=$?" >> $O/r06z.summary
+timeout 1000 python tests/manual/stress_parity.py 900 7007 > $O/r06z_stress_parity.log 2>&1; echo "stress_parity rc=$?" >> $O/r06z.summary
+timeout 420 python tests/manual/stress_gangs.py 300 707 > $O/r06z_stress_gangs.log 2>&1; echo "stress_gangs rc=$?" >> $O/r06z.summary
 cat $O/r06z.summary; tail -3 $O/r06z_pytest.log; tail -2 $O/r06z_stress_parity.log; tail -2 $O/r06z_stress_gangs.log; tail -9 $O/r06_rccl_init.txt
