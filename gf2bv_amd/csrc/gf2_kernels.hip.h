@@ -1691,19 +1691,6 @@ k_block_sparse(u64 *__restrict__ M, i64 rows, i64 srows, int j0, int gb, int fas
 #ifdef GF2_SPARSE_DEBUG
 			if (t == 0) st->self_giveups++;
 #endif
-#ifdef GF2_SPARSE_ROUNDS
-			{       // (diagnostic build, tools/r06/job11_rounds.sh) candidates still non-zero after this round, columns covered
-				if (t == 0) F.wsum[0] = 0;
-				__syncthreads();
-				int nzc = 0;
-#pragma unroll
-				for (int k = 0; k < CPT; k++) nzc += xr[k] != 0;
-				if (nzc) atomicAdd(&F.wsum[0], nzc);
-				__syncthreads();
-				if (t == 0 && (blk == 5 || blk == 40 || blk == 70)) printf("ROUNDS blk %d panel %d round %d: survivors %d covered %d\n", blk, g, round, F.wsum[0], (int)__popcll(nh));
-				__syncthreads();
-			}
-#endif
 			if (nh == hv || nh == ~0ull) { hv = nh; break; }
 			hv = nh;
 		}
